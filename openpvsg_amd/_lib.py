@@ -1,0 +1,64 @@
+"""ctypes binding of the C ABI in include/openpvsg_hip.h.
+
+torch is imported first so that the library's NEEDED `libamdhip64.so.7` resolves to the HIP
+runtime torch already loaded (one runtime per process: device pointers and streams are shared).
+There is no fallback: if the shared library is missing or a symbol is absent this raises, and
+every op in `ops.py` goes through here.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libopenpvsg_hip.so')
+
+_c_f = ctypes.c_void_p  # device pointers travel as raw addresses
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+# name -> argtypes; must list every function include/openpvsg_hip.h declares
+# (tests/test_capi.py cross-checks this table against the header).
+SIGNATURES = {
+    'pvsg_ms_deform_attn_forward': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _i, _i, _i, _c_f],
+}
+
+_lib = None
+
+
+class BackendMissingError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendMissingError(
+            'HIP backend library not built: %s (run `python -c "import __graft_entry__ as g; '
+            'g.build()"` or `python -m openpvsg_amd.build`). There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for fn in ('pvsg_last_error', 'pvsg_version'):
+        getattr(lib, fn).restype = ctypes.c_char_p
+        getattr(lib, fn).argtypes = []
+    lib.pvsg_abi_version.restype = _i
+    lib.pvsg_abi_version.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        try:
+            f = getattr(lib, name)
+        except AttributeError as e:
+            raise BackendMissingError('symbol %s missing from %s' % (name, LIB_PATH)) from e
+        f.restype = _i
+        f.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke a C-ABI entry point; non-zero status -> RuntimeError with the library's message."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.pvsg_last_error()
+        raise RuntimeError('%s failed (code %d): %s' % (name, rc, msg.decode() if msg else '?'))

@@ -1,0 +1,56 @@
+// Shared helpers for the gfx950 kernels of the OpenPVSG hot path.
+// Everything here targets CDNA4 (MI355X) directly: 64-lane wavefronts, 8 XCDs,
+// f32-input MFMA.  No portability layer on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+// ---- status codes shared with include/openpvsg_hip.h ----------------------
+#define PVSG_OK 0
+#define PVSG_ERR_INVALID_ARG 1
+#define PVSG_ERR_UNSUPPORTED 2
+#define PVSG_ERR_HIP 3
+
+namespace pvsg {
+
+// thread-local last-error text, read through pvsg_last_error()
+char* err_buf();
+int set_err(int code, const char* fmt, ...);
+
+#define PVSG_REQUIRE(cond, ...)                                      \
+  do {                                                               \
+    if (!(cond)) return ::pvsg::set_err(PVSG_ERR_INVALID_ARG, __VA_ARGS__); \
+  } while (0)
+
+#define PVSG_LAUNCH_CHECK(name)                                                    \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess)                                                         \
+      return ::pvsg::set_err(PVSG_ERR_HIP, "%s: launch failed: %s", name,          \
+                             hipGetErrorString(e__));                              \
+  } while (0)
+
+// Observed on gfx950: workgroup b runs on XCD (b % 8), each XCD has a private
+// 4 MiB L2.  Remap the linear block id so that every XCD walks ONE contiguous
+// range of logical work items (speed only; correctness never depends on it).
+// Bijective for every nblk (cdna_hip_programming.md, 256^2 template note).
+__device__ __forceinline__ unsigned xcd_contiguous_block(unsigned bid, unsigned nblk) {
+  const unsigned q = nblk >> 3, r = nblk & 7u;
+  const unsigned xcd = bid & 7u, slot = bid >> 3;
+  const unsigned base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+  return base + slot;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) {
+  return *reinterpret_cast<const float4*>(p);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) {
+  *reinterpret_cast<float4*>(p) = v;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+}  // namespace pvsg

@@ -1,0 +1,563 @@
+"""Golden-vector generator.  Runs ONLY in the build container (it reads /root/reference);
+what it writes -- small .npz fixtures under tests/golden/ -- is what travels.
+
+It imports the REFERENCE's own Python:
+  * models/relation_head/*.py and utils/rel_metrics.py by file path (pure torch / numpy);
+  * models/mask2former/mask2former_head.py, mask2former_fusion_head.py,
+    models/mask2former_vps/{position_encoding,maskformer_video_head,mask2former_video_head,
+    mask2former,mask2former_min_vis}.py under a throw-away stub `mmcv`/`mmdet` namespace whose
+    builders hand back the oracle's third-party blocks (oracle/blocks3p.py).  The stubs exist only
+    inside this process; no reference text is written anywhere.
+Weights are never stored: they are derived from (key, shape, seed) by oracle/detweights.py on
+both sides.  Usage:  python -m oracle.make_golden
+"""
+import copy
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle import blocks3p  # noqa: E402
+from oracle.detweights import det_input, det_state_dict  # noqa: E402
+
+
+def load_by_path(name, relpath, package=None):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    if package:
+        mod.__package__ = package
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class AttrDict(dict):
+    """Enough of mmcv.ConfigDict for the heads: attribute access, .get, .update, deepcopy."""
+
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError:
+            raise AttributeError(k)
+        return v
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __deepcopy__(self, memo):
+        return AttrDict({k: copy.deepcopy(v, memo) for k, v in self.items()})
+
+
+def to_attr(d):
+    if isinstance(d, dict):
+        return AttrDict({k: to_attr(v) for k, v in d.items()})
+    if isinstance(d, (list, tuple)):
+        return type(d)(to_attr(v) for v in d)
+    return d
+
+
+class Registry:
+    def __init__(self, name):
+        self.name, self.mods = name, {}
+
+    def register_module(self, name=None, force=False, module=None):
+        def deco(cls):
+            self.mods[name or cls.__name__] = cls
+            return cls
+        return deco
+
+    def build(self, cfg, **extra):
+        cfg = dict(cfg)
+        cls = self.mods[cfg.pop('type')]
+        cfg.update(extra)
+        return cls(**cfg)
+
+
+def install_stubs():
+    def mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+
+    HEADS, DETECTORS, POSENC = Registry('head'), Registry('detector'), Registry('posenc')
+
+    class BaseModule(nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+            self.init_cfg = init_cfg
+
+    class BaseDenseHead(BaseModule):
+        pass
+
+    class AnchorFreeHead(BaseDenseHead):
+        pass
+
+    class MaskFormerHead(AnchorFreeHead):
+        pass
+
+    class BasePanopticFusionHead(BaseModule):
+        def __init__(self, num_things_classes=80, num_stuff_classes=53, test_cfg=None,
+                     loss_panoptic=None, init_cfg=None, **kwargs):
+            super().__init__(init_cfg)
+            self.num_things_classes, self.num_stuff_classes = num_things_classes, num_stuff_classes
+            self.num_classes = num_things_classes + num_stuff_classes
+            self.test_cfg = test_cfg
+
+    class BaseDetector(BaseModule):
+        @property
+        def with_neck(self):
+            return hasattr(self, 'neck') and self.neck is not None
+
+    class SingleStageDetector(BaseDetector):
+        def extract_feat(self, img):
+            x = self.backbone(img)
+            return self.neck(x) if self.with_neck else x
+
+    def build_plugin_layer(cfg, *a, **k):
+        cfg = dict(cfg)
+        assert cfg.pop('type') == 'MSDeformAttnPixelDecoder'
+        enc = cfg['encoder']
+        attn = enc['transformerlayers']['attn_cfgs']
+        pd = blocks3p.MSDeformAttnPixelDecoder(
+            in_channels=cfg['in_channels'], strides=cfg.get('strides', [4, 8, 16, 32]),
+            feat_channels=cfg['feat_channels'], out_channels=cfg['out_channels'],
+            num_outs=cfg['num_outs'], num_encoder_layers=enc['num_layers'],
+            num_heads=attn['num_heads'], num_levels=attn['num_levels'],
+            num_points=attn['num_points'],
+            ffn_channels=enc['transformerlayers']['ffn_cfgs']['feedforward_channels'],
+            gn_groups=cfg['norm_cfg']['num_groups'])
+        return 'pixel_decoder', pd
+
+    def build_transformer_layer_sequence(cfg):
+        tl = cfg['transformerlayers']
+        return blocks3p.DetrTransformerDecoder(
+            num_layers=cfg['num_layers'], embed_dims=tl['attn_cfgs']['embed_dims'],
+            num_heads=tl['attn_cfgs']['num_heads'], ffn_channels=tl['feedforward_channels'])
+
+    def build_positional_encoding(cfg):
+        cfg = dict(cfg)
+        t = cfg.pop('type')
+        if t == 'SinePositionalEncoding':
+            return blocks3p.SinePositionalEncoding(**cfg)
+        return POSENC.mods[t](**cfg)
+
+    def force_fp32(apply_to=None, out_fp16=False):
+        return lambda f: f
+
+    def multi_apply(func, *args, **kwargs):
+        res = map(func, *args)
+        return tuple(map(list, zip(*res)))
+
+    def mask2bbox(masks):
+        n = masks.shape[0]
+        bboxes = masks.new_zeros((n, 4), dtype=torch.float32)
+        x_any, y_any = torch.any(masks, dim=1), torch.any(masks, dim=2)
+        for i in range(n):
+            x, y = torch.where(x_any[i, :])[0], torch.where(y_any[i, :])[0]
+            if len(x) > 0 and len(y) > 0:
+                bboxes[i, :] = bboxes.new_tensor([x[0], y[0], x[-1] + 1, y[-1] + 1])
+        return bboxes
+
+    def bbox2result(bboxes, labels, num_classes):
+        if bboxes.shape[0] == 0:
+            return [np.zeros((0, bboxes.shape[1]), dtype=np.float32) for _ in range(num_classes)]
+        b, lab = bboxes.detach().cpu().numpy(), labels.detach().cpu().numpy()
+        return [b[lab == i, :] for i in range(num_classes)]
+
+    mmcv = mod('mmcv')
+    cnn = mod('mmcv.cnn')
+    cnn.Conv2d, cnn.build_plugin_layer = nn.Conv2d, build_plugin_layer
+    cnn.caffe2_xavier_init = lambda m, bias=0: None
+    mod('mmcv.cnn.bricks')
+    tr = mod('mmcv.cnn.bricks.transformer')
+    tr.build_positional_encoding = build_positional_encoding
+    tr.build_transformer_layer_sequence = build_transformer_layer_sequence
+    tr.POSITIONAL_ENCODING = POSENC
+    ops = mod('mmcv.ops')
+    ops.point_sample = None
+    runner = mod('mmcv.runner')
+    runner.ModuleList, runner.force_fp32, runner.BaseModule = nn.ModuleList, force_fp32, BaseModule
+    mmcv.cnn, mmcv.ops, mmcv.runner = cnn, ops, runner
+
+    mmdet = mod('mmdet')
+    core = mod('mmdet.core')
+    core.build_assigner = core.build_sampler = lambda *a, **k: None
+    core.reduce_mean, core.multi_apply = (lambda t: t), multi_apply
+    core.INSTANCE_OFFSET, core.bbox2result = 1000, bbox2result
+    core.encode_mask_results = lambda r: r
+    ev = mod('mmdet.core.evaluation')
+    pu = mod('mmdet.core.evaluation.panoptic_utils')
+    pu.INSTANCE_OFFSET = 1000
+    mk = mod('mmdet.core.mask')
+    mk.mask2bbox = mask2bbox
+    vis = mod('mmdet.core.visualization')
+    vis.imshow_det_bboxes = None
+    utils = mod('mmdet.utils')
+    utils.get_root_logger = lambda *a, **k: types.SimpleNamespace(info=lambda *x, **y: None)
+    models = mod('mmdet.models')
+    mutils = mod('mmdet.models.utils')
+    mutils.get_uncertain_point_coords_with_randomness = None
+    builder = mod('mmdet.models.builder')
+    builder.HEADS, builder.DETECTORS = HEADS, DETECTORS
+    builder.build_loss = lambda cfg: None
+    builder.build_backbone = lambda cfg: blocks3p.ResNet50()
+    builder.build_neck = lambda cfg: None
+    builder.build_head = lambda cfg: HEADS.build(cfg)
+    dh = mod('mmdet.models.dense_heads')
+    af = mod('mmdet.models.dense_heads.anchor_free_head')
+    af.AnchorFreeHead = AnchorFreeHead
+    mf = mod('mmdet.models.dense_heads.maskformer_head')
+    mf.MaskFormerHead = MaskFormerHead
+    mod('mmdet.models.seg_heads')
+    mod('mmdet.models.seg_heads.panoptic_fusion_heads')
+    bp = mod('mmdet.models.seg_heads.panoptic_fusion_heads.base_panoptic_fusion_head')
+    bp.BasePanopticFusionHead = BasePanopticFusionHead
+    mod('mmdet.models.detectors')
+    ss = mod('mmdet.models.detectors.single_stage')
+    ss.SingleStageDetector = SingleStageDetector
+    # the VPS package pulls cv2 / pycocotools / unitrack through mask2former_vps/utils.py:4-12
+    for name in ('cv2', 'pycocotools', 'pycocotools.mask', 'models', 'models.unitrack',
+                 'models.unitrack.utils', 'models.unitrack.utils.log',
+                 'models.unitrack.utils.meter', 'models.unitrack.utils.visualize',
+                 'models.unitrack.utils.io'):
+        if name not in sys.modules:
+            mod(name)
+    sys.modules['models.unitrack.utils.log'].logger = None
+    sys.modules['models.unitrack.utils.meter'].Timer = None
+    sys.modules['models.unitrack.utils'].visualize = sys.modules['models.unitrack.utils.visualize']
+    sys.modules['models.unitrack.utils'].io = sys.modules['models.unitrack.utils.io']
+    pkg = mod('models.mask2former_vps')
+    pkg.__path__ = [os.path.join(REF, 'models', 'mask2former_vps')]
+    return HEADS, DETECTORS, POSENC
+
+
+# ------------------------------------------------------------------------------------------------
+HEAD_CFG = dict(
+    in_channels=[256, 512, 1024, 2048], strides=[4, 8, 16, 32], feat_channels=256, out_channels=256,
+    num_things_classes=115, num_stuff_classes=11, num_queries=100, num_transformer_feat_level=3,
+    pixel_decoder=dict(
+        type='MSDeformAttnPixelDecoder', num_outs=3, norm_cfg=dict(type='GN', num_groups=32),
+        act_cfg=dict(type='ReLU'),
+        encoder=dict(type='DetrTransformerEncoder', num_layers=6, transformerlayers=dict(
+            type='BaseTransformerLayer',
+            attn_cfgs=dict(type='MultiScaleDeformableAttention', embed_dims=256, num_heads=8,
+                           num_levels=3, num_points=4, im2col_step=64, dropout=0.0,
+                           batch_first=False, norm_cfg=None, init_cfg=None),
+            ffn_cfgs=dict(type='FFN', embed_dims=256, feedforward_channels=1024, num_fcs=2,
+                          ffn_drop=0.0, act_cfg=dict(type='ReLU', inplace=True)),
+            operation_order=('self_attn', 'norm', 'ffn', 'norm')), init_cfg=None),
+        positional_encoding=dict(type='SinePositionalEncoding', num_feats=128, normalize=True),
+        init_cfg=None),
+    enforce_decoder_input_project=False,
+    positional_encoding=dict(type='SinePositionalEncoding', num_feats=128, normalize=True),
+    transformer_decoder=dict(
+        type='DetrTransformerDecoder', return_intermediate=True, num_layers=9,
+        transformerlayers=dict(
+            type='DetrTransformerDecoderLayer',
+            attn_cfgs=dict(type='MultiheadAttention', embed_dims=256, num_heads=8, attn_drop=0.0,
+                           proj_drop=0.0, dropout_layer=None, batch_first=False),
+            ffn_cfgs=dict(embed_dims=256, feedforward_channels=2048, num_fcs=2,
+                          act_cfg=dict(type='ReLU', inplace=True), ffn_drop=0.0,
+                          dropout_layer=None, add_identity=True),
+            feedforward_channels=2048,
+            operation_order=('cross_attn', 'norm', 'self_attn', 'norm', 'ffn', 'norm')),
+        init_cfg=None),
+    loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=2.0, reduction='mean',
+                  class_weight=[1.0] * 126 + [0.1]),
+    loss_mask=dict(type='CrossEntropyLoss', use_sigmoid=True, reduction='mean', loss_weight=5.0),
+    loss_dice=dict(type='DiceLoss', use_sigmoid=True, activate=True, reduction='mean',
+                   naive_dice=True, eps=1.0, loss_weight=5.0),
+    train_cfg=None,
+    test_cfg=dict(panoptic_on=True, semantic_on=False, instance_on=True, max_per_image=100,
+                  iou_thr=0.8, filter_low_score=True, return_query=True, object_mask_thr=0.8))
+
+GAINS = {'cls_embed.weight': 12.0}  # peaky class logits so that `score > 0.8` keeps some queries
+LAYERS_KEPT = (0, 1, 5, 9)
+FEAT_SHAPES = ((16, 24), (8, 12), (4, 6), (2, 3))
+
+
+def synth_feats(nimg, seed):
+    return [det_input('feat%d' % i, (nimg, c) + hw, seed)
+            for i, (c, hw) in enumerate(zip(HEAD_CFG['in_channels'], FEAT_SHAPES))]
+
+
+def gen_head(HEADS):
+    ips = load_by_path('ref_m2f_head', 'models/mask2former/mask2former_head.py')
+    load_by_path('models.mask2former_vps.utils', 'models/mask2former_vps/utils.py',
+                 'models.mask2former_vps')
+    load_by_path('models.mask2former_vps.position_encoding',
+                 'models/mask2former_vps/position_encoding.py', 'models.mask2former_vps')
+    load_by_path('models.mask2former_vps.maskformer_video_head',
+                 'models/mask2former_vps/maskformer_video_head.py', 'models.mask2former_vps')
+    vid = load_by_path('models.mask2former_vps.mask2former_video_head',
+                       'models/mask2former_vps/mask2former_video_head.py', 'models.mask2former_vps')
+
+    def trace(head, fwd_head_name):
+        rec = {'am': []}
+        orig = getattr(head, fwd_head_name)
+
+        def wrapped(*a, **k):
+            out = orig(*a, **k)
+            rec['am'].append(out[2].clone())
+            return out
+        setattr(head, fwd_head_name, wrapped)
+        return rec
+
+    # ---- IPS head, one image -------------------------------------------------------------------
+    for seed in (1,):
+        head = ips.Mask2FormerHeadCustom(**to_attr(copy.deepcopy(HEAD_CFG))).eval()
+        head.load_state_dict(det_state_dict(head, seed, GAINS))
+        rec = trace(head, 'forward_head')
+        feats = synth_feats(1, seed)
+        metas = [dict(batch_input_shape=(64, 96), img_shape=(60, 90, 3), ori_shape=(45, 70, 3))]
+        with torch.no_grad():
+            cls_list, mask_list, q = head.forward(feats, metas, return_query=True)
+            head.forward_head = getattr(head, 'forward_head')
+            cls_f, mask_f, qf = head.simple_test_with_query(feats, metas)
+        np.savez_compressed(
+            os.path.join(OUT, 'head_ips_s%d.npz' % seed), seed=seed,
+            cls=np.stack([cls_list[i].numpy() for i in LAYERS_KEPT]),
+            mask=np.stack([mask_list[i].numpy() for i in LAYERS_KEPT]),
+            layers=np.array(LAYERS_KEPT), query=q.numpy(),
+            am_popcount=np.stack([a[0].sum(-1).numpy() for a in rec['am'][:10]]),
+            am_first=np.packbits(rec['am'][0][0].numpy(), axis=-1),
+            final_cls=cls_f.numpy(), final_mask_sample=mask_f[:, ::7, ::5, ::5].numpy(),
+            final_query=qf.numpy())
+        print('head_ips', seed, 'kept am popcount range', rec['am'][1][0].sum(-1).min().item(),
+              rec['am'][1][0].sum(-1).max().item())
+
+    # ---- video head, clip-level (T flattened into the key axis) ----------------------------------
+    vcfg = copy.deepcopy(HEAD_CFG)
+    vcfg['positional_encoding'] = dict(type='SinePositionalEncoding3D', num_feats=128, normalize=True)
+    vcfg['loss_sem_seg'] = None
+    for seed, T in ((2, 1), (3, 3)):
+        head = vid.Mask2FormerVideoHead(**to_attr(copy.deepcopy(vcfg))).eval()
+        head.load_state_dict(det_state_dict(head, seed, GAINS))
+        rec = trace(head, 'forward_head_video')
+        feats = synth_feats(T, seed)
+        metas = [[dict(batch_input_shape=(64, 96), img_shape=(60, 90, 3), ori_shape=(45, 70, 3))] * T]
+        with torch.no_grad():
+            cls_list, mask_list, q = head.forward(feats, metas, return_query=True)
+            cls_f, mask_f, qf = head.simple_test_with_query(feats, metas)
+        np.savez_compressed(
+            os.path.join(OUT, 'head_vps_s%d_T%d.npz' % (seed, T)), seed=seed, T=T,
+            cls=np.stack([cls_list[i].numpy() for i in LAYERS_KEPT]),
+            mask=np.stack([mask_list[i].numpy() for i in LAYERS_KEPT]),
+            layers=np.array(LAYERS_KEPT), query=q.numpy(),
+            am_popcount=np.stack([a[0].sum(-1).numpy() for a in rec['am'][:10]]),
+            final_cls=cls_f.numpy(), final_mask_sample=mask_f[:, :, ::7, ::5, ::5].numpy(),
+            final_query=qf.numpy())
+        print('head_vps', seed, T)
+
+    # ---- 3-D sine encoding alone -----------------------------------------------------------------
+    pe_mod = sys.modules['models.mask2former_vps.position_encoding']
+    pe = pe_mod.SinePositionalEncoding3D(num_feats=128, normalize=True)
+    out = pe(torch.zeros(1, 3, 4, 6, dtype=torch.bool))
+    pe2 = pe_mod.SinePositionalEncoding3D(num_feats=8, normalize=False, temperature=20)
+    out2 = pe2(torch.zeros(2, 2, 3, 5, dtype=torch.bool))
+    np.savez_compressed(os.path.join(OUT, 'pe3d.npz'), a=out.numpy(), b=out2.numpy())
+    return ips, vid
+
+
+from tests.synth_inputs import blob_masks, peaky_cls  # noqa: E402
+
+
+def gen_fusion(HEADS):
+    fus = load_by_path('ref_fusion_head', 'models/mask2former/mask2former_fusion_head.py')
+    cases = []
+    for ci, (nconf, hw, img, ori, low) in enumerate((
+            (12, (64, 96), (60, 90), (45, 70), True),
+            (30, (96, 128), (96, 128), (96, 128), True),
+            (10, (64, 96), (64, 80), (128, 160), False),
+            (0, (32, 32), (32, 32), (32, 32), True))):
+        test_cfg = to_attr(dict(panoptic_on=True, semantic_on=False, instance_on=True,
+                                max_per_image=100, iou_thr=0.8, filter_low_score=low,
+                                object_mask_thr=0.8))
+        head = fus.MaskFormerFusionHeadCustom(num_things_classes=115, num_stuff_classes=11,
+                                              test_cfg=test_cfg)
+        cls, conf = peaky_cls(100, 126, nconf, ci)
+        cls = cls[None]
+        masks = blob_masks(100, hw[0], hw[1], conf, ci)[None]
+        qf = det_input('fusion_q%d' % ci, (1, 100, 1, 256), ci)
+        metas = [dict(img_shape=img + (3,), ori_shape=ori + (3,), batch_input_shape=hw)]
+        with torch.no_grad():
+            res = head.simple_test_with_query(cls, masks, qf, metas, rescale=True)[0]
+        ids = sorted(res['query_feats'].keys())
+        labels, boxes, binm = res['ins_results']
+        cases.append(dict(
+            cls=cls.numpy(), conf=np.asarray(conf, dtype=np.int64), hw=np.array(hw), img=np.array(img), ori=np.array(ori),
+            low=np.array(low), nconf=np.array(nconf),
+            pan=res['pan_results'].numpy(), ids=np.array(ids, dtype=np.int64),
+            feat_first=np.stack([res['query_feats'][i][0].numpy() for i in ids]) if ids else np.zeros((0, 1, 256), np.float32),
+            feat_count=np.array([len(res['query_feats'][i]) for i in ids], dtype=np.int64),
+            ins_labels=labels.numpy(), ins_boxes=boxes.numpy(),
+            ins_area=binm.flatten(1).sum(1).numpy()))
+        print('fusion case', ci, 'segments', ids)
+    flat = {}
+    for i, c in enumerate(cases):
+        for k, v in c.items():
+            flat['c%d_%s' % (i, k)] = v
+    np.savez_compressed(os.path.join(OUT, 'fusion.npz'), n=len(cases), **flat)
+    return fus
+
+
+def gen_detector(HEADS, DETECTORS):
+    """Per-frame VPS flow as shipped (mask2former_vps/mask2former.py:125-200).  As shipped it only
+    runs at T == 1: the head asserts B*T == feats batch (mask2former_video_head.py:384) while the
+    detector feeds one frame at a time with T-long metas, and frame >= 2 would call
+    self.match_from_embds which only the MinVIS class defines.  So the
+    end-to-end golden is T=1 (= configs/.../mask2former_video_r50_single_video_test.py:33,
+    ref_seq_len_test=1); the MinVIS matcher is pinned on its own."""
+    det_mod = load_by_path('models.mask2former_vps.mask2former',
+                           'models/mask2former_vps/mask2former.py', 'models.mask2former_vps')
+    mv = load_by_path('models.mask2former_vps.mask2former_min_vis',
+                      'models/mask2former_vps/mask2former_min_vis.py', 'models.mask2former_vps')
+    # matching alone
+    tgt, cur = det_input('mv_tgt', (100, 256), 5), det_input('mv_cur', (100, 256), 6)
+    cur2 = tgt[torch.from_numpy(np.random.RandomState(3).permutation(100))] + 0.05 * cur
+    idx_a = mv.Mask2FormerVideoCustomMinVIS.match_from_embds(None, tgt, cur)
+    idx_b = mv.Mask2FormerVideoCustomMinVIS.match_from_embds(None, tgt, cur2)
+    np.savez_compressed(os.path.join(OUT, 'minvis_match.npz'), idx_a=np.asarray(idx_a),
+                        idx_b=np.asarray(idx_b))
+
+    det_mod.Mask2FormerVideoCustom.match_from_embds = mv.Mask2FormerVideoCustomMinVIS.match_from_embds
+    vcfg = copy.deepcopy(HEAD_CFG)
+    vcfg['type'] = 'Mask2FormerVideoHead'
+    vcfg['positional_encoding'] = dict(type='SinePositionalEncoding3D', num_feats=128, normalize=True)
+    vcfg['loss_sem_seg'] = None
+    vcfg.pop('train_cfg'), vcfg.pop('test_cfg')
+    test_cfg = dict(panoptic_on=True, semantic_on=False, instance_on=False, max_per_image=100,
+                    iou_thr=0.8, filter_low_score=True, return_query=True, object_mask_thr=0.8)
+    model = det_mod.Mask2FormerVideoCustom(
+        backbone=to_attr(dict(type='ResNet', depth=50)), panoptic_head=to_attr(vcfg),
+        panoptic_fusion_head=to_attr(dict(type='MaskFormerFusionHeadCustom', num_things_classes=115,
+                                          num_stuff_classes=11, loss_panoptic=None, init_cfg=None)),
+        train_cfg=None, test_cfg=to_attr(test_cfg)).eval()
+    seed, T = 4, 1
+    model.load_state_dict(det_state_dict(model, seed, {'cls_embed.weight': 40.0}))
+    img = det_input('clip', (1, T, 3, 64, 96), seed)
+    metas = [[dict(batch_input_shape=(64, 96), img_shape=(64, 96, 3), ori_shape=(64, 96, 3))
+              for _ in range(T)]]
+    with torch.no_grad():
+        results = model.simple_test(None, None, img, metas, rescale=True)
+    pans = np.stack([results[0][t]['pan_results'] for t in range(T)])
+    ids = [sorted(results[0][t]['query_feats'].keys()) for t in range(T)]
+    print('detector vps: segment ids per frame', ids)
+    feat0 = np.stack([results[0][0]['query_feats'][i][0].numpy() for i in ids[0]]) if ids[0] \
+        else np.zeros((0, 256), np.float32)
+    np.savez_compressed(os.path.join(OUT, 'detector_vps_T1.npz'), seed=seed, T=T, pan=pans,
+                        ids0=np.array(ids[0], dtype=np.int64), feat0=feat0)
+
+
+def gen_relation():
+    base = load_by_path('ref_rel_base', 'models/relation_head/base.py')
+    conv = load_by_path('ref_rel_conv', 'models/relation_head/convolution.py')
+    trans = load_by_path('ref_rel_trans', 'models/relation_head/transformer.py')
+    tu = load_by_path('ref_rel_test_utils', 'models/relation_head/test_utils.py')
+    tru = load_by_path('ref_rel_train_utils', 'models/relation_head/train_utils.py')
+    met = load_by_path('ref_rel_metrics', 'utils/rel_metrics.py')
+    classes = {'vanilla': base.VanillaModel, 'filter': conv.HandcraftedFilter,
+               'conv': conv.Learnable1DConv, 'transformer': trans.TemporalTransformer}
+    K_values = [20, 50, 100]
+    for seed, (N, T), names in ((1, (4, 8), ('transformer', 'vanilla')),
+                                (2, (8, 16), ('transformer', 'filter', 'conv')),
+                                (3, (17, 33), ('transformer',)),
+                                (4, (2, 5), ('vanilla',)),
+                                (5, (12, 9), ('transformer',))):
+        feats = det_input('rel_feats', (N, T, 256), seed)
+        se, oe = base.ObjectEncoder(feature_dim=256).eval(), base.ObjectEncoder(feature_dim=256).eval()
+        se.load_state_dict(det_state_dict(se, seed))
+        oe.load_state_dict(det_state_dict(oe, seed + 100))
+        pp = base.PairProposalNetwork(256, 1024).eval()
+        pp.load_state_dict(det_state_dict(pp, seed))
+        with torch.no_grad():
+            sub, obj = se(feats), oe(feats)
+            pm = pp(sub, obj)
+            pairs = tu.pick_top_pairs_eval(pm, 100)
+            cat = tru.concatenate_sub_obj(sub, obj, pairs)
+        save = dict(seed=seed, N=N, T=T, sub=sub.numpy(), obj=obj.numpy(), pred_matrix=pm.numpy(),
+                    pairs=np.array(pairs, dtype=np.int64).reshape(-1, 2))
+        # synthetic ground truth: some top pairs with their best relation and the predicted span,
+        # some with a wrong span, some pairs outside the selection
+        rs = np.random.RandomState(seed)
+        for name in names:
+            rm = classes[name](512, 57).eval()
+            rm.load_state_dict(det_state_dict(rm, seed))
+            with torch.no_grad():
+                span, prob = rm(cat)
+                res_pw = tu.generate_pairwise_results(span, prob, pairs)
+                res_all = tu.generate_results(span, prob, pairs)
+            gts = []
+            for r in res_pw[::2][:6]:
+                gts.append(dict(subject_index=r['subject_index'], object_index=r['object_index'],
+                                relation=r['relation'], relation_span=r['relation_span'].copy()))
+            for r in res_pw[1::2][:4]:
+                gts.append(dict(subject_index=r['subject_index'], object_index=r['object_index'],
+                                relation=(r['relation'] + 1) % 57,
+                                relation_span=(rs.rand(T) > 0.5).astype(float)))
+            for r in res_all[5:60:11]:
+                gts.append(dict(subject_index=r['subject_index'], object_index=r['object_index'],
+                                relation=r['relation'], relation_span=1.0 - r['relation_span']))
+            rrd = {K: {i: {'name': str(i), 'total': 0, 'hit': 0, 'weak_hit': 0} for i in range(57)}
+                   for K in K_values}
+            for strat, results in (('pw', res_pw), ('all', res_all)):
+                rr = copy.deepcopy(rrd)
+                for gt in gts:
+                    key = (gt['subject_index'], gt['object_index'], gt['relation'])
+                    for K in K_values:
+                        rr[K][key[2]]['total'] += 1
+                    for idx, r in enumerate(results):
+                        if (r['subject_index'], r['object_index'], r['relation']) == key:
+                            tiou = met.calculate_iou(gt['relation_span'], r['relation_span'])
+                            for K in K_values:
+                                if idx < K:
+                                    rr[K][key[2]]['weak_hit'] += 1
+                                    if tiou >= 0.5:
+                                        rr[K][key[2]]['hit'] += 1
+                            break
+                fm = met.calculate_final_metrics(rr, K_values)
+                save['%s_metrics_%s' % (name, strat)] = np.array(
+                    [[fm[K][m] for m in ('recall', 'mean_recall', 'weak_recall', 'weak_mean_recall')]
+                     for K in K_values], dtype=np.float64)
+            gt_pairs = [[g['subject_index'], g['object_index']] for g in gts]
+            save['%s_pair_recall20' % name] = np.array(
+                met.calculate_pair_recall_at_k(pairs, gt_pairs, 20))
+            save['%s_span' % name] = span.numpy()
+            save['%s_prob' % name] = prob.numpy()
+            top = res_pw[:20]
+            save['%s_pw_top' % name] = np.array(
+                [[r['subject_index'], r['object_index'], r['relation']] for r in top], dtype=np.int64)
+            save['%s_pw_top_span' % name] = np.stack([r['relation_span'] for r in top])
+            top = res_all[:20]
+            save['%s_all_top' % name] = np.array(
+                [[r['subject_index'], r['object_index'], r['relation']] for r in top], dtype=np.int64)
+            save['%s_gt' % name] = np.array(
+                [[g['subject_index'], g['object_index'], g['relation']] for g in gts], dtype=np.int64)
+            save['%s_gt_span' % name] = np.stack([g['relation_span'] for g in gts])
+        np.savez_compressed(os.path.join(OUT, 'rel_s%d_N%d_T%d.npz' % (seed, N, T)), **save)
+        print('relation', seed, N, T, names)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    gen_relation()
+    HEADS, DETECTORS, POSENC = install_stubs()
+    gen_head(HEADS)
+    gen_fusion(HEADS)
+    gen_detector(HEADS, DETECTORS)
+    print('golden fixtures written to', OUT)
+
+
+if __name__ == '__main__':
+    main()
