@@ -52,6 +52,67 @@ int pvsg_ms_deform_attn_forward(const float* value, const int64_t* spatial_shape
                                 const float* attn_weight, float* out, int B, int S, int M, int D,
                                 int Lq, int L, int P, int im2col_step, void* stream);
 
+/* ---- a3: per-query mask-logit projection (fp32 matrix cores) --------------------------------
+ * Replaces torch.einsum('bqc,bchw->bqhw') models/mask2former/mask2former_head.py:382 and
+ * torch.einsum('bqc,btchw->btqhw') models/mask2former_vps/mask2former_video_head.py:344.
+ *   mask_embed   (B, Q, C)      output of the 3-layer mask MLP
+ *   mask_feature (B, T, C, N)   N = h*w of the stride-4 map (T = 1 for the image head)
+ *   out          (B, T, Q, N)
+ * Supported: Q <= 112, C % 16 == 0, C <= 320 (else PVSG_ERR_UNSUPPORTED); N % 4 == 0 takes the
+ * vectorised path. */
+int pvsg_mask_logits_forward(const float* mask_embed, const float* mask_feature, float* out, int B,
+                             int T, int Q, int C, int N, void* stream);
+
+/* ---- a3: attention-mask bits straight from low-resolution features --------------------------
+ * Replaces F.interpolate(mask_pred, level size) -> flatten -> repeat(num_heads) -> sigmoid() < 0.5
+ * (mask2former_head.py:383-393, video_head.py:346-357) and the all-masked-row test that feeds the
+ * reset at mask2former_head.py:453-454, for levels whose size divides the stride-4 map by 2/4/8
+ * (bilinear resize is then linear and commutes with the projection).
+ *   feature_lowres (B, T, C, N_l)  = pvsg_center_downsample output for that level
+ *   bits           (B, T*N_l, 4) uint32: bit q of a key's 128-bit word = 1 <=> query q is BLOCKED
+ *   flags          (B, 4) uint32:        bit q = 1 <=> query q has at least one unblocked key */
+int pvsg_attn_mask_bits_forward(const float* mask_embed, const float* feature_lowres, uint32_t* bits,
+                                uint32_t* flags, int B, int T, int Q, int C, int N, void* stream);
+
+/* Same bits/flags from already resized logits (general sizes; exact for any interpolate factor).
+ *   logits_lowres (B, T, Q, HW) */
+int pvsg_attn_mask_pack(const float* logits_lowres, uint32_t* bits, uint32_t* flags, int B, int T,
+                        int Q, int HW, void* stream);
+
+/* Centre-tap (== bilinear, align_corners=False) down-sampling of (planes, H, W) by 2, 4 and 8 in one
+ * pass; H % 8 == 0 and W % 8 == 0.  Replaces the three F.interpolate calls per decoder layer. */
+int pvsg_center_downsample(const float* feature, float* d2, float* d4, float* d8, long long planes,
+                           int H, int W, void* stream);
+
+/* ---- a4/a5: masked cross-attention (streaming, split over key ranges) ------------------------
+ * Replaces [3P] mmcv MultiheadAttention -> nn.MultiheadAttention with a (B*heads, Q, K) bool mask as
+ * driven by mask2former_head.py:457-468 / video_head.py:435-446.
+ *   q_proj (B, Q, 256)  = ((query + query_pos) Wq + bq) / sqrt(32)
+ *   k_proj (B, K, 256)  = (key + key_pos) Wk + bk ;  v_proj (B, K, 256) = value Wv + bv
+ *   mask_bits / mask_flags as above, or both NULL for unmasked attention
+ *   part_o (B, NS, 8, Q, 32), part_ml (B, NS, 8, Q, 2): un-normalised partial output, running max
+ *   and sum per key range.  pvsg_xattn_combine merges NS ranges (also the ranges gathered from other
+ *   GPUs) into out (B, Q, 256); the caller applies Wo and the residual. */
+int pvsg_xattn_num_splits(int B, long long K);
+int pvsg_masked_xattn_partial(const float* q_proj, const float* k_proj, const float* v_proj,
+                              const uint32_t* mask_bits, const uint32_t* mask_flags, float* part_o,
+                              float* part_ml, int B, int Q, long long K, int M, int D, int NS,
+                              void* stream);
+int pvsg_xattn_combine(const float* part_o, const float* part_ml, float* out, int B, int Q, int M,
+                       int D, int NS, void* stream);
+
+/* ---- a11: pairwise relation proposal scorer -------------------------------------------------
+ * Replaces models/relation_head/base.py:49-62 PairProposalNetwork.forward (N^2 Python loop).
+ *   sub_feats, obj_feats (N, T, 256)  encoder outputs; tokens = max over T (base.py:50-51)
+ *   W1 (1024, 512), b1 (1024), w2 (1024), b2 (1)   = pair_ffn.0 / pair_ffn.2 parameters
+ *   W1T (2, 256, 1024) = pvsg_pair_prepare_weights(W1), computed once per checkpoint
+ *   work_uv (2, N, 1024) scratch; tokens_out (2, N, 256) or NULL; pair_matrix (N, N), diagonal 0 */
+int pvsg_pair_prepare_weights(const float* W1, float* W1T, int C, int Hd, void* stream);
+int pvsg_pair_score_forward(const float* sub_feats, const float* obj_feats, const float* W1T,
+                            const float* b1, const float* w2, const float* b2, float* work_uv,
+                            float* tokens_out, float* pair_matrix, int N, int T, int C, int Hd,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

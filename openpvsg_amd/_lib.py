@@ -16,12 +16,24 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libopenpvsg_hip.so')
 _c_f = ctypes.c_void_p  # device pointers travel as raw addresses
 _i = ctypes.c_int
 _f = ctypes.c_float
+_ll = ctypes.c_longlong
 
 # name -> argtypes; must list every function include/openpvsg_hip.h declares
 # (tests/test_capi.py cross-checks this table against the header).
 SIGNATURES = {
     'pvsg_ms_deform_attn_forward': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _i, _i, _i, _c_f],
+    'pvsg_mask_logits_forward': [_c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _c_f],
+    'pvsg_attn_mask_bits_forward': [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _c_f],
+    'pvsg_attn_mask_pack': [_c_f, _c_f, _c_f, _i, _i, _i, _i, _c_f],
+    'pvsg_center_downsample': [_c_f, _c_f, _c_f, _c_f, _ll, _i, _i, _c_f],
+    'pvsg_xattn_num_splits': [_i, _ll],
+    'pvsg_masked_xattn_partial': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _ll, _i, _i, _i, _c_f],
+    'pvsg_xattn_combine': [_c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _c_f],
+    'pvsg_pair_prepare_weights': [_c_f, _c_f, _i, _i, _c_f],
+    'pvsg_pair_score_forward': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _c_f],
 }
+# entry points that return a value instead of a status code
+VALUE_RETURNING = ('pvsg_xattn_num_splits',)
 
 _lib = None
 

@@ -53,3 +53,169 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
                   loc.data_ptr(), w.data_ptr(), out.data_ptr(), B, S, M, D, Lq, L, P,
                   int(im2col_step), _stream_ptr())
     return out
+
+
+def mask_logits(mask_embed, mask_feature):
+    """einsum('bqc,bchw->bqhw') / ('bqc,btchw->btqhw') (mask2former_head.py:382, video_head.py:344).
+
+    mask_embed (B,Q,C); mask_feature (B,C,h,w) or (B,T,C,h,w) -> (B,Q,h,w) or (B,T,Q,h,w)."""
+    e = _chk(mask_embed, 'mask_embed')
+    f = _chk(mask_feature, 'mask_feature')
+    video = f.dim() == 5
+    if f.dim() not in (4, 5) or e.dim() != 3:
+        raise RuntimeError('mask_logits: bad ranks')
+    B, Q, C = e.shape
+    T = f.shape[1] if video else 1
+    h, w = f.shape[-2:]
+    if f.shape[0] != B or f.shape[-3] != C:
+        raise RuntimeError('mask_logits: inconsistent shapes %s vs %s' % (tuple(e.shape), tuple(f.shape)))
+    out = torch.empty((B, T, Q, h, w), device=e.device, dtype=torch.float32)
+    with torch.cuda.device(e.device):
+        _lib.call('pvsg_mask_logits_forward', e.data_ptr(), f.data_ptr(), out.data_ptr(), B, T, Q, C,
+                  h * w, _stream_ptr())
+    return out if video else out[:, 0]
+
+
+def center_downsample(feature):
+    """Bilinear (align_corners=False) resize of (..., H, W) by exactly 1/2, 1/4, 1/8 in one pass."""
+    f = _chk(feature, 'feature')
+    H, W = f.shape[-2:]
+    lead = tuple(f.shape[:-2])
+    planes = 1
+    for s in lead:
+        planes *= s
+    outs = [torch.empty(lead + (H // s, W // s), device=f.device, dtype=torch.float32) for s in (2, 4, 8)]
+    with torch.cuda.device(f.device):
+        _lib.call('pvsg_center_downsample', f.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(),
+                  outs[2].data_ptr(), planes, H, W, _stream_ptr())
+    return outs
+
+
+class AttnMask:
+    """Key-major attention-mask bits (B, K, 4) uint32 + per-query 'has an unblocked key' flags (B, 4)."""
+
+    def __init__(self, bits, flags, num_queries):
+        self.bits, self.flags, self.num_queries = bits, flags, num_queries
+
+    def to_bool(self, reset_all_blocked=True):
+        """(B, Q, K) bool, True = blocked, optionally after the all-blocked-row reset (tests)."""
+        B, K, _ = self.bits.shape
+        q = torch.arange(self.num_queries, device=self.bits.device)
+        words = self.bits.to(torch.int64)[:, :, (q // 32)]            # (B, K, Q)
+        m = ((words >> (q % 32)) & 1).bool().permute(0, 2, 1)
+        if reset_all_blocked:
+            fl = self.flags.to(torch.int64)[:, (q // 32)]
+            has = ((fl >> (q % 32)) & 1).bool()                        # (B, Q)
+            m = m & has[:, :, None]
+        return m
+
+
+def attn_mask_from_lowres_feature(mask_embed, feature_lowres):
+    """mask bits for one decoder level from the down-sampled mask features (integer-factor levels).
+
+    mask_embed (B,Q,C); feature_lowres (B,C,h,w) or (B,T,C,h,w); keys ordered (t, y, x)."""
+    e = _chk(mask_embed, 'mask_embed')
+    f = _chk(feature_lowres, 'feature_lowres')
+    B, Q, C = e.shape
+    T = f.shape[1] if f.dim() == 5 else 1
+    N = f.shape[-1] * f.shape[-2]
+    bits = torch.empty((B, T * N, 4), device=e.device, dtype=torch.int32)
+    flags = torch.empty((B, 4), device=e.device, dtype=torch.int32)
+    with torch.cuda.device(e.device):
+        _lib.call('pvsg_attn_mask_bits_forward', e.data_ptr(), f.data_ptr(), bits.data_ptr(),
+                  flags.data_ptr(), B, T, Q, C, N, _stream_ptr())
+    return AttnMask(bits, flags, Q)
+
+
+def attn_mask_pack(logits_lowres):
+    """mask bits from resized logits (B,Q,h,w) or (B,T,Q,h,w): bit = sigmoid(x) < 0.5."""
+    x = _chk(logits_lowres, 'logits_lowres')
+    if x.dim() == 4:
+        x = x[:, None]
+    B, T, Q, h, w = x.shape
+    bits = torch.empty((B, T * h * w, 4), device=x.device, dtype=torch.int32)
+    flags = torch.empty((B, 4), device=x.device, dtype=torch.int32)
+    with torch.cuda.device(x.device):
+        _lib.call('pvsg_attn_mask_pack', x.data_ptr(), bits.data_ptr(), flags.data_ptr(), B, T, Q, h * w,
+                  _stream_ptr())
+    return AttnMask(bits, flags, Q)
+
+
+def xattn_num_splits(B, K):
+    return _lib.load().pvsg_xattn_num_splits(int(B), int(K))
+
+
+def masked_xattn_partial(q_proj, k_proj, v_proj, mask=None, num_heads=8, num_splits=None):
+    """Streaming masked attention over the local keys -> un-normalised partials.
+
+    q_proj (B,Q,256) already scaled by 1/sqrt(D); k_proj/v_proj (B,K,256); mask: AttnMask or None.
+    Returns part_o (B,NS,M,Q,D), part_ml (B,NS,M,Q,2)."""
+    q, k, v = _chk(q_proj, 'q_proj'), _chk(k_proj, 'k_proj'), _chk(v_proj, 'v_proj')
+    B, Q, HD = q.shape
+    K = k.shape[1]
+    if k.shape != v.shape or k.shape[0] != B or k.shape[2] != HD or HD % num_heads:
+        raise RuntimeError('masked_xattn: inconsistent shapes')
+    D = HD // num_heads
+    NS = num_splits or xattn_num_splits(B, K)
+    part_o = torch.empty((B, NS, num_heads, Q, D), device=q.device, dtype=torch.float32)
+    part_ml = torch.empty((B, NS, num_heads, Q, 2), device=q.device, dtype=torch.float32)
+    if mask is not None and (mask.bits.shape[1] != K or mask.bits.shape[0] != B):
+        raise RuntimeError('masked_xattn: mask covers %d keys, K=%d' % (mask.bits.shape[1], K))
+    with torch.cuda.device(q.device):
+        _lib.call('pvsg_masked_xattn_partial', q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                  mask.bits.data_ptr() if mask is not None else None,
+                  mask.flags.data_ptr() if mask is not None else None,
+                  part_o.data_ptr(), part_ml.data_ptr(), B, Q, K, num_heads, D, NS, _stream_ptr())
+    return part_o, part_ml
+
+
+def xattn_combine(part_o, part_ml):
+    """Log-sum-exp merge of key-range partials (local or gathered from other ranks) -> (B,Q,M*D)."""
+    po, pml = _chk(part_o, 'part_o'), _chk(part_ml, 'part_ml')
+    B, NS, M, Q, D = po.shape
+    out = torch.empty((B, Q, M * D), device=po.device, dtype=torch.float32)
+    with torch.cuda.device(po.device):
+        _lib.call('pvsg_xattn_combine', po.data_ptr(), pml.data_ptr(), out.data_ptr(), B, Q, M, D, NS,
+                  _stream_ptr())
+    return out
+
+
+def masked_xattn(q_proj, k_proj, v_proj, mask=None, num_heads=8):
+    return xattn_combine(*masked_xattn_partial(q_proj, k_proj, v_proj, mask, num_heads))
+
+
+def pair_prepare_weights(W1):
+    """(Hd, 2C) pair_ffn.0.weight -> (2, C, Hd) hidden-fastest copy the scorer streams (once per load)."""
+    W1 = _chk(W1, 'W1')
+    Hd, C2 = W1.shape
+    out = torch.empty((2, C2 // 2, Hd), device=W1.device, dtype=torch.float32)
+    with torch.cuda.device(W1.device):
+        _lib.call('pvsg_pair_prepare_weights', W1.data_ptr(), out.data_ptr(), C2 // 2, Hd, _stream_ptr())
+    return out
+
+
+def pair_score(sub_feats, obj_feats, W1, b1, w2, b2, return_tokens=False, W1T=None):
+    """PairProposalNetwork.forward (models/relation_head/base.py:49-62) in closed form.
+    sub/obj (N,T,256); W1 (1024,512); b1 (1024); w2 (1,1024) or (1024,); b2 (1,) -> (N,N) on device.
+    W1T: cached pair_prepare_weights(W1) (recomputed when omitted)."""
+    s, o = _chk(sub_feats, 'sub_feats'), _chk(obj_feats, 'obj_feats')
+    W1, b1 = _chk(W1, 'W1'), _chk(b1, 'b1')
+    w2, b2 = _chk(w2, 'w2').reshape(-1), _chk(b2, 'b2').reshape(-1)
+    if s.shape != o.shape or s.dim() != 3:
+        raise RuntimeError('pair_score: sub/obj must both be (N,T,C)')
+    N, T, C = s.shape
+    Hd = W1.shape[0]
+    if tuple(W1.shape) != (Hd, 2 * C) or b1.numel() != Hd or w2.numel() != Hd or b2.numel() != 1:
+        raise RuntimeError('pair_score: inconsistent parameter shapes')
+    out = torch.empty((N, N), device=s.device, dtype=torch.float32)
+    if N == 0:
+        return (out, None) if return_tokens else out
+    if W1T is None:
+        W1T = pair_prepare_weights(W1)
+    work = torch.empty((2, N, Hd), device=s.device, dtype=torch.float32)
+    tok = torch.empty((2, N, C), device=s.device, dtype=torch.float32) if return_tokens else None
+    with torch.cuda.device(s.device):
+        _lib.call('pvsg_pair_score_forward', s.data_ptr(), o.data_ptr(), W1T.data_ptr(), b1.data_ptr(),
+                  w2.data_ptr(), b2.data_ptr(), work.data_ptr(), tok.data_ptr() if tok is not None else None,
+                  out.data_ptr(), N, T, C, Hd, _stream_ptr())
+    return (out, tok) if return_tokens else out

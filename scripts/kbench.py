@@ -1,0 +1,112 @@
+"""Per-kernel micro-benchmarks (HIP events on torch's current stream).  Usage:
+   python scripts/kbench.py msda|maskgemm|xattn|pair|all [--frames N]"""
+import argparse
+import json
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+
+def timeit(fn, iters=20, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def bench_msda(frames):
+    from openpvsg_amd import ops
+    dev = torch.device('cuda:0')
+    shapes = [(23, 40), (46, 80), (92, 160)]
+    B, M, D, P, L = frames, 8, 32, 4, 3
+    S = sum(h * w for h, w in shapes)
+    g = torch.Generator().manual_seed(0)
+    v = torch.randn(B, S, M, D, generator=g).to(dev)
+    # realistic locations: reference point + small offsets
+    ref = []
+    for h, w in shapes:
+        ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing='ij')
+        ref.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    ref = torch.cat(ref, 0)[None, :, None, None, None, :]
+    loc = (ref + 0.05 * torch.randn(B, S, M, L, P, 2, generator=g)).to(dev)
+    w = torch.softmax(torch.randn(B, S, M, L * P, generator=g), -1).view(B, S, M, L, P).to(dev)
+    ss = torch.tensor(shapes, dtype=torch.long, device=dev)
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    ms = timeit(lambda: ops.ms_deform_attn_forward(v, ss, lsi, loc, w))
+    alg = 4 * (2 * S * 256 + 3 * S * M * L * P) * B
+    print(json.dumps(dict(kernel='msda', frames=B, ms=ms, alg_bytes=alg, GBps=alg / ms / 1e6)))
+
+
+def bench_maskgemm(frames):
+    from openpvsg_amd import ops
+    dev = torch.device('cuda:0')
+    T, Q, C, hw = frames, 100, 256, (184, 320)
+    N = hw[0] * hw[1]
+    emb = torch.randn(1, Q, C, device=dev)
+    feat = torch.randn(1, T, C, hw[0], hw[1], device=dev)
+    ms = timeit(lambda: ops.mask_logits(emb, feat))
+    flops = 2.0 * Q * C * N * T
+    print(json.dumps(dict(kernel='mask_logits', frames=T, ms=ms, TFLOPs=flops / ms / 1e9,
+                          GBps=4.0 * N * T * (C + Q) / ms / 1e6)))
+    ms = timeit(lambda: ops.center_downsample(feat))
+    print(json.dumps(dict(kernel='center_downsample', frames=T, ms=ms, GBps=4.0 * N * T * C * (1 + 21 / 64) / ms / 1e6)))
+    lows = ops.center_downsample(feat)
+    for lf in lows:
+        n = lf.shape[-1] * lf.shape[-2]
+        ms = timeit(lambda: ops.attn_mask_from_lowres_feature(emb, lf))
+        print(json.dumps(dict(kernel='attn_mask_bits', keys=n * T, ms=ms, TFLOPs=2.0 * Q * C * n * T / ms / 1e9)))
+
+
+def bench_xattn(frames):
+    from openpvsg_amd import ops
+    dev = torch.device('cuda:0')
+    Q = 100
+    for hw in ((23, 40), (46, 80), (92, 160)):
+        K = frames * hw[0] * hw[1]
+        q = torch.randn(1, Q, 256, device=dev) * 0.2
+        k = torch.randn(1, K, 256, device=dev)
+        v = torch.randn(1, K, 256, device=dev)
+        low = torch.randn(1, frames, Q, hw[0], hw[1], device=dev)
+        mask = ops.attn_mask_pack(low)
+        ms = timeit(lambda: ops.masked_xattn(q, k, v, mask, 8))
+        ms_pack = timeit(lambda: ops.attn_mask_pack(low))
+        print(json.dumps(dict(kernel='masked_xattn', keys=K, ms=ms, GBps=(2.0 * K * 1024 + K * 16) / ms / 1e6,
+                              TFLOPs=4.0 * Q * 256 * K / ms / 1e9, ns=ops.xattn_num_splits(1, K), pack_ms=ms_pack)))
+
+
+def bench_pair():
+    from openpvsg_amd import ops
+    dev = torch.device('cuda:0')
+    for N in (32, 64, 100, 256, 1024):
+        s, o = torch.randn(N, 64, 256, device=dev), torch.randn(N, 64, 256, device=dev)
+        W1, b1 = torch.randn(1024, 512, device=dev) * 0.05, torch.randn(1024, device=dev)
+        w2, b2 = torch.randn(1, 1024, device=dev) * 0.05, torch.randn(1, device=dev)
+        WT = ops.pair_prepare_weights(W1)
+        ms = timeit(lambda: ops.pair_score(s, o, W1, b1, w2, b2, W1T=WT))
+        print(json.dumps(dict(kernel='pair_score', N=N, T=64, us=ms * 1e3)))
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('which')
+    ap.add_argument('--frames', type=int, default=8)
+    a = ap.parse_args()
+    if a.which in ('msda', 'all'):
+        bench_msda(a.frames)
+        bench_msda(32)
+    if a.which in ('maskgemm', 'all'):
+        bench_maskgemm(a.frames)
+        bench_maskgemm(32)
+    if a.which in ('xattn', 'all'):
+        bench_xattn(a.frames)
+        bench_xattn(32)
+    if a.which in ('pair', 'all'):
+        bench_pair()

@@ -1,0 +1,62 @@
+"""The C-ABI library loads and exports every symbol include/openpvsg_hip.h declares (CPU only: no
+compute calls), and the ctypes signature table covers the header."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, 'include', 'openpvsg_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(pvsg_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_declares_something():
+    fns = header_functions()
+    assert 'pvsg_ms_deform_attn_forward' in fns and len(fns) >= 10
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    for fn in header_functions():
+        assert hasattr(hip_lib, fn), 'missing export: ' + fn
+    assert hip_lib.pvsg_abi_version() == 1
+    assert b'gfx950' in hip_lib.pvsg_version()
+
+
+def test_signature_table_matches_header():
+    from openpvsg_amd import _lib
+    declared = set(header_functions()) - {'pvsg_last_error', 'pvsg_version', 'pvsg_abi_version'}
+    assert declared == set(_lib.SIGNATURES)
+
+
+def test_invalid_args_report_errors_without_gpu(hip_lib):
+    # argument validation happens before any launch: exercisable on CPU
+    rc = hip_lib.pvsg_ms_deform_attn_forward(None, None, None, None, None, None, 1, 1, 8, 32, 1, 3, 4, 64, None)
+    assert rc == 1 and b'null pointer' in hip_lib.pvsg_last_error()
+    one = ctypes.c_void_p(16)
+    rc = hip_lib.pvsg_mask_logits_forward(one, one, one, 1, 1, 200, 256, 64, None)
+    assert rc == 2 and b'Q<=112' in hip_lib.pvsg_last_error()
+    rc = hip_lib.pvsg_pair_score_forward(one, one, one, one, one, one, one, None, one, 0, 4, 256, 1024, None)
+    assert rc == 1
+
+
+def test_cpu_tensors_are_rejected(hip_lib):
+    import torch
+    from openpvsg_amd import ops
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        ops.mask_logits(torch.zeros(1, 100, 256), torch.zeros(1, 256, 8, 8))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        ops.pair_score(torch.zeros(3, 2, 256), torch.zeros(3, 2, 256), torch.zeros(1024, 512),
+                       torch.zeros(1024), torch.zeros(1, 1024), torch.zeros(1))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from openpvsg_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.BackendMissingError):
+        _lib.load()
