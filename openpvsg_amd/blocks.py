@@ -1,0 +1,552 @@
+"""Host-side mirror of the third-party blocks the reference's configs select (mmcv-full 1.4.0 /
+mmdet 2.25.0 names, constructor arguments and state_dict keys), running on the HIP backend.
+
+    ATTENTION['MultiScaleDeformableAttention']        -> ops.ms_deform_attn_forward  (msda.hip)
+    ATTENTION['MultiheadAttention']                   -> ops.masked_xattn            (masked_xattn.hip)
+    PLUGIN_LAYERS['MSDeformAttnPixelDecoder'], TRANSFORMER_LAYER_SEQUENCE['DetrTransformerEncoder'|
+    'DetrTransformerDecoder'], TRANSFORMER_LAYER['BaseTransformerLayer'|'DetrTransformerDecoderLayer'],
+    FEEDFORWARD_NETWORK['FFN'], POSITIONAL_ENCODING['SinePositionalEncoding'|'SinePositionalEncoding3D']
+
+Selected by configs/mask2former/mask2former_r50_lsj_8x2_50e_coco-panoptic_custom_single_video_test.py:36-97
+and configs/mask2former_vps/mask2former_video_r50_base.py:27-88; driven from
+models/mask2former/mask2former_head.py:93-95,417,457-468.  Semantics: SURVEY.md Appendix A.
+
+Dense GEMMs (projections, FFN), LayerNorm/GroupNorm and convolutions stay PyTorch-ROCm library
+calls; the gather, the masked attention and the mask projection are the hand-written kernels.
+Tensors keep the reference's (L, B, C) convention at module boundaries and are batch-first
+internally.  Nothing here runs on CPU tensors (ops.py raises).
+"""
+import copy
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .registry import (ATTENTION, FEEDFORWARD_NETWORK, PLUGIN_LAYERS, POSITIONAL_ENCODING,
+                       TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, build_attention,
+                       build_feedforward_network, build_positional_encoding,
+                       build_transformer_layer)
+
+
+class BaseModule(nn.Module):
+    """mmcv.runner.BaseModule surface: init_cfg + init_weights()."""
+
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self.init_cfg = copy.deepcopy(init_cfg)
+
+    def init_weights(self):
+        for m in self.children():
+            if hasattr(m, 'init_weights'):
+                m.init_weights()
+
+
+class ModuleList(BaseModule, nn.ModuleList):
+    def __init__(self, modules=None, init_cfg=None):
+        BaseModule.__init__(self, init_cfg)
+        nn.ModuleList.__init__(self, modules)
+
+
+# ------------------------------------------------------------------------------------------------
+# positional encodings (cached per shape: the padding mask is all-False on this path)
+# ------------------------------------------------------------------------------------------------
+def _interleave_sin_cos(p):
+    return torch.stack((p[..., 0::2].sin(), p[..., 1::2].cos()), dim=-1).flatten(-2)
+
+
+@POSITIONAL_ENCODING.register_module()
+class SinePositionalEncoding(BaseModule):
+    """[3P] mmdet SinePositionalEncoding (Appendix A5).  mask (B,h,w) -> (B, 2*num_feats, h, w)."""
+
+    def __init__(self, num_feats, temperature=10000, normalize=False, scale=2 * math.pi, eps=1e-6,
+                 offset=0., init_cfg=None):
+        super().__init__(init_cfg)
+        self.num_feats, self.temperature, self.normalize = num_feats, temperature, normalize
+        self.scale, self.eps, self.offset = scale, eps, offset
+        self._cache = {}
+
+    def grid(self, h, w, device):
+        """(2*num_feats, h, w) encoding of an unpadded h x w map (batch independent)."""
+        key = (h, w, str(device))
+        if key not in self._cache:
+            ys = torch.arange(1, h + 1, dtype=torch.float32, device=device)[:, None].expand(h, w)
+            xs = torch.arange(1, w + 1, dtype=torch.float32, device=device)[None, :].expand(h, w)
+            if self.normalize:
+                ys = (ys + self.offset) / (h + self.eps) * self.scale
+                xs = (xs + self.offset) / (w + self.eps) * self.scale
+            f = torch.arange(self.num_feats, dtype=torch.float32, device=device)
+            f = self.temperature ** (2 * (f // 2) / self.num_feats)
+            pos = torch.cat((_interleave_sin_cos(ys[..., None] / f), _interleave_sin_cos(xs[..., None] / f)), -1)
+            self._cache[key] = pos.permute(2, 0, 1).contiguous()
+        return self._cache[key]
+
+    def forward(self, mask):
+        if bool(mask.any()):
+            raise RuntimeError('SinePositionalEncoding: padded positions are not on the supported path '
+                               '(the reference always passes an all-False mask, mask2former_head.py:429)')
+        B, h, w = mask.shape
+        return self.grid(h, w, mask.device)[None].expand(B, -1, -1, -1)
+
+
+@POSITIONAL_ENCODING.register_module()
+class SinePositionalEncoding3D(BaseModule):
+    """models/mask2former_vps/position_encoding.py:9-99.  mask (B,T,h,w) -> (B,T,2*num_feats,h,w);
+    pos = cat(pos_y, pos_x) + pos_z with z over 2*num_feats channels."""
+
+    def __init__(self, num_feats, temperature=10000, normalize=False, scale=2 * math.pi, eps=1e-6,
+                 offset=0., init_cfg=None):
+        super().__init__(init_cfg)
+        self.num_feats, self.temperature, self.normalize = num_feats, temperature, normalize
+        self.scale, self.eps, self.offset = scale, eps, offset
+        self._cache = {}
+
+    def grid(self, T, h, w, device, t0=0, t_total=None):
+        """(T, 2*num_feats, h, w) for frames t0..t0+T-1 of a clip of t_total frames (frame shards on
+        other ranks see the same normalisation)."""
+        t_total = T if t_total is None else t_total
+        key = (T, h, w, t0, t_total, str(device))
+        if key not in self._cache:
+            zs = torch.arange(t0 + 1, t0 + T + 1, dtype=torch.float32, device=device)[:, None, None].expand(T, h, w)
+            ys = torch.arange(1, h + 1, dtype=torch.float32, device=device)[None, :, None].expand(T, h, w)
+            xs = torch.arange(1, w + 1, dtype=torch.float32, device=device)[None, None, :].expand(T, h, w)
+            if self.normalize:
+                zs = (zs + self.offset) / (t_total + self.eps) * self.scale
+                ys = (ys + self.offset) / (h + self.eps) * self.scale
+                xs = (xs + self.offset) / (w + self.eps) * self.scale
+            n = self.num_feats
+            f = torch.arange(n, dtype=torch.float32, device=device)
+            f = self.temperature ** (2 * (f // 2) / n)
+            fz = torch.arange(2 * n, dtype=torch.float32, device=device)
+            fz = self.temperature ** (2 * (fz // 2) / (2 * n))
+            pos = torch.cat((_interleave_sin_cos(ys[..., None] / f), _interleave_sin_cos(xs[..., None] / f)), -1)
+            pos = pos + _interleave_sin_cos(zs[..., None] / fz)
+            self._cache[key] = pos.permute(0, 3, 1, 2).contiguous()
+        return self._cache[key]
+
+    def forward(self, mask):
+        assert mask.dim() == 4
+        if bool(mask.any()):
+            raise RuntimeError('SinePositionalEncoding3D: padded positions are not on the supported path')
+        B, T, h, w = mask.shape
+        return self.grid(T, h, w, mask.device)[None].expand(B, -1, -1, -1, -1)
+
+
+# ------------------------------------------------------------------------------------------------
+# FFN
+# ------------------------------------------------------------------------------------------------
+@FEEDFORWARD_NETWORK.register_module()
+class FFN(BaseModule):
+    """[3P] mmcv FFN: layers = [[Linear, act, drop] x (num_fcs-1), Linear, drop]; + identity."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2,
+                 act_cfg=dict(type='ReLU', inplace=True), ffn_drop=0., dropout_layer=None,
+                 add_identity=True, init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        assert num_fcs >= 2
+        if act_cfg.get('type', 'ReLU') != 'ReLU':
+            raise NotImplementedError('FFN: only ReLU is used by the reference configs')
+        layers, cin = [], embed_dims
+        for _ in range(num_fcs - 1):
+            layers.append(nn.Sequential(nn.Linear(cin, feedforward_channels), nn.ReLU(inplace=True),
+                                        nn.Dropout(ffn_drop)))
+            cin = feedforward_channels
+        layers += [nn.Linear(feedforward_channels, embed_dims), nn.Dropout(ffn_drop)]
+        self.layers = nn.Sequential(*layers)
+        self.embed_dims, self.add_identity = embed_dims, add_identity
+
+    def forward(self, x, identity=None):
+        out = self.layers(x)
+        if not self.add_identity:
+            return out
+        return (x if identity is None else identity) + out
+
+
+# ------------------------------------------------------------------------------------------------
+# attention blocks
+# ------------------------------------------------------------------------------------------------
+@ATTENTION.register_module()
+class MultiScaleDeformableAttention(BaseModule):
+    """[3P] mmcv MultiScaleDeformableAttention (Appendix A1) on the HIP sampling kernel."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, im2col_step=64,
+                 dropout=0.1, batch_first=False, norm_cfg=None, init_cfg=None):
+        super().__init__(init_cfg)
+        if embed_dims % num_heads:
+            raise ValueError('embed_dims must be divisible by num_heads')
+        self.embed_dims, self.num_heads = embed_dims, num_heads
+        self.num_levels, self.num_points = num_levels, num_points
+        self.im2col_step, self.batch_first = im2col_step, batch_first
+        self.dropout = nn.Dropout(dropout)
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.init_weights()
+
+    def init_weights(self):
+        nn.init.constant_(self.sampling_offsets.weight, 0.)
+        thetas = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(self.num_heads, 1, 1, 2).repeat(
+            1, self.num_levels, self.num_points, 1)
+        for i in range(self.num_points):
+            grid[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias.copy_(grid.view(-1))
+        nn.init.constant_(self.attention_weights.weight, 0.)
+        nn.init.constant_(self.attention_weights.bias, 0.)
+        nn.init.xavier_uniform_(self.value_proj.weight)
+        nn.init.constant_(self.value_proj.bias, 0.)
+        nn.init.xavier_uniform_(self.output_proj.weight)
+        nn.init.constant_(self.output_proj.bias, 0.)
+
+    def forward_bsc(self, x, pos, reference_points, spatial_shapes, level_start_index,
+                    value=None, identity=None):
+        """Batch-first core.  x (B,S,C) query, pos (1|B,S,C) or None, reference_points (B|1,S,L,2)."""
+        B, S, C = x.shape
+        M, L, P = self.num_heads, self.num_levels, self.num_points
+        identity = x if identity is None else identity
+        value = x if value is None else value
+        q = x if pos is None else x + pos
+        v = self.value_proj(value).view(B, value.shape[1], M, C // M)
+        off = self.sampling_offsets(q).view(B, S, M, L, P, 2)
+        w = self.attention_weights(q).view(B, S, M, L * P).softmax(-1).view(B, S, M, L, P)
+        if reference_points.shape[-1] != 2:
+            raise NotImplementedError('only 2-d reference points are on the Mask2Former path')
+        normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1).to(off.dtype)
+        loc = reference_points[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+        out = ops.ms_deform_attn_forward(v, spatial_shapes, level_start_index, loc, w, self.im2col_step)
+        return self.dropout(self.output_proj(out)) + identity
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None,
+                key_padding_mask=None, reference_points=None, spatial_shapes=None,
+                level_start_index=None, **kwargs):
+        if key_padding_mask is not None and bool(key_padding_mask.any()):
+            raise NotImplementedError('padded keys are not on the reference path (all-False masks)')
+        value = query if value is None else value
+        identity = query if identity is None else identity
+        if not self.batch_first:
+            query, value, identity = (t.permute(1, 0, 2) for t in (query, value, identity))
+            query_pos = None if query_pos is None else query_pos.permute(1, 0, 2)
+        out = self.forward_bsc(query, query_pos, reference_points, spatial_shapes, level_start_index,
+                               value=value, identity=identity)
+        return out if self.batch_first else out.permute(1, 0, 2)
+
+
+def _bool_mask_to_attnmask(attn_mask, batch, heads):
+    """(B*heads, Q, K) bool (True = blocked; the decoder repeats one mask over heads,
+    mask2former_head.py:390-391) -> key-major bits.  The caller has already applied the
+    all-blocked-row reset, exactly as the reference does before calling the layer."""
+    if attn_mask.dim() != 3 or attn_mask.shape[0] != batch * heads:
+        raise RuntimeError('attn_mask must be (B*num_heads, Q, K)')
+    m = attn_mask.view(batch, heads, attn_mask.shape[1], attn_mask.shape[2])[:, 0]
+    low = torch.where(m, -1.0, 1.0).to(torch.float32).unsqueeze(-1)  # (B, Q, K, 1): "logits"
+    return ops.attn_mask_pack(low)
+
+
+@ATTENTION.register_module()
+class MultiheadAttention(BaseModule):
+    """[3P] mmcv MultiheadAttention wrapper (Appendix A3): q = query+query_pos, k = key+key_pos,
+    v = value; out = identity + attn(q, k, v, mask).  `attn` keeps nn.MultiheadAttention's packed
+    parameters (state_dict keys attn.in_proj_weight / attn.in_proj_bias / attn.out_proj.*); the
+    attention itself is the streaming HIP kernel.  attn_mask may be an ops.AttnMask (bit form,
+    fast path) or the reference's (B*heads, Q, K) bool tensor."""
+
+    def __init__(self, embed_dims, num_heads, attn_drop=0., proj_drop=0.,
+                 dropout_layer=dict(type='Dropout', drop_prob=0.), init_cfg=None, batch_first=False,
+                 **kwargs):
+        super().__init__(init_cfg)
+        if 'dropout' in kwargs:
+            attn_drop = kwargs.pop('dropout')
+        if attn_drop or proj_drop or (dropout_layer and dropout_layer.get('drop_prob', 0.)):
+            raise NotImplementedError('inference backend: dropout must be 0 (as in the reference configs)')
+        self.embed_dims, self.num_heads, self.batch_first = embed_dims, num_heads, batch_first
+        self.attn = nn.MultiheadAttention(embed_dims, num_heads, attn_drop, **kwargs)
+
+    def project_kv(self, key, value):
+        """(B,K,C) x2 -> projected keys / values (B,K,C): the two big GEMMs of the decoder."""
+        C = self.embed_dims
+        W, b = self.attn.in_proj_weight, self.attn.in_proj_bias
+        return F.linear(key, W[C:2 * C], b[C:2 * C]), F.linear(value, W[2 * C:], b[2 * C:])
+
+    def project_q(self, q):
+        C = self.embed_dims
+        scale = (C // self.num_heads) ** -0.5
+        return F.linear(q, self.attn.in_proj_weight[:C], self.attn.in_proj_bias[:C]) * scale
+
+    def attend_bqc(self, q, k, v, mask, identity, combine=None):
+        """Batch-first core: q (B,Q,C) (pos already added), k/v (B,K,C) un-projected inputs."""
+        kp, vp = self.project_kv(k, v)
+        part = ops.masked_xattn_partial(self.project_q(q), kp, vp, mask, self.num_heads)
+        core = ops.xattn_combine(*part) if combine is None else combine(*part)
+        return identity + self.attn.out_proj(core)
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None,
+                attn_mask=None, key_padding_mask=None, **kwargs):
+        if key_padding_mask is not None:
+            raise NotImplementedError('key_padding_mask is always None on the reference path '
+                                      '(mask2former_head.py:465-468)')
+        key = query if key is None else key
+        value = key if value is None else value
+        identity = query if identity is None else identity
+        if key_pos is None and query_pos is not None and query_pos.shape == key.shape:
+            key_pos = query_pos
+        q = query if query_pos is None else query + query_pos
+        k = key if key_pos is None else key + key_pos
+        if not self.batch_first:
+            q, k, value, identity = (t.transpose(0, 1) for t in (q, k, value, identity))
+        if attn_mask is not None and not isinstance(attn_mask, ops.AttnMask):
+            attn_mask = _bool_mask_to_attnmask(attn_mask, q.shape[0], self.num_heads)
+        out = self.attend_bqc(q.contiguous(), k.contiguous(), value.contiguous(), attn_mask, identity)
+        return out if self.batch_first else out.transpose(0, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# transformer layers
+# ------------------------------------------------------------------------------------------------
+@TRANSFORMER_LAYER.register_module()
+class BaseTransformerLayer(BaseModule):
+    """[3P] mmcv BaseTransformerLayer: attentions / ffns / norms applied in `operation_order`."""
+
+    def __init__(self, attn_cfgs=None, ffn_cfgs=dict(type='FFN', embed_dims=256, feedforward_channels=1024,
+                                                     num_fcs=2, ffn_drop=0., act_cfg=dict(type='ReLU', inplace=True)),
+                 operation_order=None, norm_cfg=dict(type='LN'), init_cfg=None, batch_first=False, **kwargs):
+        super().__init__(init_cfg)
+        ffn_cfgs = copy.deepcopy(dict(ffn_cfgs))
+        for old, new in (('feedforward_channels', 'feedforward_channels'), ('ffn_dropout', 'ffn_drop'),
+                         ('ffn_num_fcs', 'num_fcs')):
+            if old in kwargs:
+                ffn_cfgs[new] = kwargs[old]
+        assert set(operation_order) <= {'self_attn', 'norm', 'ffn', 'cross_attn'}
+        n_attn = operation_order.count('self_attn') + operation_order.count('cross_attn')
+        if isinstance(attn_cfgs, dict):
+            attn_cfgs = [copy.deepcopy(attn_cfgs) for _ in range(n_attn)]
+        assert len(attn_cfgs) == n_attn
+        self.batch_first, self.operation_order = batch_first, tuple(operation_order)
+        self.pre_norm = operation_order[0] == 'norm'
+        self.attentions = ModuleList()
+        for cfg in attn_cfgs:
+            cfg = dict(cfg)
+            cfg.setdefault('batch_first', batch_first)
+            self.attentions.append(build_attention(cfg))
+        self.embed_dims = self.attentions[0].embed_dims
+        n_ffn = operation_order.count('ffn')
+        ffn_list = [copy.deepcopy(ffn_cfgs) for _ in range(n_ffn)] if isinstance(ffn_cfgs, dict) else ffn_cfgs
+        self.ffns = ModuleList()
+        for cfg in ffn_list:
+            cfg = dict(cfg)
+            cfg.setdefault('embed_dims', self.embed_dims)
+            self.ffns.append(build_feedforward_network(cfg, dict(type='FFN')))
+        if norm_cfg.get('type', 'LN') != 'LN':
+            raise NotImplementedError('only LayerNorm transformer norms are used by the reference')
+        self.norms = ModuleList([nn.LayerNorm(self.embed_dims) for _ in range(operation_order.count('norm'))])
+
+    def forward(self, query, key=None, value=None, query_pos=None, key_pos=None, attn_masks=None,
+                query_key_padding_mask=None, key_padding_mask=None, **kwargs):
+        ai = ni = fi = 0
+        identity = query
+        if attn_masks is None:
+            attn_masks = [None] * len(self.attentions)
+        elif not isinstance(attn_masks, (list, tuple)):
+            attn_masks = [copy.deepcopy(attn_masks) for _ in self.attentions]
+        for op in self.operation_order:
+            if op == 'self_attn':
+                query = self.attentions[ai](query, query, query, identity if self.pre_norm else None,
+                                            query_pos=query_pos, key_pos=query_pos,
+                                            attn_mask=attn_masks[ai],
+                                            key_padding_mask=query_key_padding_mask, **kwargs)
+                ai += 1
+                identity = query
+            elif op == 'norm':
+                query = self.norms[ni](query)
+                ni += 1
+            elif op == 'cross_attn':
+                query = self.attentions[ai](query, key, value, identity if self.pre_norm else None,
+                                            query_pos=query_pos, key_pos=key_pos,
+                                            attn_mask=attn_masks[ai], key_padding_mask=key_padding_mask,
+                                            **kwargs)
+                ai += 1
+                identity = query
+            else:
+                query = self.ffns[fi](query, identity if self.pre_norm else None)
+                fi += 1
+        return query
+
+
+@TRANSFORMER_LAYER.register_module()
+class DetrTransformerDecoderLayer(BaseTransformerLayer):
+    """[3P] mmdet DetrTransformerDecoderLayer (Appendix A4)."""
+
+    def __init__(self, attn_cfgs, feedforward_channels=None, ffn_dropout=0.0, operation_order=None,
+                 act_cfg=dict(type='ReLU', inplace=True), norm_cfg=dict(type='LN'), ffn_num_fcs=2, **kwargs):
+        extra = {}
+        if feedforward_channels is not None:
+            extra['feedforward_channels'] = feedforward_channels
+        super().__init__(attn_cfgs=attn_cfgs, operation_order=operation_order, norm_cfg=norm_cfg,
+                         **extra, **kwargs)
+        assert len(operation_order) == 6
+        assert set(operation_order) == {'self_attn', 'norm', 'cross_attn', 'ffn'}
+
+
+class TransformerLayerSequence(BaseModule):
+    def __init__(self, transformerlayers=None, num_layers=None, init_cfg=None):
+        super().__init__(init_cfg)
+        if isinstance(transformerlayers, dict):
+            transformerlayers = [copy.deepcopy(transformerlayers) for _ in range(num_layers)]
+        assert len(transformerlayers) == num_layers
+        self.num_layers = num_layers
+        self.layers = ModuleList([build_transformer_layer(dict(c)) for c in transformerlayers])
+        self.embed_dims = self.layers[0].embed_dims
+        self.pre_norm = self.layers[0].pre_norm
+
+    def forward(self, query, key, value, query_pos=None, key_pos=None, attn_masks=None,
+                query_key_padding_mask=None, key_padding_mask=None, **kwargs):
+        for layer in self.layers:
+            query = layer(query, key, value, query_pos=query_pos, key_pos=key_pos, attn_masks=attn_masks,
+                          query_key_padding_mask=query_key_padding_mask,
+                          key_padding_mask=key_padding_mask, **kwargs)
+        return query
+
+
+@TRANSFORMER_LAYER_SEQUENCE.register_module()
+class DetrTransformerEncoder(TransformerLayerSequence):
+    def __init__(self, *args, post_norm_cfg=dict(type='LN'), **kwargs):
+        super().__init__(*args, **kwargs)
+        self.post_norm = nn.LayerNorm(self.embed_dims) if (post_norm_cfg is not None and self.pre_norm) else None
+
+    def forward(self, *args, **kwargs):
+        x = super().forward(*args, **kwargs)
+        return x if self.post_norm is None else self.post_norm(x)
+
+
+@TRANSFORMER_LAYER_SEQUENCE.register_module()
+class DetrTransformerDecoder(TransformerLayerSequence):
+    """The Mask2Former heads call `.layers[i]` and `.post_norm` directly
+    (mask2former_head.py:375,457), never `.forward`."""
+
+    def __init__(self, *args, post_norm_cfg=dict(type='LN'), return_intermediate=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.return_intermediate = return_intermediate
+        self.post_norm = nn.LayerNorm(self.embed_dims) if post_norm_cfg is not None else None
+
+
+# ------------------------------------------------------------------------------------------------
+# pixel decoder
+# ------------------------------------------------------------------------------------------------
+class ConvModule(nn.Module):
+    """mmcv ConvModule subset used here: conv -> GN -> (ReLU); submodule names `conv`, `gn`."""
+
+    def __init__(self, cin, cout, k, padding=0, bias=True, norm_cfg=None, act=False):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=padding, bias=bias)
+        self.gn = None
+        if norm_cfg is not None:
+            if norm_cfg.get('type') != 'GN':
+                raise NotImplementedError('pixel decoder norms are GN in the reference configs')
+            self.gn = nn.GroupNorm(norm_cfg['num_groups'], cout)
+        self.act = act
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.gn is not None:
+            x = self.gn(x)
+        return F.relu(x, inplace=True) if self.act else x
+
+
+@PLUGIN_LAYERS.register_module()
+class MSDeformAttnPixelDecoder(BaseModule):
+    """[3P] mmdet MSDeformAttnPixelDecoder (Appendix A2).
+    forward(feats[4]) -> (mask_feature (B,C,H/4,W/4), [3 memory maps, low -> high resolution])."""
+
+    def __init__(self, in_channels=[256, 512, 1024, 2048], strides=[4, 8, 16, 32], feat_channels=256,
+                 out_channels=256, num_outs=3, norm_cfg=dict(type='GN', num_groups=32),
+                 act_cfg=dict(type='ReLU'), encoder=None,
+                 positional_encoding=dict(type='SinePositionalEncoding', num_feats=128, normalize=True),
+                 init_cfg=None):
+        super().__init__(init_cfg)
+        self.strides = list(strides)
+        self.num_input_levels = len(in_channels)
+        self.num_encoder_levels = encoder['transformerlayers']['attn_cfgs']['num_levels']
+        assert self.num_encoder_levels >= 1
+        self.input_convs = ModuleList()
+        for i in range(self.num_input_levels - 1, self.num_input_levels - self.num_encoder_levels - 1, -1):
+            self.input_convs.append(ConvModule(in_channels[i], feat_channels, 1, bias=True, norm_cfg=norm_cfg))
+        from .registry import build_transformer_layer_sequence
+        self.encoder = build_transformer_layer_sequence(dict(encoder))
+        self.postional_encoding = build_positional_encoding(dict(positional_encoding))
+        self.level_encoding = nn.Embedding(self.num_encoder_levels, feat_channels)
+        self.lateral_convs, self.output_convs = ModuleList(), ModuleList()
+        use_bias = norm_cfg is None
+        for i in range(self.num_input_levels - self.num_encoder_levels - 1, -1, -1):
+            self.lateral_convs.append(ConvModule(in_channels[i], feat_channels, 1, bias=use_bias, norm_cfg=norm_cfg))
+            self.output_convs.append(ConvModule(feat_channels, feat_channels, 3, padding=1, bias=use_bias,
+                                                norm_cfg=norm_cfg, act=act_cfg is not None))
+        self.mask_feature = nn.Conv2d(feat_channels, out_channels, 1)
+        self.num_outs = num_outs
+        self._geom = {}
+
+    def init_weights(self):
+        for m in list(self.input_convs) + list(self.lateral_convs) + list(self.output_convs):
+            nn.init.xavier_uniform_(m.conv.weight)
+            if m.conv.bias is not None:
+                nn.init.constant_(m.conv.bias, 0)
+        nn.init.kaiming_uniform_(self.mask_feature.weight, a=1)
+        nn.init.constant_(self.mask_feature.bias, 0)
+        nn.init.normal_(self.level_encoding.weight, mean=0, std=1)
+        for p in self.encoder.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_normal_(p)
+        for layer in self.encoder.layers:
+            for attn in layer.attentions:
+                if isinstance(attn, MultiScaleDeformableAttention):
+                    attn.init_weights()
+
+    def _geometry(self, shapes, device):
+        """Per input geometry: sine encodings, reference points, level index tensors (cached)."""
+        key = (tuple(shapes), str(device))
+        if key not in self._geom:
+            pos, refs = [], []
+            for i, (h, w) in enumerate(shapes):
+                pos.append(self.postional_encoding.grid(h, w, device).flatten(1).t())  # (hw, C)
+                stride = self.strides[self.num_input_levels - 1 - i]
+                xs = (torch.arange(w, dtype=torch.float32, device=device) + 0.5) * stride
+                ys = (torch.arange(h, dtype=torch.float32, device=device) + 0.5) * stride
+                yy, xx = torch.meshgrid(ys, xs, indexing='ij')
+                ref = torch.stack([xx.reshape(-1), yy.reshape(-1)], -1)
+                refs.append(ref / (torch.tensor([[w, h]], dtype=torch.float32, device=device) * stride))
+            ss = torch.tensor(shapes, dtype=torch.long, device=device)
+            lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+            ref = torch.cat(refs, 0)[None, :, None].repeat(1, 1, self.num_encoder_levels, 1)
+            self._geom[key] = (pos, ref.contiguous(), ss, lsi)
+        return self._geom[key]
+
+    def forward(self, feats):
+        B = feats[0].shape[0]
+        shapes = [tuple(feats[self.num_input_levels - 1 - i].shape[-2:]) for i in range(self.num_encoder_levels)]
+        pos_l, ref, ss, lsi = self._geometry(shapes, feats[0].device)
+        tokens, pos = [], []
+        for i in range(self.num_encoder_levels):
+            f = self.input_convs[i](feats[self.num_input_levels - 1 - i])
+            tokens.append(f.flatten(2).transpose(1, 2))                         # (B, hw, C)
+            pos.append(pos_l[i] + self.level_encoding.weight[i][None, :])
+        x = torch.cat(tokens, 1)
+        pos = torch.cat(pos, 0)[None]                                           # (1, S, C)
+        for layer in self.encoder.layers:
+            # BaseTransformerLayer ('self_attn','norm','ffn','norm') on batch-first tensors
+            x = layer.attentions[0].forward_bsc(x, pos, ref, ss, lsi)
+            x = layer.norms[0](x)
+            x = layer.ffns[0](x)
+            x = layer.norms[1](x)
+        if self.encoder.post_norm is not None:
+            x = self.encoder.post_norm(x)
+        outs, start = [], 0
+        for (h, w) in shapes:
+            outs.append(x[:, start:start + h * w].transpose(1, 2).reshape(B, -1, h, w))
+            start += h * w
+        for i in range(self.num_input_levels - self.num_encoder_levels - 1, -1, -1):
+            lat = self.lateral_convs[i](feats[i])
+            y = lat + F.interpolate(outs[-1], size=lat.shape[-2:], mode='bilinear', align_corners=False)
+            outs.append(self.output_convs[i](y))
+        return self.mask_feature(outs[-1]), outs[:self.num_outs]

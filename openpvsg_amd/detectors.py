@@ -1,0 +1,181 @@
+"""DETECTORS['Mask2FormerCustom'], ['Mask2FormerVideoCustom'], ['Mask2FormerVideoCustomMinVIS'].
+
+Mirror of models/mask2former/mask2former.py:14-57,121-191 and
+models/mask2former_vps/mask2former.py:19-86,125-240, mask2former_min_vis.py:36-70,132-258:
+backbone -> panoptic_head.simple_test_with_query -> panoptic_fusion_head.simple_test_with_query,
+same result dictionaries (numpy `pan_results`, {segment id: [feature]} `query_feats`).
+
+`Mask2FormerVideoCustom` additionally exposes the clip-level path (`inference_mode='clip'`): all T
+frames go through `Mask2FormerVideoHead` at once (keys = T*h*w), which the reference only
+exercises in training (mask2former_vps/mask2former.py:107-121) but is the north-star kernel's
+target; `inference_mode='per_frame'` is the shipped flow (one frame per head call + MinVIS
+matching across frames, which the shipped class borrows from the MinVIS class -- SURVEY.md fact 5).
+"""
+import copy
+
+import numpy as np
+import torch
+
+from .blocks import BaseModule
+from .config import _wrap
+from .registry import DETECTORS, build_backbone, build_head, build_neck
+
+
+def bbox2result(bboxes, labels, num_classes):
+    """[3P] mmdet.core.bbox2result."""
+    if bboxes.shape[0] == 0:
+        return [np.zeros((0, bboxes.shape[1]), dtype=np.float32) for _ in range(num_classes)]
+    b, lab = bboxes.detach().cpu().numpy(), labels.detach().cpu().numpy()
+    return [b[lab == i, :] for i in range(num_classes)]
+
+
+class _Base(BaseModule):
+    def __init__(self, backbone, neck=None, panoptic_head=None, panoptic_fusion_head=None, train_cfg=None,
+                 test_cfg=None, init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        self.backbone = build_backbone(dict(backbone))
+        self.neck = build_neck(dict(neck)) if neck is not None else None
+        head = copy.deepcopy(_wrap(panoptic_head))
+        head.update(train_cfg=train_cfg, test_cfg=test_cfg)
+        self.panoptic_head = build_head(head)
+        fusion = copy.deepcopy(_wrap(panoptic_fusion_head))
+        fusion.update(test_cfg=test_cfg)
+        self.panoptic_fusion_head = build_head(fusion)
+        self.num_things_classes = self.panoptic_head.num_things_classes
+        self.num_stuff_classes = self.panoptic_head.num_stuff_classes
+        self.num_classes = self.panoptic_head.num_classes
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+    @property
+    def with_neck(self):
+        return self.neck is not None
+
+    def extract_feat(self, img):
+        x = self.backbone(img)
+        return self.neck(x) if self.with_neck else x
+
+    def forward(self, img=None, img_metas=None, return_loss=True, **kwargs):
+        if return_loss:
+            raise NotImplementedError('training is outside the MI355X inference hot path')
+        with torch.no_grad():
+            return self.forward_test(img, img_metas, **kwargs)
+
+    def forward_train(self, *a, **k):
+        raise NotImplementedError('training is outside the MI355X inference hot path')
+
+    @staticmethod
+    def _finish(res, num_things, keep_device=False):
+        """Device -> host conversion of one image's result (mask2former.py:165-186)."""
+        if 'pan_results' in res and not keep_device:
+            res['pan_results'] = res['pan_results'].detach().cpu().numpy()
+        if 'query_feats' in res and not keep_device:
+            res['query_feats'] = {k: [x.detach().cpu().numpy() for x in v] for k, v in res['query_feats'].items()}
+        if 'ins_results' in res:
+            labels, bboxes, binm = res['ins_results']
+            bbox_results = bbox2result(bboxes, labels, num_things)
+            masks_np = binm.detach().cpu().numpy()
+            mask_results = [[] for _ in range(num_things)]
+            for j, lab in enumerate(labels.tolist()):
+                mask_results[lab].append(masks_np[j])
+            res['ins_results'] = bbox_results, mask_results
+        return res
+
+
+@DETECTORS.register_module()
+class Mask2FormerCustom(_Base):
+    def forward_test(self, imgs, img_metas, **kwargs):
+        """[3P] BaseDetector.forward_test: one augmentation, sets batch_input_shape."""
+        if isinstance(imgs, (list, tuple)):
+            imgs, img_metas = imgs[0], img_metas[0]
+        for meta in img_metas:
+            meta['batch_input_shape'] = tuple(imgs.shape[-2:])
+        return self.simple_test(imgs, img_metas, **kwargs)
+
+    def simple_test(self, imgs, img_metas, **kwargs):
+        feats = self.extract_feat(imgs)
+        cls, masks, qf = self.panoptic_head.simple_test_with_query(feats, img_metas, **kwargs)
+        results = self.panoptic_fusion_head.simple_test_with_query(cls, masks, qf, img_metas, **kwargs)
+        results = [self._finish(r, self.num_things_classes) for r in results]
+        if self.num_stuff_classes == 0:
+            results = [r['ins_results'] for r in results]
+        return results
+
+
+def match_from_embds(tgt_embds, cur_embds):
+    """mask2former_min_vis.py:244-258: cosine-cost Hungarian assignment, indices[j] = current query
+    placed on target slot j.  (Host LAP; the on-device matcher is SURVEY.md section 8f row 3.)"""
+    from scipy.optimize import linear_sum_assignment
+    cur = cur_embds / cur_embds.norm(dim=1)[:, None]
+    tgt = tgt_embds / tgt_embds.norm(dim=1)[:, None]
+    cost = 1 - torch.mm(cur, tgt.transpose(0, 1))
+    return linear_sum_assignment(cost.cpu().transpose(0, 1))[1]
+
+
+@DETECTORS.register_module()
+class Mask2FormerVideoCustom(_Base):
+    def __init__(self, *args, inference_mode='per_frame', dataset=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        assert inference_mode in ('per_frame', 'clip')
+        self.inference_mode = inference_mode
+
+    match_from_embds = staticmethod(match_from_embds)
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        ref_img, ref_metas = kwargs['ref_img'], kwargs['ref_img_metas']
+        if isinstance(ref_img, (list, tuple)):
+            ref_img, ref_metas = ref_img[0], ref_metas[0]
+            imgs = imgs[0] if isinstance(imgs, (list, tuple)) else imgs
+            img_metas = img_metas[0] if img_metas and isinstance(img_metas[0], (list, tuple)) else img_metas
+        for per_video in ref_metas:
+            for meta in per_video:
+                meta['batch_input_shape'] = tuple(ref_img.shape[-2:])
+        kw = {k: v for k, v in kwargs.items() if k not in ('ref_img', 'ref_img_metas')}
+        return self.simple_test(imgs, img_metas, ref_img, ref_metas, **kw)
+
+    def simple_test(self, img, img_metas, ref_img, ref_img_metas, **kwargs):
+        bs, T = ref_img.shape[:2]
+        feats = self.extract_feat(ref_img.reshape((bs * T,) + tuple(ref_img.shape[2:])))
+        if self.inference_mode == 'clip':
+            cls, masks, q = self.panoptic_head.simple_test_with_query(feats, ref_img_metas, **kwargs)
+            logits, embds = cls, q.permute(1, 0, 2)                    # (bs,Q,C+1), (bs,Q,C)
+        else:
+            if bs != 1:
+                raise NotImplementedError('per-frame VPS inference runs one video per call (as shipped)')
+            one = [[ref_img_metas[0][0]]]
+            f_logits, f_masks, f_embds = [], [], []
+            for i in range(feats[0].size(0)):
+                cur = [f[i:i + 1] for f in feats]
+                c, m, qq = self.panoptic_head.simple_test_with_query(cur, one, **kwargs)
+                f_logits.append(c[0])
+                f_masks.append(m[0, 0])
+                f_embds.append(qq[:, 0])
+            o_logits, o_masks, o_embds = [f_logits[0]], [f_masks[0]], [f_embds[0]]
+            for i in range(1, len(f_logits)):
+                idx = torch.as_tensor(self.match_from_embds(o_embds[-1], f_embds[i]), device=f_logits[i].device)
+                o_logits.append(f_logits[i][idx])
+                o_masks.append(f_masks[i][idx])
+                o_embds.append(f_embds[i][idx])
+            logits = (sum(o_logits) / len(o_logits)).unsqueeze(0)
+            embds = (sum(o_embds) / len(o_embds)).unsqueeze(0)
+            masks = torch.stack(o_masks, dim=0).unsqueeze(0)           # (1,T,Q,H,W)
+        results = [[] for _ in range(bs)]
+        for t in range(T):
+            res = self.panoptic_fusion_head.simple_test_with_query(
+                logits, masks[:, t], embds, [ref_img_metas[b][t] for b in range(bs)], **kwargs)
+            for b in range(len(res)):
+                r = res[b]
+                if 'pan_results' in r:
+                    r['pan_results'] = r['pan_results'].detach().cpu().numpy()
+                if 'query_feats' in r:
+                    r['query_feats'] = {k: [x.detach().cpu().numpy() for x in v] for k, v in r['query_feats'].items()}
+                if 'ins_results' in r:
+                    labels, bboxes, binm = r['ins_results']
+                    ids = torch.arange(len(bboxes), dtype=bboxes.dtype, device=bboxes.device)[:, None] + 1
+                    r['ins_results'] = labels, torch.cat([ids, bboxes], dim=1), binm
+                results[b].append(r)
+        return results
+
+
+@DETECTORS.register_module()
+class Mask2FormerVideoCustomMinVIS(Mask2FormerVideoCustom):
+    pass

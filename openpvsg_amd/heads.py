@@ -1,0 +1,233 @@
+"""HEADS['Mask2FormerHeadCustom'] and HEADS['Mask2FormerVideoHead'] on the HIP backend.
+
+Mirror of the reference's inference surface (same constructor arguments, parameter names and
+return conventions):
+  models/mask2former/mask2former_head.py:20-135 (ctor), :355-395 forward_head, :397-479 forward,
+                                          :650-681 simple_test_with_query
+  models/mask2former_vps/mask2former_video_head.py:21-151, :337-359, :361-462, :637-669
+Training (losses, assigners, point sampling; :148-353, :481-616) is out of scope.
+
+What changes underneath:
+  * keys/values stay batch-first (B, T*h*w, C); K/V input tensors are built once per level and
+    shared by the 3 layers that attend to that level;
+  * the (B*8, Q, K) bool attention mask is one bit per (query, key) + a per-query flag word
+    (ops.AttnMask); the all-masked-row reset (head.py:453-454) is the flag test in the kernel;
+  * `simple_test_with_query` needs only the LAST layer's full-resolution mask logits, so the 9
+    intermediate `forward_head` calls compute just the attention-mask bits, from the stride-4
+    features down-sampled ONCE per forward to the three level sizes (bilinear resize by 2/4/8 is
+    linear, hence commutes with the per-query projection).  `forward` keeps the reference contract
+    (all 10 cls / mask predictions): full logits by the MFMA kernel, torch bilinear resize, bit
+    pack -- bit-exact w.r.t. the resized logits.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .blocks import BaseModule, ModuleList
+from .config import ConfigDict, _wrap
+from .registry import (HEADS, build_plugin_layer, build_positional_encoding,
+                       build_transformer_layer_sequence)
+
+FAST_ORDER = ('cross_attn', 'norm', 'self_attn', 'norm', 'ffn', 'norm')
+
+
+class _Mask2FormerHeadBase(BaseModule):
+    video = False
+
+    def __init__(self, in_channels, feat_channels, out_channels, num_things_classes=80,
+                 num_stuff_classes=53, num_queries=100, num_transformer_feat_level=3, pixel_decoder=None,
+                 enforce_decoder_input_project=False, transformer_decoder=None, positional_encoding=None,
+                 loss_cls=None, loss_mask=None, loss_dice=None, train_cfg=None, test_cfg=None,
+                 init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        pixel_decoder, transformer_decoder = _wrap(pixel_decoder), _wrap(transformer_decoder)
+        self.num_things_classes, self.num_stuff_classes = num_things_classes, num_stuff_classes
+        self.num_classes = num_things_classes + num_stuff_classes
+        self.num_queries = num_queries
+        self.num_transformer_feat_level = num_transformer_feat_level
+        self.num_heads = transformer_decoder.transformerlayers.attn_cfgs.num_heads
+        self.num_transformer_decoder_layers = transformer_decoder.num_layers
+        assert pixel_decoder.encoder.transformerlayers.attn_cfgs.num_levels == num_transformer_feat_level
+        pd = copy.deepcopy(pixel_decoder)
+        pd.update(in_channels=in_channels, feat_channels=feat_channels, out_channels=out_channels)
+        self.pixel_decoder = build_plugin_layer(pd)[1]
+        self.transformer_decoder = build_transformer_layer_sequence(transformer_decoder)
+        self.decoder_embed_dims = self.transformer_decoder.embed_dims
+        self.decoder_input_projs = ModuleList()
+        for _ in range(num_transformer_feat_level):
+            if self.decoder_embed_dims != feat_channels or enforce_decoder_input_project:
+                self.decoder_input_projs.append(nn.Conv2d(feat_channels, self.decoder_embed_dims, 1))
+            else:
+                self.decoder_input_projs.append(nn.Identity())
+        self.decoder_positional_encoding = build_positional_encoding(dict(positional_encoding))
+        self.query_embed = nn.Embedding(num_queries, feat_channels)
+        self.query_feat = nn.Embedding(num_queries, feat_channels)
+        self.level_embed = nn.Embedding(num_transformer_feat_level, feat_channels)
+        self.cls_embed = nn.Linear(feat_channels, self.num_classes + 1)
+        self.mask_embed = nn.Sequential(
+            nn.Linear(feat_channels, feat_channels), nn.ReLU(inplace=True),
+            nn.Linear(feat_channels, feat_channels), nn.ReLU(inplace=True),
+            nn.Linear(feat_channels, out_channels))
+        self.test_cfg, self.train_cfg = test_cfg, train_cfg
+        self.class_weight = loss_cls.get('class_weight') if loss_cls else None
+        self.loss_cls = self.loss_mask = self.loss_dice = None  # inference backend
+        # hook for frame-sharded clips: merges attention partials across ranks (parallel.py)
+        self.partial_combine = None
+        self.clip_frame_offset, self.clip_total_frames = 0, None
+
+    def init_weights(self):
+        self.pixel_decoder.init_weights()
+        for p in self.transformer_decoder.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_normal_(p)
+
+    # ---- one `forward_head` step ----------------------------------------------------------------
+    def _head_step(self, q, mask_features, lows, level, want_logits, need_mask=True):
+        """q (B,Q,C) -> cls (B,Q,classes+1), mask logits or None, ops.AttnMask for `level` or None."""
+        x = self.transformer_decoder.post_norm(q)
+        cls_pred = self.cls_embed(x)
+        emb = self.mask_embed(x)
+        logits = ops.mask_logits(emb, mask_features) if (want_logits or lows is None) else None
+        mask = None
+        if need_mask:
+            if lows is not None:
+                mask = ops.attn_mask_from_lowres_feature(emb, lows[level])
+            else:
+                size = self._level_sizes[level]
+                if self.video:
+                    b, t = logits.shape[:2]
+                    low = F.interpolate(logits.flatten(0, 1), size, mode='bilinear',
+                                        align_corners=False).unflatten(0, (b, t))
+                else:
+                    low = F.interpolate(logits, size, mode='bilinear', align_corners=False)
+                mask = ops.attn_mask_pack(low)
+        return cls_pred, (logits if want_logits else None), mask
+
+    def forward_head(self, decoder_out, mask_feature, attn_mask_target_size):
+        """Reference signature (head.py:355): decoder_out (Q,B,C) -> cls_pred, mask_pred and the
+        (B*heads, Q, K) bool attention mask (materialised here only for API parity / tests)."""
+        self._level_sizes = {0: tuple(attn_mask_target_size)}
+        cls_pred, logits, mask = self._head_step(decoder_out.transpose(0, 1).contiguous(), mask_feature,
+                                                 None, 0, True)
+        m = mask.to_bool(reset_all_blocked=False)
+        return cls_pred, logits, m.unsqueeze(1).repeat(1, self.num_heads, 1, 1).flatten(0, 1)
+
+    # ---- decoder ------------------------------------------------------------------------------
+    def _decode(self, feats, batch_size, num_frames, all_masks, exact_masks=False):
+        B, T = batch_size, num_frames
+        mask_features, memories = self.pixel_decoder(feats)
+        if mask_features.shape[0] != B * T:
+            raise RuntimeError('head: feats batch %d != batch_size*num_frames %d' % (mask_features.shape[0], B * T))
+        C = mask_features.shape[1]
+        H4, W4 = mask_features.shape[-2:]
+        mf = mask_features.reshape(B, T, C, H4, W4) if self.video else mask_features
+        L = self.num_transformer_feat_level
+        dev = mask_features.device
+        k_in, v_in, sizes = [], [], {}
+        for i in range(L):
+            mem = self.decoder_input_projs[i](memories[i])
+            h, w = mem.shape[-2:]
+            sizes[i] = (h, w)
+            tok = mem.reshape(B, T, C, h * w).permute(0, 1, 3, 2).reshape(B, T * h * w, C)
+            v = tok + self.level_embed.weight[i][None, None, :]
+            if self.video:
+                pe = self.decoder_positional_encoding.grid(T, h, w, dev, self.clip_frame_offset,
+                                                           self.clip_total_frames)
+                pe = pe.flatten(2).permute(0, 2, 1).reshape(T * h * w, C)
+            else:
+                pe = self.decoder_positional_encoding.grid(h, w, dev).flatten(1).t()
+            v_in.append(v)
+            k_in.append(v + pe[None])
+        self._level_sizes = sizes
+        # integer-factor levels: bits straight from down-sampled features
+        lows = None
+        fast = (not exact_masks and L == 3 and H4 % 8 == 0 and W4 % 8 == 0 and
+                all(sizes[i] == (H4 >> (3 - i), W4 >> (3 - i)) for i in range(3)))
+        if fast:
+            d2, d4, d8 = ops.center_downsample(mf)
+            lows = {0: d8, 1: d4, 2: d2}
+        q = self.query_feat.weight[None].expand(B, -1, -1).contiguous()
+        q_pos = self.query_embed.weight[None]
+        cls_list, mask_list = [], []
+        n_layers = self.num_transformer_decoder_layers
+        cls_pred, logits, mask = self._head_step(q, mf, lows, 0, all_masks or n_layers == 0)
+        cls_list.append(cls_pred)
+        mask_list.append(logits)
+        for i in range(n_layers):
+            layer = self.transformer_decoder.layers[i]
+            if layer.operation_order != FAST_ORDER:
+                raise NotImplementedError('decoder operation_order %s' % (layer.operation_order,))
+            lvl = i % L
+            q = layer.attentions[0].attend_bqc(q + q_pos, k_in[lvl], v_in[lvl], mask, q,
+                                               combine=self.partial_combine)
+            q = layer.norms[0](q)
+            qk = q + q_pos
+            q = layer.attentions[1].attend_bqc(qk, qk, q, None, q)
+            q = layer.norms[1](q)
+            q = layer.norms[2](layer.ffns[0](q))
+            last = i == n_layers - 1
+            cls_pred, logits, mask = self._head_step(q, mf, lows, (i + 1) % L, all_masks or last,
+                                                     need_mask=not last or all_masks)
+            cls_list.append(cls_pred)
+            mask_list.append(logits)
+        return cls_list, mask_list, q.transpose(0, 1)  # query_feat in the reference's (Q,B,C)
+
+    def forward(self, feats, img_metas, return_query=False, **kwargs):
+        """Reference contract: all 10 class / mask predictions (head.py:397-479)."""
+        batch_size = len(img_metas)
+        num_frames = len(img_metas[0]) if self.video else 1
+        cls_list, mask_list, q = self._decode(feats, batch_size, num_frames, all_masks=True, exact_masks=True)
+        return (cls_list, mask_list, q) if return_query else (cls_list, mask_list)
+
+    def forward_train(self, *args, **kwargs):
+        raise NotImplementedError('training is outside the MI355X inference hot path (SURVEY.md #13)')
+
+
+@HEADS.register_module()
+class Mask2FormerHeadCustom(_Mask2FormerHeadBase):
+    video = False
+
+    def simple_test_with_query(self, feats, img_metas, **kwargs):
+        """-> mask_cls (B,Q,classes+1), mask_pred (B,Q,H,W) up-sampled to batch_input_shape,
+        query_feats (1,Q,B,C)  (head.py:650-681)."""
+        cls_list, mask_list, q = self._decode(feats, len(img_metas), 1, all_masks=False)
+        h, w = img_metas[0]['batch_input_shape'][:2]
+        masks = F.interpolate(mask_list[-1], size=(h, w), mode='bilinear', align_corners=False)
+        return cls_list[-1], masks, q.unsqueeze(0)
+
+    def simple_test(self, feats, img_metas, **kwargs):
+        cls, masks, _ = self.simple_test_with_query(feats, img_metas, **kwargs)
+        return cls, masks
+
+
+@HEADS.register_module()
+class Mask2FormerVideoHead(_Mask2FormerHeadBase):
+    video = True
+
+    def __init__(self, *args, point_loss=True, loss_split_thing_stuff=False, loss_sem_seg=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.point_loss, self.loss_split_th_st = point_loss, loss_split_thing_stuff
+        self.loss_sem_seg = None
+        if loss_sem_seg is not None:
+            self.sem_seg_head = nn.Conv2d(kwargs['feat_channels'] if 'feat_channels' in kwargs else args[1],
+                                          self.num_classes, 1)
+
+    def forward_head_video(self, decoder_out, mask_feature, attn_mask_target_size):
+        return self.forward_head(decoder_out, mask_feature, attn_mask_target_size)
+
+    def clip_logits(self, feats, batch_size, num_frames):
+        """Last layer's class logits (B,Q,classes+1), stride-4 mask logits (B,T,Q,H/4,W/4), queries."""
+        cls_list, mask_list, q = self._decode(feats, batch_size, num_frames, all_masks=False)
+        return cls_list[-1], mask_list[-1], q
+
+    def simple_test_with_query(self, feats, img_metas, **kwargs):
+        """-> mask_cls (B,Q,classes+1), mask_pred (B,T,Q,H,W), query (Q,B,C)  (video_head.py:637-669)."""
+        B, T = len(img_metas), len(img_metas[0])
+        cls, masks, q = self.clip_logits(feats, B, T)
+        h, w = img_metas[0][0]['batch_input_shape'][:2]
+        masks = F.interpolate(masks.flatten(0, 1), size=(h, w), mode='bilinear',
+                              align_corners=False).unflatten(0, (B, T))
+        return cls, masks, q

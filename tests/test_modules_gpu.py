@@ -1,0 +1,227 @@
+"""Product modules (openpvsg_amd/, HIP backend) against (a) the golden vectors written by the
+REFERENCE's own classes and (b) the CPU oracle, on the same deterministic weights and inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import heads as oheads
+from oracle import pipeline as opipe
+from oracle import relation as orel
+from oracle.detweights import det_input, det_state_dict
+from tests.synth_inputs import blob_masks
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+GAINS = {'cls_embed.weight': 12.0}
+FEAT_SHAPES = ((16, 24), (8, 12), (4, 6), (2, 3))
+CH = (256, 512, 1024, 2048)
+
+
+def head_cfg(video):
+    from openpvsg_amd.model_zoo import mask2former_r50_model_cfg, panoptic_head_cfg
+    cfg = panoptic_head_cfg(video)
+    cfg.update(train_cfg=None, test_cfg=mask2former_r50_model_cfg(video)['test_cfg'])
+    return cfg
+
+
+def feats(n, seed, shapes=FEAT_SHAPES):
+    return [det_input('feat%d' % i, (n, c) + hw, seed) for i, (c, hw) in enumerate(zip(CH, shapes))]
+
+
+def build_head(video, seed):
+    from openpvsg_amd import blocks, heads  # noqa: F401 (registers modules)
+    from openpvsg_amd.registry import build_head as bh
+    h = bh(head_cfg(video)).eval()
+    h.load_state_dict(det_state_dict(h, seed, GAINS))
+    return h.to(DEV)
+
+
+@pytest.mark.parametrize('name,video,T', [('head_ips_s1.npz', False, 1), ('head_vps_s2_T1.npz', True, 1),
+                                          ('head_vps_s3_T3.npz', True, 3)])
+def test_head_forward_vs_reference_golden(hip_lib, golden_dir, name, video, T):
+    g = np.load(os.path.join(golden_dir, name))
+    seed = int(g['seed'])
+    h = build_head(video, seed)
+    f = [x.to(DEV) for x in feats(T, seed)]
+    meta = dict(batch_input_shape=(64, 96), img_shape=(60, 90, 3), ori_shape=(45, 70, 3))
+    metas = [[meta] * T] if video else [meta]
+    with torch.no_grad():
+        cls_list, mask_list, q = h.forward(f, metas, return_query=True)
+        cls_f, mask_f, qf = h.simple_test_with_query(f, metas)
+    for j, li in enumerate(g['layers']):
+        np.testing.assert_allclose(cls_list[li].cpu().numpy(), g['cls'][j], rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(mask_list[li].cpu().numpy(), g['mask'][j], rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(q.cpu().numpy(), g['query'], rtol=1e-3, atol=1e-3)
+    # fast path (bits from down-sampled features, only the last layer's logits) == reference outputs
+    np.testing.assert_allclose(cls_f.cpu().numpy(), g['final_cls'], rtol=1e-3, atol=1e-3)
+    samp = mask_f[:, ::7, ::5, ::5] if not video else mask_f[:, :, ::7, ::5, ::5]
+    np.testing.assert_allclose(samp.cpu().numpy(), g['final_mask_sample'], rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(qf.cpu().numpy(), g['final_query'], rtol=1e-3, atol=1e-3)
+
+
+def test_forward_head_mask_bits_match_reference(hip_lib, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'head_ips_s1.npz'))
+    h = build_head(False, int(g['seed']))
+    f = [x.to(DEV) for x in feats(1, int(g['seed']))]
+    with torch.no_grad():
+        mf, mems = h.pixel_decoder(f)
+        q0 = h.query_feat.weight.unsqueeze(1)
+        _, _, am = h.forward_head(q0, mf, mems[0].shape[-2:])
+    bits = np.packbits(am[0].cpu().numpy(), axis=-1)
+    assert (bits != g['am_first']).mean() < 0.01
+    pop = am[0].sum(-1).cpu().numpy()
+    assert np.abs(pop - g['am_popcount'][0]).max() <= 1
+
+
+def test_fusion_vs_reference_golden(hip_lib, golden_dir):
+    from openpvsg_amd.fusion import MaskFormerFusionHeadCustom
+    g = np.load(os.path.join(golden_dir, 'fusion.npz'))
+    for ci in range(int(g['n'])):
+        p = 'c%d_' % ci
+        hw, img, ori = tuple(g[p + 'hw']), tuple(g[p + 'img']), tuple(g[p + 'ori'])
+        cfg = dict(panoptic_on=True, instance_on=True, max_per_image=100, iou_thr=0.8,
+                   filter_low_score=bool(g[p + 'low']), object_mask_thr=0.8)
+        head = MaskFormerFusionHeadCustom(115, 11, test_cfg=cfg)
+        cls = torch.from_numpy(g[p + 'cls']).to(DEV)
+        masks = blob_masks(100, hw[0], hw[1], g[p + 'conf'], ci)[None].to(DEV)
+        qf = det_input('fusion_q%d' % ci, (1, 100, 1, 256), ci).to(DEV)
+        metas = [dict(img_shape=img + (3,), ori_shape=ori + (3,))]
+        res = head.simple_test_with_query(cls, masks, qf, metas, rescale=True)[0]
+        pan = res['pan_results'].cpu().numpy()
+        assert (pan != g[p + 'pan']).mean() < 1e-3      # resize on GPU vs CPU: border pixels may differ
+        ids = sorted(res['query_feats'].keys())
+        assert ids == list(g[p + 'ids'])
+        if ids:
+            first = np.stack([res['query_feats'][i][0].cpu().numpy() for i in ids])
+            np.testing.assert_allclose(first, g[p + 'feat_first'], rtol=0, atol=0)
+            assert [len(res['query_feats'][i]) for i in ids] == list(g[p + 'feat_count'])
+        labels, boxes, binm = res['ins_results']
+        assert (labels.cpu().numpy() == g[p + 'ins_labels']).all()
+        np.testing.assert_allclose(boxes.cpu().numpy()[:, :4], g[p + 'ins_boxes'][:, :4], rtol=0, atol=1.0)
+        np.testing.assert_allclose(boxes.cpu().numpy()[:, 4], g[p + 'ins_boxes'][:, 4], rtol=1e-3, atol=1e-4)
+        area = binm.flatten(1).sum(1).cpu().numpy()
+        assert np.abs(area - g[p + 'ins_area']).max() <= max(2, 1e-3 * g[p + 'ins_area'].max())
+
+
+def build_detector(video, seed, gains, mode=None):
+    from openpvsg_amd import backbone, blocks, detectors, fusion, heads  # noqa: F401
+    from openpvsg_amd.model_zoo import mask2former_r50_model_cfg
+    from openpvsg_amd.registry import build_detector as bd
+    m = bd(mask2former_r50_model_cfg(video)).eval()
+    if mode:
+        m.inference_mode = mode
+    m.load_state_dict(det_state_dict(m, seed, gains))
+    return m.to(DEV)
+
+
+def mask_iou(a, b, ignore):
+    ids = set(np.unique(a)) | set(np.unique(b))
+    ious = []
+    for i in ids:
+        if i == ignore:
+            continue
+        u = ((a == i) | (b == i)).sum()
+        ious.append(((a == i) & (b == i)).sum() / u)
+    return min(ious) if ious else 1.0
+
+
+def test_vps_detector_T1_vs_reference_golden(hip_lib, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'detector_vps_T1.npz'))
+    seed, T = int(g['seed']), int(g['T'])
+    m = build_detector(True, seed, {'cls_embed.weight': 40.0})
+    m.panoptic_fusion_head.test_cfg = dict(m.panoptic_fusion_head.test_cfg, instance_on=False)
+    img = det_input('clip', (1, T, 3, 64, 96), seed).to(DEV)
+    meta = dict(img_shape=(64, 96, 3), ori_shape=(64, 96, 3))
+    res = m.forward(img=None, img_metas=None, return_loss=False, rescale=True, ref_img=img,
+                    ref_img_metas=[[dict(meta) for _ in range(T)]])
+    pan = np.stack([res[0][t]['pan_results'] for t in range(T)])
+    assert (pan != g['pan']).mean() < 1e-3
+    assert mask_iou(pan, g['pan'], 126) > 1 - 1e-3
+    assert sorted(res[0][0]['query_feats'].keys()) == list(g['ids0'])
+    if len(g['ids0']):
+        f0 = np.stack([res[0][0]['query_feats'][i][0] for i in g['ids0']])
+        np.testing.assert_allclose(f0, g['feat0'], rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize('mode', ['clip', 'per_frame'])
+def test_vps_detector_T3_vs_oracle(hip_lib, mode):
+    seed, T = 6, 3
+    gains = {'cls_embed.weight': 40.0}
+    m = build_detector(True, seed, gains, mode)
+    m.panoptic_fusion_head.test_cfg = dict(m.panoptic_fusion_head.test_cfg, instance_on=False)
+    o = opipe.VPSDetectorOracle().eval()
+    o.load_state_dict(det_state_dict(o, seed, gains))
+    img = det_input('clip', (1, T, 3, 64, 96), seed)
+    meta = dict(batch_input_shape=(64, 96), img_shape=(64, 96, 3), ori_shape=(64, 96, 3))
+    with torch.no_grad():
+        ref = (o.clip_test if mode == 'clip' else o.simple_test)(img, [[meta] * T], rescale=True)
+    res = m.forward(img=None, img_metas=None, return_loss=False, rescale=True, ref_img=img.to(DEV),
+                    ref_img_metas=[[dict(meta) for _ in range(T)]])
+    for t in range(T):
+        a, b = res[0][t]['pan_results'], ref[0][t]['pan_results'].numpy()
+        assert (a != b).mean() < 1e-3
+        assert mask_iou(a, b, 126) > 1 - 1e-3
+        assert sorted(res[0][t]['query_feats'].keys()) == sorted(ref[0][t]['query_feats'].keys())
+        for k in res[0][t]['query_feats']:
+            np.testing.assert_allclose(res[0][t]['query_feats'][k][0], ref[0][t]['query_feats'][k][0].numpy(),
+                                       rtol=1e-3, atol=1e-3)
+
+
+def test_ips_detector_vs_oracle(hip_lib):
+    seed = 7
+    gains = {'cls_embed.weight': 40.0}
+    m = build_detector(False, seed, gains)
+    o = opipe.IPSDetectorOracle().eval()
+    o.load_state_dict(det_state_dict(o, seed, gains))
+    img = det_input('img', (1, 3, 64, 96), seed)
+    meta = dict(img_shape=(60, 90, 3), ori_shape=(45, 70, 3))
+    with torch.no_grad():
+        ref = o.simple_test(img, [dict(meta, batch_input_shape=(64, 96))], rescale=True)[0]
+    res = m.forward([img.to(DEV)], [[dict(meta)]], return_loss=False, rescale=True)[0]
+    a, b = res['pan_results'], ref['pan_results'].numpy()
+    assert a.shape == (45, 70) and (a != b).mean() < 2e-3
+    assert sorted(res['query_feats'].keys()) == sorted(ref['query_feats'].keys())
+    labels_ref = ref['ins_results'][0].numpy()
+    assert sum(len(x) for x in res['ins_results'][1]) == len(labels_ref)
+
+
+REL_CASES = [('rel_s1_N4_T8.npz', ('transformer', 'vanilla')), ('rel_s2_N8_T16.npz', ('transformer', 'filter', 'conv')),
+             ('rel_s3_N17_T33.npz', ('transformer',)), ('rel_s4_N2_T5.npz', ('vanilla',)),
+             ('rel_s5_N12_T9.npz', ('transformer',))]
+
+
+@pytest.mark.parametrize('name,models', REL_CASES)
+def test_relation_pipeline_vs_reference_golden(hip_lib, golden_dir, name, models):
+    from openpvsg_amd import relation as prel
+    g = np.load(os.path.join(golden_dir, name))
+    seed, N, T = int(g['seed']), int(g['N']), int(g['T'])
+    feats_ = det_input('rel_feats', (N, T, 256), seed)
+    se, oe = prel.ObjectEncoder(256).eval(), prel.ObjectEncoder(256).eval()
+    se.load_state_dict(det_state_dict(se, seed))
+    oe.load_state_dict(det_state_dict(oe, seed + 100))
+    pp = prel.PairProposalNetwork(256, 1024).eval()
+    pp.load_state_dict(det_state_dict(pp, seed))
+    se, oe, pp = se.to(DEV), oe.to(DEV), pp.to(DEV)
+    K_values = [20, 50, 100]
+    for mname in models:
+        rm = prel.MODEL_CLASSES[mname](512, 57).eval()
+        rm.load_state_dict(det_state_dict(rm, seed))
+        rm = rm.to(DEV)
+        with torch.no_grad():
+            out = prel.relation_forward(se, oe, pp, rm, feats_.to(DEV), 100)
+        np.testing.assert_allclose(out['sub'].cpu().numpy(), g['sub'], rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(out['pred_matrix'].cpu().numpy(), g['pred_matrix'], rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(out['span_pred'].cpu().numpy()[:3], g[mname + '_span'][:3], rtol=1e-2, atol=2e-3)
+        # Recall@K / pair recall through the reference's evaluate() bookkeeping
+        gts = [dict(subject_index=int(a), object_index=int(b), relation=int(c), relation_span=s)
+               for (a, b, c), s in zip(g[mname + '_gt'], g[mname + '_gt_span'])]
+        loader = [dict(feats=[feats_.double().numpy()], relations=gts)]
+        for strat, pw in (('pw', True), ('all', False)):
+            final, prl = prel.evaluate(se, oe, pp, rm, loader, 100, [str(i) for i in range(57)], DEV,
+                                       pairwise=pw, verbose=False)
+            got = np.array([[final[K][k] for k in ('recall', 'mean_recall', 'weak_recall', 'weak_mean_recall')]
+                            for K in K_values])
+            np.testing.assert_allclose(got, g['%s_metrics_%s' % (mname, strat)], rtol=0, atol=1e-3)
+            assert abs(prl[0] - float(g[mname + '_pair_recall20'])) <= 1e-3
