@@ -1,0 +1,326 @@
+#!/usr/bin/env python
+"""bench.py -- frames/sec of the 720p 32-frame VPS + relation forward on N MI355X (BASELINE.json).
+
+One "step" = one pass of the hot path over one synthetic clip already resident in HBM:
+  ResNet-50 -> MSDeformAttn pixel decoder -> clip-level masked-attention decoder (keys = T*h*w)
+  -> last-layer mask logits -> per-frame x4 up-sampling + panoptic fusion -> tube assembly ->
+  relation head (object encoders, N^2 pair scorer, top-100 pairs, temporal transformer).
+N > 1: the clip's frames are sharded contiguously over the ranks (strong scaling: total work fixed);
+attention partials and the per-frame segment records are exchanged with RCCL all-gathers.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around every C-ABI
+launch of the timed steps; `cpu_baseline` times the CPU oracle (oracle/, "port") on a bounded
+sample of the same workload on this box's host cores.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_MFMA_PEAK_TF = 157.3     # f32-input MFMA peak
+CLS_GAIN = 40.0              # random-init class logits are flat; peaky logits keep a few queries
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--frames', type=int, default=32)
+    ap.add_argument('--height', type=int, default=720)
+    ap.add_argument('--width', type=int, default=1280)
+    ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'off'])
+    ap.add_argument('--cpu-frames', type=int, default=2)
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    return ap.parse_args()
+
+
+def make_clip(T, H, W, seed=0):
+    """seed-0 uint8 U[0,255] pixels, ImageNet normalisation of the PVSG test pipeline
+    (configs/_base_/datasets/pvsg_vps_single_video_test.py:4-6), zero-padded to a multiple of 32."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randint(0, 256, (T, 3, H, W), generator=g, dtype=torch.uint8).float()
+    mean = torch.tensor([123.675, 116.28, 103.53]).view(1, 3, 1, 1)
+    std = torch.tensor([58.395, 57.12, 57.375]).view(1, 3, 1, 1)
+    img = (img - mean) / std
+    Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
+    out = torch.zeros(T, 3, Hp, Wp)
+    out[:, :, :H, :W] = img
+    return out, (Hp, Wp)
+
+
+def build_models(seed=0):
+    from openpvsg_amd import backbone, blocks, detectors, fusion, heads  # noqa: F401
+    from openpvsg_amd import relation as prel
+    from openpvsg_amd.model_zoo import mask2former_r50_model_cfg
+    from openpvsg_amd.registry import build_detector
+    torch.manual_seed(seed)
+    cfg = mask2former_r50_model_cfg(video=True)
+    cfg['test_cfg'] = dict(cfg['test_cfg'], instance_on=False)
+    det = build_detector(cfg).eval()
+    det.inference_mode = 'clip'
+    det.panoptic_head.init_weights()
+    with torch.no_grad():
+        det.panoptic_head.cls_embed.weight.mul_(CLS_GAIN)
+        det.panoptic_head.query_feat.weight.mul_(8.0)
+    rel = dict(subject_encoder=prel.ObjectEncoder(256), object_encoder=prel.ObjectEncoder(256),
+               pair_model=prel.PairProposalNetwork(256, 1024), relation_model=prel.TemporalTransformer(512, 57))
+    for m in rel.values():
+        m.eval()
+    return det, rel
+
+
+class KernelTimer:
+    """HIP events around every C-ABI launch (same stream the launch goes to)."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+
+    def install(self):
+        from openpvsg_amd import _lib
+        orig = _lib.call
+        timer = self
+
+        def timed(name, *args):
+            if not timer.enabled:
+                return orig(name, *args)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            orig(name, *args)
+            e.record()
+            timer.records.append((name, args, s, e))
+        _lib.call = timed
+        import openpvsg_amd.ops as ops
+        ops._lib.call = timed
+
+    @staticmethod
+    def work(name, a):
+        """(algorithmic bytes, flops) of one launch from its scalar arguments."""
+        if name == 'pvsg_ms_deform_attn_forward':
+            B, S, M, D, Lq, L, P = a[6:13]
+            return 4.0 * (B * S * M * D + B * Lq * M * D + 3 * B * Lq * M * L * P), 9.0 * B * Lq * M * L * P * D
+        if name == 'pvsg_mask_logits_forward':
+            B, T, Q, C, N = a[3:8]
+            return 4.0 * B * T * N * (C + Q), 2.0 * B * T * Q * C * N
+        if name == 'pvsg_attn_mask_bits_forward':
+            B, T, Q, C, N = a[4:9]
+            return 4.0 * B * T * N * C + 16.0 * B * T * N, 2.0 * B * T * Q * C * N
+        if name == 'pvsg_masked_xattn_partial':
+            B, Q, K, M, D, NS = a[7:13]
+            return B * K * (2.0 * M * D * 4 + (16 if a[3] else 0)) + 4.0 * B * NS * M * Q * (D + 2), 4.0 * B * Q * M * D * K
+        if name == 'pvsg_center_downsample':
+            planes, H, W = a[4:7]
+            return 4.0 * planes * H * W * (1 + 21.0 / 64), 0.0
+        return 0.0, 0.0
+
+    def summary(self):
+        agg = {}
+        for name, args, s, e in self.records:
+            ms = s.elapsed_time(e)
+            by, fl = self.work(name, args)
+            key = name
+            if name == 'pvsg_masked_xattn_partial':
+                key = name + ('[K=%d]' % args[9])
+            d = agg.setdefault(key, dict(calls=0, ms=0.0, bytes=0.0, flops=0.0))
+            d['calls'] += 1
+            d['ms'] += ms
+            d['bytes'] += by
+            d['flops'] += fl
+        return agg
+
+
+def cpu_baseline_and_parity(det_gpu, rel_gpu, pipe, args, dev):
+    """Oracle (CPU restatement of the reference algorithm) on a bounded sample: a `cpu_frames`-frame
+    720p clip through the same clip-level flow + relation head; also compares the product's panoptic
+    maps with the oracle's on that sample."""
+    from oracle import pipeline as opipe
+    from oracle import relation as orel
+    T = args.cpu_frames
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(ncpu)
+    clip, (Hp, Wp) = make_clip(T, args.height, args.width)
+    o = opipe.VPSDetectorOracle(test_cfg=dict(opipe.DEFAULT_TEST_CFG)).eval()
+    o.load_state_dict({k: v.detach().cpu() for k, v in det_gpu.state_dict().items()})
+    orl = dict(se=orel.ObjectEncoder(256).eval(), oe=orel.ObjectEncoder(256).eval(),
+               pp=orel.PairProposalNetwork(256, 1024).eval(), rm=orel.TemporalTransformer(512, 57).eval())
+    for k, m in (('se', 'subject_encoder'), ('oe', 'object_encoder'), ('pp', 'pair_model'), ('rm', 'relation_model')):
+        orl[k].load_state_dict({n: v.detach().cpu() for n, v in rel_gpu[m].state_dict().items()
+                                if n in orl[k].state_dict()})
+    meta = dict(batch_input_shape=(Hp, Wp), img_shape=(args.height, args.width, 3),
+                ori_shape=(args.height, args.width, 3))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        res = o.clip_test(clip[None], [[meta] * T], rescale=True)[0]
+        # tubes exactly as the product assembles them, then the reference's relation flow
+        order, frames = [], []
+        for t in range(T):
+            frames.append(res[t]['query_feats'])
+            for sid in res[t]['query_feats']:
+                if sid not in order:
+                    order.append(sid)
+        feats = torch.zeros(len(order), T, 256)
+        for t in range(T):
+            for sid, lst in frames[t].items():
+                feats[order.index(sid), t] = lst[0].reshape(-1)
+        rel_out = None
+        if len(order) >= 2:
+            rel_out = orel.evaluate_video(orl['se'], orl['oe'], orl['pp'], orl['rm'], feats, [], 100)
+    cpu_s = time.perf_counter() - t0
+    # product on the same sample
+    out = pipe(clip.to(dev), (Hp, Wp), (args.height, args.width))
+    torch.cuda.synchronize()
+    a = out['pan_results'].cpu().numpy()
+    import numpy as np
+    b = np.stack([res[t]['pan_results'].numpy() for t in range(T)])
+    ids = (set(np.unique(a)) | set(np.unique(b))) - {126}
+    inter = sum(((a == i) & (b == i)).sum() for i in ids)
+    union = sum(((a == i) | (b == i)).sum() for i in ids)
+    parity = dict(frames=T, pixel_mismatch=float((a != b).mean()),
+                  mask_iou=float(inter / union) if union else 1.0, segments=len(ids),
+                  tubes=int(out['tube_feats'].shape[0]), tubes_oracle=len(order))
+    if rel_out is not None and out['relation'] is not None:
+        pm_a = out['relation']['pred_matrix'].cpu()
+        parity['pair_matrix_max_abs_diff'] = float((pm_a - rel_out['pred_matrix']).abs().max()) \
+            if pm_a.shape == rel_out['pred_matrix'].shape else None
+        pa = out['relation']['pairs'].cpu().tolist()
+        parity['top20_pairs_equal'] = pa[:20] == rel_out['pairs'][:20]
+    base = dict(value=T / cpu_s, unit='frames/s', cores=ncpu, kind='port',
+                sample='%d-frame 720p clip, clip-level VPS forward + fusion + relation head (oracle/, torch CPU '
+                       'fp32, %d threads), %.1f s' % (T, torch.get_num_threads(), cpu_s))
+    return base, parity
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', init_method='env://')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    torch.backends.cudnn.benchmark = True
+
+    from openpvsg_amd import build
+    if rank == 0 and not os.path.exists(build.lib_path()):
+        build.build_hip_lib(verbose=False)
+    if world > 1:
+        dist.barrier()
+    from openpvsg_amd import parallel
+    from openpvsg_amd.pipeline import PVSGPipeline
+
+    det, rel = build_models(0)
+    det = det.to(dev)
+    rel = {k: m.to(dev) for k, m in rel.items()}
+    pipe = PVSGPipeline(det, rel['subject_encoder'], rel['object_encoder'], rel['pair_model'],
+                        rel['relation_model']).eval()
+
+    T = args.frames
+    clip, (Hp, Wp) = make_clip(T, args.height, args.width)
+    t0, t_local = parallel.shard_frames(T, rank, world)
+    clip_local = clip[t0:t0 + t_local].to(dev)           # resident in HBM before the timed region
+    group = None
+
+    timer = KernelTimer()
+    if not args.no_kernel_timing and rank == 0:
+        timer.install()
+
+    def step():
+        return pipe(clip_local, (Hp, Wp), (args.height, args.width), total_frames=T, group=group)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    start = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - start
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        fps = T * args.steps / elapsed
+        line = {
+            'metric': 'frames/sec for 720p 32-frame VPS+relation forward',
+            'value': fps, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'Mask2Former-VPS R50 clip-level forward, %d frames %dx%d (padded %dx%d), '
+                                   '100 queries, 9 decoder layers over T*h*w keys, panoptic fusion per frame, '
+                                   'tube assembly, relation head (TemporalTransformer, top-100 pairs)'
+                                   % (T, args.height, args.width, Hp, Wp),
+                       'frames': T, 'frames_per_gpu': t_local, 'backbone': 'ResNet-50 (reference ships no Swin-B config)',
+                       'weights': 'random init seed 0 (cls logits x%g so that some queries pass score>0.8)' % CLS_GAIN,
+                       'tubes': int(out['tube_feats'].shape[0]), 'parallelism': 'frame-shard x%d' % world},
+        }
+        if timer.records:
+            agg = timer.summary()
+            kern = {}
+            for k, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
+                per = d['ms'] / d['calls']
+                kern[k] = dict(calls_per_step=d['calls'] / args.steps, avg_ms=per,
+                               GBps=d['bytes'] / d['calls'] / per / 1e6 if per > 0 else None,
+                               TFLOPs=d['flops'] / d['calls'] / per / 1e9 if per > 0 and d['flops'] else None,
+                               ms_per_step=d['ms'] / args.steps)
+            line['kernels'] = kern
+            dom = max((k for k in agg if agg[k]['bytes'] > 0), key=lambda k: agg[k]['ms'])
+            d = agg[dom]
+            per = d['ms'] / d['calls']
+            mfma_bound = dom.startswith(('pvsg_mask_logits', 'pvsg_attn_mask_bits', 'pvsg_masked_xattn'))
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(dom.split('[')[0], {}).get('hbm_bytes_per_launch_T%d' % t_local)
+            if mfma_bound:
+                ach = d['flops'] / d['calls'] / per / 1e9
+                line['roofline'] = dict(kernel=dom, bound='mfma', achieved=ach, peak=F32_MFMA_PEAK_TF,
+                                        unit='TFLOP/s', frac=ach / F32_MFMA_PEAK_TF, traffic=traffic,
+                                        avg_launch_ms=per, launches_per_step=d['calls'] / args.steps)
+            else:
+                ach = d['bytes'] / d['calls'] / per / 1e6
+                line['roofline'] = dict(kernel=dom, bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
+                                        frac=ach / HBM_PEAK_GBS, traffic=traffic, avg_launch_ms=per,
+                                        launches_per_step=d['calls'] / args.steps,
+                                        algorithmic_bytes_per_launch=d['bytes'] / d['calls'])
+        if args.cpu_baseline != 'off' and world == 1:
+            try:
+                base, parity = cpu_baseline_and_parity(det, rel, pipe, args, dev)
+                line['cpu_baseline'] = base
+                line['parity_on_cpu_sample'] = parity
+                line['speedup_vs_cpu_baseline'] = fps / base['value']
+            except Exception as e:  # the bench line must still be printed
+                line['cpu_baseline'] = dict(value=None, unit='frames/s', cores=os.cpu_count(), kind='port',
+                                            sample='failed: %r' % (e,))
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -76,6 +76,7 @@ class _Mask2FormerHeadBase(BaseModule):
         self.loss_cls = self.loss_mask = self.loss_dice = None  # inference backend
         # hook for frame-sharded clips: merges attention partials across ranks (parallel.py)
         self.partial_combine = None
+        self.mask_sync = None
         self.clip_frame_offset, self.clip_total_frames = 0, None
 
     def init_weights(self):
@@ -104,6 +105,8 @@ class _Mask2FormerHeadBase(BaseModule):
                 else:
                     low = F.interpolate(logits, size, mode='bilinear', align_corners=False)
                 mask = ops.attn_mask_pack(low)
+            if self.mask_sync is not None:
+                mask = self.mask_sync(mask)   # frame-sharded clip: OR the per-query flags over ranks
         return cls_pred, (logits if want_logits else None), mask
 
     def forward_head(self, decoder_out, mask_feature, attn_mask_target_size):

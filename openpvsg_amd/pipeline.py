@@ -1,0 +1,102 @@
+"""VPS -> tubes -> relation, device-resident: the "VPS + relation forward" BASELINE.json's metric
+is quoted on.
+
+Reference flow (file-based between stages): tools/prepare_query_tube_vps.py:230-258 runs the VPS
+detector frame by frame and `concat_seq` (models/mask2former_vps/utils.py:20-89) groups the
+per-frame `{segment id: [query feature]}` dictionaries into tubes keyed by segment id (absent
+frames = None -> zeros in utils/relation_matching.py:431-444), written to query_feats.pickle;
+tools/rel_test.py:33-66 then scores relations on `feats [N,T,256]`.
+Here the same records stay on the GPU: kept segment ids per frame -> tube index -> `feats`.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import parallel
+
+
+def assemble_tubes(seg_ids, kept_feats, num_frames):
+    """seg_ids: list over frames of (K_t,) int64 tensors (-1 = dropped), kept_feats: list of (K_t,C)
+    -> (tube_ids (N,) sorted by first appearance, feats (N,T,C) with zeros where absent)."""
+    dev = kept_feats[0].device if kept_feats else torch.device('cpu')
+    C = kept_feats[0].shape[-1] if kept_feats else 256
+    host = [s.tolist() for s in seg_ids]                    # one small transfer per frame
+    order = []
+    seen = set()
+    for ids in host:
+        for sid in ids:
+            if sid >= 0 and sid not in seen:
+                seen.add(sid)
+                order.append(sid)
+    index = {sid: i for i, sid in enumerate(order)}
+    feats = torch.zeros((len(order), num_frames, C), dtype=torch.float32, device=dev)
+    for t, ids in enumerate(host):
+        first = {}
+        for k, sid in enumerate(ids):
+            if sid >= 0 and sid not in first:               # `feat[0]` of the id's list (utils.py:48)
+                first[sid] = k
+        if first:
+            rows = torch.tensor([index[s] for s in first], device=dev)
+            cols = torch.tensor(list(first.values()), device=dev)
+            feats[rows, t] = kept_feats[t][cols]
+    return torch.tensor(order, dtype=torch.long, device=dev), feats
+
+
+class PVSGPipeline(torch.nn.Module):
+    """detector (clip-level VPS) + fusion post-processing per frame + tube assembly + relation head."""
+
+    def __init__(self, detector, subject_encoder, object_encoder, pair_model, relation_model,
+                 num_top_pairs=100):
+        super().__init__()
+        self.detector = detector
+        self.subject_encoder, self.object_encoder = subject_encoder, object_encoder
+        self.pair_model, self.relation_model = pair_model, relation_model
+        self.num_top_pairs = num_top_pairs
+
+    @torch.no_grad()
+    def vps_clip(self, clip, batch_input_shape, img_shape=None, total_frames=None, group=None):
+        """clip (T_local,3,H,W) normalised frames of ONE video (this rank's shard).
+        Returns per-frame panoptic maps (T_local,H,W) int32, seg ids / kept features per frame."""
+        det = self.detector
+        head, fusion = det.panoptic_head, det.panoptic_fusion_head
+        T = clip.shape[0]
+        shard = None
+        if parallel.is_dist(group):
+            shard = parallel.ClipShard(head, total_frames, group)
+        try:
+            feats = det.extract_feat(clip)
+            cls, masks4, q = head.clip_logits(feats, 1, T)          # (1,Q,C+1), (1,T,Q,H/4,W/4), (Q,1,C)
+        finally:
+            if shard is not None:
+                shard.release()
+        H, W = batch_input_shape
+        ih, iw = (img_shape or batch_input_shape)[:2]
+        scores, labels, keep = fusion.panoptic_select(cls[0])
+        k_scores, k_classes = scores[keep], labels[keep]
+        k_feats = q[:, 0][keep]
+        pans, seg_ids = [], []
+        for t in range(T):
+            up = F.interpolate(masks4[0, t][keep][None], size=(H, W), mode='bilinear', align_corners=False)[0]
+            seg, sid = fusion.panoptic_from_kept(k_scores, k_classes, up[:, :ih, :iw].sigmoid())
+            pans.append(seg)
+            seg_ids.append(sid)
+        return torch.stack(pans), seg_ids, [k_feats] * T, cls, q
+
+    @torch.no_grad()
+    def forward(self, clip, batch_input_shape, img_shape=None, total_frames=None, group=None):
+        from .relation import relation_forward
+        T_local = clip.shape[0]
+        pans, seg_ids, k_feats, cls, q = self.vps_clip(clip, batch_input_shape, img_shape, total_frames, group)
+        if parallel.is_dist(group):
+            # tube reassembly: every rank needs each frame's segment-id record (K is identical on all
+            # ranks in clip mode because queries and class logits are replicated after the merge)
+            sid = torch.stack(seg_ids)                                   # (T_local, K)
+            sid = parallel.all_gather_cat(sid, 0, group)
+            seg_ids = list(sid.unbind(0))
+            k_feats = [k_feats[0]] * len(seg_ids)
+        T = len(seg_ids)
+        tube_ids, feats = assemble_tubes(seg_ids, k_feats, T)
+        rel = None
+        if feats.shape[0] >= 2:
+            rel = relation_forward(self.subject_encoder, self.object_encoder, self.pair_model,
+                                   self.relation_model, feats, self.num_top_pairs)
+        return dict(pan_results=pans, tube_ids=tube_ids, tube_feats=feats, relation=rel, cls=cls, query=q)

@@ -1,0 +1,76 @@
+/* ORACLE (test infrastructure, never shipped): plain-C scalar restatement of the two kernels whose
+ * arithmetic is spelled out element by element in the reference path.
+ *
+ *  oracle_msda_forward  -- [3P] mmcv-full 1.4.0 ms_deform_attn forward semantics (SURVEY.md Appendix
+ *      A1 step 6): x = loc_x*W - 0.5, y = loc_y*H - 0.5, window (-1, size), per-corner zero padding,
+ *      out += weight * bilinear.  "parity unpinned" like the rest of the third-party blocks; checked
+ *      against F.grid_sample in tests/test_oracle_c.py.
+ *  oracle_pair_score    -- models/relation_head/base.py:49-62: tokens = max over T, then for every
+ *      i != j  pair[i][j] = w2 . relu(W1 [s_i ; o_j] + b1) + b2, diagonal 0.  Pinned by
+ *      tests/golden/rel_*.npz (pred_matrix of the reference module).
+ * Build: gcc -O2 -shared -fPIC oracle/c/ref_kernels.c -o oracle/_build/libpvsg_oracle.so -lm
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+void oracle_msda_forward(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
+                         const float* w, float* out, int B, int S, int M, int D, int Lq, int L, int P) {
+  for (int b = 0; b < B; ++b)
+    for (int q = 0; q < Lq; ++q)
+      for (int m = 0; m < M; ++m) {
+        float* o = out + (((int64_t)b * Lq + q) * M + m) * D;
+        for (int d = 0; d < D; ++d) o[d] = 0.f;
+        for (int l = 0; l < L; ++l) {
+          const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+          for (int p = 0; p < P; ++p) {
+            const int64_t li = ((((int64_t)b * Lq + q) * M + m) * L + l) * P + p;
+            const float x = loc[2 * li] * W - 0.5f, y = loc[2 * li + 1] * H - 0.5f;
+            if (!(y > -1 && x > -1 && y < H && x < W)) continue;
+            const int y0 = (int)floorf(y), x0 = (int)floorf(x);
+            const float ly = y - y0, lx = x - x0, hy = 1 - ly, hx = 1 - lx;
+            for (int d = 0; d < D; ++d) {
+              float v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+#define VAL(yy, xx) value[((((int64_t)b * S + lsi[l] + (int64_t)(yy) * W + (xx)) * M) + m) * D + d]
+              if (y0 >= 0 && x0 >= 0) v1 = VAL(y0, x0);
+              if (y0 >= 0 && x0 + 1 <= W - 1) v2 = VAL(y0, x0 + 1);
+              if (y0 + 1 <= H - 1 && x0 >= 0) v3 = VAL(y0 + 1, x0);
+              if (y0 + 1 <= H - 1 && x0 + 1 <= W - 1) v4 = VAL(y0 + 1, x0 + 1);
+#undef VAL
+              o[d] += w[li] * (hy * hx * v1 + hy * lx * v2 + ly * hx * v3 + ly * lx * v4);
+            }
+          }
+        }
+      }
+}
+
+void oracle_pair_score(const float* sub, const float* obj, const float* W1, const float* b1,
+                       const float* w2, const float* b2, float* out, int N, int T, int C, int Hd) {
+  float* st = (float*)malloc(sizeof(float) * (size_t)N * C * 2);
+  float* ot = st + (size_t)N * C;
+  for (int i = 0; i < N; ++i)
+    for (int c = 0; c < C; ++c) {
+      float ms = -INFINITY, mo = -INFINITY;
+      for (int t = 0; t < T; ++t) {
+        const float a = sub[((int64_t)i * T + t) * C + c], b = obj[((int64_t)i * T + t) * C + c];
+        if (a > ms) ms = a;
+        if (b > mo) mo = b;
+      }
+      st[(size_t)i * C + c] = ms;
+      ot[(size_t)i * C + c] = mo;
+    }
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      if (i == j) { out[(size_t)i * N + j] = 0.f; continue; }
+      float acc = b2[0];
+      for (int k = 0; k < Hd; ++k) {
+        float h = b1[k];
+        const float* wr = W1 + (size_t)k * 2 * C;
+        for (int c = 0; c < C; ++c) h += wr[c] * st[(size_t)i * C + c];
+        for (int c = 0; c < C; ++c) h += wr[C + c] * ot[(size_t)j * C + c];
+        if (h > 0) acc += w2[k] * h;
+      }
+      out[(size_t)i * N + j] = acc;
+    }
+  free(st);
+}
