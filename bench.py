@@ -32,6 +32,19 @@ F32_MFMA_PEAK_TF = 157.3     # f32-input MFMA peak
 CLS_GAIN = 40.0              # random-init class logits are flat; peaky logits keep a few queries
 
 
+def host_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box
+    exposes 256 logical CPUs but a 16-CPU quota; 256 torch threads then run 50x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -41,7 +54,7 @@ def parse():
     ap.add_argument('--height', type=int, default=720)
     ap.add_argument('--width', type=int, default=1280)
     ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'off'])
-    ap.add_argument('--cpu-frames', type=int, default=2)
+    ap.add_argument('--cpu-frames', type=int, default=4)
     ap.add_argument('--no-kernel-timing', action='store_true')
     return ap.parse_args()
 
@@ -148,7 +161,7 @@ def cpu_baseline_and_parity(det_gpu, rel_gpu, pipe, args, dev):
     from oracle import pipeline as opipe
     from oracle import relation as orel
     T = args.cpu_frames
-    ncpu = os.cpu_count() or 1
+    ncpu = host_cores()
     torch.set_num_threads(ncpu)
     clip, (Hp, Wp) = make_clip(T, args.height, args.width)
     o = opipe.VPSDetectorOracle(test_cfg=dict(opipe.DEFAULT_TEST_CFG)).eval()
@@ -212,7 +225,7 @@ def main():
         dist.init_process_group('nccl', init_method='env://')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = os.environ.get("PVSG_MIOPEN_FIND", "0") == "1"  # exhaustive MIOpen find costs ~5 min per fresh box
 
     from openpvsg_amd import build
     if rank == 0 and not os.path.exists(build.lib_path()):
@@ -314,7 +327,7 @@ def main():
                 line['parity_on_cpu_sample'] = parity
                 line['speedup_vs_cpu_baseline'] = fps / base['value']
             except Exception as e:  # the bench line must still be printed
-                line['cpu_baseline'] = dict(value=None, unit='frames/s', cores=os.cpu_count(), kind='port',
+                line['cpu_baseline'] = dict(value=None, unit='frames/s', cores=host_cores(), kind='port',
                                             sample='failed: %r' % (e,))
         print(json.dumps(line))
     if world > 1:

@@ -1,0 +1,112 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise the frame sharding, the flag OR, the
+attention-partial exchange + log-sum-exp merge, and the tube-record all-gather (openpvsg_amd/parallel.py).
+The GPU kernels are replaced by their torch statements here; the exchange logic is the product's."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def partial_attention(q, k, v, blocked, honor):
+    """torch statement of xattn_partial_kernel for ONE key range: q (B,M,Q,D) scaled, k/v (B,M,K,D),
+    blocked (B,Q,K) bool, honor (B,Q) bool -> o (B,1,M,Q,D), ml (B,1,M,Q,2)."""
+    s = torch.einsum('bmqd,bmkd->bmqk', q, k)
+    eff = blocked & honor[:, :, None]
+    s = s.masked_fill(eff[:, None], float('-inf'))
+    m = s.max(-1).values
+    p = torch.exp(s - torch.where(torch.isinf(m), torch.zeros_like(m), m)[..., None])
+    p = torch.where(torch.isinf(m)[..., None], torch.zeros_like(p), p)
+    o = torch.einsum('bmqk,bmkd->bmqd', p, v)
+    return o[:, None], torch.stack([m, p.sum(-1)], -1)[:, None]
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from openpvsg_amd import parallel
+    from openpvsg_amd.pipeline import assemble_tubes
+    torch.manual_seed(0)   # same "clip" on every rank
+    B, M, Q, D, T, hw = 1, 8, 20, 32, 4, 6
+    K = T * hw
+    q = torch.randn(B, M, Q, D) * 0.3
+    k, v = torch.randn(B, M, K, D), torch.randn(B, M, K, D)
+    blocked = torch.rand(B, Q, K) < 0.5
+    blocked[0, 3] = True                 # blocked everywhere -> reset: attends to every key
+    blocked[0, 5] = True
+    blocked[0, 5, K - 1] = False         # its only allowed key lives on the LAST rank
+    # ---- frame sharding -------------------------------------------------------------------------
+    t0, tl = parallel.shard_frames(T, rank, world)
+    assert (t0, tl) == (rank * T // world, T // world)
+    with pytest.raises(ValueError):
+        parallel.shard_frames(5, rank, world)
+    ks = slice(t0 * hw, (t0 + tl) * hw)
+    # ---- flags: OR over ranks (NCCL has no BOR -> gather + fold) ---------------------------------
+    local_has = (~blocked[:, :, ks]).any(-1)                               # (B,Q)
+    words = torch.zeros(B, 4, dtype=torch.int32)
+    for qq in range(Q):
+        if local_has[0, qq]:
+            words[0, qq // 32] |= (1 << (qq % 32))
+    allw = parallel.or_flags(words)
+    honor = torch.tensor([[(int(allw[0, qq // 32]) >> (qq % 32)) & 1 for qq in range(Q)]]).bool()
+    assert honor[0, 5] and not honor[0, 3]
+    assert torch.equal(honor, (~blocked).any(-1))
+    # ---- partial exchange + merge ---------------------------------------------------------------
+    po, pml = partial_attention(q, k[:, :, ks], v[:, :, ks], blocked[:, :, ks], honor)
+    go, gml = parallel.all_gather_cat(po, 1), parallel.all_gather_cat(pml, 1)
+    assert go.shape[1] == world
+    merged = parallel.merge_partials_reference(go, gml)                    # (B,Q,M*D)
+    eff = blocked & honor[:, :, None]
+    s = torch.einsum('bmqd,bmkd->bmqk', q, k).masked_fill(eff[:, None], float('-inf'))
+    full = torch.einsum('bmqk,bmkd->bmqd', s.softmax(-1), v).permute(0, 2, 1, 3).reshape(B, Q, M * D)
+    assert torch.allclose(merged, full, rtol=1e-5, atol=1e-6)
+    # ---- tube records: every rank rebuilds the same tubes -----------------------------------------
+    ids_all = torch.tensor([[1005, 120, -1], [1005, -1, 2007], [-1, 120, 2007], [1005, 120, 2007]])
+    feats = torch.arange(3 * 8, dtype=torch.float32).view(3, 8)
+    local = ids_all[t0:t0 + tl]
+    gathered = parallel.all_gather_cat(local, 0)
+    assert torch.equal(gathered, ids_all)
+    tube_ids, tubes = assemble_tubes(list(gathered.unbind(0)), [feats] * T, T)
+    assert tube_ids.tolist() == [1005, 120, 2007]
+    assert tubes.shape == (3, T, 8) and torch.equal(tubes[0, 2], torch.zeros(8)) and torch.equal(tubes[2, 1], feats[2])
+    torch.save(dict(ok=True, merged=merged), os.path.join(tmp, 'r%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchange(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = (torch.load(os.path.join(str(tmp_path), 'r%d.pt' % r)) for r in range(world))
+    assert a['ok'] and b['ok'] and torch.equal(a['merged'], b['merged'])
+
+
+def test_single_process_helpers_are_identity():
+    from openpvsg_amd import parallel
+    x = torch.arange(6).view(2, 3)
+    assert parallel.all_gather_cat(x, 0) is x and parallel.or_flags(x) is x
+    assert parallel.shard_frames(32, 0, 1) == (0, 32) and parallel.shard_frames(32, 3, 8) == (12, 4)
+
+
+def test_merge_reference_handles_empty_ranges():
+    from openpvsg_amd import parallel
+    o = torch.zeros(1, 3, 8, 4, 32)
+    ml = torch.zeros(1, 3, 8, 4, 2)
+    ml[:, 0, ..., 0] = float('-inf')       # an all-blocked range: m=-inf, l=0, o=0
+    o[:, 1] = 2.0
+    ml[:, 1, ..., 1] = 4.0                 # m=0, l=4, o=2  -> 0.5
+    o[:, 2] = 6.0
+    ml[:, 2, ..., 0] = 0.0
+    ml[:, 2, ..., 1] = 4.0
+    out = parallel.merge_partials_reference(o, ml)
+    assert torch.allclose(out, torch.full_like(out, 1.0))
