@@ -113,6 +113,23 @@ int pvsg_pair_score_forward(const float* sub_feats, const float* obj_feats, cons
                             float* tokens_out, float* pair_matrix, int N, int T, int C, int Hd,
                             void* stream);
 
+/* ---- a7 + a8: fused x4 up-sampling + panoptic fusion ---------------
+ * Replaces F.interpolate(mask_pred, batch_input_shape) models/mask2former/mask2former_head.py:675-679
+ * (video_head.py:660-667), the crop at mask2former_fusion_head.py:372-374 and
+ * panoptic_postprocess_with_query mask2former_fusion_head.py:96-171, for T frames that share one
+ * kept-query set (clip mode) or T = 1.
+ *   mask_logits (T, Q, h, w)   last layer's stride-4 logits
+ *   kept_idx / kept_score / kept_class (K)   queries with label != background and score > thr, in
+ *                                            query order; score = softmax max (fusion_head.py:117-120)
+ *   panoptic (T, ih, iw) int32; seg_id (T, K) int32 (-1 = dropped, else class + 1000*instance)
+ *   owner_ws (T*ih*iw) bytes, counter_ws (T*3*128) int32: scratch
+ *   (H, W) = batch_input_shape, (ih, iw) = img_shape crop; second resize to ori_shape NOT included */
+int pvsg_panoptic_fuse(const float* mask_logits, const int* kept_idx, const float* kept_score,
+                       const int* kept_class, int* panoptic, int* seg_id, unsigned char* owner_ws,
+                       int* counter_ws, int T, int Q, int K, int h, int w, int H, int W, int ih, int iw,
+                       int num_things, int num_classes, double iou_thr, int filter_low_score,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

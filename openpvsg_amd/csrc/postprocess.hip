@@ -1,0 +1,158 @@
+// Fused panoptic post-processing: bilinear up-sampling of the stride-4 mask logits to the input
+// size + sigmoid + score*mask argmax over the kept queries + area / low-score filters + segment-id
+// write, without ever materialising the (Q, H, W) up-sampled tensor.
+//
+// Replaces (reference):
+//   F.interpolate(mask_pred, batch_input_shape, bilinear)   models/mask2former/mask2former_head.py:675-679,
+//                                                           models/mask2former_vps/mask2former_video_head.py:660-667
+//   crop to img_shape                                        models/mask2former/mask2former_fusion_head.py:372-374
+//   panoptic_postprocess_with_query                          mask2former_fusion_head.py:96-171
+// (SURVEY.md section 8f row 1).  The reference writes 100*736*1280*4 B = 377 MB per 720p frame and
+// re-reads it >= 4 times, with 3-5 device syncs per kept query; here a frame costs one read of the
+// kept queries' stride-4 logits (<= 23.5 MB, L2 resident) and 5 B per output pixel.
+//
+// Three launches for all T frames of a clip (the kept set is shared by the frames in clip mode):
+//   1 owner      per output pixel: p_k = sigmoid(up4(L_k)), owner = argmax_k s_k p_k (first max wins,
+//                like torch.argmax), conf = p_owner >= 0.5; per-query histograms area[k] (pixels owned),
+//                orig[k] (pixels with p_k >= 0.5), region[k] (owned [and confident if filter_low_score])
+//                via wave ballots + LDS counters + one global atomic per query and block.
+//   2 decide     per frame: ok_k = area>0 && orig>0 && !(area/orig < iou_thr) && region>0 (float64 ratio
+//                as in the Python original); instance ids = running count of accepted THING queries in
+//                query order; seg_id_k = class (+ instance*1000 for things) or -1.
+//   3 paint      panoptic[y,x] = ok[owner] && (conf || !filter) ? seg_id[owner] : num_classes.
+// The up-sampling arithmetic is ATen's upsample_bilinear2d (align_corners=False): src = (dst+0.5)*in/out
+// - 0.5 clamped at 0, i1 = min(i0+1, in-1), and the same association of the four products.
+#include "common.h"
+
+namespace pvsg {
+
+constexpr int MAXK = 128;
+
+__global__ __launch_bounds__(256) void pan_owner_kernel(
+    const float* __restrict__ logits, const int* __restrict__ kept_idx, const float* __restrict__ kept_score,
+    unsigned char* __restrict__ owner_out, int* __restrict__ counters, int Q, int K, int h, int w,
+    int H, int W, int ih, int iw) {
+  __shared__ int s_area[MAXK], s_orig[MAXK], s_region_conf[MAXK];
+  __shared__ int s_idx[MAXK];
+  __shared__ float s_score[MAXK];
+  const int t = blockIdx.z;
+  for (int k = threadIdx.x; k < MAXK; k += blockDim.x) {
+    s_area[k] = 0; s_orig[k] = 0; s_region_conf[k] = 0;
+    if (k < K) { s_idx[k] = kept_idx[k]; s_score[k] = kept_score[k]; }
+  }
+  __syncthreads();
+  // 64 x 4 pixel tile per block: a wave = one 64-pixel row segment (coalesced owner stores)
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const bool inside = x < iw && y < ih;
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  float fy = sy * ((float)y + 0.5f) - 0.5f, fx = sx * ((float)x + 0.5f) - 0.5f;
+  fy = fy < 0.f ? 0.f : fy;
+  fx = fx < 0.f ? 0.f : fx;
+  int y0 = (int)fy, x0 = (int)fx;
+  y0 = y0 > h - 1 ? h - 1 : y0;
+  x0 = x0 > w - 1 ? w - 1 : x0;
+  const int yp = (y0 < h - 1) ? 1 : 0, xp = (x0 < w - 1) ? 1 : 0;
+  const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+  const float* base = logits + (long long)t * Q * h * w + (long long)y0 * w + x0;
+  float best = -1.f;
+  int own = 0;
+  float pown = 0.f;
+  const int lane = threadIdx.x & 63;
+  for (int k = 0; k < K; ++k) {
+    const float* p = base + (long long)s_idx[k] * h * w;
+    float v = 0.f;
+    if (inside)
+      v = ly0 * (lx0 * p[0] + lx1 * p[xp]) + ly1 * (lx0 * p[yp * w] + lx1 * p[yp * w + xp]);
+    const float prob = 1.f / (1.f + expf(-v));
+    const float sc = s_score[k] * prob;
+    if (sc > best) { best = sc; own = k; pown = prob; }
+    const unsigned long long conf = __ballot(inside && prob >= 0.5f);
+    if (lane == 0 && conf) atomicAdd(&s_orig[k], __popcll(conf));
+  }
+  if (inside) {
+    const bool c = pown >= 0.5f;
+    atomicAdd(&s_area[own], 1);
+    if (c) atomicAdd(&s_region_conf[own], 1);
+    owner_out[((long long)t * ih + y) * iw + x] = (unsigned char)(own | (c ? 0x80 : 0));
+  }
+  __syncthreads();
+  int* ct = counters + (long long)t * 3 * MAXK;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    if (s_area[k]) atomicAdd(ct + k, s_area[k]);
+    if (s_orig[k]) atomicAdd(ct + MAXK + k, s_orig[k]);
+    if (s_region_conf[k]) atomicAdd(ct + 2 * MAXK + k, s_region_conf[k]);
+  }
+}
+
+__global__ void pan_decide_kernel(const int* __restrict__ counters, const int* __restrict__ kept_class,
+                                  int* __restrict__ seg_id, int K, int num_things, double iou_thr,
+                                  int filter_low) {
+  const int t = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const int* ct = counters + (long long)t * 3 * MAXK;
+  int inst = 0;
+  for (int k = 0; k < K; ++k) {
+    const int area = ct[k], orig = ct[MAXK + k];
+    const int region = filter_low ? ct[2 * MAXK + k] : area;
+    bool ok = area > 0 && orig > 0;
+    if (ok && ((double)area / (double)orig < iou_thr)) ok = false;
+    if (ok && region <= 0) ok = false;
+    const int cls = kept_class[k];
+    int id = -1;
+    if (ok) {
+      if (cls < num_things) { ++inst; id = cls + inst * 1000; }
+      else id = cls;
+    }
+    seg_id[(long long)t * K + k] = id;
+  }
+}
+
+__global__ __launch_bounds__(256) void pan_paint_kernel(const unsigned char* __restrict__ owner,
+                                                       const int* __restrict__ seg_id,
+                                                       int* __restrict__ panoptic, int K, long long npix,
+                                                       int num_classes, int filter_low) {
+  const int t = blockIdx.y;
+  __shared__ int s_id[MAXK];
+  for (int k = threadIdx.x; k < MAXK; k += blockDim.x) s_id[k] = k < K ? seg_id[(long long)t * K + k] : -1;
+  __syncthreads();
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+       i += (long long)gridDim.x * blockDim.x) {
+    const unsigned char o = owner[(long long)t * npix + i];
+    const int id = s_id[o & 0x7f];
+    const bool paint = id >= 0 && (!filter_low || (o & 0x80));
+    panoptic[(long long)t * npix + i] = paint ? id : num_classes;
+  }
+}
+
+}  // namespace pvsg
+
+extern "C" int pvsg_panoptic_fuse(const float* mask_logits, const int* kept_idx, const float* kept_score,
+                                  const int* kept_class, int* panoptic, int* seg_id,
+                                  unsigned char* owner_ws, int* counter_ws, int T, int Q, int K, int h,
+                                  int w, int H, int W, int ih, int iw, int num_things, int num_classes,
+                                  double iou_thr, int filter_low_score, hipStream_t stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(mask_logits && panoptic && owner_ws && counter_ws, "panoptic_fuse: null pointer argument");
+  PVSG_REQUIRE(T > 0 && Q > 0 && h > 0 && w > 0 && H > 0 && W > 0 && ih > 0 && iw > 0 && ih <= H && iw <= W,
+               "panoptic_fuse: bad geometry (h=%d w=%d H=%d W=%d ih=%d iw=%d)", h, w, H, W, ih, iw);
+  PVSG_REQUIRE(K >= 0 && K <= MAXK - 1, "panoptic_fuse: at most %d kept queries (got %d)", MAXK - 1, K);
+  PVSG_REQUIRE(K == 0 || (kept_idx && kept_score && kept_class && seg_id), "panoptic_fuse: null kept-query tables");
+  const long long npix = (long long)ih * iw;
+  hipError_t e = hipMemsetAsync(counter_ws, 0, (size_t)T * 3 * MAXK * sizeof(int), stream);
+  if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "panoptic_fuse: memset: %s", hipGetErrorString(e));
+  if (K > 0) {
+    hipLaunchKernelGGL(pan_owner_kernel, dim3((iw + 63) / 64, (ih + 3) / 4, T), dim3(256), 0, stream,
+                       mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, H, W, ih, iw);
+    PVSG_LAUNCH_CHECK("panoptic_fuse(owner)");
+    hipLaunchKernelGGL(pan_decide_kernel, dim3(T), dim3(64), 0, stream, counter_ws, kept_class, seg_id, K,
+                       num_things, iou_thr, filter_low_score);
+    PVSG_LAUNCH_CHECK("panoptic_fuse(decide)");
+  }
+  long long nb = (npix + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(pan_paint_kernel, dim3((unsigned)nb, T), dim3(256), 0, stream, owner_ws, seg_id,
+                     panoptic, K, npix, num_classes, filter_low_score);
+  PVSG_LAUNCH_CHECK("panoptic_fuse(paint)");
+  return PVSG_OK;
+}

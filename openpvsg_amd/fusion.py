@@ -14,6 +14,7 @@ from collections import defaultdict
 import torch
 import torch.nn.functional as F
 
+from . import ops
 from .blocks import BaseModule
 from .registry import HEADS
 
@@ -82,6 +83,18 @@ class MaskFormerFusionHeadCustom(BaseModule):
         paint = ok[owner] & region_px.bool()
         seg = torch.where(paint, seg_id[owner].to(torch.int32), seg)
         return seg, seg_id
+
+    def panoptic_fused(self, mask_cls, mask_logits4, batch_input_shape, img_shape):
+        """Fused path (postprocess.hip): class decision here, everything per-pixel in the kernel.
+        mask_cls (Q,classes+1); mask_logits4 (T,Q,h,w) stride-4 logits of T frames that share the
+        class logits -> (panoptic (T,ih,iw) int32, seg_id (T,K) int32, keep (Q,) bool)."""
+        scores, labels, keep = self.panoptic_select(mask_cls)
+        idx = keep.nonzero()[:, 0]
+        pan, seg = ops.panoptic_fuse(mask_logits4, idx, scores[idx], labels[idx], batch_input_shape,
+                                     img_shape[:2], self.num_things_classes, self.num_classes,
+                                     self.test_cfg.get('iou_thr', 0.8),
+                                     self.test_cfg.get('filter_low_score', False))
+        return pan, seg, keep
 
     def panoptic_postprocess_with_query(self, mask_cls, mask_pred, query_feats):
         """mask_cls (Q,classes+1), mask_pred (Q,H,W) logits, query_feats (Q,...) ->

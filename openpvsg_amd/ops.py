@@ -219,3 +219,36 @@ def pair_score(sub_feats, obj_feats, W1, b1, w2, b2, return_tokens=False, W1T=No
                   w2.data_ptr(), b2.data_ptr(), work.data_ptr(), tok.data_ptr() if tok is not None else None,
                   out.data_ptr(), N, T, C, Hd, _stream_ptr())
     return (out, tok) if return_tokens else out
+
+
+def panoptic_fuse(mask_logits, kept_idx, kept_score, kept_class, out_hw, crop_hw, num_things,
+                  num_classes, iou_thr=0.8, filter_low_score=False):
+    """Fused x4 up-sampling + panoptic fusion for T frames sharing one kept-query set.
+
+    mask_logits (T,Q,h,w) stride-4 logits; kept_* (K,) in query order ->
+    (panoptic (T,ih,iw) int32, seg_id (T,K) int32 with -1 for dropped queries)."""
+    x = _chk(mask_logits, 'mask_logits')
+    if x.dim() != 4:
+        raise RuntimeError('panoptic_fuse: mask_logits must be (T,Q,h,w)')
+    T, Q, h, w = x.shape
+    K = int(kept_idx.numel())
+    H, W = int(out_hw[0]), int(out_hw[1])
+    ih, iw = int(crop_hw[0]), int(crop_hw[1])
+    dev = x.device
+    pan = torch.empty((T, ih, iw), device=dev, dtype=torch.int32)
+    seg = torch.empty((T, K), device=dev, dtype=torch.int32)
+    owner = torch.empty((T * ih * iw,), device=dev, dtype=torch.uint8)
+    counters = torch.empty((T * 3 * 128,), device=dev, dtype=torch.int32)
+    if K:
+        ki = _chk(kept_idx.to(torch.int32), 'kept_idx', torch.int32)
+        ks = _chk(kept_score, 'kept_score')
+        kc = _chk(kept_class.to(torch.int32), 'kept_class', torch.int32)
+        ptrs = (ki.data_ptr(), ks.data_ptr(), kc.data_ptr())
+    else:
+        ptrs = (None, None, None)
+    with torch.cuda.device(dev):
+        _lib.call('pvsg_panoptic_fuse', x.data_ptr(), ptrs[0], ptrs[1], ptrs[2], pan.data_ptr(),
+                  seg.data_ptr() if K else None, owner.data_ptr(), counters.data_ptr(), T, Q, K, h, w, H, W,
+                  ih, iw, int(num_things), int(num_classes), float(iou_thr), int(bool(filter_low_score)),
+                  _stream_ptr())
+    return pan, seg

@@ -45,8 +45,9 @@ class PVSGPipeline(torch.nn.Module):
     """detector (clip-level VPS) + fusion post-processing per frame + tube assembly + relation head."""
 
     def __init__(self, detector, subject_encoder, object_encoder, pair_model, relation_model,
-                 num_top_pairs=100):
+                 num_top_pairs=100, fused_postprocess=True):
         super().__init__()
+        self.fused_postprocess = fused_postprocess
         self.detector = detector
         self.subject_encoder, self.object_encoder = subject_encoder, object_encoder
         self.pair_model, self.relation_model = pair_model, relation_model
@@ -70,6 +71,11 @@ class PVSGPipeline(torch.nn.Module):
                 shard.release()
         H, W = batch_input_shape
         ih, iw = (img_shape or batch_input_shape)[:2]
+        if self.fused_postprocess:
+            pans, seg, keep = fusion.panoptic_fused(cls[0], masks4[0], (H, W), (ih, iw))
+            seg_ids = list(seg.to(torch.long).unbind(0))
+            k_feats = q[:, 0][keep]
+            return pans, seg_ids, [k_feats] * T, cls, q
         scores, labels, keep = fusion.panoptic_select(cls[0])
         k_scores, k_classes = scores[keep], labels[keep]
         k_feats = q[:, 0][keep]
