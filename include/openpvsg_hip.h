@@ -130,6 +130,21 @@ int pvsg_panoptic_fuse(const float* mask_logits, const int* kept_idx, const floa
                        int num_things, int num_classes, double iou_thr, int filter_low_score,
                        void* stream);
 
+/* ---- a1/a2 fused forms used inside the pixel decoder ------------------------------------------
+ * pvsg_msda_fused_forward: [3P] MultiScaleDeformableAttention.forward steps 4-6 (softmax over the
+ * L*P logits, loc = ref + off/(W_l,H_l), sampling) from the raw projection outputs:
+ *   value (B, S, 256) with row stride value_row_stride floats; oa (B, Lq, 288) raw [offsets(192) |
+ *   logits(96)] with row stride oa_row_stride; pos_oa (Lq, 288) additive term or NULL;
+ *   ref_points (Lq, 2) normalised (x, y), shared by the levels (valid_ratios = 1);  M=8 D=32 L=3 P=4.
+ * pvsg_add_layernorm: out = LayerNorm_256(a + b + bias) (b, bias optional): the residual add +
+ *   norm pair of BaseTransformerLayer in one pass. */
+int pvsg_msda_fused_forward(const float* value, long long value_row_stride, const float* oa,
+                            long long oa_row_stride, const float* pos_oa, const float* ref_points,
+                            const int64_t* spatial_shapes, const int64_t* level_start_index, float* out,
+                            int B, int S, int M, int D, int Lq, int L, int P, void* stream);
+int pvsg_add_layernorm(const float* a, const float* b, const float* bias, const float* gamma,
+                       const float* beta, float* out, long long rows, int C, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

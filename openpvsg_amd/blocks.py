@@ -522,6 +522,42 @@ class MSDeformAttnPixelDecoder(BaseModule):
             self._geom[key] = (pos, ref.contiguous(), ss, lsi)
         return self._geom[key]
 
+    fuse_encoder = True
+
+    def _fusable(self, layer, x):
+        a = layer.attentions[0]
+        return (self.fuse_encoder and x.is_cuda and not torch.is_grad_enabled() and
+                layer.operation_order == ('self_attn', 'norm', 'ffn', 'norm') and
+                isinstance(a, MultiScaleDeformableAttention) and a.embed_dims == 256 and a.num_heads == 8 and
+                a.num_levels == 3 and a.num_points == 4 and len(layer.ffns[0].layers) == 3 and
+                layer.ffns[0].add_identity)
+
+    @staticmethod
+    def _encoder_layer_fused(layer, x, pos, ref2d, ss, lsi):
+        """One encoder layer in 4 GEMMs + 3 fused kernels (same arithmetic as the generic path up to fp32
+        re-association):
+          (x+pos) W_oa = x W_oa + pos W_oa           -> ONE projection GEMM x [Wv|Woff|Watt]^T, the
+                                                        position term is a small per-layer (S,288) table
+          softmax / loc / sampling                   -> msda_fused kernel (no offsets/weights/locations in HBM)
+          output_proj, + identity, LayerNorm         -> GEMM + add_layernorm kernel
+          FFN: Linear+ReLU fused epilogue, Linear, + identity, LayerNorm -> 2 GEMMs + add_layernorm"""
+        a = layer.attentions[0]
+        w_oa = torch.cat([a.sampling_offsets.weight, a.attention_weights.weight], 0)
+        b_oa = torch.cat([a.sampling_offsets.bias, a.attention_weights.bias], 0)
+        pos_oa = F.linear(pos, w_oa, b_oa)                                     # (S, 288)
+        w_cat = torch.cat([a.value_proj.weight, w_oa], 0)                      # (544, 256)
+        b_cat = torch.cat([a.value_proj.bias, torch.zeros_like(b_oa)], 0)
+        y = F.linear(x, w_cat, b_cat)                                          # (B, S, 544)
+        core = ops.msda_fused(y, pos_oa, ref2d, ss, lsi)
+        t = F.linear(core, a.output_proj.weight)
+        x = ops.add_layernorm(t, x, a.output_proj.bias, layer.norms[0])
+        ffn = layer.ffns[0]
+        fc1, fc2 = ffn.layers[0][0], ffn.layers[1]
+        B, S, C = x.shape
+        h = torch._addmm_activation(fc1.bias, x.view(B * S, C), fc1.weight.t())   # bias + ReLU epilogue
+        t = F.linear(h, fc2.weight).view(B, S, C)
+        return ops.add_layernorm(t, x, fc2.bias, layer.norms[1])
+
     def forward(self, feats):
         B = feats[0].shape[0]
         shapes = [tuple(feats[self.num_input_levels - 1 - i].shape[-2:]) for i in range(self.num_encoder_levels)]
@@ -535,6 +571,9 @@ class MSDeformAttnPixelDecoder(BaseModule):
         pos = torch.cat(pos, 0)[None]                                           # (1, S, C)
         for layer in self.encoder.layers:
             # BaseTransformerLayer ('self_attn','norm','ffn','norm') on batch-first tensors
+            if self._fusable(layer, x):
+                x = self._encoder_layer_fused(layer, x, pos[0], ref[0, :, 0].contiguous(), ss, lsi)
+                continue
             x = layer.attentions[0].forward_bsc(x, pos, ref, ss, lsi)
             x = layer.norms[0](x)
             x = layer.ffns[0](x)

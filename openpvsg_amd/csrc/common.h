@@ -50,6 +50,18 @@ __device__ __forceinline__ void st4(float* p, float4 v) {
   *reinterpret_cast<float4*>(p) = v;
 }
 
+// streaming (touched once) operands: non-temporal so they do not evict the gathered rows from L2
+__device__ __forceinline__ float4 ld4_stream(const float* p) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const v4 t = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void st4_stream(float* p, float4 v) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  v4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<v4*>(p));
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

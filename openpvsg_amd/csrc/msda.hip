@@ -199,3 +199,176 @@ extern "C" int pvsg_ms_deform_attn_forward(const float* value, const int64_t* sp
   PVSG_LAUNCH_CHECK("ms_deform_attn_forward");
   return PVSG_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Fused form used by the pixel decoder (a1 + the elementwise work around it):
+//   inputs are the RAW outputs of ONE projection GEMM per layer,  y = x [Wv | Woff | Watt]^T :
+//     value      = y[..., 0:256]            (row stride = 544 floats: no copy)
+//     oa         = y[..., 256:544] + pos_oa (pos_oa = pos [Woff | Watt]^T + b, cached per layer/shape)
+//   the kernel does the softmax over the 12 (level, point) logits of its head, forms
+//   loc = ref + off / (W_l, H_l) and samples -- i.e. mmcv MultiScaleDeformableAttention.forward
+//   steps 4-6 without materialising offsets, weights or locations
+//   (1.2 KB/query written + read by the un-fused path) and without the `query + query_pos` pass.
+// ------------------------------------------------------------------------------------------------
+namespace pvsg {
+
+template <int L, int P>
+__global__ __launch_bounds__(256) void msda_fused_m8d32(
+    const float* __restrict__ value, long long value_stride, const float* __restrict__ oa,
+    long long oa_stride, const float* __restrict__ pos_oa, const float* __restrict__ ref,
+    const long long* __restrict__ shapes, const long long* __restrict__ lsi, float* __restrict__ out,
+    int S, int Lq, long long nq_total, unsigned nblk) {
+  constexpr int M = 8, D = 32, LP = L * P;
+  const unsigned lb = xcd_contiguous_block(blockIdx.x, nblk);
+  const long long gq = (long long)lb * 4 + (threadIdx.x >> 6);
+  if (gq >= nq_total) return;
+  const int lane = threadIdx.x & 63;
+  const int m = lane >> 3, c4 = lane & 7;
+  const int b = (int)(gq / Lq);
+  const int q = (int)(gq - (long long)b * Lq);
+
+  const float* offp = oa + gq * oa_stride + m * (LP * 2);
+  const float* logp = oa + gq * oa_stride + M * LP * 2 + m * LP;
+  const float* poff = pos_oa ? pos_oa + (long long)q * (M * LP * 3) + m * (LP * 2) : nullptr;
+  const float* plog = pos_oa ? pos_oa + (long long)q * (M * LP * 3) + M * LP * 2 + m * LP : nullptr;
+  float ox[LP], oy[LP], aw[LP];
+#pragma unroll
+  for (int i = 0; i < LP / 2; ++i) {
+    float4 t = ld4_stream(offp + 4 * i);
+    if (poff) { const float4 u = ld4(poff + 4 * i); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    ox[2 * i] = t.x; oy[2 * i] = t.y; ox[2 * i + 1] = t.z; oy[2 * i + 1] = t.w;
+  }
+#pragma unroll
+  for (int i = 0; i < LP / 4; ++i) {
+    float4 t = ld4_stream(logp + 4 * i);
+    if (plog) { const float4 u = ld4(plog + 4 * i); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    aw[4 * i] = t.x; aw[4 * i + 1] = t.y; aw[4 * i + 2] = t.z; aw[4 * i + 3] = t.w;
+  }
+  // softmax over the head's L*P logits
+  float mx = aw[0];
+#pragma unroll
+  for (int i = 1; i < LP; ++i) mx = fmaxf(mx, aw[i]);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) { aw[i] = __expf(aw[i] - mx); sum += aw[i]; }
+  const float inv = 1.f / sum;
+  const float rx = ref[2 * q], ry = ref[2 * q + 1];
+  const float* vbase = value + (long long)b * S * value_stride + m * D + c4 * 4;
+
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const float* vl = vbase + lsi[l] * value_stride;
+    const float invW = 1.f / (float)W, invH = 1.f / (float)H;   // wave-uniform reciprocals
+    float4 v[P][4];
+    float cw[P][4];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float locx = rx + ox[l * P + p] * invW, locy = ry + oy[l * P + p] * invH;
+      const float him = locy * (float)H - 0.5f, wim = locx * (float)W - 0.5f;
+      const float hf = floorf(him), wf = floorf(wim);
+      const float lh = him - hf, lw = wim - wf, hh = 1.f - lh, hw = 1.f - lw;
+      const float hfc = fminf(fmaxf(hf, -2.f), (float)H + 1.f);
+      const float wfc = fminf(fmaxf(wf, -2.f), (float)W + 1.f);
+      const int h0 = (int)hfc, w0 = (int)wfc, h1 = h0 + 1, w1 = w0 + 1;
+      const bool inside = (him > -1.f) && (wim > -1.f) && (him < (float)H) && (wim < (float)W);
+      const bool vh0 = inside && h0 >= 0, vh1 = inside && h1 <= H - 1;
+      const bool vw0 = w0 >= 0, vw1 = w1 <= W - 1;
+      const int h0c = min(max(h0, 0), H - 1), h1c = min(max(h1, 0), H - 1);
+      const int w0c = min(max(w0, 0), W - 1), w1c = min(max(w1, 0), W - 1);
+      cw[p][0] = (vh0 && vw0) ? hh * hw : 0.f;
+      cw[p][1] = (vh0 && vw1) ? hh * lw : 0.f;
+      cw[p][2] = (vh1 && vw0) ? lh * hw : 0.f;
+      cw[p][3] = (vh1 && vw1) ? lh * lw : 0.f;
+      v[p][0] = ld4(vl + (long long)(h0c * W + w0c) * value_stride);
+      v[p][1] = ld4(vl + (long long)(h0c * W + w1c) * value_stride);
+      v[p][2] = ld4(vl + (long long)(h1c * W + w0c) * value_stride);
+      v[p][3] = ld4(vl + (long long)(h1c * W + w1c) * value_stride);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float a = aw[l * P + p] * inv;
+      float4 s;
+      s.x = cw[p][0] * v[p][0].x + cw[p][1] * v[p][1].x + cw[p][2] * v[p][2].x + cw[p][3] * v[p][3].x;
+      s.y = cw[p][0] * v[p][0].y + cw[p][1] * v[p][1].y + cw[p][2] * v[p][2].y + cw[p][3] * v[p][3].y;
+      s.z = cw[p][0] * v[p][0].z + cw[p][1] * v[p][1].z + cw[p][2] * v[p][2].z + cw[p][3] * v[p][3].z;
+      s.w = cw[p][0] * v[p][0].w + cw[p][1] * v[p][1].w + cw[p][2] * v[p][2].w + cw[p][3] * v[p][3].w;
+      acc.x += a * s.x; acc.y += a * s.y; acc.z += a * s.z; acc.w += a * s.w;
+    }
+  }
+  st4_stream(out + gq * (M * D) + m * D + c4 * 4, acc);
+}
+
+// out = LayerNorm(a + b + bias) * gamma + beta over the last dim C = 256; one wave per row.
+__global__ __launch_bounds__(256) void add_layernorm256_kernel(
+    const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out,
+    long long rows, float eps) {
+  const int lane = threadIdx.x & 63;
+  const float4 g = ld4(gamma + lane * 4), be = ld4(beta + lane * 4);
+  float4 bi = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) bi = ld4(bias + lane * 4);
+  for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+    float4 x = ld4(a + row * 256 + lane * 4);
+    if (b) { const float4 y = ld4(b + row * 256 + lane * 4); x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w; }
+    x.x += bi.x; x.y += bi.y; x.z += bi.z; x.w += bi.w;
+    float s = x.x + x.y + x.z + x.w;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s * (1.f / 256.f);
+    const float dx = x.x - mean, dy = x.y - mean, dz = x.z - mean, dw = x.w - mean;
+    float v = dx * dx + dy * dy + dz * dz + dw * dw;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    const float rstd = rsqrtf(v * (1.f / 256.f) + eps);
+    st4(out + row * 256 + lane * 4,
+        make_float4(dx * rstd * g.x + be.x, dy * rstd * g.y + be.y, dz * rstd * g.z + be.z, dw * rstd * g.w + be.w));
+  }
+}
+
+}  // namespace pvsg
+
+extern "C" int pvsg_msda_fused_forward(const float* value, long long value_row_stride, const float* oa,
+                                       long long oa_row_stride, const float* pos_oa, const float* ref_points,
+                                       const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                       float* out, int B, int S, int M, int D, int Lq, int L, int P,
+                                       hipStream_t stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(value && oa && ref_points && spatial_shapes && level_start_index && out,
+               "msda_fused_forward: null pointer argument");
+  PVSG_REQUIRE(B > 0 && S > 0 && Lq > 0, "msda_fused_forward: non-positive dimension");
+  if (M != 8 || D != 32 || L != 3 || P != 4)
+    return set_err(PVSG_ERR_UNSUPPORTED, "msda_fused_forward: built for M=8 D=32 L=3 P=4 (got %d %d %d %d)", M, D, L, P);
+  PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(oa) |
+                  reinterpret_cast<uintptr_t>(pos_oa) | reinterpret_cast<uintptr_t>(out)) & 15u) &&
+               !(value_row_stride & 3) && !(oa_row_stride & 3) && value_row_stride >= M * D,
+               "msda_fused_forward: 16-byte alignment / row strides multiple of 4 floats required");
+  const long long nq = (long long)B * Lq;
+  const long long nblk_ll = (nq + 3) / 4;
+  PVSG_REQUIRE(nblk_ll < (1ll << 31), "msda_fused_forward: too many queries");
+  const unsigned nblk = (unsigned)nblk_ll;
+  hipLaunchKernelGGL((msda_fused_m8d32<3, 4>), dim3(nblk), dim3(256), 0, stream, value, value_row_stride, oa,
+                     oa_row_stride, pos_oa, ref_points, reinterpret_cast<const long long*>(spatial_shapes),
+                     reinterpret_cast<const long long*>(level_start_index), out, S, Lq, nq, nblk);
+  PVSG_LAUNCH_CHECK("msda_fused_forward");
+  return PVSG_OK;
+}
+
+extern "C" int pvsg_add_layernorm(const float* a, const float* b, const float* bias, const float* gamma,
+                                  const float* beta, float* out, long long rows, int C, float eps,
+                                  hipStream_t stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(a && gamma && beta && out, "add_layernorm: null pointer argument");
+  PVSG_REQUIRE(rows > 0, "add_layernorm: no rows");
+  if (C != 256) return set_err(PVSG_ERR_UNSUPPORTED, "add_layernorm: built for 256 channels (got %d)", C);
+  PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out) |
+                  reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(gamma) |
+                  reinterpret_cast<uintptr_t>(beta)) & 15u), "add_layernorm: 16-byte alignment required");
+  long long nb = (rows + 3) / 4;
+  if (nb > 256 * 16) nb = 256 * 16;
+  hipLaunchKernelGGL(add_layernorm256_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a, b, bias, gamma, beta,
+                     out, rows, eps);
+  PVSG_LAUNCH_CHECK("add_layernorm");
+  return PVSG_OK;
+}

@@ -252,3 +252,35 @@ def panoptic_fuse(mask_logits, kept_idx, kept_score, kept_class, out_hw, crop_hw
                   ih, iw, int(num_things), int(num_classes), float(iou_thr), int(bool(filter_low_score)),
                   _stream_ptr())
     return pan, seg
+
+
+def msda_fused(y, pos_oa, ref_points, spatial_shapes, level_start_index, num_heads=8, num_levels=3,
+               num_points=4):
+    """Fused MSDA from ONE projection output y (B,S,256+288) = x [Wv|Woff|Watt]^T (+ value bias):
+    value = y[..., :256] (strided view, no copy), raw offsets/logits = y[..., 256:] + pos_oa (S,288)."""
+    y = _chk(y, 'y')
+    B, S, W = y.shape
+    C = W - num_heads * num_levels * num_points * 3
+    pos = _chk(pos_oa, 'pos_oa') if pos_oa is not None else None
+    ref = _chk(ref_points, 'ref_points')
+    ss = _chk(spatial_shapes, 'spatial_shapes', torch.int64)
+    lsi = _chk(level_start_index, 'level_start_index', torch.int64)
+    out = torch.empty((B, S, C), device=y.device, dtype=torch.float32)
+    with torch.cuda.device(y.device):
+        _lib.call('pvsg_msda_fused_forward', y.data_ptr(), W, y.data_ptr() + 4 * C, W,
+                  pos.data_ptr() if pos is not None else None, ref.data_ptr(), ss.data_ptr(), lsi.data_ptr(),
+                  out.data_ptr(), B, S, num_heads, C // num_heads, S, num_levels, num_points, _stream_ptr())
+    return out
+
+
+def add_layernorm(a, b, bias, norm):
+    """LayerNorm(a + b + bias) with `norm` an nn.LayerNorm(256): residual add + norm in one pass."""
+    a = _chk(a, 'a')
+    b = _chk(b, 'b') if b is not None else None
+    out = torch.empty_like(a)
+    rows = a.numel() // a.shape[-1]
+    with torch.cuda.device(a.device):
+        _lib.call('pvsg_add_layernorm', a.data_ptr(), b.data_ptr() if b is not None else None,
+                  bias.data_ptr() if bias is not None else None, norm.weight.data_ptr(), norm.bias.data_ptr(),
+                  out.data_ptr(), rows, a.shape[-1], float(norm.eps), _stream_ptr())
+    return out

@@ -1,0 +1,55 @@
+"""Fused pixel-decoder encoder layer (one projection GEMM + msda_fused + add_layernorm kernels)
+against the generic path and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import blocks3p
+from oracle.detweights import det_input, det_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def test_add_layernorm(hip_lib):
+    from openpvsg_amd import ops
+    a, b, bias = det_input('a', (3, 37, 256), 1), det_input('b', (3, 37, 256), 2), det_input('bias', (256,), 3)
+    ln = torch.nn.LayerNorm(256)
+    ln.load_state_dict(det_state_dict(ln, 1))
+    ref, ref2 = ln(a + b + bias).detach(), ln(a).detach()
+    lnd = ln.to(DEV)
+    out = ops.add_layernorm(a.to(DEV), b.to(DEV), bias.to(DEV), lnd)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    out2 = ops.add_layernorm(a.to(DEV), None, None, lnd)
+    np.testing.assert_allclose(out2.cpu().numpy(), ref2.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('B,shapes', [(2, ((2, 3), (4, 6), (8, 12))), (1, ((23, 40), (46, 80), (92, 160)))])
+def test_pixel_decoder_fused_equals_generic_and_oracle(hip_lib, B, shapes):
+    from openpvsg_amd import blocks  # noqa: F401
+    from openpvsg_amd.model_zoo import panoptic_head_cfg
+    from openpvsg_amd.registry import build_plugin_layer
+    cfg = dict(panoptic_head_cfg(False)['pixel_decoder'], in_channels=[256, 512, 1024, 2048], feat_channels=256,
+               out_channels=256)
+    pd = build_plugin_layer(cfg)[1].eval()
+    sd = det_state_dict(pd, 5)
+    pd.load_state_dict(sd)
+    o = blocks3p.MSDeformAttnPixelDecoder().eval()
+    o.load_state_dict(sd)
+    hw4 = (shapes[2][0] * 2, shapes[2][1] * 2)
+    feats = [det_input('f%d' % i, (B, c) + hw, 5) for i, (c, hw) in
+             enumerate(zip((256, 512, 1024, 2048), (hw4, shapes[2], shapes[1], shapes[0])))]
+    with torch.no_grad():
+        mf_ref, mem_ref = o(feats)
+        pd = pd.to(DEV)
+        fd = [f.to(DEV) for f in feats]
+        pd.fuse_encoder = True
+        mf_a, mem_a = pd(fd)
+        pd.fuse_encoder = False
+        mf_b, mem_b = pd(fd)
+    scale = float(mf_ref.abs().max())
+    np.testing.assert_allclose(mf_a.cpu().numpy(), mf_ref.numpy(), rtol=1e-3, atol=1e-4 * scale)
+    np.testing.assert_allclose(mf_b.cpu().numpy(), mf_ref.numpy(), rtol=1e-3, atol=1e-4 * scale)
+    for a, b, r in zip(mem_a, mem_b, mem_ref):
+        np.testing.assert_allclose(a.cpu().numpy(), r.numpy(), rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(b.cpu().numpy(), r.numpy(), rtol=1e-3, atol=1e-4)
