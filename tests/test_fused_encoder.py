@@ -53,3 +53,31 @@ def test_pixel_decoder_fused_equals_generic_and_oracle(hip_lib, B, shapes):
     for a, b, r in zip(mem_a, mem_b, mem_ref):
         np.testing.assert_allclose(a.cpu().numpy(), r.numpy(), rtol=1e-3, atol=1e-4)
         np.testing.assert_allclose(b.cpu().numpy(), r.numpy(), rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize('B,h0w0,scale', [(2, (2, 3), 1.0), (1, (5, 7), 8.0), (3, (23, 40), 3.0), (1, (3, 4), 40.0)])
+def test_msda_fused_equals_oracle(hip_lib, B, h0w0, scale):
+    """Fused kernel (softmax + location math in-kernel, strided value rows) vs the oracle's explicit
+    softmax / locations + grid_sample, including offsets far outside the image (zero padding)."""
+    from openpvsg_amd import ops
+    shapes = [(h0w0[0] << i, h0w0[1] << i) for i in range(3)]
+    S = sum(h * w for h, w in shapes)
+    y = det_input('y', (B, S, 544), 3)
+    y[..., 256:448] *= scale
+    pos_oa = det_input('pos_oa', (S, 288), 4, 0.3)
+    refs = []
+    for h, w in shapes:
+        ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing='ij')
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    ref = torch.cat(refs, 0)
+    ss = torch.tensor(shapes, dtype=torch.long)
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    oa = y[..., 256:] + pos_oa[None]
+    off = oa[..., :192].reshape(B, S, 8, 3, 4, 2)
+    w = oa[..., 192:].reshape(B, S, 8, 12).softmax(-1).reshape(B, S, 8, 3, 4)
+    norm = torch.stack([ss[:, 1], ss[:, 0]], -1).float()
+    loc = ref[None, :, None, None, None, :] + off / norm[None, None, None, :, None, :]
+    expect = blocks3p.msda_core_grid_sample(y[..., :256].reshape(B, S, 8, 32).contiguous(), shapes, loc, w)
+    a = ops.msda_fused(y.to(DEV), pos_oa.to(DEV), ref.to(DEV), ss.to(DEV), lsi.to(DEV))
+    sc = float(expect.abs().max())
+    np.testing.assert_allclose(a.cpu().numpy(), expect.numpy(), rtol=1e-4, atol=2e-5 * sc)
