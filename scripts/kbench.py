@@ -43,12 +43,6 @@ def bench_msda(frames):
     ms = timeit(lambda: ops.ms_deform_attn_forward(v, ss, lsi, loc, w))
     alg = 4 * (2 * S * 256 + 3 * S * M * L * P) * B
     print(json.dumps(dict(kernel='msda', frames=B, ms=ms, alg_bytes=alg, GBps=alg / ms / 1e6)))
-    y = torch.randn(B, S, 544, generator=g).to(dev)
-    pos_oa = torch.randn(S, 288, generator=g).to(dev) * 0.1
-    ref2 = ref[0, :, 0, 0, 0, :].contiguous().to(dev)
-    ms = timeit(lambda: ops.msda_fused(y, pos_oa, ref2, ss, lsi))
-    algf = 4 * (2 * S * 256 + S * 288) * B + 4 * S * 288
-    print(json.dumps(dict(kernel='msda_fused', frames=B, ms=ms, alg_bytes=algf, GBps=algf / ms / 1e6)))
     # fused form: y = [value | raw offsets | raw logits]
     y = torch.randn(B, S, 544, generator=g).to(dev)
     y[..., 256:448] *= 2.0
