@@ -56,6 +56,8 @@ def parse():
     ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'off'])
     ap.add_argument('--cpu-frames', type=int, default=4)
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='nccl (= RCCL over xGMI); gloo only for same-device logic tests')
+    ap.add_argument('--checksum', action='store_true', help='add a result checksum (sharding-invariance check)')
     return ap.parse_args()
 
 
@@ -222,7 +224,9 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', init_method='env://')
+        dist.init_process_group(args.backend, init_method='env://')
+    if os.environ.get('PVSG_ONE_DEVICE') == '1':   # logic test: every rank on GPU 0 (gloo backend)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     torch.backends.cudnn.benchmark = os.environ.get("PVSG_MIOPEN_FIND", "0") == "1"  # exhaustive MIOpen find costs ~5 min per fresh box
@@ -291,6 +295,15 @@ def main():
                        'weights': 'random init seed 0 (cls logits x%g so that some queries pass score>0.8)' % CLS_GAIN,
                        'tubes': int(out['tube_feats'].shape[0]), 'parallelism': 'frame-shard x%d' % world},
         }
+        if args.checksum:
+            pans = out['pan_results']
+            line['checksum'] = dict(pan_local_sum=int(pans.to(torch.int64).sum().item()),
+                                    pan_local_frames=int(pans.shape[0]),
+                                    tube_ids=out['tube_ids'].tolist(),
+                                    tube_feat_sum=float(out['tube_feats'].double().sum().item()),
+                                    query_sum=float(out['query'].double().sum().item()),
+                                    pair_sum=float(out['relation']['pred_matrix'].double().sum().item())
+                                    if out['relation'] is not None else None)
         if timer.records:
             agg = timer.summary()
             kern = {}

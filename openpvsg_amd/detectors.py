@@ -45,6 +45,7 @@ class _Base(BaseModule):
         self.num_stuff_classes = self.panoptic_head.num_stuff_classes
         self.num_classes = self.panoptic_head.num_classes
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.fused_postprocess = True
 
     @property
     def with_neck(self):
@@ -91,10 +92,31 @@ class Mask2FormerCustom(_Base):
             meta['batch_input_shape'] = tuple(imgs.shape[-2:])
         return self.simple_test(imgs, img_metas, **kwargs)
 
-    def simple_test(self, imgs, img_metas, **kwargs):
+    def _fused_ok(self, metas, rescale):
+        """Fused up-sample + panoptic kernel applies when the map is produced at img_shape (no second
+        resize to a different ori_shape) and only panoptic output is requested."""
+        cfg = self.panoptic_fusion_head.test_cfg
+        if cfg.get('instance_on', False) or cfg.get('semantic_on', False) or not cfg.get('panoptic_on', True):
+            return False
+        return all((not rescale) or tuple(m['ori_shape'][:2]) == tuple(m['img_shape'][:2]) for m in metas)
+
+    def simple_test(self, imgs, img_metas, rescale=False, **kwargs):
         feats = self.extract_feat(imgs)
+        if self.fused_postprocess and self._fused_ok(img_metas, rescale) and len(img_metas) == 1:
+            # one image per call (the reference's own limit, SURVEY.md section 3.1 quirk)
+            head, fusion = self.panoptic_head, self.panoptic_fusion_head
+            cls_list, mask_list, q = head._decode(feats, 1, 1, all_masks=False)
+            pan, seg, keep = fusion.panoptic_fused(cls_list[-1][0], mask_list[-1], img_metas[0]['batch_input_shape'],
+                                                   img_metas[0]['img_shape'])
+            kf = q[:, 0][keep]
+            qd = {}
+            for i, sid in enumerate(seg[0].tolist()):
+                if sid >= 0:
+                    qd.setdefault(sid, []).append(kf[i][None])      # (1, C) as the reference's query_feat_k
+            return [self._finish(dict(pan_results=pan[0], query_feats=qd), self.num_things_classes)]
         cls, masks, qf = self.panoptic_head.simple_test_with_query(feats, img_metas, **kwargs)
-        results = self.panoptic_fusion_head.simple_test_with_query(cls, masks, qf, img_metas, **kwargs)
+        results = self.panoptic_fusion_head.simple_test_with_query(cls, masks, qf, img_metas, rescale=rescale,
+                                                                   **kwargs)
         results = [self._finish(r, self.num_things_classes) for r in results]
         if self.num_stuff_classes == 0:
             results = [r['ins_results'] for r in results]
@@ -132,9 +154,30 @@ class Mask2FormerVideoCustom(_Base):
         kw = {k: v for k, v in kwargs.items() if k not in ('ref_img', 'ref_img_metas')}
         return self.simple_test(imgs, img_metas, ref_img, ref_metas, **kw)
 
-    def simple_test(self, img, img_metas, ref_img, ref_img_metas, **kwargs):
+    def simple_test(self, img, img_metas, ref_img, ref_img_metas, rescale=False, **kwargs):
+        kwargs['rescale'] = rescale
         bs, T = ref_img.shape[:2]
         feats = self.extract_feat(ref_img.reshape((bs * T,) + tuple(ref_img.shape[2:])))
+        flat_metas = [m for per_video in ref_img_metas for m in per_video]
+        if (self.inference_mode == 'clip' and self.fused_postprocess and bs == 1 and
+                Mask2FormerCustom._fused_ok(self, flat_metas, rescale) and
+                len({tuple(m['img_shape'][:2]) for m in flat_metas}) == 1):
+            # all frames of the clip share the class logits -> one fused up-sample + panoptic launch set
+            head, fusion = self.panoptic_head, self.panoptic_fusion_head
+            cls, masks4, q = head.clip_logits(feats, 1, T)
+            pan, seg, keep = fusion.panoptic_fused(cls[0], masks4[0], flat_metas[0]['batch_input_shape'],
+                                                   flat_metas[0]['img_shape'])
+            kf = q[:, 0][keep]
+            pan_np, seg_l = pan.cpu().numpy(), seg.tolist()
+            kf_np = kf.detach().cpu().numpy()
+            out = []
+            for t in range(T):
+                qd = {}
+                for i, sid in enumerate(seg_l[t]):
+                    if sid >= 0:
+                        qd.setdefault(sid, []).append(kf_np[i])
+                out.append(dict(pan_results=pan_np[t], query_feats=qd))
+            return [out]
         if self.inference_mode == 'clip':
             cls, masks, q = self.panoptic_head.simple_test_with_query(feats, ref_img_metas, **kwargs)
             logits, embds = cls, q.permute(1, 0, 2)                    # (bs,Q,C+1), (bs,Q,C)

@@ -255,3 +255,42 @@ def test_relation_pipeline_vs_reference_golden(hip_lib, golden_dir, name, models
                             for K in K_values])
             np.testing.assert_allclose(got, g['%s_metrics_%s' % (mname, strat)], rtol=0, atol=1e-3)
             assert abs(prl[0] - float(g[mname + '_pair_recall20'])) <= 1e-3
+
+
+def test_detectors_fused_postprocess_path(hip_lib):
+    """panoptic-only test_cfg and ori_shape == img_shape -> the detectors use the fused up-sample +
+    panoptic kernel; results must match the oracle's reference flow."""
+    seed, T = 6, 3
+    gains = {'cls_embed.weight': 40.0, 'query_feat.weight': 30.0}
+    m = build_detector(True, seed, gains, 'clip')
+    m.panoptic_fusion_head.test_cfg = dict(m.panoptic_fusion_head.test_cfg, instance_on=False)
+    o = opipe.VPSDetectorOracle().eval()
+    o.load_state_dict(det_state_dict(o, seed, gains))
+    img = det_input('clip', (1, T, 3, 64, 96), seed)
+    meta = dict(batch_input_shape=(64, 96), img_shape=(60, 90, 3), ori_shape=(60, 90, 3))
+    with torch.no_grad():
+        ref = o.clip_test(img, [[meta] * T], rescale=True)
+        ocls, omasks, _ = o.clip_forward(img, (64, 96))
+    assert m.fused_postprocess
+    res = m.forward(img=None, img_metas=None, return_loss=False, rescale=True, ref_img=img.to(DEV),
+                    ref_img_metas=[[dict(meta) for _ in range(T)]])
+    for t in range(T):
+        a, b = res[0][t]['pan_results'], ref[0][t]['pan_results'].numpy()
+        assert a.shape == (60, 90)
+        assert_panoptic_matches(a, b, decision_margin(ocls[0], omasks[0, t][:, :60, :90]))
+        assert sorted(res[0][t]['query_feats'].keys()) == sorted(ref[0][t]['query_feats'].keys())
+    # image detector
+    mi = build_detector(False, 7, {'cls_embed.weight': 40.0})
+    mi.panoptic_fusion_head.test_cfg = dict(mi.panoptic_fusion_head.test_cfg, instance_on=False)
+    oi = opipe.IPSDetectorOracle(test_cfg=dict(opipe.DEFAULT_TEST_CFG)).eval()
+    oi.load_state_dict(det_state_dict(oi, 7, {'cls_embed.weight': 40.0}))
+    im = det_input('img', (1, 3, 64, 96), 7)
+    meta = dict(img_shape=(60, 90, 3), ori_shape=(60, 90, 3))
+    with torch.no_grad():
+        refi = oi.simple_test(im, [dict(meta, batch_input_shape=(64, 96))], rescale=True)[0]
+    resi = mi.forward([im.to(DEV)], [[dict(meta)]], return_loss=False, rescale=True)[0]
+    a, b = resi['pan_results'], refi['pan_results'].numpy()
+    assert a.shape == (60, 90) and (a != b).mean() < 5e-3
+    assert sorted(resi['query_feats'].keys()) == sorted(refi['query_feats'].keys())
+    for k in resi['query_feats']:
+        np.testing.assert_allclose(resi['query_feats'][k][0], refi['query_feats'][k][0].numpy(), rtol=1e-3, atol=1e-3)

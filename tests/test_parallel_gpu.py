@@ -1,0 +1,80 @@
+"""Frame-sharded clip on the GPU: two ranks (gloo, both on cuda:0) run the sharded pipeline --
+attention partials all-gathered + merged by the HIP combine kernel, flag words OR-ed, segment records
+all-gathered -- and must reproduce the single-process result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(seed=6):
+    from openpvsg_amd import backbone, blocks, detectors, fusion, heads  # noqa: F401
+    from openpvsg_amd import relation as prel
+    from openpvsg_amd.model_zoo import mask2former_r50_model_cfg
+    from openpvsg_amd.pipeline import PVSGPipeline
+    from openpvsg_amd.registry import build_detector
+    from oracle.detweights import det_state_dict
+    cfg = mask2former_r50_model_cfg(video=True)
+    cfg['test_cfg'] = dict(cfg['test_cfg'], instance_on=False)
+    det = build_detector(cfg).eval()
+    det.load_state_dict(det_state_dict(det, seed, {'cls_embed.weight': 40.0, 'query_feat.weight': 30.0}))
+    mods = [prel.ObjectEncoder(256), prel.ObjectEncoder(256), prel.PairProposalNetwork(256, 1024),
+            prel.TemporalTransformer(512, 57)]
+    for i, m in enumerate(mods):
+        m.eval()
+        m.load_state_dict(det_state_dict(m, seed + i))
+    dev = torch.device('cuda:0')
+    return PVSGPipeline(det.to(dev), *[m.to(dev) for m in mods]).eval()
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from openpvsg_amd import parallel
+    from oracle.detweights import det_input
+    torch.cuda.set_device(0)
+    pipe = _build()
+    T = 4
+    clip = det_input('clip', (T, 3, 64, 96), 6)
+    t0, tl = parallel.shard_frames(T, rank, world)
+    out = pipe(clip[t0:t0 + tl].cuda(), (64, 96), total_frames=T, group=None)
+    torch.cuda.synchronize()
+    torch.save(dict(pan=out['pan_results'].cpu(), query=out['query'].cpu(), cls=out['cls'].cpu(),
+                    tube_ids=out['tube_ids'].cpu(), tube_feats=out['tube_feats'].cpu(),
+                    pm=None if out['relation'] is None else out['relation']['pred_matrix'].cpu(), t0=t0),
+               os.path.join(tmp, 'r%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_clip_equals_single_process(hip_lib, tmp_path):
+    from oracle.detweights import det_input
+    world, T = 2, 4
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    pipe = _build()
+    clip = det_input('clip', (T, 3, 64, 96), 6)
+    ref = pipe(clip.cuda(), (64, 96))
+    parts = [torch.load(os.path.join(str(tmp_path), 'r%d.pt' % r)) for r in range(world)]
+    for p in parts:
+        np.testing.assert_allclose(p['query'].numpy(), ref['query'].cpu().numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(p['cls'].numpy(), ref['cls'].cpu().numpy(), rtol=1e-4, atol=1e-4)
+        assert p['tube_ids'].tolist() == ref['tube_ids'].tolist()
+        np.testing.assert_allclose(p['tube_feats'].numpy(), ref['tube_feats'].cpu().numpy(), rtol=1e-4, atol=1e-4)
+        if ref['relation'] is not None:
+            np.testing.assert_allclose(p['pm'].numpy(), ref['relation']['pred_matrix'].cpu().numpy(), rtol=1e-3, atol=1e-4)
+    pan = torch.cat([p['pan'] for p in sorted(parts, key=lambda d: d['t0'])]).numpy()
+    assert (pan != ref['pan_results'].cpu().numpy()).mean() < 2e-3
