@@ -135,6 +135,18 @@ class KernelTimer:
         if name == 'pvsg_masked_xattn_partial':
             B, Q, K, M, D, NS = a[7:13]
             return B * K * (2.0 * M * D * 4 + (16 if a[3] else 0)) + 4.0 * B * NS * M * Q * (D + 2), 4.0 * B * Q * M * D * K
+        if name == 'pvsg_affine_act_nchw':
+            planes, C, HW = a[4:7]
+            return 4.0 * planes * HW * (3 if a[3] else 2), 0.0
+        if name == 'pvsg_msda_fused_forward':
+            B, S, M, D, Lq, L, P = a[9:16]
+            return 4.0 * (B * S * M * D + B * Lq * M * D + B * Lq * M * L * P * 3 + Lq * M * L * P * 3), 9.0 * B * Lq * M * L * P * D
+        if name == 'pvsg_add_layernorm':
+            rows, C = a[6:8]
+            return 4.0 * rows * C * (3 if a[1] else 2), 0.0
+        if name == 'pvsg_panoptic_fuse':
+            T, Q, K, h, w, H, W, ih, iw = a[8:17]
+            return 4.0 * T * K * h * w + 5.0 * T * ih * iw + 1.0 * T * ih * iw, 0.0
         if name == 'pvsg_center_downsample':
             planes, H, W = a[4:7]
             return 4.0 * planes * H * W * (1 + 21.0 / 64), 0.0

@@ -145,6 +145,11 @@ int pvsg_msda_fused_forward(const float* value, long long value_row_stride, cons
 int pvsg_add_layernorm(const float* a, const float* b, const float* bias, const float* gamma,
                        const float* beta, float* out, long long rows, int C, float eps, void* stream);
 
+/* ---- backbone glue: frozen BatchNorm (+ residual) (+ ReLU) in one in-place pass ------------------
+ * [3P] mmdet ResNet (norm_eval=True): y = relu(x * scale[c] + shift[c] (+ residual)) over (planes = N*C, HW). */
+int pvsg_affine_act_nchw(float* x, const float* scale, const float* shift, const float* residual,
+                         long long planes, int C, long long HW, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .blocks import BaseModule
 from .registry import BACKBONES
 
@@ -35,6 +36,17 @@ class _Bottleneck(nn.Module):
         out = self.bn3(self.conv3(out))
         return F.relu(out + identity, inplace=True)
 
+    def forward_fused(self, x, aff):
+        """Frozen BN as per-channel affine: BN+ReLU and BN+residual+ReLU are one in-place HIP pass each
+        (csrc/elementwise.hip) behind MIOpen's convolutions."""
+        if self.downsample is None:
+            identity = x
+        else:
+            identity = ops.affine_act_nchw_(self.downsample[0](x), *aff['ds'], relu=False)
+        out = ops.affine_act_nchw_(self.conv1(x), *aff['bn1'])
+        out = ops.affine_act_nchw_(self.conv2(out), *aff['bn2'])
+        return ops.affine_act_nchw_(self.conv3(out), *aff['bn3'], residual=identity)
+
 
 @BACKBONES.register_module()
 class ResNet(BaseModule):
@@ -47,6 +59,7 @@ class ResNet(BaseModule):
         if depth not in self.arch or style != 'pytorch' or num_stages != 4:
             raise NotImplementedError('ResNet: the reference configs use depth 50/101, style pytorch')
         self.out_indices, self.norm_eval = tuple(out_indices), norm_eval
+        self.fuse_bn_act = True
         self.conv1 = nn.Conv2d(in_channels, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         cin = 64
@@ -67,11 +80,40 @@ class ResNet(BaseModule):
                     m.eval()
         return self
 
+    @staticmethod
+    def _affine(bn):
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        return scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous()
+
+    def _affines(self):
+        """(scale, shift) of every frozen BN, recomputed when parameters/buffers change."""
+        ver = tuple(t._version for t in list(self.parameters()) + list(self.buffers())) + (str(self.conv1.weight.device),)
+        if getattr(self, '_aff_cache', None) is None or self._aff_cache[0] != ver:
+            with torch.no_grad():
+                d = {'stem': self._affine(self.bn1)}
+                for li in range(1, 5):
+                    for bi, blk in enumerate(getattr(self, 'layer%d' % li)):
+                        e = {'bn1': self._affine(blk.bn1), 'bn2': self._affine(blk.bn2), 'bn3': self._affine(blk.bn3)}
+                        if blk.downsample is not None:
+                            e['ds'] = self._affine(blk.downsample[1])
+                        d[(li, bi)] = e
+            self._aff_cache = (ver, d)
+        return self._aff_cache[1]
+
     def forward(self, x):
-        # Measured on MI355X (scripts/backbone_bench.py, 32x736x1280 fp32): folding the frozen BN and using
-        # aten::miopen_convolution_relu / _add_relu fused epilogues is SLOWER (77.9 ms vs 72.9 ms: the fusion
-        # plans pick slower conv algorithms) and channels_last falls to naive kernels (7.3 s), so the
-        # backbone stays plain NCHW conv + BN(eval) + ReLU.
+        # Measured on MI355X (32x736x1280 fp32): MIOpen's fused conv+bias+ReLU plans (aten::miopen_convolution_relu
+        # / _add_relu) are SLOWER than plain conv (77.9 vs 72.9 ms) and channels_last falls to naive kernels, so the
+        # convolutions stay plain NCHW MIOpen calls and only the BN/ReLU/residual passes are fused (own kernel).
+        if self.norm_eval and x.is_cuda and not torch.is_grad_enabled() and self.fuse_bn_act:
+            aff = self._affines()
+            x = F.max_pool2d(ops.affine_act_nchw_(self.conv1(x), *aff['stem']), 3, stride=2, padding=1)
+            outs = []
+            for li in range(1, 5):
+                for bi, blk in enumerate(getattr(self, 'layer%d' % li)):
+                    x = blk.forward_fused(x, aff[(li, bi)])
+                if li - 1 in self.out_indices:
+                    outs.append(x)
+            return tuple(outs)
         x = F.max_pool2d(F.relu(self.bn1(self.conv1(x)), inplace=True), 3, stride=2, padding=1)
         outs = []
         for li in range(1, 5):

@@ -284,3 +284,17 @@ def add_layernorm(a, b, bias, norm):
                   bias.data_ptr() if bias is not None else None, norm.weight.data_ptr(), norm.bias.data_ptr(),
                   out.data_ptr(), rows, a.shape[-1], float(norm.eps), _stream_ptr())
     return out
+
+
+def affine_act_nchw_(x, scale, shift, residual=None, relu=True):
+    """In place: x = relu(x * scale[c] + shift[c] (+ residual)) for x (N,C,H,W) contiguous."""
+    if not (x.is_cuda and x.is_contiguous() and x.dtype == torch.float32):
+        raise RuntimeError('affine_act_nchw_: needs a contiguous float32 HIP tensor; the MI355X backend has no CPU path')
+    N, C, H, W = x.shape
+    r = _chk(residual, 'residual') if residual is not None else None
+    if r is not None and r.shape != x.shape:
+        raise RuntimeError('affine_act_nchw_: residual shape mismatch')
+    with torch.cuda.device(x.device):
+        _lib.call('pvsg_affine_act_nchw', x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                  r.data_ptr() if r is not None else None, N * C, C, H * W, int(bool(relu)), _stream_ptr())
+    return x

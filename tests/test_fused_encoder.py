@@ -81,3 +81,25 @@ def test_msda_fused_equals_oracle(hip_lib, B, h0w0, scale):
     a = ops.msda_fused(y.to(DEV), pos_oa.to(DEV), ref.to(DEV), ss.to(DEV), lsi.to(DEV))
     sc = float(expect.abs().max())
     np.testing.assert_allclose(a.cpu().numpy(), expect.numpy(), rtol=1e-4, atol=2e-5 * sc)
+
+
+def test_backbone_fused_bn_act_equals_plain(hip_lib):
+    """ResNet-50 with the fused BN(+residual)(+ReLU) passes vs plain conv/BN/ReLU modules vs the oracle."""
+    from openpvsg_amd.backbone import ResNet
+    m = ResNet(depth=50).eval()
+    sd = det_state_dict(m, 9)
+    m.load_state_dict(sd)
+    o = blocks3p.ResNet50()
+    o.load_state_dict(sd)
+    x = det_input('img', (2, 3, 64, 96), 9)
+    with torch.no_grad():
+        ref = o(x)
+        m = m.to(DEV)
+        m.fuse_bn_act = True
+        a = m(x.to(DEV))
+        m.fuse_bn_act = False
+        b = m(x.to(DEV))
+    for u, v, r in zip(a, b, ref):
+        sc = float(r.abs().max())
+        np.testing.assert_allclose(u.cpu().numpy(), r.numpy(), rtol=1e-3, atol=1e-4 * sc)
+        np.testing.assert_allclose(v.cpu().numpy(), r.numpy(), rtol=1e-3, atol=1e-4 * sc)
