@@ -10,16 +10,20 @@
 // (mask_gemm.hip) and the reset is a per-query flag test.
 //
 // Work split: a workgroup = one (batch element, key range); its 8 waves are the 8 heads, so the
-// workgroup consumes whole 1 KiB key/value rows.  Each wave keeps its head's Q (100x32, padded to
-// 7 tiles of 16 rows) in registers for the whole range and walks the keys 16 at a time:
-//   S^T = K_tile (16x32) . Q^T          56 x v_mfma_f32_16x16x4_f32   (A = K from HBM, B = Q regs)
-//   mask bits, running max / sum        per query column, 2 cross-lane steps (rows live in 4 lane groups)
+// workgroup consumes whole 1 KiB key/value rows: they are staged in LDS by LDS-DMA, 32 keys per tile,
+// double buffered (details at the kernel).  Each wave keeps its head's Q (100x32, padded to 7 tiles of 16
+// rows) in registers for the whole range and walks the tile 16 keys at a time:
+//   S^T = K_tile (16x32) . Q^T          56 x v_mfma_f32_16x16x4_f32   (A = K fragment from LDS, B = Q regs)
+//   mask bits, running max / sum        per query column; the 16 key rows live in 4 lane groups, reduced
+//                                       with v_permlane16_swap / v_permlane32_swap (VALU, no LDS crossbar)
 //   O^T += V_tile^T (32x16) . P^T       56 x v_mfma; the S^T accumulator registers ARE the B operand
 //                                       (key index of k-step r = 4*(lane>>4)+r on both sides), so P
 //                                       never moves between lanes or through LDS
 // O^T keeps each lane's values in ONE query column, so the online-softmax rescale is lane-local.
-// K fragments are 2 x 16 B and V fragments 4 x 8 B per lane per tile, every 128 B head row is
-// consumed entirely by one wave instruction pair (full cache lines, each HBM byte read once).
+// Every HBM byte of K/V is read once, in full 1 KiB rows.  Measured (round 1, 471 040 keys): 0.75 ms =
+// 64 TF (41 % of the f32 matrix peak); a variant loading fragments straight from HBM into registers
+// measured 0.72 ms -- both are limited by the QK -> softmax -> PV dependency inside a wave at 2 waves
+// per SIMD, not by the loads.
 // Ranges are combined by `xattn_combine_kernel` (log-sum-exp merge); the same partial format is
 // what ranks exchange when a clip's frames are sharded over GPUs (openpvsg_amd/parallel.py).
 #include "common.h"
@@ -28,32 +32,56 @@ namespace pvsg {
 
 constexpr int XQT = 7;  // 7 x 16 = 112 query rows
 
-__device__ __forceinline__ float group_max4(float v) {  // reduce over the 4 lane groups (lane>>4)
-  v = fmaxf(v, __shfl_xor(v, 16));
-  return fmaxf(v, __shfl_xor(v, 32));
+// Reductions over the 4 lane groups (lane>>4) that hold the 16 key rows of one S^T tile.  gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows between two registers in the VALU
+// (no LDS crossbar trip like ds_bpermute): with both operands = v the results are (r0,r0,r2,r2) and
+// (r1,r1,r3,r3), so one max/add gives the xor-16 butterfly step; the 32-lane swap gives the xor-32 step.
+__device__ __forceinline__ float group_max4(float v) {
+  unsigned u = __float_as_uint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  u = __float_as_uint(v);
+  auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 __device__ __forceinline__ float group_sum4(float v) {
-  v += __shfl_xor(v, 16);
-  return v + __shfl_xor(v, 32);
+  unsigned u = __float_as_uint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  u = __float_as_uint(v);
+  auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-__global__ __launch_bounds__(512) void xattn_partial_kernel(
+// ------------------------------------------------------------------------------------------------
+// K/V staging: the workgroup's 8 waves (= heads) share the key/value ROWS (1 KiB = all heads),
+// so rows are brought in whole by LDS-DMA (global_load_lds_dwordx4: one row per wave instruction, fully
+// coalesced, no VGPR staging), 32 keys per tile, double buffered: the DMA of tile t+1 flies while tile t
+// is consumed.  A row r is stored with its 16-byte chunks XOR-swizzled by (r & 15) -- applied on the
+// SOURCE address, the LDS side of the DMA is lane-linear -- which makes the per-head fragment reads
+// (16 keys x 32 B for K, 4 keys x 128 B for V) bank-conflict free.
+// ------------------------------------------------------------------------------------------------
+constexpr int TK = 32;                                   // keys per LDS tile
+constexpr int XLDS_TILE_FLOATS = TK * 256 * 2 + TK * 4;  // K rows + V rows + mask words (as floats)
+
+__global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
     const float* __restrict__ qp, const float* __restrict__ kp, const float* __restrict__ vp,
     const uint32_t* __restrict__ bits, const uint32_t* __restrict__ flags, float* __restrict__ part_o,
     float* __restrict__ part_ml, int Q, long long K, int NS, long long chunk) {
   constexpr int HD = 256, D = 32, M = 8;
+  extern __shared__ __attribute__((aligned(16))) float xl[];   // [2][XLDS_TILE_FLOATS]
   const int b = blockIdx.x / NS, s = blockIdx.x - b * NS;
   const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = lane & 15, g = lane >> 4;
   const long long k0 = (long long)s * chunk;
   const long long k1 = (k0 + chunk < K) ? k0 + chunk : K;
+  const bool use_mask = bits != nullptr;
 
-  // ---- Q fragments (B operand of S^T = K.Q^T): row q = qt*16+j, d = g*8 + step ---------------
   float qf[XQT][8];
-  uint32_t honor = 0u;  // bit qt: this lane's query in tile qt honours the mask
+  uint32_t honor = 0u;
   {
     uint32_t fw[4] = {0u, 0u, 0u, 0u};
-    if (bits != nullptr) {
+    if (use_mask) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) fw[k] = flags[b * 4 + k];
     }
@@ -69,107 +97,127 @@ __global__ __launch_bounds__(512) void xattn_partial_kernel(
 #pragma unroll
         for (int i = 0; i < 8; ++i) qf[qt][i] = 0.f;
       }
-      // a query whose mask blocks EVERY key attends to all keys instead (flag bit = has an
-      // allowed key somewhere, over all ranges / ranks)
-      if (bits != nullptr && ((fw[qt >> 1] >> ((qt & 1) * 16 + j)) & 1u)) honor |= 1u << qt;
+      if (use_mask && ((fw[qt >> 1] >> ((qt & 1) * 16 + j)) & 1u)) honor |= 1u << qt;
     }
   }
-
   float mrun[XQT], lrun[XQT];
   f32x4 o[XQT][2];
 #pragma unroll
   for (int qt = 0; qt < XQT; ++qt) {
-    mrun[qt] = -INFINITY;
-    lrun[qt] = 0.f;
-    o[qt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    o[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mrun[qt] = -INFINITY; lrun[qt] = 0.f;
+    o[qt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  const float* kb = kp + (long long)b * K * HD;
+  const float* vb = vp + (long long)b * K * HD;
+  const uint32_t* mb = use_mask ? bits + (long long)b * K * 4 : nullptr;
+  const long long klast = k1 - 1;
 
-  const float* kb = kp + (long long)b * K * HD + h * D;
-  const float* vb = vp + (long long)b * K * HD + h * D;
-  const uint32_t* mb = bits ? bits + (long long)b * K * 4 : nullptr;
+  // wave w brings rows 4w..4w+3 of K and of V (+ 16 mask dwords) of a tile: 9 DMA instructions per wave
+  auto issue = [&](long long kt, int buf) {
+    float* base = xl + buf * XLDS_TILE_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = h * 4 + i;
+      long long key = kt + r;
+      key = key < klast ? key : klast;
+      const int src_chunk = lane ^ (r & 15);
+      __builtin_amdgcn_global_load_lds(kb + key * HD + src_chunk * 4,
+                                       (__attribute__((address_space(3))) void*)(base + r * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(vb + key * HD + src_chunk * 4,
+                                       (__attribute__((address_space(3))) void*)(base + TK * 256 + r * 256), 16, 0, 0);
+    }
+    if (use_mask && lane < 16) {
+      long long word = (kt + (h * 16 + lane) / 4) ;
+      word = word < klast ? word : klast;
+      __builtin_amdgcn_global_load_lds(mb + word * 4 + (lane & 3),
+                                       (__attribute__((address_space(3))) void*)(base + TK * 512 + h * 16), 4, 0, 0);
+    }
+  };
 
-  for (long long kt = k0; kt < k1; kt += 16) {
-    // ---- loads for this tile ------------------------------------------------------------------
-    const long long ka = kt + j;  // row of the K fragment held by this lane
-    float kf[8];
-    if (ka < k1) {
-      const float* p = kb + ka * HD + g * 8;
-      const float4 a = ld4(p), c = ld4(p + 4);
-      kf[0] = a.x; kf[1] = a.y; kf[2] = a.z; kf[3] = a.w;
-      kf[4] = c.x; kf[5] = c.y; kf[6] = c.z; kf[7] = c.w;
+  const int ntile = (int)((k1 - k0 + TK - 1) / TK);
+  if (ntile > 0) issue(k0, 0);
+  for (int t = 0; t < ntile; ++t) {
+    const long long kt = k0 + (long long)t * TK;
+    if (t + 1 < ntile) {
+      issue(kt + TK, (t + 1) & 1);
+      if (use_mask) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // tile t landed, tile t+1 in flight
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) kf[i] = 0.f;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    float2 vf[4];
-    uint4 mw[4];
-    bool kvalid[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long long kr = kt + g * 4 + r;  // key of S^T row (g*4+r) == key of PV k-step r
-      kvalid[r] = kr < k1;
-      vf[r] = kvalid[r] ? *reinterpret_cast<const float2*>(vb + kr * HD + 2 * j) : make_float2(0.f, 0.f);
-      mw[r] = (mb != nullptr && kvalid[r]) ? *reinterpret_cast<const uint4*>(mb + kr * 4)
-                                           : make_uint4(0u, 0u, 0u, 0u);
-    }
+    __builtin_amdgcn_s_barrier();                                      // every wave's rows of tile t are in LDS
+    const float* tb = xl + (t & 1) * XLDS_TILE_FLOATS;
+    const uint32_t* tm = reinterpret_cast<const uint32_t*>(tb + TK * 512);
 
-    // ---- S^T = K . Q^T ------------------------------------------------------------------------
-    f32x4 st[XQT];
+#pragma unroll 1
+    for (int sub = 0; sub < 2; ++sub) {
+      // ---- S^T = K . Q^T for 16 keys: K fragment = two swizzled 16-byte chunks of row sub*16 + j ----------
+      const int rk = sub * 16 + j;
+      const float4 a = *reinterpret_cast<const float4*>(tb + rk * 256 + (((h * 8 + g * 2) ^ (rk & 15)) << 2));
+      const float4 c = *reinterpret_cast<const float4*>(tb + rk * 256 + (((h * 8 + g * 2 + 1) ^ (rk & 15)) << 2));
+      const float kf[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+      f32x4 st[XQT];
 #pragma unroll
-    for (int qt = 0; qt < XQT; ++qt) st[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int qt = 0; qt < XQT; ++qt) st[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int qt = 0; qt < XQT; ++qt)
-        st[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[i], qf[qt][i], st[qt], 0, 0, 0);
-
-    // ---- mask + online softmax (per query column) ---------------------------------------------
+        for (int qt = 0; qt < XQT; ++qt)
+          st[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[i], qf[qt][i], st[qt], 0, 0, 0);
+      bool kvalid[4];
 #pragma unroll
-    for (int qt = 0; qt < XQT; ++qt) {
-      const bool hq = (honor >> qt) & 1u;
-      const int sh = (qt & 1) * 16 + j;
-      float sv[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const uint32_t w = (qt >> 1) == 0 ? mw[r].x : (qt >> 1) == 1 ? mw[r].y : (qt >> 1) == 2 ? mw[r].z : mw[r].w;
-        const bool masked = !kvalid[r] || (hq && ((w >> sh) & 1u));
-        sv[r] = masked ? -INFINITY : st[qt][r];
-      }
-      const float tmax = group_max4(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
-      const float mnew = fmaxf(mrun[qt], tmax);
-      float alpha = 1.f, psum = 0.f;
-      if (mnew == -INFINITY) {  // nothing allowed so far for this query
-#pragma unroll
-        for (int r = 0; r < 4; ++r) st[qt][r] = 0.f;
-      } else {
-        alpha = __expf(mrun[qt] - mnew);  // exp(-inf) = 0 on first hit
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __expf(sv[r] - mnew);
-          st[qt][r] = p;
-          psum += p;
-        }
-      }
-      psum = group_sum4(psum);
-      lrun[qt] = lrun[qt] * alpha + psum;
-      mrun[qt] = mnew;
-      o[qt][0] *= alpha;
-      o[qt][1] *= alpha;
-    }
-
-    // ---- O^T += V^T . P^T ---------------------------------------------------------------------
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r) kvalid[r] = kt + sub * 16 + g * 4 + r < k1;
+      // ---- mask + online softmax (per query column) ---------------------------------------------------------
 #pragma unroll
       for (int qt = 0; qt < XQT; ++qt) {
-        o[qt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r].x, st[qt][r], o[qt][0], 0, 0, 0);
-        o[qt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r].y, st[qt][r], o[qt][1], 0, 0, 0);
+        const bool hq = (honor >> qt) & 1u;
+        const int sh = (qt & 1) * 16 + j;
+        float sv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // mask word of this key for query tile qt, read on demand from the LDS copy
+          const uint32_t w = hq ? tm[(sub * 16 + g * 4 + r) * 4 + (qt >> 1)] : 0u;
+          const bool masked = !kvalid[r] || ((w >> sh) & 1u);
+          sv[r] = masked ? -INFINITY : st[qt][r];
+        }
+        const float tmax = group_max4(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
+        const float mnew = fmaxf(mrun[qt], tmax);
+        float alpha = 1.f, psum = 0.f;
+        if (mnew == -INFINITY) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[qt][r] = 0.f;
+        } else {
+          alpha = __expf(mrun[qt] - mnew);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __expf(sv[r] - mnew);
+            st[qt][r] = p;
+            psum += p;
+          }
+        }
+        psum = group_sum4(psum);
+        lrun[qt] = lrun[qt] * alpha + psum;
+        mrun[qt] = mnew;
+        o[qt][0] *= alpha;
+        o[qt][1] *= alpha;
       }
+      // ---- O^T += V^T . P^T (V fragments from LDS right before use) ---------------------------------------------
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = sub * 16 + g * 4 + r;
+        const int ch = (h * 8 + (j >> 1)) ^ (row & 15);
+        const float2 vf = *reinterpret_cast<const float2*>(tb + TK * 256 + row * 256 + ch * 4 + (j & 1) * 2);
+#pragma unroll
+        for (int qt = 0; qt < XQT; ++qt) {
+          o[qt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, st[qt][r], o[qt][0], 0, 0, 0);
+          o[qt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, st[qt][r], o[qt][1], 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // everyone is done with this buffer before tile t+2 overwrites it
   }
 
-  // ---- write the un-normalised partial (o, m, l) ------------------------------------------------
-  // lane holds O[q = qt*16+j][d = 8g + 2r' + dt]  -> 8 consecutive floats
   const long long slot = ((long long)b * NS + s) * M + h;
 #pragma unroll
   for (int qt = 0; qt < XQT; ++qt) {
@@ -178,10 +226,7 @@ __global__ __launch_bounds__(512) void xattn_partial_kernel(
       float* op = part_o + (slot * Q + q) * D + g * 8;
       st4(op, make_float4(o[qt][0][0], o[qt][1][0], o[qt][0][1], o[qt][1][1]));
       st4(op + 4, make_float4(o[qt][0][2], o[qt][1][2], o[qt][0][3], o[qt][1][3]));
-      if (g == 0) {
-        float* mp = part_ml + (slot * Q + q) * 2;
-        *reinterpret_cast<float2*>(mp) = make_float2(mrun[qt], lrun[qt]);
-      }
+      if (g == 0) *reinterpret_cast<float2*>(part_ml + (slot * Q + q) * 2) = make_float2(mrun[qt], lrun[qt]);
     }
   }
 }
@@ -256,7 +301,11 @@ extern "C" int pvsg_masked_xattn_partial(const float* q_proj, const float* k_pro
   long long chunk = (K + NS - 1) / NS;
   chunk = (chunk + 15) / 16 * 16;
   // ranges past the end are legal: they publish (m=-inf, l=0, o=0) and the merge skips them
-  hipLaunchKernelGGL(xattn_partial_kernel, dim3(B * NS), dim3(512), 0, stream, q_proj, k_proj, v_proj,
+  chunk = (chunk + TK - 1) / TK * TK;
+  const size_t lds = (size_t)2 * XLDS_TILE_FLOATS * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_partial_lds_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(xattn_partial_lds_kernel, dim3(B * NS), dim3(512), lds, stream, q_proj, k_proj, v_proj,
                      mask_bits, mask_flags, part_o, part_ml, Q, K, NS, chunk);
   PVSG_LAUNCH_CHECK("masked_xattn_partial");
   return PVSG_OK;
