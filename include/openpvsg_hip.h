@@ -150,6 +150,13 @@ int pvsg_add_layernorm(const float* a, const float* b, const float* bias, const 
 int pvsg_affine_act_nchw(float* x, const float* scale, const float* shift, const float* residual,
                          long long planes, int C, long long HW, int relu, void* stream);
 
+/* ---- a9: MinVIS frame-to-frame query matching, whole video in one launch ------
+ * Replaces match_from_embds (models/mask2former_vps/mask2former_min_vis.py:244-258: cosine cost, C.cpu(),
+ * scipy linear_sum_assignment per frame) + the chaining loop models/mask2former_vps/mask2former.py:146-158.
+ *   embds (V, T, Q, C) per-frame query embeddings of V videos;  perm (V, T, Q) int32:
+ *   perm[v,0] = identity, perm[v,t][j] = query of frame t placed on slot j (chained through t-1). */
+int pvsg_minvis_chain(const float* embds, int* perm, int V, int T, int Q, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@ import copy
 import numpy as np
 import torch
 
+from . import ops
 from .blocks import BaseModule
 from .config import _wrap
 from .registry import DETECTORS, build_backbone, build_head, build_neck
@@ -184,23 +185,36 @@ class Mask2FormerVideoCustom(_Base):
         else:
             if bs != 1:
                 raise NotImplementedError('per-frame VPS inference runs one video per call (as shipped)')
-            one = [[ref_img_metas[0][0]]]
-            f_logits, f_masks, f_embds = [], [], []
-            for i in range(feats[0].size(0)):
-                cur = [f[i:i + 1] for f in feats]
-                c, m, qq = self.panoptic_head.simple_test_with_query(cur, one, **kwargs)
-                f_logits.append(c[0])
-                f_masks.append(m[0, 0])
-                f_embds.append(qq[:, 0])
-            o_logits, o_masks, o_embds = [f_logits[0]], [f_masks[0]], [f_embds[0]]
-            for i in range(1, len(f_logits)):
-                idx = torch.as_tensor(self.match_from_embds(o_embds[-1], f_embds[i]), device=f_logits[i].device)
-                o_logits.append(f_logits[i][idx])
-                o_masks.append(f_masks[i][idx])
-                o_embds.append(f_embds[i][idx])
-            logits = (sum(o_logits) / len(o_logits)).unsqueeze(0)
-            embds = (sum(o_embds) / len(o_embds)).unsqueeze(0)
-            masks = torch.stack(o_masks, dim=0).unsqueeze(0)           # (1,T,Q,H,W)
+            # Shipped flow: one head call per frame (mask2former.py:136-143) + MinVIS chaining (:146-165).
+            # Frames are independent inside the head, so they run as ONE batch of T; the matching chain
+            # over the T frames is one on-device launch (ops.minvis_chain) instead of T-1 host LAPs.
+            head = self.panoptic_head
+            cls_list, mask_list, qq = head._decode(feats, T, 1, all_masks=False)
+            cls_t, masks4 = cls_list[-1], mask_list[-1][:, 0]                 # (T,Q,C+1), (T,Q,h,w)
+            embds_t = qq.permute(1, 0, 2).contiguous()                        # (T,Q,C)
+            perm = ops.minvis_chain(embds_t)                                  # (T,Q)
+            ar = torch.arange(T, device=perm.device)[:, None]
+            logits = cls_t[ar, perm].mean(0, keepdim=True)                    # (1,Q,C+1)
+            embds = embds_t[ar, perm].mean(0, keepdim=True)                   # (1,Q,C)
+            masks4 = masks4[ar, perm]                                         # (T,Q,h,w) on frame-0 slots
+            if (self.fused_postprocess and Mask2FormerCustom._fused_ok(self, flat_metas, rescale) and
+                    len({tuple(m['img_shape'][:2]) for m in flat_metas}) == 1):
+                fusion = self.panoptic_fusion_head
+                pan, seg, keep = fusion.panoptic_fused(logits[0], masks4, flat_metas[0]['batch_input_shape'],
+                                                       flat_metas[0]['img_shape'])
+                kf_np = embds[0][keep].detach().cpu().numpy()
+                pan_np, seg_l = pan.cpu().numpy(), seg.tolist()
+                out = []
+                for t in range(T):
+                    qd = {}
+                    for i, sid in enumerate(seg_l[t]):
+                        if sid >= 0:
+                            qd.setdefault(sid, []).append(kf_np[i])
+                    out.append(dict(pan_results=pan_np[t], query_feats=qd))
+                return [out]
+            h, w = flat_metas[0]['batch_input_shape'][:2]
+            masks = torch.nn.functional.interpolate(masks4, size=(h, w), mode='bilinear',
+                                                    align_corners=False).unsqueeze(0)   # (1,T,Q,H,W)
         results = [[] for _ in range(bs)]
         for t in range(T):
             res = self.panoptic_fusion_head.simple_test_with_query(

@@ -298,3 +298,19 @@ def affine_act_nchw_(x, scale, shift, residual=None, relu=True):
         _lib.call('pvsg_affine_act_nchw', x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                   r.data_ptr() if r is not None else None, N * C, C, H * W, int(bool(relu)), _stream_ptr())
     return x
+
+
+def minvis_chain(embds):
+    """MinVIS matching chained over the frames of a video, on the device.
+    embds (T,Q,C) or (V,T,Q,C) -> perm int64 of the same leading shape + (Q,): perm[t][j] = query of frame t
+    on slot j (mask2former_min_vis.py:244-258 applied frame after frame, mask2former.py:146-158)."""
+    e = _chk(embds, 'embds')
+    squeeze = e.dim() == 3
+    if squeeze:
+        e = e[None]
+    V, T, Q, C = e.shape
+    perm = torch.empty((V, T, Q), device=e.device, dtype=torch.int32)
+    with torch.cuda.device(e.device):
+        _lib.call('pvsg_minvis_chain', e.data_ptr(), perm.data_ptr(), V, T, Q, C, _stream_ptr())
+    perm = perm.to(torch.long)
+    return perm[0] if squeeze else perm

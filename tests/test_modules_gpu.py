@@ -294,3 +294,26 @@ def test_detectors_fused_postprocess_path(hip_lib):
     assert sorted(resi['query_feats'].keys()) == sorted(refi['query_feats'].keys())
     for k in resi['query_feats']:
         np.testing.assert_allclose(resi['query_feats'][k][0], refi['query_feats'][k][0].numpy(), rtol=1e-3, atol=1e-3)
+
+
+def test_vps_per_frame_fused_path_vs_oracle(hip_lib):
+    """Shipped per-frame flow, panoptic-only: batched head call + on-device MinVIS chain + fused fusion."""
+    seed, T = 6, 3
+    gains = {'cls_embed.weight': 40.0, 'query_feat.weight': 30.0}
+    m = build_detector(True, seed, gains, 'per_frame')
+    m.panoptic_fusion_head.test_cfg = dict(m.panoptic_fusion_head.test_cfg, instance_on=False)
+    o = opipe.VPSDetectorOracle().eval()
+    o.load_state_dict(det_state_dict(o, seed, gains))
+    img = det_input('clip', (1, T, 3, 64, 96), seed)
+    meta = dict(batch_input_shape=(64, 96), img_shape=(64, 96, 3), ori_shape=(64, 96, 3))
+    with torch.no_grad():
+        ref = o.simple_test(img, [[meta] * T], rescale=True)
+    res = m.forward(img=None, img_metas=None, return_loss=False, rescale=True, ref_img=img.to(DEV),
+                    ref_img_metas=[[dict(meta) for _ in range(T)]])
+    for t in range(T):
+        a, b = res[0][t]['pan_results'], ref[0][t]['pan_results'].numpy()
+        assert (a != b).mean() < 5e-3 and mask_iou(a, b, 126) > 1 - 5e-3
+        assert sorted(res[0][t]['query_feats'].keys()) == sorted(ref[0][t]['query_feats'].keys())
+        for k in res[0][t]['query_feats']:
+            np.testing.assert_allclose(res[0][t]['query_feats'][k][0], ref[0][t]['query_feats'][k][0].numpy(),
+                                       rtol=1e-3, atol=1e-3)
