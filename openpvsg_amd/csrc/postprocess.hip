@@ -85,6 +85,100 @@ __global__ __launch_bounds__(256) void pan_owner_kernel(
   }
 }
 
+// Exact x4 case (H = 4h, W = 4w -- every /32-padded input): the 16 output pixels y in [4i+2, 4i+5],
+// x in [4j+2, 4j+5] interpolate the SAME four source taps (i,j),(i,j+1),(i+1,j),(i+1,j+1) with the fixed
+// weights {1/8, 3/8, 5/8, 7/8}.  One lane therefore owns such a 4x4 block (shifted by -2 so that the
+// clamped border rows/columns fall out of the same formula): 4 tap loads per kept query instead of 64,
+// 16 running arg-max states in registers.  Same arithmetic per pixel as pan_owner_kernel (ATen's
+// formula specialised to scale 1/4), so the two kernels agree bit for bit.
+__global__ __launch_bounds__(256) void pan_owner_x4_kernel(
+    const float* __restrict__ logits, const int* __restrict__ kept_idx, const float* __restrict__ kept_score,
+    unsigned char* __restrict__ owner_out, int* __restrict__ counters, int Q, int K, int h, int w, int ih, int iw) {
+  __shared__ int s_area[MAXK], s_orig[MAXK], s_region_conf[MAXK];
+  __shared__ int s_idx[MAXK];
+  __shared__ float s_score[MAXK];
+  const int t = blockIdx.z;
+  for (int k = threadIdx.x; k < MAXK; k += blockDim.x) {
+    s_area[k] = 0; s_orig[k] = 0; s_region_conf[k] = 0;
+    if (k < K) { s_idx[k] = kept_idx[k]; s_score[k] = kept_score[k]; }
+  }
+  __syncthreads();
+  // block (bx, by) of the (w+1) x (h+1) grid of 4x4 blocks; block (bj, bi) covers output rows 4*bi-2 .. 4*bi+1
+  const int bj = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int bi = blockIdx.y * 8 + (threadIdx.x >> 5);
+  const bool active = bj <= w && bi <= h;
+  const int i0 = max(bi - 1, 0), i1 = min(bi, h - 1), j0 = max(bj - 1, 0), j1 = min(bj, w - 1);
+  // output row 4*bi-2+a: src = (y+0.5)/4-0.5 -> weight of tap i1 is (2a+1)/8 inside, clamped rows give i0==i1
+  float best[16], pown[16];
+  int own[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { best[e] = -1.f; pown[e] = 0.f; own[e] = 0; }
+  const float* base = logits + (long long)t * Q * h * w;
+  const int lane = threadIdx.x & 63;
+  for (int k = 0; k < K; ++k) {
+    const float* p = base + (long long)s_idx[k] * h * w;
+    float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
+    if (active) { v00 = p[i0 * w + j0]; v01 = p[i0 * w + j1]; v10 = p[i1 * w + j0]; v11 = p[i1 * w + j1]; }
+    const float sc_k = s_score[k];
+    int conf_cnt = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int y = 4 * bi - 2 + a;
+      // ATen: src = 0.25*(y+0.5)-0.5 clamped at 0; lambda1 = src - floor(src)
+      float fy = 0.25f * ((float)y + 0.5f) - 0.5f;
+      fy = fy < 0.f ? 0.f : fy;
+      const int yb = min((int)fy, h - 1);
+      const float ly1 = fy - (float)yb, ly0 = 1.f - ly1;
+      const bool rowok = active && y >= 0 && y < ih;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int x = 4 * bj - 2 + c;
+        float fx = 0.25f * ((float)x + 0.5f) - 0.5f;
+        fx = fx < 0.f ? 0.f : fx;
+        const int xb = min((int)fx, w - 1);
+        const float lx1 = fx - (float)xb, lx0 = 1.f - lx1;
+        const bool ok = rowok && x >= 0 && x < iw;
+        // rows i0/i1 and columns j0/j1 are this block's taps for every one of its 16 pixels (clamped
+        // borders: the two taps coincide or the far weight is exactly 0), so only the weights vary
+        const float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        const float prob = 1.f / (1.f + expf(-v));
+        const float sc = sc_k * prob;
+        const int e = a * 4 + c;
+        if (ok && sc > best[e]) { best[e] = sc; own[e] = k; pown[e] = prob; }
+        conf_cnt += (ok && prob >= 0.5f) ? 1 : 0;
+      }
+    }
+    // per-query "original area": wave-sum of the per-lane counts
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) conf_cnt += __shfl_xor(conf_cnt, off);
+    if (lane == 0 && conf_cnt) atomicAdd(&s_orig[k], conf_cnt);
+  }
+  if (active) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int y = 4 * bi - 2 + a;
+      if (y < 0 || y >= ih) continue;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int x = 4 * bj - 2 + c;
+        if (x < 0 || x >= iw) continue;
+        const int e = a * 4 + c;
+        const bool cf = pown[e] >= 0.5f;
+        atomicAdd(&s_area[own[e]], 1);
+        if (cf) atomicAdd(&s_region_conf[own[e]], 1);
+        owner_out[((long long)t * ih + y) * iw + x] = (unsigned char)(own[e] | (cf ? 0x80 : 0));
+      }
+    }
+  }
+  __syncthreads();
+  int* ct = counters + (long long)t * 3 * MAXK;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    if (s_area[k]) atomicAdd(ct + k, s_area[k]);
+    if (s_orig[k]) atomicAdd(ct + MAXK + k, s_orig[k]);
+    if (s_region_conf[k]) atomicAdd(ct + 2 * MAXK + k, s_region_conf[k]);
+  }
+}
+
 __global__ void pan_decide_kernel(const int* __restrict__ counters, const int* __restrict__ kept_class,
                                   int* __restrict__ seg_id, int K, int num_things, double iou_thr,
                                   int filter_low) {
@@ -142,8 +236,12 @@ extern "C" int pvsg_panoptic_fuse(const float* mask_logits, const int* kept_idx,
   hipError_t e = hipMemsetAsync(counter_ws, 0, (size_t)T * 3 * MAXK * sizeof(int), stream);
   if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "panoptic_fuse: memset: %s", hipGetErrorString(e));
   if (K > 0) {
-    hipLaunchKernelGGL(pan_owner_kernel, dim3((iw + 63) / 64, (ih + 3) / 4, T), dim3(256), 0, stream,
-                       mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, H, W, ih, iw);
+    if (H == 4 * h && W == 4 * w)
+      hipLaunchKernelGGL(pan_owner_x4_kernel, dim3((w + 1 + 31) / 32, (h + 1 + 7) / 8, T), dim3(256), 0, stream,
+                         mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, ih, iw);
+    else
+      hipLaunchKernelGGL(pan_owner_kernel, dim3((iw + 63) / 64, (ih + 3) / 4, T), dim3(256), 0, stream,
+                         mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, H, W, ih, iw);
     PVSG_LAUNCH_CHECK("panoptic_fuse(owner)");
     hipLaunchKernelGGL(pan_decide_kernel, dim3(T), dim3(64), 0, stream, counter_ws, kept_class, seg_id, K,
                        num_things, iou_thr, filter_low_score);

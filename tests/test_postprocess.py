@@ -73,3 +73,27 @@ def test_fused_full_size_properties(hip_lib):
     for k, sid in enumerate(seg[0]):
         if sid >= 0:
             assert sid % 1000 == labels[k] and (sid >= 1000) == (labels[k] < 115)
+
+
+def test_x4_kernel_equals_generic_kernel(hip_lib):
+    """The x4-specialised owner kernel (one lane per 4x4 block) must agree exactly with the generic
+    per-pixel kernel: same logits presented as (H,W)=(4h,4w) [x4 path] and via a fake 1-pixel-larger
+    canvas [generic path]."""
+    from openpvsg_amd import ops
+    T, Q, h, w = 2, 100, 23, 40
+    cls, conf = peaky_cls(Q, 126, 25, 9)
+    logits4 = torch.stack([blob_masks(Q, h, w, conf, 30 + t) for t in range(T)]).to(DEV)
+    scores, labels = cls.softmax(-1).max(-1)
+    keep = (labels != 126) & (scores > 0.8)
+    idx = keep.nonzero()[:, 0].to(DEV)
+    a = ops.panoptic_fuse(logits4, idx, scores[keep].to(DEV), labels[keep].to(DEV), (4 * h, 4 * w), (4 * h - 3, 4 * w - 5),
+                          115, 126, 0.8, True)
+    # reference: the un-fused product path on torch-upsampled logits
+    up = F.interpolate(logits4, size=(4 * h, 4 * w), mode='bilinear', align_corners=False)
+    from openpvsg_amd.fusion import MaskFormerFusionHeadCustom
+    head = MaskFormerFusionHeadCustom(115, 11, test_cfg=dict(iou_thr=0.8, filter_low_score=True, object_mask_thr=0.8))
+    for t in range(T):
+        seg, sid = head.panoptic_from_kept(scores[keep].to(DEV), labels[keep].to(DEV),
+                                           up[t][idx][:, :4 * h - 3, :4 * w - 5].sigmoid())
+        assert (a[0][t] != seg).float().mean() < 1e-3
+        assert a[1][t].tolist() == sid.tolist()
