@@ -317,3 +317,61 @@ def test_vps_per_frame_fused_path_vs_oracle(hip_lib):
         for k in res[0][t]['query_feats']:
             np.testing.assert_allclose(res[0][t]['query_feats'][k][0], ref[0][t]['query_feats'][k][0].numpy(),
                                        rtol=1e-3, atol=1e-3)
+
+
+def test_rel_test_flow_with_dataset_and_dataloader(hip_lib, tmp_path):
+    """tools/rel_test.py __main__ flow on the backend: PVSGRelationDataset (compat) -> DataLoader(batch_size=1)
+    -> evaluate(...) ; metrics must equal the oracle's bookkeeping on the same synthetic videos."""
+    import json
+    import pickle
+    import sys
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'openpvsg_amd', 'compat')
+    sys.path.insert(0, compat)
+    try:
+        for k in [k for k in sys.modules if k.split('.')[0] == 'datasets']:
+            del sys.modules[k]
+        from datasets import PVSGRelationDataset
+    finally:
+        sys.path.remove(compat)
+    from openpvsg_amd import relation as prel
+    K_values, T, seed = [20, 50, 100], 12, 11
+    anno = dict(split=dict(vidor=dict(val=['v1', 'v2']), epic_kitchen=dict(val=[]), ego4d=dict(val=[])),
+                objects=dict(thing=['a'], stuff=['b']), relations=[str(i) for i in range(57)],
+                data=[dict(video_id='v1'), dict(video_id='v2')])
+    (tmp_path / 'pvsg.json').write_text(json.dumps(anno))
+    mods = dict(se=(prel.ObjectEncoder(256), orel.ObjectEncoder(256), seed), oe=(prel.ObjectEncoder(256), orel.ObjectEncoder(256), seed + 1),
+                pp=(prel.PairProposalNetwork(256, 1024), orel.PairProposalNetwork(256, 1024), seed),
+                rm=(prel.TemporalTransformer(512, 57), orel.TemporalTransformer(512, 57), seed))
+    P, O = {}, {}
+    for k, (p, o, s) in mods.items():
+        sd = det_state_dict(p.eval(), s)
+        p.load_state_dict(sd)
+        o.eval().load_state_dict({n: v for n, v in sd.items() if n in o.state_dict()})
+        P[k], O[k] = p.to(DEV), o
+    rrd = {K: {i: {'name': str(i), 'total': 0, 'hit': 0, 'weak_hit': 0} for i in range(57)} for K in K_values}
+    prl_ref = []
+    for vid, n in (('v1', 9), ('v2', 6)):
+        feats = det_input('feats_' + vid, (n, T, 256), seed).double().numpy()
+        with torch.no_grad():
+            out = orel.evaluate_video(O['se'], O['oe'], O['pp'], O['rm'], torch.from_numpy(feats).float(), [], 100)
+        gts = [dict(subject_index=r['subject_index'], object_index=r['object_index'], relation=r['relation'],
+                    relation_span=r['relation_span'].copy()) for r in out['results'][:7:2]]
+        gts.append(dict(subject_index=0, object_index=1, relation=3, relation_span=np.ones(T)))
+        with torch.no_grad():
+            out = orel.evaluate_video(O['se'], O['oe'], O['pp'], O['rm'], torch.from_numpy(feats).float(), gts, 100)
+        orel.accumulate_recall(rrd, out['hits'], K_values)
+        prl_ref.append(out['pair_recall'])
+        os.makedirs(tmp_path / 'wd' / vid)
+        with open(tmp_path / 'wd' / vid / 'relations.pickle', 'wb') as f:   # tube ids 100.. as dict keys
+            pickle.dump(dict(feats={100 + i: feats[i] for i in range(n)},
+                             relations=[dict(g, subject_index=100 + g['subject_index'], object_index=100 + g['object_index'])
+                                        for g in gts]), f)
+    ref = orel.calculate_final_metrics(rrd, K_values)
+    ds = PVSGRelationDataset(str(tmp_path / 'pvsg.json'), 'val', str(tmp_path / 'wd'))
+    loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False)
+    final, prl = prel.evaluate(P['se'], P['oe'], P['pp'], P['rm'], loader, 100, ds.relations, DEV,
+                               csv_file_path=str(tmp_path / 'out' / 'r.csv'), mark='t', verbose=False)
+    for K in K_values:
+        for k in ('recall', 'mean_recall', 'weak_recall', 'weak_mean_recall'):
+            assert abs(final[K][k] - ref[K][k]) <= 1e-3, (K, k)
+    assert np.allclose(prl, prl_ref, atol=1e-3) and os.path.exists(tmp_path / 'out' / 'r.csv')
