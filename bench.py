@@ -5,8 +5,10 @@ One "step" = one pass of the hot path over one synthetic clip already resident i
   ResNet-50 -> MSDeformAttn pixel decoder -> clip-level masked-attention decoder (keys = T*h*w)
   -> last-layer mask logits -> per-frame x4 up-sampling + panoptic fusion -> tube assembly ->
   relation head (object encoders, N^2 pair scorer, top-100 pairs, temporal transformer).
-N > 1: the clip's frames are sharded contiguously over the ranks (strong scaling: total work fixed);
-attention partials and the per-frame segment records are exchanged with RCCL all-gathers.
+N > 1 (default --scaling weak): every rank runs the same step on its own 32-frame segment of a longer video
+(per-GPU work fixed); the per-frame segment records and kept query features are all-gathered (RCCL) and the
+relation head scores tubes over all N*32 frames.  --scaling strong shards ONE clip by frame instead
+(attention partials merged across ranks every decoder layer).
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around every C-ABI
 launch of the timed steps; `cpu_baseline` times the CPU oracle (oracle/, "port") on a bounded
@@ -56,6 +58,9 @@ def parse():
     ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'off'])
     ap.add_argument('--cpu-frames', type=int, default=4)
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='N>1: weak = one 32-frame clip (segment of a longer video) per GPU, tube records all-gathered; '
+                         'strong = ONE clip sharded by frame, attention partials merged across GPUs every layer')
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL over xGMI); gloo only for same-device logic tests')
     ap.add_argument('--checksum', action='store_true', help='add a result checksum (sharding-invariance check)')
     return ap.parse_args()
@@ -258,17 +263,25 @@ def main():
                         rel['relation_model']).eval()
 
     T = args.frames
-    clip, (Hp, Wp) = make_clip(T, args.height, args.width)
-    t0, t_local = parallel.shard_frames(T, rank, world)
-    clip_local = clip[t0:t0 + t_local].to(dev)           # resident in HBM before the timed region
+    weak = world > 1 and args.scaling == 'weak'
+    if weak:
+        clip, (Hp, Wp) = make_clip(T, args.height, args.width, seed=rank)   # this rank's own segment of the video
+        t0, t_local = 0, T
+        clip_local = clip.to(dev)
+    else:
+        clip, (Hp, Wp) = make_clip(T, args.height, args.width)
+        t0, t_local = parallel.shard_frames(T, rank, world)
+        clip_local = clip[t0:t0 + t_local].to(dev)       # resident in HBM before the timed region
     group = None
+    frames_per_step = T * world if weak else T
 
     timer = KernelTimer()
     if not args.no_kernel_timing and rank == 0:
         timer.install()
 
     def step():
-        return pipe(clip_local, (Hp, Wp), (args.height, args.width), total_frames=T, group=group)
+        return pipe(clip_local, (Hp, Wp), (args.height, args.width), total_frames=T, group=group,
+                    shard='segments' if weak else 'frames')
 
     for _ in range(args.warmup):
         out = step()
@@ -293,11 +306,12 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        fps = T * args.steps / elapsed
+        fps = frames_per_step * args.steps / elapsed
         line = {
             'metric': 'frames/sec for 720p 32-frame VPS+relation forward',
             'value': fps, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak' if (weak or world == 1) else 'strong',
+            'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'Mask2Former-VPS R50 clip-level forward, %d frames %dx%d (padded %dx%d), '
                                    '100 queries, 9 decoder layers over T*h*w keys, panoptic fusion per frame, '
@@ -305,7 +319,9 @@ def main():
                                    % (T, args.height, args.width, Hp, Wp),
                        'frames': T, 'frames_per_gpu': t_local, 'backbone': 'ResNet-50 (reference ships no Swin-B config)',
                        'weights': 'random init seed 0 (cls logits x%g so that some queries pass score>0.8)' % CLS_GAIN,
-                       'tubes': int(out['tube_feats'].shape[0]), 'parallelism': 'frame-shard x%d' % world},
+                       'tubes': int(out['tube_feats'].shape[0]), 'frames_per_step': frames_per_step,
+                       'parallelism': ('%d x 32-frame segments, all-gather of tube records' % world) if weak
+                       else ('frame-shard x%d, attention partials merged per layer' % world)},
         }
         if args.checksum:
             pans = out['pan_results']

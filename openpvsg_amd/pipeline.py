@@ -54,14 +54,14 @@ class PVSGPipeline(torch.nn.Module):
         self.num_top_pairs = num_top_pairs
 
     @torch.no_grad()
-    def vps_clip(self, clip, batch_input_shape, img_shape=None, total_frames=None, group=None):
+    def vps_clip(self, clip, batch_input_shape, img_shape=None, total_frames=None, group=None, solo=False):
         """clip (T_local,3,H,W) normalised frames of ONE video (this rank's shard).
         Returns per-frame panoptic maps (T_local,H,W) int32, seg ids / kept features per frame."""
         det = self.detector
         head, fusion = det.panoptic_head, det.panoptic_fusion_head
         T = clip.shape[0]
         shard = None
-        if parallel.is_dist(group):
+        if parallel.is_dist(group) and not solo:
             shard = parallel.ClipShard(head, total_frames, group)
         try:
             feats = det.extract_feat(clip)
@@ -73,10 +73,12 @@ class PVSGPipeline(torch.nn.Module):
         ih, iw = (img_shape or batch_input_shape)[:2]
         if self.fused_postprocess:
             pans, seg, keep = fusion.panoptic_fused(cls[0], masks4[0], (H, W), (ih, iw))
+            self._last_keep = keep
             seg_ids = list(seg.to(torch.long).unbind(0))
             k_feats = q[:, 0][keep]
             return pans, seg_ids, [k_feats] * T, cls, q
         scores, labels, keep = fusion.panoptic_select(cls[0])
+        self._last_keep = keep
         k_scores, k_classes = scores[keep], labels[keep]
         k_feats = q[:, 0][keep]
         pans, seg_ids = [], []
@@ -88,17 +90,44 @@ class PVSGPipeline(torch.nn.Module):
         return torch.stack(pans), seg_ids, [k_feats] * T, cls, q
 
     @torch.no_grad()
-    def forward(self, clip, batch_input_shape, img_shape=None, total_frames=None, group=None):
+    def forward(self, clip, batch_input_shape, img_shape=None, total_frames=None, group=None, shard='frames'):
+        """clip: this rank's frames.  With a process group:
+        shard='frames'   ONE clip split by frame over the ranks (strong scaling): clip-level attention merges
+                         partials across ranks every decoder layer; the per-frame segment records are gathered.
+        shard='segments' every rank holds its OWN clip = one segment of a longer video (weak scaling): no
+                         exchange inside the VPS forward; segment records + kept query features of all
+                         segments are all-gathered and the relation head scores tubes over the whole video
+                         (a tube lives in its segment's frames, zeros elsewhere -- the reference's convention
+                         for absent frames, utils/relation_matching.py:431-444)."""
         from .relation import relation_forward
-        T_local = clip.shape[0]
-        pans, seg_ids, k_feats, cls, q = self.vps_clip(clip, batch_input_shape, img_shape, total_frames, group)
-        if parallel.is_dist(group):
-            # tube reassembly: every rank needs each frame's segment-id record (K is identical on all
-            # ranks in clip mode because queries and class logits are replicated after the merge)
-            sid = torch.stack(seg_ids)                                   # (T_local, K)
-            sid = parallel.all_gather_cat(sid, 0, group)
-            seg_ids = list(sid.unbind(0))
-            k_feats = [k_feats[0]] * len(seg_ids)
+        dist_on = parallel.is_dist(group)
+        if dist_on and shard == 'segments':
+            pans, seg_ids, k_feats, cls, q = self.vps_clip(clip, batch_input_shape, img_shape, None, None, solo=True)
+            Q, C = q.shape[0], q.shape[2]
+            T_local = len(seg_ids)
+            # fixed-size records: segment id per (frame, query) with -1 for dropped / not kept, all Q features
+            kept_idx = self._last_keep.nonzero()[:, 0]
+            full = torch.full((T_local, Q), -1, dtype=torch.long, device=clip.device)
+            if kept_idx.numel():
+                full[:, kept_idx] = torch.stack(seg_ids)
+            rank_off = 1000000                                   # ids of different segments never collide
+            allseg = parallel.all_gather_cat(full[None], 0, group)              # (R, T_local, Q)
+            allfeat = parallel.all_gather_cat(q[:, 0][None], 0, group)          # (R, Q, C)
+            R = allseg.shape[0]
+            seg_ids, k_feats = [], []
+            for r in range(R):
+                ids = torch.where(allseg[r] >= 0, allseg[r] + r * rank_off, allseg[r])
+                for t in range(T_local):
+                    seg_ids.append(ids[t])
+                    k_feats.append(allfeat[r])
+        else:
+            pans, seg_ids, k_feats, cls, q = self.vps_clip(clip, batch_input_shape, img_shape, total_frames, group)
+            if dist_on:
+                # tube reassembly: every rank needs each frame's segment-id record (K is identical on all ranks
+                # in this mode because queries and class logits are replicated after the merge)
+                sid = parallel.all_gather_cat(torch.stack(seg_ids), 0, group)
+                seg_ids = list(sid.unbind(0))
+                k_feats = [k_feats[0]] * len(seg_ids)
         T = len(seg_ids)
         tube_ids, feats = assemble_tubes(seg_ids, k_feats, T)
         rel = None

@@ -53,6 +53,14 @@ def _worker(rank, world, port, tmp):
     t0, tl = parallel.shard_frames(T, rank, world)
     out = pipe(clip[t0:t0 + tl].cuda(), (64, 96), total_frames=T, group=None)
     torch.cuda.synchronize()
+    # weak-scaling mode: every rank owns a whole segment (here: the same 4-frame clip) of a longer video
+    seg = pipe(clip.cuda(), (64, 96), group=None, shard='segments')
+    solo = pipe(clip.cuda(), (64, 96))
+    ids = solo['tube_ids'].tolist()
+    assert seg['tube_ids'].tolist() == ids + [i + 1000000 for i in ids]
+    assert seg['tube_feats'].shape == (2 * len(ids), 2 * T, 256)
+    assert torch.allclose(seg['tube_feats'][:len(ids), :T], solo['tube_feats'], atol=1e-5)
+    assert float(seg['tube_feats'][:len(ids), T:].abs().max()) == 0.0      # absent outside its own segment
     torch.save(dict(pan=out['pan_results'].cpu(), query=out['query'].cpu(), cls=out['cls'].cpu(),
                     tube_ids=out['tube_ids'].cpu(), tube_feats=out['tube_feats'].cpu(),
                     pm=None if out['relation'] is None else out['relation']['pred_matrix'].cpu(), t0=t0),
