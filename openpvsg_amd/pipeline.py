@@ -100,7 +100,7 @@ class PVSGPipeline(torch.nn.Module):
                          (a tube lives in its segment's frames, zeros elsewhere -- the reference's convention
                          for absent frames, utils/relation_matching.py:431-444)."""
         from .relation import relation_forward
-        dist_on = parallel.is_dist(group)
+        dist_on = parallel.is_dist(group) and shard != 'none'     # shard='none': purely local run
         if dist_on and shard == 'segments':
             pans, seg_ids, k_feats, cls, q = self.vps_clip(clip, batch_input_shape, img_shape, None, None, solo=True)
             Q, C = q.shape[0], q.shape[2]
@@ -121,7 +121,8 @@ class PVSGPipeline(torch.nn.Module):
                     seg_ids.append(ids[t])
                     k_feats.append(allfeat[r])
         else:
-            pans, seg_ids, k_feats, cls, q = self.vps_clip(clip, batch_input_shape, img_shape, total_frames, group)
+            pans, seg_ids, k_feats, cls, q = self.vps_clip(clip, batch_input_shape, img_shape, total_frames, group,
+                                                           solo=not dist_on)
             if dist_on:
                 # tube reassembly: every rank needs each frame's segment-id record (K is identical on all ranks
                 # in this mode because queries and class logits are replicated after the merge)

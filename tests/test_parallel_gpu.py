@@ -55,7 +55,7 @@ def _worker(rank, world, port, tmp):
     torch.cuda.synchronize()
     # weak-scaling mode: every rank owns a whole segment (here: the same 4-frame clip) of a longer video
     seg = pipe(clip.cuda(), (64, 96), group=None, shard='segments')
-    solo = pipe(clip.cuda(), (64, 96))
+    solo = pipe(clip.cuda(), (64, 96), shard='none')
     ids = solo['tube_ids'].tolist()
     assert seg['tube_ids'].tolist() == ids + [i + 1000000 for i in ids]
     assert seg['tube_feats'].shape == (2 * len(ids), 2 * T, 256)
