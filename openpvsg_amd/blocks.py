@@ -523,6 +523,7 @@ class MSDeformAttnPixelDecoder(BaseModule):
         return self._geom[key]
 
     fuse_encoder = True
+    fpn_nchw = True
 
     def _fusable(self, layer, x):
         a = layer.attentions[0]
@@ -586,6 +587,10 @@ class MSDeformAttnPixelDecoder(BaseModule):
             start += h * w
         for i in range(self.num_input_levels - self.num_encoder_levels - 1, -1, -1):
             lat = self.lateral_convs[i](feats[i])
-            y = lat + F.interpolate(outs[-1], size=lat.shape[-2:], mode='bilinear', align_corners=False)
+            # `outs` are channel-last strided VIEWS of the token tensor (free for the decoder, which wants
+            # tokens); the FPN branch wants plain NCHW so that the resize, the add and MIOpen's 3x3 conv
+            # (2.2 TFLOP per 32-frame clip) do not run through layout transposes
+            top = outs[-1].contiguous() if self.fpn_nchw else outs[-1]
+            y = lat + F.interpolate(top, size=lat.shape[-2:], mode='bilinear', align_corners=False)
             outs.append(self.output_convs[i](y))
         return self.mask_feature(outs[-1]), outs[:self.num_outs]
