@@ -10,4 +10,4 @@ from openpvsg_amd.detectors import (Mask2FormerCustom, Mask2FormerVideoCustom,  
                                     Mask2FormerVideoCustomMinVIS)
 from openpvsg_amd.fusion import MaskFormerFusionHeadCustom  # noqa: F401
 from openpvsg_amd.heads import Mask2FormerHeadCustom, Mask2FormerVideoHead  # noqa: F401
-from . import relation_head  # noqa: F401
+from . import mask2former_vps, relation_head  # noqa: F401

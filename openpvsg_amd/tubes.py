@@ -1,0 +1,162 @@
+"""Tube records between the VPS stage and the relation stage: the on-disk formats the reference's tools
+exchange, written from the backend's results.
+
+  concat_seq            models/mask2former_vps/utils.py:20-89   per-frame {segment id: [query feat]} -> tubes keyed
+                                                                 by first appearance; `quantitive/masks.txt`
+                                                                 (MOTS lines `frame id cid h w rle`) and
+                                                                 `query_feats.pickle` (list of SimpleTracker)
+  write_mots_results    models/unitrack/utils/io.py:14-36
+  process_feats         utils/relation_matching.py:431-444      tubes -> {tube id: float64 [T,256]} (zeros = absent)
+
+The masks use COCO run-length encoding: [3P] pycocotools `mask.encode` (column-major runs, first run counts
+zeros, counts[i>2] delta-coded against counts[i-2], 5 bits per character + continuation bit, offset 48).
+pycocotools is not installed here: the codec below follows the published algorithm and is checked by round
+trips and hand-computed vectors only (parity with pycocotools' strings is unpinned).
+"""
+import os
+import pickle
+
+import numpy as np
+
+
+def rle_encode(mask):
+    """(H,W) bool/uint8 -> {'size': [H,W], 'counts': str} in COCO compressed RLE."""
+    m = np.asarray(mask)
+    h, w = m.shape
+    flat = np.asfortranarray(m.astype(np.uint8)).reshape(-1, order='F')
+    change = np.flatnonzero(flat[1:] != flat[:-1]) + 1
+    bounds = np.concatenate(([0], change, [flat.size]))
+    counts = np.diff(bounds).tolist()
+    if flat.size and flat[0] == 1:
+        counts = [0] + counts
+    chars = []
+    for i, c in enumerate(counts):
+        x = c - counts[i - 2] if i > 2 else c
+        more = True
+        while more:
+            bits = x & 0x1f
+            x >>= 5
+            more = not ((x == 0 and not (bits & 0x10)) or (x == -1 and (bits & 0x10)))
+            if more:
+                bits |= 0x20
+            chars.append(chr(bits + 48))
+    return {'size': [int(h), int(w)], 'counts': ''.join(chars)}
+
+
+def rle_decode(rle):
+    """Inverse of rle_encode -> (H,W) uint8."""
+    h, w = rle['size']
+    s = rle['counts']
+    s = s.decode('ascii') if isinstance(s, bytes) else s
+    counts, p = [], 0
+    while p < len(s):
+        x, k, more = 0, 0, True
+        while more:
+            c = ord(s[p]) - 48
+            x |= (c & 0x1f) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(counts) > 2:
+            x += counts[-2]
+        counts.append(x)
+    flat = np.zeros(h * w, dtype=np.uint8)
+    pos, val = 0, 0
+    for c in counts:
+        if val:
+            flat[pos:pos + c] = 1
+        pos += c
+        val ^= 1
+    return flat.reshape((h, w), order='F')
+
+
+class SimpleTracker:
+    """models/mask2former_vps/utils.py:14-18: what query_feats.pickle holds."""
+
+    def __init__(self, track_id, qf_tube):
+        self.track_id = track_id
+        self.qf_tube = qf_tube
+
+
+def write_mots_results(filename, results):
+    """results: [(frame_id (1-based), _, [rle dicts with 'class_id'], [track ids])]"""
+    os.makedirs(os.path.dirname(filename) or '.', exist_ok=True)
+    with open(filename, 'w') as f:
+        for frame_id, _, rles, track_ids in results:
+            for rle, tid in zip(rles or [], track_ids or []):
+                if tid < 0:
+                    continue
+                f.write('{frame} {id} {cid} {imh} {imw} {rle}\n'.format(
+                    frame=frame_id, id=tid, cid=rle['class_id'], imh=rle['size'][0], imw=rle['size'][1],
+                    rle=rle['counts']))
+
+
+def concat_seq(outputs, save_root=None, tracker_cls=SimpleTracker):
+    """Per-frame detector outputs (each `[{'pan_results': (H,W) ndarray, 'query_feats': {id: [feat]}}]`) ->
+    (query_feat_tubes, mots_results); writes `<save_root>/quantitive/masks.txt` and
+    `<save_root>/query_feats.pickle` when save_root is given."""
+    results, object_list, feat_tubes = [], [], {}
+    for frame_id, output in enumerate(outputs):
+        output = output[0] if isinstance(output, (list, tuple)) else output
+        if len(output['query_feats']) == 0:
+            results.append((frame_id + 1, [], [], []))
+            continue
+        ids, masks = [], []
+        for ins_id, feat in output['query_feats'].items():
+            if ins_id not in object_list:
+                object_list.append(ins_id)
+                feat_tubes[object_list.index(ins_id) + 1] = {}
+            tid = object_list.index(ins_id) + 1
+            f0 = feat[0]
+            f0 = f0.detach().cpu().numpy() if hasattr(f0, 'detach') else np.asarray(f0)
+            feat_tubes[tid][frame_id] = {'query_feat': f0.astype(np.float32), 'cls_id': int(ins_id % 1000)}
+            pan = output['pan_results']
+            pan = pan.detach().cpu().numpy() if hasattr(pan, 'detach') else np.asarray(pan)
+            rle = rle_encode(pan == ins_id)
+            rle['class_id'] = ins_id % 1000
+            ids.append(tid)
+            masks.append(rle)
+        results.append((frame_id + 1, None, masks, ids))
+    tubes = []
+    for tid, ft in feat_tubes.items():
+        tubes.append(tracker_cls(tid, [ft.get(i) for i in range(len(outputs))]))
+    if save_root is not None:
+        write_mots_results(os.path.join(save_root, 'quantitive', 'masks.txt'), results)
+        with open(os.path.join(save_root, 'query_feats.pickle'), 'wb') as f:
+            pickle.dump(tubes, f)
+    return tubes, results
+
+
+def read_mots_results(filename):
+    """masks.txt -> {track id: {'cid': most common class, 'mask': [{frame index: (H,W) uint8}, ...]}}
+    (utils/relation_matching.py:65-105)."""
+    from collections import Counter
+    by_tid = {}
+    with open(filename) as f:
+        for line in f:
+            fid, tid, cid, h, w, m = line.strip().split()
+            by_tid.setdefault(tid, []).append((fid, cid, rle_decode({'size': (int(h), int(w)), 'counts': m})))
+    out = {}
+    for tid in sorted(by_tid):
+        rows = by_tid[tid]
+        cls = Counter(c for _, c, _ in rows).most_common(1)[0][0]
+        out[int(tid)] = {'cid': cls, 'mask': [{int(fid) - 1: mask} for fid, _, mask in rows]}
+    return out
+
+
+def process_feats(query_feat_tubes, d=256):
+    """[SimpleTracker] -> {track id: float64 [T,d]} with zeros where the tube is absent."""
+    feat_dict = {t.track_id: t.qf_tube for t in query_feat_tubes}
+    if not feat_dict:
+        return {}
+    T = len(next(iter(feat_dict.values())))
+    out = {}
+    for tid, tube in feat_dict.items():
+        arr = np.zeros([T, d])
+        for t in range(T):
+            if tube[t] is not None:
+                arr[t] = tube[t]['query_feat']
+        out[tid] = arr
+    return out

@@ -1,0 +1,105 @@
+"""Tube records / on-disk formats between the VPS and relation stages (CPU)."""
+import os
+import pickle
+import sys
+
+import numpy as np
+import torch
+
+from openpvsg_amd import tubes
+
+
+def test_rle_round_trip_and_known_vectors():
+    rs = np.random.RandomState(0)
+    for shape in ((1, 1), (3, 5), (17, 9), (64, 96), (720, 1280)):
+        for p in (0.0, 0.03, 0.5, 1.0):
+            m = (rs.rand(*shape) < p).astype(np.uint8)
+            if shape == (720, 1280):     # blobby, like a segment
+                m[:] = 0
+                m[100:300, 200:900] = 1
+                m[350:360, 5:7] = 1
+            r = tubes.rle_encode(m)
+            assert r['size'] == list(shape) and (tubes.rle_decode(r) == m).all()
+    # hand-computed: 2x2 all ones -> counts [0,4] -> chars '0','4'
+    assert tubes.rle_encode(np.ones((2, 2)))['counts'] == '04'
+    # 1x3 [0,1,0] -> counts [1,1,1] -> '111'
+    assert tubes.rle_encode(np.array([[0, 1, 0]]))['counts'] == '111'
+    # column-major: [[0,1],[0,1]] -> flat F = [0,0,1,1] -> counts [2,2] -> '22'
+    assert tubes.rle_encode(np.array([[0, 1], [0, 1]]))['counts'] == '22'
+    # long run needs continuation: 40 zeros then 1 one: 40 = 0b01000 (8) + 1<<5 -> chars chr(8|32+48)='X', chr(1+48)='1'
+    m = np.zeros((41, 1))
+    m[40] = 1
+    assert tubes.rle_encode(m)['counts'] == 'X11'
+    # delta coding of the 4th count (index 3) against index 1
+    m = np.array([[0, 1, 1, 0, 0, 0, 1, 1, 1, 1]]).T      # counts [1,2,3,4] -> 4th stored as 4-2 = 2
+    assert tubes.rle_encode(m)['counts'] == '1232'
+
+
+def _outputs(T=5):
+    rs = np.random.RandomState(1)
+    outs = []
+    for t in range(T):
+        pan = np.full((16, 24), 126, np.int32)
+        qf = {}
+        if t != 2:
+            pan[2:8, 3:10] = 1005
+            qf[1005] = [torch.full((256,), float(t))]
+        if t >= 1:
+            pan[9:14, 12:20] = 120
+            qf[120] = [torch.full((256,), 10.0 + t), torch.zeros(256)]
+        outs.append([dict(pan_results=pan, query_feats=qf)])
+    return outs
+
+
+def test_concat_seq_files_and_process_feats(tmp_path):
+    outs = _outputs()
+    tb, results = tubes.concat_seq(outs, str(tmp_path))
+    assert [t.track_id for t in tb] == [1, 2]
+    assert [x is None for x in tb[0].qf_tube] == [False, False, True, False, False]
+    assert tb[1].qf_tube[0] is None and tb[1].qf_tube[3]['cls_id'] == 120 and tb[0].qf_tube[0]['cls_id'] == 5
+    lines = open(tmp_path / 'quantitive' / 'masks.txt').read().strip().split('\n')
+    assert len(lines) == 4 + 4
+    f, tid, cid, h, w, rle = lines[0].split()
+    assert (f, tid, cid, h, w) == ('1', '1', '5', '16', '24')
+    masks = tubes.read_mots_results(str(tmp_path / 'quantitive' / 'masks.txt'))
+    assert masks[1]['cid'] == '5' and masks[2]['cid'] == '120'
+    fr = {k: v for d in masks[1]['mask'] for k, v in d.items()}
+    assert sorted(fr) == [0, 1, 3, 4] and (fr[0] == (outs[0][0]['pan_results'] == 1005)).all()
+    with open(tmp_path / 'query_feats.pickle', 'rb') as fh:
+        back = pickle.load(fh)
+    feats = tubes.process_feats(back)
+    assert feats[1].shape == (5, 256) and feats[1].dtype == np.float64
+    assert (feats[1][2] == 0).all() and (feats[1][3] == 3.0).all() and (feats[2][0] == 0).all() and (feats[2][4] == 14.0).all()
+    # device-side assembly (pipeline.assemble_tubes) gives the same [N,T,256]
+    from openpvsg_amd.pipeline import assemble_tubes
+    seg_ids, kf = [], []
+    for t, o in enumerate(outs):
+        ids = list(o[0]['query_feats'])
+        seg_ids.append(torch.tensor(ids, dtype=torch.long))
+        kf.append(torch.stack([o[0]['query_feats'][i][0] for i in ids]) if ids else torch.zeros(0, 256))
+    tube_ids, dev_feats = assemble_tubes(seg_ids, kf, len(outs))
+    assert tube_ids.tolist() == [1005, 120]
+    assert np.allclose(dev_feats.numpy(), np.stack([feats[1], feats[2]]))
+
+
+def test_pickle_resolves_through_compat_namespace(tmp_path):
+    """query_feats.pickle written through the compat `models.mask2former_vps.utils.concat_seq` stores the class
+    path the reference's tools unpickle (`models.mask2former_vps.utils.SimpleTracker`)."""
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'openpvsg_amd', 'compat')
+    saved = {k: v for k, v in sys.modules.items() if k.split('.')[0] in ('models', 'mmcv', 'mmdet')}
+    for k in saved:
+        del sys.modules[k]
+    sys.path.insert(0, compat)
+    try:
+        from models.mask2former_vps.utils import concat_seq
+        concat_seq(_outputs(3), str(tmp_path))
+        raw = open(tmp_path / 'query_feats.pickle', 'rb').read()
+        assert b'models.mask2former_vps.utils' in raw and b'SimpleTracker' in raw
+        with open(tmp_path / 'query_feats.pickle', 'rb') as fh:
+            back = pickle.load(fh)
+        assert type(back[0]).__module__ == 'models.mask2former_vps.utils' and len(back[0].qf_tube) == 3
+    finally:
+        sys.path.remove(compat)
+        for k in [k for k in sys.modules if k.split('.')[0] in ('models', 'mmcv', 'mmdet')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
