@@ -62,6 +62,7 @@ def parse():
                     help='N>1: weak = one 32-frame clip (segment of a longer video) per GPU, tube records all-gathered; '
                          'strong = ONE clip sharded by frame, attention partials merged across GPUs every layer')
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL over xGMI); gloo only for same-device logic tests')
+    ap.add_argument('--graph', action='store_true', help='replay backbone+head as one hipGraph (experimental)')
     ap.add_argument('--checksum', action='store_true', help='add a result checksum (sharding-invariance check)')
     return ap.parse_args()
 
@@ -260,7 +261,7 @@ def main():
     det = det.to(dev)
     rel = {k: m.to(dev) for k, m in rel.items()}
     pipe = PVSGPipeline(det, rel['subject_encoder'], rel['object_encoder'], rel['pair_model'],
-                        rel['relation_model']).eval()
+                        rel['relation_model'], use_graph=args.graph).eval()
 
     T = args.frames
     weak = world > 1 and args.scaling == 'weak'

@@ -45,13 +45,51 @@ class PVSGPipeline(torch.nn.Module):
     """detector (clip-level VPS) + fusion post-processing per frame + tube assembly + relation head."""
 
     def __init__(self, detector, subject_encoder, object_encoder, pair_model, relation_model,
-                 num_top_pairs=100, fused_postprocess=True):
+                 num_top_pairs=100, fused_postprocess=True, use_graph=False):
         super().__init__()
         self.fused_postprocess = fused_postprocess
+        self.use_graph = use_graph
+        self._graphs = {}
         self.detector = detector
         self.subject_encoder, self.object_encoder = subject_encoder, object_encoder
         self.pair_model, self.relation_model = pair_model, relation_model
         self.num_top_pairs = num_top_pairs
+
+    def _graphed_forward(self, clip):
+        """backbone + pixel decoder + decoder (about 2 000 launches, static shapes, no host sync) replayed as
+        ONE hipGraph per input shape: the launches come from torch ops and from the C ABI alike, all on the
+        capturing stream.  First call per shape: two eager warm-up runs (MIOpen / hipBLASLt pick their
+        kernels), then capture.  Falls back to eager if capture is not possible."""
+        key = (tuple(clip.shape), str(clip.device))
+        entry = self._graphs.get(key)
+        det, head = self.detector, self.detector.panoptic_head
+        T = clip.shape[0]
+        if entry is None:
+            def run(x):
+                return head.clip_logits(det.extract_feat(x), 1, T)
+            try:
+                static_in = clip.clone()
+                side = torch.cuda.Stream(device=clip.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        run(static_in)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = run(static_in)
+                entry = (graph, static_in, static_out)
+            except Exception as e:   # capture unsupported for some op: stay eager, say so once
+                import warnings
+                warnings.warn('hipGraph capture of the VPS forward failed (%r); running eagerly' % (e,))
+                entry = False
+            self._graphs[key] = entry
+        if entry is False:
+            return head.clip_logits(det.extract_feat(clip), 1, T)
+        graph, static_in, static_out = entry
+        static_in.copy_(clip)
+        graph.replay()
+        return static_out
 
     @torch.no_grad()
     def vps_clip(self, clip, batch_input_shape, img_shape=None, total_frames=None, group=None, solo=False):
@@ -64,8 +102,11 @@ class PVSGPipeline(torch.nn.Module):
         if parallel.is_dist(group) and not solo:
             shard = parallel.ClipShard(head, total_frames, group)
         try:
-            feats = det.extract_feat(clip)
-            cls, masks4, q = head.clip_logits(feats, 1, T)          # (1,Q,C+1), (1,T,Q,H/4,W/4), (Q,1,C)
+            if self.use_graph and shard is None:
+                cls, masks4, q = self._graphed_forward(clip)
+            else:
+                feats = det.extract_feat(clip)
+                cls, masks4, q = head.clip_logits(feats, 1, T)      # (1,Q,C+1), (1,T,Q,H/4,W/4), (Q,1,C)
         finally:
             if shard is not None:
                 shard.release()
