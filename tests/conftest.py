@@ -24,3 +24,23 @@ def hip_lib():
     from openpvsg_amd import build, _lib
     build.build_hip_lib(verbose=False)
     return _lib.load()
+
+
+def _usable_cpus():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _sane_torch_threads():
+    """The GPU box shows 256 logical CPUs behind a 16-CPU cgroup quota: torch's default of one thread per
+    logical CPU makes the CPU oracle ~50x slower there."""
+    import torch
+    torch.set_num_threads(min(_usable_cpus(), 32))
+    yield

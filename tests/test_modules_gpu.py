@@ -375,3 +375,113 @@ def test_rel_test_flow_with_dataset_and_dataloader(hip_lib, tmp_path):
         for k in ('recall', 'mean_recall', 'weak_recall', 'weak_mean_recall'):
             assert abs(final[K][k] - ref[K][k]) <= 1e-3, (K, k)
     assert np.allclose(prl, prl_ref, atol=1e-3) and os.path.exists(tmp_path / 'out' / 'r.csv')
+
+
+def test_config1_ips_480p_through_tools_test_plumbing(hip_lib):
+    """BASELINE config 1 (R50 IPS, one 480x640 frame) through the tools/test.py call chain on the compat
+    namespace: build_detector -> build_dp (MMDataParallel) -> single_gpu_test over a DataLoader-like iterable
+    -> results list; compared with the CPU oracle's flow at the same size."""
+    import sys
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'openpvsg_amd', 'compat')
+    saved = {k: v for k, v in sys.modules.items() if k.split('.')[0] in ('mmcv', 'mmdet', 'models', 'datasets', 'utils')}
+    for k in saved:
+        del sys.modules[k]
+    sys.path.insert(0, compat)
+    try:
+        from mmdet.apis import single_gpu_test
+        from mmdet.models import build_detector as bd
+        from mmdet.utils import build_dp
+        from openpvsg_amd.model_zoo import mask2former_r50_model_cfg
+        seed, gains = 8, {'cls_embed.weight': 40.0}
+        cfg = mask2former_r50_model_cfg(False)
+        cfg['test_cfg'] = dict(cfg['test_cfg'], instance_on=False)
+        model = bd(cfg).eval()
+        model.load_state_dict(det_state_dict(model, seed, gains))
+        model = build_dp(model, 'cuda', device_ids=[0])
+        imgs = [det_input('img480_%d' % i, (1, 3, 480, 640), seed) for i in range(2)]
+        meta = dict(img_shape=(480, 640, 3), ori_shape=(480, 640, 3), pad_shape=(480, 640, 3), scale_factor=1.0, flip=False)
+        loader = [dict(img=[im], img_metas=[[dict(meta)]]) for im in imgs]
+        results = single_gpu_test(model, loader)
+    finally:
+        sys.path.remove(compat)
+        for k in [k for k in sys.modules if k.split('.')[0] in ('mmcv', 'mmdet', 'models', 'datasets', 'utils')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    assert len(results) == 2 and results[0]['pan_results'].shape == (480, 640)
+    o = opipe.IPSDetectorOracle(test_cfg=dict(opipe.DEFAULT_TEST_CFG)).eval()
+    o.load_state_dict(det_state_dict(o, seed, gains))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    for im, res in zip(imgs, results):
+        with torch.no_grad():
+            feats = o.backbone(im)
+            ocls, omasks, _ = o.panoptic_head.simple_test_with_query(feats, (480, 640), 1)
+            ref = oheads.fusion_simple_test_with_query(ocls, omasks, torch.zeros(1, 100, 1, 256), [dict(meta)], 115, 11,
+                                                       dict(opipe.DEFAULT_TEST_CFG), rescale=True)[0]
+        a, b = res['pan_results'], ref['pan_results'].numpy()
+        assert_panoptic_matches(a, b, decision_margin(ocls[0], omasks[0]))
+        assert mask_iou(a, b, 126) > 1 - 1e-3
+        assert sorted(res['query_feats'].keys()) == sorted(ref['query_feats'].keys())
+
+
+def test_config2_ips_720p_batch_independence(hip_lib):
+    """BASELINE config 2 size (R50 IPS, 720p frames batched through the per-frame decoder): a frame's
+    predictions must not depend on which other frames share the batch (catches batch-index bugs in the kernels
+    at real key counts: 920 / 3 680 / 14 720 keys per frame)."""
+    from openpvsg_amd.model_zoo import panoptic_head_cfg
+    from openpvsg_amd.registry import build_head as bh
+    from openpvsg_amd import blocks, heads  # noqa: F401
+    h = bh(dict(panoptic_head_cfg(False), train_cfg=None, test_cfg=None)).eval()
+    h.load_state_dict(det_state_dict(h, 4, GAINS))
+    h = h.to(DEV)
+    g = torch.Generator().manual_seed(0)
+    shapes = ((184, 320), (92, 160), (46, 80), (23, 40))
+    f3 = [torch.randn(3, c, *hw, generator=g).to(DEV) for c, hw in zip(CH, shapes)]
+    with torch.no_grad():
+        cls3, m3, q3 = h._decode(f3, 3, 1, all_masks=False)
+        cls1, m1, q1 = h._decode([f[1:2] for f in f3], 1, 1, all_masks=False)
+    assert torch.allclose(cls3[-1][1], cls1[-1][0], rtol=1e-3, atol=1e-3)
+    assert torch.allclose(q3[:, 1], q1[:, 0], rtol=1e-3, atol=1e-3)
+    sc = float(m1[-1].abs().max())
+    assert float((m3[-1][1] - m1[-1][0]).abs().max()) < 2e-3 * sc
+
+
+def test_config5_sizes_1080p_and_relation_N100_T64(hip_lib):
+    """BASELINE config 5 sizes: 1088x1920 frames (levels 34x60 / 68x120 / 136x240, stride-4 map 272x480)
+    through the clip-level head, and the relation head at N=100 tubes x T=64 frames against the oracle."""
+    from openpvsg_amd.model_zoo import panoptic_head_cfg
+    from openpvsg_amd.registry import build_head as bh
+    from openpvsg_amd import blocks, heads  # noqa: F401
+    from openpvsg_amd import relation as prel
+    h = bh(dict(panoptic_head_cfg(True), train_cfg=None, test_cfg=None)).eval()
+    h.load_state_dict(det_state_dict(h, 5, GAINS))
+    h = h.to(DEV)
+    g = torch.Generator().manual_seed(1)
+    T = 2
+    shapes = ((272, 480), (136, 240), (68, 120), (34, 60))
+    f = [torch.randn(T, c, *hw, generator=g).to(DEV) for c, hw in zip(CH, shapes)]
+    with torch.no_grad():
+        cls, masks4, q = h.clip_logits(f, 1, T)
+        cls_e, masks_e, q_e = h._decode(f, 1, T, all_masks=True, exact_masks=True)   # exact-mask (reference-contract) path
+    assert masks4.shape == (1, T, 100, 272, 480) and torch.isfinite(masks4).all()
+    assert torch.allclose(cls, cls_e[-1], rtol=1e-3, atol=1e-3) and torch.allclose(q, q_e, rtol=1e-3, atol=1e-3)
+    # relation head at N=100, T=64
+    seed, N, T = 3, 100, 64
+    feats_ = det_input('rel_feats', (N, T, 256), seed)
+    P, O = {}, {}
+    for k, (pc, oc, s) in dict(se=(prel.ObjectEncoder, orel.ObjectEncoder, seed), oe=(prel.ObjectEncoder, orel.ObjectEncoder, seed + 1)).items():
+        p, o = pc(256).eval(), oc(256).eval()
+        sd = det_state_dict(p, s)
+        p.load_state_dict(sd), o.load_state_dict(sd)
+        P[k], O[k] = p.to(DEV), o
+    pp, opp = prel.PairProposalNetwork(256, 1024).eval(), orel.PairProposalNetwork(256, 1024).eval()
+    sd = det_state_dict(pp, seed)
+    pp.load_state_dict(sd), opp.load_state_dict(sd)
+    rm, orm = prel.TemporalTransformer(512, 57).eval(), orel.TemporalTransformer(512, 57).eval()
+    sd = det_state_dict(rm, seed)
+    rm.load_state_dict(sd), orm.load_state_dict({n: v for n, v in sd.items() if n in orm.state_dict()})
+    with torch.no_grad():
+        out = prel.relation_forward(P['se'], P['oe'], pp.to(DEV), rm.to(DEV), feats_.to(DEV), 100)
+        ref = orel.evaluate_video(O['se'], O['oe'], opp, orm, feats_, [], 100)
+    np.testing.assert_allclose(out['pred_matrix'].cpu().numpy(), ref['pred_matrix'].numpy(), rtol=1e-3, atol=1e-4)
+    assert out['pairs'].cpu().tolist()[:20] == ref['pairs'][:20]                  # Recall@20 candidates identical
+    np.testing.assert_allclose(out['prob'].cpu().numpy()[:20], ref['prob'].numpy()[:20], rtol=1e-3, atol=1e-3)
