@@ -54,6 +54,7 @@ class VPSDetectorOracle(nn.Module):
             f_masks.append(masks.squeeze())
             f_embds.append(q.permute(0, 2, 1).squeeze())
         logits, masks, embds = heads.chain_frames(f_logits, f_masks, f_embds)
+        self.last_raw = (logits, masks, embds)       # kept for tests (decision margins of the hard thresholds)
         results = [[] for _ in range(bs)]
         for t in range(T):
             res = heads.fusion_simple_test_with_query(
