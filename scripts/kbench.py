@@ -50,7 +50,21 @@ def bench_msda(frames):
     ref2 = ref[0, :, 0, 0, 0, :].contiguous().to(dev)
     ms = timeit(lambda: ops.msda_fused(y, pos_oa, ref2, ss, lsi))
     algf = 4 * (2 * S * 256 + S * 288) * B + 4 * S * 288
-    print(json.dumps(dict(kernel='msda_fused', frames=B, ms=ms, alg_bytes=algf, GBps=algf / ms / 1e6)))
+    print(json.dumps(dict(kernel='msda_fused', offsets='iid N(0,2) px', frames=B, ms=ms, alg_bytes=algf,
+                          GBps=algf / ms / 1e6)))
+    # offsets as the mmcv initialisation leaves them (head m looks along direction m, point p at p+1 px)
+    # plus content noise: neighbouring queries then sample neighbouring pixels
+    import math
+    th = torch.arange(M, dtype=torch.float32) * (2.0 * math.pi / M)
+    grid = torch.stack([th.cos(), th.sin()], -1)
+    grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(M, 1, 1, 2).repeat(1, L, P, 1)
+    for p_ in range(P):
+        grid[:, :, p_, :] *= p_ + 1
+    y[..., 256:448] = (grid.reshape(-1)[None, None, :] + 0.3 * torch.randn(B, S, 192, generator=g)).to(dev)
+    pos_oa[:, :192] = 0
+    ms = timeit(lambda: ops.msda_fused(y, pos_oa, ref2, ss, lsi))
+    print(json.dumps(dict(kernel='msda_fused', offsets='mmcv init + N(0,0.3) px', frames=B, ms=ms,
+                          alg_bytes=algf, GBps=algf / ms / 1e6)))
 
 
 def bench_maskgemm(frames):
