@@ -157,6 +157,18 @@ int pvsg_affine_act_nchw(float* x, const float* scale, const float* shift, const
  *   perm[v,0] = identity, perm[v,t][j] = query of frame t placed on slot j (chained through t-1). */
 int pvsg_minvis_chain(const float* embds, int* perm, int V, int T, int Q, int C, void* stream);
 
+/* ---- 8f row 4: IPS tube association (UniTrack flavour) -- per-object appearance embeddings ----------
+ * Replaces MaskAssociationTracker.extract_emb, models/unitrack/mask.py:21-47 (mask * feature map,
+ * F.interpolate(bilinear, scale_factor = sqrt(max_mask_area/area)) of the whole product, nearest resize of
+ * the mask, boolean gather): only the kept cells are evaluated.
+ *   feat_hwd (h,w,d) NHWC appearance features;  pan_low (h,w) int32 object id per feature cell;
+ *   entries (k,3) int32 = (object slot, out row, out col), row-major per object;  obj_id (n) int32;
+ *   obj_inv_scale (n) = float(1/scale_factor) (1 = not rescaled);
+ *   out (k,d) raw embedding rows;  out_normalised (k,d) or NULL = rows / max(||row||, 1e-12). */
+int pvsg_mask_embed_forward(const float* feat_hwd, const int* pan_low, const int* entries, const int* obj_id,
+                            const float* obj_inv_scale, float* out, float* out_normalised, int h, int w, int d,
+                            int k, int n_obj, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,7 @@ SIGNATURES = {
     'pvsg_add_layernorm': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _ll, _i, _f, _c_f],
     'pvsg_affine_act_nchw': [_c_f, _c_f, _c_f, _c_f, _ll, _i, _ll, _i, _c_f],
     'pvsg_minvis_chain': [_c_f, _c_f, _i, _i, _i, _i, _c_f],
+    'pvsg_mask_embed_forward': [_c_f] * 7 + [_i] * 5 + [_c_f],
 }
 # entry points that return a value instead of a status code
 VALUE_RETURNING = ('pvsg_xattn_num_splits',)

@@ -92,7 +92,7 @@ class ResNet(BaseModule):
             with torch.no_grad():
                 d = {'stem': self._affine(self.bn1)}
                 for li in range(1, 5):
-                    for bi, blk in enumerate(getattr(self, 'layer%d' % li)):
+                    for bi, blk in enumerate(getattr(self, 'layer%d' % li, ())):
                         e = {'bn1': self._affine(blk.bn1), 'bn2': self._affine(blk.bn2), 'bn3': self._affine(blk.bn3)}
                         if blk.downsample is not None:
                             e['ds'] = self._affine(blk.downsample[1])

@@ -314,3 +314,23 @@ def minvis_chain(embds):
         _lib.call('pvsg_minvis_chain', e.data_ptr(), perm.data_ptr(), V, T, Q, C, _stream_ptr())
     perm = perm.to(torch.long)
     return perm[0] if squeeze else perm
+
+
+def mask_embed(feat_hwd, pan_low, entries, obj_id, obj_inv_scale, normalised=True):
+    """Per-object appearance embeddings of the IPS tracker (models/unitrack/mask.py:21-47), kept cells only.
+    feat_hwd (h,w,d) f32, pan_low (h,w) int32, entries (k,3) int32, obj_id (n) int32, obj_inv_scale (n) f32
+    -> (raw (k,d), normalised (k,d) or None)."""
+    f = _chk(feat_hwd, 'feat_hwd')
+    h, w, d = f.shape
+    k = int(entries.shape[0])
+    for t, name, dt in ((pan_low, 'pan_low', torch.int32), (entries, 'entries', torch.int32),
+                        (obj_id, 'obj_id', torch.int32), (obj_inv_scale, 'obj_inv_scale', torch.float32)):
+        if not t.is_cuda or t.dtype != dt or not t.is_contiguous():
+            raise RuntimeError('mask_embed: %s must be a contiguous %s tensor on the GPU (no CPU path)' % (name, dt))
+    out = torch.empty((k, d), device=f.device, dtype=torch.float32)
+    out_n = torch.empty_like(out) if normalised else None
+    with torch.cuda.device(f.device):
+        _lib.call('pvsg_mask_embed_forward', f.data_ptr(), pan_low.data_ptr(), entries.data_ptr(), obj_id.data_ptr(),
+                  obj_inv_scale.data_ptr(), out.data_ptr(), out_n.data_ptr() if normalised else None, h, w, d, k,
+                  int(obj_id.shape[0]), _stream_ptr())
+    return out, out_n
