@@ -19,28 +19,48 @@ import pickle
 import numpy as np
 
 
+def rle_counts_to_string(counts):
+    """COCO compressed-RLE string of run lengths (zeros first): delta against counts[i-2] from the 4th on,
+    5 bits per character + continuation bit, offset 48.  Vectorised over the counts (<= 13 chunks of 5 bits)."""
+    x = np.asarray(counts, dtype=np.int64).copy()
+    if x.size > 3:
+        x[3:] -= np.asarray(counts, dtype=np.int64)[1:-2]
+    cols, alive = [], np.ones(x.shape, bool)
+    while alive.any():
+        bits = x & 0x1f
+        x = x >> 5                                          # arithmetic shift: negative deltas end at -1
+        more = ~(((x == 0) & ((bits & 0x10) == 0)) | ((x == -1) & ((bits & 0x10) != 0)))
+        cols.append(np.where(alive, bits | np.where(more, 0x20, 0), -1))
+        alive = alive & more
+    if not cols:
+        return ''
+    m = np.stack(cols, 1)
+    return (m[m >= 0] + 48).astype(np.uint8).tobytes().decode('ascii')
+
+
 def rle_encode(mask):
     """(H,W) bool/uint8 -> {'size': [H,W], 'counts': str} in COCO compressed RLE."""
     m = np.asarray(mask)
     h, w = m.shape
-    flat = np.asfortranarray(m.astype(np.uint8)).reshape(-1, order='F')
+    flat = (m != 0).T.reshape(-1)                      # column-major order
     change = np.flatnonzero(flat[1:] != flat[:-1]) + 1
     bounds = np.concatenate(([0], change, [flat.size]))
     counts = np.diff(bounds).tolist()
-    if flat.size and flat[0] == 1:
+    if flat.size and flat[0]:
         counts = [0] + counts
-    chars = []
-    for i, c in enumerate(counts):
-        x = c - counts[i - 2] if i > 2 else c
-        more = True
-        while more:
-            bits = x & 0x1f
-            x >>= 5
-            more = not ((x == 0 and not (bits & 0x10)) or (x == -1 and (bits & 0x10)))
-            if more:
-                bits |= 0x20
-            chars.append(chr(bits + 48))
-    return {'size': [int(h), int(w)], 'counts': ''.join(chars)}
+    return {'size': [int(h), int(w)], 'counts': rle_counts_to_string(counts)}
+
+
+def rle_from_runs(starts, lengths, h, w):
+    """RLE of the mask whose foreground is the given maximal runs (column-major start offsets, lengths)."""
+    counts, pos = [], 0
+    for s0, l0 in zip(starts, lengths):
+        counts.append(int(s0) - pos)
+        counts.append(int(l0))
+        pos = int(s0) + int(l0)
+    if pos < h * w or not counts:
+        counts.append(h * w - pos)
+    return {'size': [int(h), int(w)], 'counts': rle_counts_to_string(counts)}
 
 
 def rle_decode(rle):

@@ -41,7 +41,7 @@ from scipy.optimize import linear_sum_assignment
 
 from . import ops
 from .backbone import ResNet, _Bottleneck
-from .tubes import rle_encode, write_mots_results
+from .tubes import rle_encode, rle_from_runs, write_mots_results
 
 INSTANCE_OFFSET = 1000
 chi2inv95 = {1: 3.8415, 2: 5.9915, 3: 7.8147, 4: 9.4877, 5: 11.070, 6: 12.592, 7: 14.067, 8: 15.507, 9: 16.919}
@@ -68,9 +68,6 @@ class _AppearanceResNet(ResNet):
                 cin = planes * 4
             setattr(self, 'layer%d' % li, nn.Sequential(*mods))
         self.eval()
-
-    def _stages(self):
-        return (1, 2, 3)
 
     def forward(self, x):
         if x.is_cuda and not torch.is_grad_enabled() and self.fuse_bn_act:
@@ -320,7 +317,7 @@ class STrack(BaseTrack):
         self.use_kalman = use_kalman
         self.is_activated = True if not use_kalman else ac
         self.score, self.category, self.tracklet_len = score, category, 0
-        self.smooth_feat = None
+        self._smooth, self._pending = None, []
         self.update_features(temp_feat)
         self.features = deque([], maxlen=buffer_size)
         self.alpha = 0.9
@@ -328,15 +325,29 @@ class STrack(BaseTrack):
         self.cls_id = None
 
     def update_features(self, feat):  # :92-100
+        """curr_feat <- feat; smooth_feat <- 0.9 smooth + 0.1 feat when the shapes agree.  The IPS flow never
+        reads smooth_feat (reconsdot_distance uses 'curr', matching.py:190-191), so the EMA is evaluated on access."""
         if isinstance(feat, tuple):
             raw, self.feat_n = feat
         else:
             raw, self.feat_n = feat, None
         self.curr_feat = raw
-        if self.smooth_feat is None:
-            self.smooth_feat = raw
-        elif self.smooth_feat.shape == raw.shape:
-            self.smooth_feat = 0.9 * self.smooth_feat + 0.1 * raw
+        if self._smooth is None:
+            self._smooth = raw
+        elif self._smooth_shape() == raw.shape:
+            self._pending.append(raw)
+            if len(self._pending) >= 8:
+                self.smooth_feat  # noqa: B018  (flush: bounds what the pending list keeps alive)
+
+    def _smooth_shape(self):
+        return self._smooth.shape
+
+    @property
+    def smooth_feat(self):
+        for raw in self._pending:
+            self._smooth = 0.9 * self._smooth + 0.1 * raw
+        self._pending = []
+        return self._smooth
 
     def predict(self):  # :102-107
         m = self.mean.copy()
@@ -501,16 +512,16 @@ def reconsdot_cost(trk_feats, det_feats, tmp=100.0):
     Nt, Pt, d = Ft.shape
     Nd, Pd, _ = Fd.shape
     A = Ft.reshape(Nt * Pt, d) @ Fd.reshape(Nd * Pd, d).t()
-    S = A * tmp
-    P = torch.softmax(S, dim=1)
-    Pc = torch.softmax(S, dim=0)
+    At = A.t().contiguous()                                  # softmax over a strided dim is 100x slower
+    P = torch.softmax(A * tmp, dim=1)                        # (Nt Pt, Nd Pd) rows: track cells
+    PcT = torch.softmax(At * tmp, dim=1)                     # (Nd Pd, Nt Pt) rows: detection cells
     num_td = (P * A).view(Nt, Pt, Nd, Pd).sum((1, 3))
-    num_dt = (Pc * A).view(Nt, Pt, Nd, Pd).sum((1, 3))
+    num_dt = (PcT * At).view(Nd, Pd, Nt, Pt).sum((1, 3)).t()
     Gd = Fd @ Fd.transpose(1, 2)
     Gt = Ft @ Ft.transpose(1, 2)
-    P3 = P.view(Nt * Pt, Nd, Pd).transpose(0, 1)
+    P3 = P.view(Nt * Pt, Nd, Pd).transpose(0, 1)             # (Nd, Nt Pt, Pd)
     q_td = (torch.bmm(P3, Gd) * P3).sum(-1).view(Nd, Nt, Pt).sum(-1).t()
-    Pc3 = Pc.view(Nt, Pt, Nd * Pd).transpose(1, 2)
+    Pc3 = PcT.view(Nd * Pd, Nt, Pt).transpose(0, 1)          # (Nt, Nd Pd, Pt)
     q_dt = (torch.bmm(Pc3, Gt) * Pc3).sum(-1).view(Nt, Nd, Pd).sum(-1)
     eps = 1e-12
     nt = Gt.diagonal(dim1=1, dim2=2).sum(-1).clamp_min(0).sqrt().clamp_min(eps)
@@ -572,6 +583,8 @@ class AssociationTracker:
     """multitracker.py:36-205.  `update(img, img0, obs, query_feats, total_num_tubes_previous)` keeps the
     reference's argument list; `img` may be the normalised (3,H,W) frame or, cheaper, the frame's appearance
     features already computed for the whole video (`Features`, see `eval_seq`)."""
+
+    tube_cls = None          # class stored in query_feats.pickle (compat/ substitutes the reference's module path)
 
     def __init__(self, tracker_cfg, app_model=None):
         self.tracker_cfg = tracker_cfg
@@ -657,7 +670,7 @@ class AssociationTracker:
             if track.score < self.det_thresh:
                 continue
             track.activate(self.kalman_filter, self.frame_id)
-            self.query_feat_tubes.append(QueryFeatTube(self.frame_id, track.track_id, query_feats[inew]))
+            self.query_feat_tubes.append((self.tube_cls or QueryFeatTube)(self.frame_id, track.track_id, query_feats[inew]))
             track.cls_id = query_feats[inew]['cls_id'] % INSTANCE_OFFSET
             activated.append(track)
         for track in self.lost_stracks:
@@ -696,12 +709,72 @@ def nearest_index(out_size, in_size, scale=None):
     return np.minimum(np.floor(np.arange(out_size, dtype=np.float32) * s).astype(np.int64), in_size - 1)
 
 
+class PanopticObs:
+    """The observations of one frame kept as what they come from: the panoptic id map on the device plus the
+    object ids.  Stands where the reference passes `obs`, an (n,H,W) stack of binary masks
+    (data/single_video.py:66-82): `len`, `.shape`, `obs[k]` work alike, the per-object full-resolution masks are
+    only materialised on request, and the MOTS run-length codes of ALL objects come from one pass over the map."""
+    ndim = 3
+
+    def __init__(self, pan, ids, device):
+        self.pan = torch.as_tensor(pan).to(device=device, dtype=torch.int32)
+        self.ids = [int(i) for i in ids]
+        self._runs = None
+
+    def __len__(self):
+        return len(self.ids)
+
+    @property
+    def shape(self):
+        return (len(self.ids),) + tuple(self.pan.shape)
+
+    def __getitem__(self, k):
+        return LazyMask(self, self.ids[int(k)])
+
+    def runs(self):
+        """column-major maximal runs of the id map: (starts, lengths, labels) as host arrays"""
+        if self._runs is None:
+            ft = self.pan.t().reshape(-1)
+            starts = torch.nonzero(ft[1:] != ft[:-1]).squeeze(1) + 1
+            starts = torch.cat([starts.new_zeros(1), starts])
+            both = torch.stack([starts, ft[starts].long()]).cpu().numpy()
+            st, lab = both[0], both[1]
+            self._runs = (st, np.diff(np.r_[st, ft.numel()]), lab)
+        return self._runs
+
+    def rle(self, oid):
+        st, ln, lab = self.runs()
+        sel = lab == oid
+        return rle_from_runs(st[sel], ln[sel], *self.pan.shape)
+
+
+class LazyMask:
+    """`STrack.mask` of an observation that lives in a PanopticObs."""
+
+    def __init__(self, frame, oid):
+        self.frame, self.oid = frame, oid
+
+    def astype(self, dtype):
+        return (self.frame.pan == self.oid).cpu().numpy().astype(dtype)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.astype(dtype or np.int64)
+
+    def sum(self):
+        st, ln, lab = self.frame.runs()
+        return int(ln[lab == self.oid].sum())
+
+    def rle(self):
+        return self.frame.rle(self.oid)
+
+
 class MaskAssociationTracker(AssociationTracker):
     """models/unitrack/mask.py:16-63."""
 
     def __init__(self, tracker_cfg, app_model=None):
         super().__init__(tracker_cfg, app_model)
         self._empty_gen = torch.Generator().manual_seed(0)
+        self._idx = {}
 
     def features(self, imgs):
         """(B,3,H,W) normalised frames -> list of `Features`."""
@@ -710,60 +783,66 @@ class MaskAssociationTracker(AssociationTracker):
             f = f.permute(0, 2, 3, 1).contiguous()
         return [Features(x) for x in f]
 
+    def _nearest(self, out_size, in_size):
+        key = (out_size, in_size)
+        if key not in self._idx:
+            self._idx[key] = torch.from_numpy(nearest_index(out_size, in_size)).to(self.device)
+        return self._idx[key]
+
     def extract_emb(self, img, obs):
-        """mask.py:21-47.  Returns (cell masks (n,h,w) bool ndarray, [(raw, normalised) (n_cells,d) tensors])."""
+        """mask.py:21-47.  Returns (cell masks (n,h,w) bool ndarray, [(raw, normalised) (n_cells,d) tensors]).
+        `obs`: the reference's (n,H,W) mask stack, or a PanopticObs (no per-object full-resolution masks)."""
         feat = img if isinstance(img, Features) else self.features(img[None] if img.dim() == 3 else img)[0]
         hwd = feat.hwd
         h, w, d = hwd.shape
-        obs = np.asarray(obs)
-        n, H, W = obs.shape
-        ys, xs = nearest_index(h, H), nearest_index(w, W)
-        low = obs[:, ys][:, :, xs] != 0                                   # F.interpolate(nearest) of the masks
-        # one id map: the observations of a panoptic frame are disjoint; keep slots separate if they are not
+        if isinstance(obs, PanopticObs):
+            n, (H, W) = len(obs), obs.pan.shape
+            pan_low_dev = obs.pan[self._nearest(h, H)][:, self._nearest(w, W)].contiguous()
+            ids = np.asarray(obs.ids, dtype=np.int32)
+            low = pan_low_dev.cpu().numpy()[None] == ids[:, None, None]          # F.interpolate(nearest) of each mask
+            groups = [(pan_low_dev, np.arange(n))]
+        else:
+            obs = np.asarray(obs)
+            n, H, W = obs.shape
+            low = obs[:, nearest_index(h, H)][:, :, nearest_index(w, W)] != 0
+            ids = np.arange(n, dtype=np.int32)
+            if (low.sum(0) > 1).any():          # overlapping masks cannot share one id map: one launch per object
+                groups = [(torch.from_numpy(np.where(low[i], i, -1).astype(np.int32)).to(self.device), np.array([i]))
+                          for i in range(n)]
+            else:
+                pl = np.full((h, w), -1, np.int32)
+                for i in range(n):
+                    pl[low[i]] = i
+                groups = [(torch.from_numpy(pl).to(self.device), np.arange(n))]
         area = low.reshape(n, -1).sum(1)
         max_area = _get(self.mots, 'max_mask_area')
-        pan_low = np.full((h, w), -1, np.int32)
-        overlap = (low.sum(0) > 1).any()
-        entries, scales, sizes = [], np.ones(n, np.float32), []
+        scales, cells = np.ones(n, np.float32), [None] * n
         for i in range(n):
             if area[i] == 0:
-                sizes.append(0)
                 continue
-            if not overlap:
-                pan_low[low[i]] = i
-            if area[i] > max_area:
+            sel = low[i]
+            if area[i] > max_area:              # mask.py:34-39: shrink to ~max_mask_area cells
                 sf = math.sqrt(max_area / float(area[i]))
-                oh, ow = int(math.floor(h * sf)), int(math.floor(w * sf))
                 inv = np.float32(1.0 / sf)
                 scales[i] = inv
-                sel = low[i][nearest_index(oh, h, inv)][:, nearest_index(ow, w, inv)]
-            else:
-                sel = low[i]
+                sel = sel[nearest_index(int(math.floor(h * sf)), h, inv)][:, nearest_index(int(math.floor(w * sf)), w, inv)]
             oy, ox = np.nonzero(sel)
-            entries.append(np.stack([np.full(len(oy), i), oy, ox], 1))
-            sizes.append(len(oy))
+            cells[i] = np.stack([np.full(len(oy), i), oy, ox], 1).astype(np.int32)
         embs = [None] * n
-        if entries:
-            ent = torch.from_numpy(np.concatenate(entries).astype(np.int32)).to(self.device)
-            ids = torch.arange(n, dtype=torch.int32, device=self.device)
-            sc = torch.from_numpy(scales).to(self.device)
-            if overlap:                                                  # rare: one launch per object
-                raws, nrms = [], []
-                for i in range(n):
-                    if sizes[i]:
-                        pl = torch.from_numpy(np.where(low[i], i, -1).astype(np.int32)).to(self.device)
-                        e = ent[ent[:, 0] == i].contiguous()
-                        r, q = ops.mask_embed(hwd, pl, e, ids, sc)
-                        raws.append(r)
-                        nrms.append(q)
-                raw, nrm = torch.cat(raws), torch.cat(nrms)
-            else:
-                raw, nrm = ops.mask_embed(hwd, torch.from_numpy(pan_low).to(self.device), ent, ids, sc)
+        for pan_low_dev, members in groups:
+            ent = [cells[i] for i in members if cells[i] is not None]
+            if not ent:
+                continue
+            ent = np.concatenate(ent)
+            buf = torch.from_numpy(np.concatenate([ent.ravel(), ids, scales.view(np.int32)])).to(self.device)
+            k = len(ent)
+            raw, nrm = ops.mask_embed(hwd, pan_low_dev, buf[:3 * k].view(k, 3), buf[3 * k:3 * k + n],
+                                      buf[3 * k + n:].view(torch.float32))
             off = 0
-            for i in range(n):
-                if sizes[i]:
-                    embs[i] = (raw[off:off + sizes[i]], nrm[off:off + sizes[i]])
-                    off += sizes[i]
+            for i in members:
+                if cells[i] is not None:
+                    embs[i] = (raw[off:off + len(cells[i])], nrm[off:off + len(cells[i])])
+                    off += len(cells[i])
         tmpl = int(np.prod(_get(self.mots, 'feat_size')))
         for i in range(n):
             if embs[i] is None:       # vanished at the feature stride: mask.py:46 draws noise (unseeded there)
@@ -795,7 +874,7 @@ class LoadOutputsFromMask2Former:
         self.mean = torch.tensor(_get(common, 'im_mean', [0.485, 0.456, 0.406])).view(3, 1, 1)
         self.std = torch.tensor(_get(common, 'im_std', [0.229, 0.224, 0.225])).view(3, 1, 1)
         outs = [o[0] if isinstance(o, (list, tuple)) else o for o in outputs]
-        self.pan_masks_all_images = [_np(o['pan_results']) for o in outs]
+        self.pan_masks_all_images = [o['pan_results'] for o in outs]        # ndarray or (device) tensor
         self.query_feat_dicts_all_images = [o['query_feats'] for o in outs]
 
     def __len__(self):
@@ -806,6 +885,7 @@ class LoadOutputsFromMask2Former:
         return fl[0] if len(fl) == 1 else np.stack(fl).mean(axis=0)
 
     def _get_binary_masks_and_query_feats(self, pan_mask, query_feat_dict):  # :52-82
+        pan_mask = _np(pan_mask)
         ids = [i for i in np.unique(pan_mask).tolist() if i != self.num_classes]
         if not ids:
             return np.array([]), []
@@ -824,8 +904,18 @@ class LoadOutputsFromMask2Former:
         labels, qfs = self._get_binary_masks_and_query_feats(self.pan_masks_all_images[idx],
                                                              self.query_feat_dicts_all_images[idx])
         img = self.image(idx) if self.frames is not None else None
-        hw = self.pan_masks_all_images[idx].shape
+        hw = tuple(self.pan_masks_all_images[idx].shape)
         return img, labels, None, hw, qfs
+
+    def panoptic_obs(self, idx, device):
+        """The same observations as `self[idx][1]` / `[4]` without building the (n,H,W) stack."""
+        pan = torch.as_tensor(self.pan_masks_all_images[idx]).to(device)
+        ids = [i for i in torch.unique(pan).tolist() if i != self.num_classes]
+        qfd = self.query_feat_dicts_all_images[idx]
+        if ids:
+            assert len(qfd) == len(ids), 'Masks and query feats should match!'
+        return PanopticObs(pan, ids, device), [dict(query_feat=self._unify_query_feat_dim(qfd[i]),
+                                                    cls_id=i % INSTANCE_OFFSET) for i in ids]
 
 
 def _np(x):
@@ -833,32 +923,32 @@ def _np(x):
 
 
 def eval_seq(data_cfg, tracker_cfg, outputs, classes, save_root=None, return_results=False, frames=None,
-             app_model=None, batch=16):
+             app_model=None, batch=16, tracker_cls=None):
     """test_mots_from_mask2former.py:29-95: associate the per-frame IPS results of one video into tubes.
     Writes `<save_root>/quantitive/masks.txt` (MOTS) and `<save_root>/query_feats.pickle` when save_root is
     given; returns (results, query_feat_tubes) when return_results.  The appearance CNN runs over the whole
     video in batches of `batch` frames before the (sequential) association starts."""
     loader = LoadOutputsFromMask2Former(data_cfg, outputs, tracker_cfg, classes, frames=frames)
     BaseTrack.reset_count()
-    tracker = MaskAssociationTracker(tracker_cfg, app_model)
+    tracker = (tracker_cls or MaskAssociationTracker)(tracker_cfg, app_model)
     down = _get(tracker_cfg['common'] if isinstance(tracker_cfg, dict) else tracker_cfg.common, 'down_factor', 8)
     feats = {}
-    need = [i for i in range(len(loader)) if (loader.pan_masks_all_images[i] != loader.num_classes).any()]
+    need = [i for i in range(len(loader)) if bool((loader.pan_masks_all_images[i] != loader.num_classes).any())]
     for s in range(0, len(need), batch):
         idx = need[s:s + batch]
-        for i, f in zip(idx, tracker.features(torch.stack([loader.image(i) for i in idx]))):
+        for i, f in zip(idx, tracker.features(torch.stack([loader.image(i).to(tracker.device) for i in idx]))):
             feats[i] = f
     results = []
     frame_id = -1
     for frame_id in range(len(loader)):
-        _, obs, img0, _, query_feats = loader[frame_id]
-        if len(obs) == 0:
+        if frame_id not in feats:              # nothing in this frame (the tracker's own frame counter stands still)
             results.append((frame_id + 1, [], [], []))
             continue
-        targets, _ = tracker.update(feats.pop(frame_id), img0, obs, query_feats, 0)
+        obs, query_feats = loader.panoptic_obs(frame_id, tracker.device)
+        targets, _ = tracker.update(feats.pop(frame_id), None, obs, query_feats, 0)
         tlwhs, ids, masks = [], [], []
         for t in targets:
-            rle = rle_encode(t.mask.astype(np.uint8))
+            rle = t.mask.rle() if isinstance(t.mask, LazyMask) else rle_encode(np.asarray(t.mask).astype(np.uint8))
             rle['class_id'] = t.cls_id
             tlwhs.append(t.tlwh * down)
             ids.append(t.track_id)

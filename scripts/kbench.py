@@ -1,5 +1,5 @@
 """Per-kernel micro-benchmarks (HIP events on torch's current stream).  Usage:
-   python scripts/kbench.py msda|maskgemm|xattn|pair|all [--frames N]"""
+   python scripts/kbench.py msda|maskgemm|xattn|pair|track|all [--frames N]"""
 import argparse
 import json
 import sys
@@ -116,6 +116,83 @@ def bench_pair():
         print(json.dumps(dict(kernel='pair_score', N=N, T=64, us=ms * 1e3)))
 
 
+
+def crowd_video(T, H, W, n_obj, seed=0):
+    """n_obj textured rectangles drifting over a 720p background (what an IPS pass hands to the tracker)."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    objs = []
+    for i in range(n_obj):
+        h, w = rs.randint(60, 260), rs.randint(60, 320)
+        objs.append(dict(cls=int(rs.randint(0, 60)), inst=i + 1, h=h, w=w, y=rs.randint(0, H - h), x=rs.randint(0, W - w),
+                         vy=rs.randint(-6, 7), vx=rs.randint(-12, 13), tex=rs.standard_normal((3, h, w)).astype(np.float32),
+                         qf=rs.standard_normal((1, 256)).astype(np.float32)))
+    bg = rs.standard_normal((3, H, W)).astype(np.float32) * 0.3
+    frames, outputs = [], []
+    for t in range(T):
+        img, pan, qf = bg.copy(), np.full((H, W), 126, np.int64), {}
+        for o in sorted(objs, key=lambda o: -o['h'] * o['w']):
+            y = int(np.clip(o['y'] + o['vy'] * t, 0, H - o['h']))
+            x = int(np.clip(o['x'] + o['vx'] * t, 0, W - o['w']))
+            img[:, y:y + o['h'], x:x + o['w']] = o['tex']
+            pan[y:y + o['h'], x:x + o['w']] = o['cls'] + 1000 * o['inst']
+        for o in objs:
+            pid = o['cls'] + 1000 * o['inst']
+            if (pan == pid).any():
+                qf[pid] = [o['qf']]
+        frames.append(torch.from_numpy(img))
+        outputs.append(dict(pan_results=pan, query_feats=qf))
+    return frames, outputs
+
+
+def bench_track(frames, n_obj=16, cpu_frames=3):
+    """IPS tube association (8f row 4): whole-video time on the GPU backend vs the oracle on the host cores."""
+    import time
+    import numpy as np
+    from openpvsg_amd import unitrack as T
+    cfg = dict(common=dict(model_type='imagenet50', remove_layers=['layer4'], down_factor=8, infer2D=True, device='cuda'),
+               mots=dict(track_buffer=300, conf_thres=0.5, max_mask_area=300, dup_iou_thres=0.15, confirm_iou_thres=0.7,
+                         feat_size=[4, 10], use_kalman=True, asso_with_motion=False, motion_lambda=1, motion_gated=False))
+    vid, outs = crowd_video(frames, 720, 1280, n_obj)
+    torch.manual_seed(0)
+    model = T.AppearanceModel(cfg).cuda()
+    stack = torch.stack(vid).cuda()
+    tr = T.MaskAssociationTracker(cfg, app_model=model)
+    cnn_ms = timeit(lambda: tr.features(stack[:16]), iters=5, warmup=2) / 16
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res, tubes = T.eval_seq(None, cfg, outs, 126, return_results=True, frames=vid, app_model=model)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    # stage timing of one mid-video update
+    feats = tr.features(stack[:2])
+    loader = T.LoadOutputsFromMask2Former(None, outs, cfg, 126, frames=vid)
+    _, obs, _, _, qfs = loader[1]
+    emb_ms = timeit(lambda: tr.extract_emb(feats[1], obs), iters=10, warmup=2)
+    low, embs = tr.extract_emb(feats[1], obs)
+    fn = [e[1] for e in embs]
+    dist_ms = timeit(lambda: T.reconsdot_cost(fn, fn), iters=10, warmup=2)
+    cells = sum(len(f) for f in fn)
+    print(json.dumps(dict(kernel='ips_tube_association', frames=frames, objects_per_frame=len(obs), tubes=len(tubes),
+                          fps=frames / wall, ms_per_frame=1e3 * wall / frames, cnn_ms_per_frame=cnn_ms,
+                          extract_emb_ms=emb_ms, reconsdot_ms=dist_ms, cells=cells,
+                          reconsdot_GFLOP=2e-9 * cells * cells * 1024)))
+    if cpu_frames:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import unitrack as U
+        import bench
+        torch.set_num_threads(bench.host_cores())
+        net = U.AppearanceResNet50()
+        net.load_state_dict({k.replace('model.', '', 1): v.cpu() for k, v in model.state_dict().items()})
+        t0 = time.perf_counter()
+        ref, _ = U.eval_seq(net, vid[:cpu_frames], outs[:cpu_frames], 126)
+        cw = time.perf_counter() - t0
+        same = [list(r[3]) for r in ref] == [list(r[3]) for r in res[:cpu_frames]]
+        print(json.dumps(dict(kernel='ips_tube_association_cpu_oracle', frames=cpu_frames, cores=torch.get_num_threads(),
+                              fps=cpu_frames / cw, ms_per_frame=1e3 * cw / cpu_frames, same_track_ids=same)))
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('which')
@@ -132,3 +209,5 @@ if __name__ == '__main__':
         bench_xattn(32)
     if a.which in ('pair', 'all'):
         bench_pair()
+    if a.which in ('track',):
+        bench_track(a.frames)

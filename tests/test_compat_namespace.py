@@ -173,3 +173,30 @@ def test_relation_dataset_contract(compat_path, tmp_path):
     assert int(batch['relations'][0]['subject_index'].item()) == 0 and batch['relations'][0]['relation_span'].shape == (1, 5)
     for k in [k for k in sys.modules if k.split('.')[0] in ('datasets',)]:
         del sys.modules[k]
+
+
+def test_unitrack_names_resolve_to_backend(compat_path):
+    """tools/prepare_query_tube_ips.py:30 and the module paths query_feats.pickle refers to."""
+    import pickle
+    import models  # noqa: F401
+    from models.unitrack.test_mots_from_mask2former import eval_seq
+    from models.unitrack.basetrack import BaseTrack, STrack, TrackState  # noqa: F401
+    from models.unitrack.core.association import matching
+    from models.unitrack.core.motion.kalman_filter import KalmanFilter, chi2inv95
+    from models.unitrack.data.query_feat_tracklet import QueryFeatTube
+    from models.unitrack.data.single_video import LoadOutputsFromMask2Former  # noqa: F401
+    from models.unitrack.mask import MaskAssociationTracker
+    from models.unitrack.model import AppearanceModel, partial_load
+    from models.unitrack.multitracker import AssociationTracker
+    from models.unitrack.utils import io
+    import openpvsg_amd.unitrack as T
+    assert callable(eval_seq) and models.eval_seq is eval_seq and issubclass(MaskAssociationTracker, AssociationTracker)
+    assert matching.reconsdot_distance is T.reconsdot_distance and KalmanFilter is T.KalmanFilter and chi2inv95[4] == 9.4877
+    assert MaskAssociationTracker.tube_cls is QueryFeatTube and callable(io.write_mots_results)
+    q = pickle.loads(pickle.dumps(QueryFeatTube(2, 1, {'cls_id': 3})))
+    assert type(q).__module__ == 'models.unitrack.data.query_feat_tracklet' and q.qf_tube == [None, {'cls_id': 3}]
+    m = AppearanceModel(dict(common=dict(model_type='imagenet50', remove_layers=['layer4'], infer2D=True)))
+    sd = {k: v + 1 for k, v in m.model.state_dict().items() if k.startswith('conv1')}
+    sd['fc.weight'] = 0
+    partial_load(sd, m.model)
+    assert float((m.model.conv1.weight - sd['conv1.weight']).abs().max()) == 0
