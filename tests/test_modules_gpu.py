@@ -487,3 +487,47 @@ def test_config5_sizes_1080p_and_relation_N100_T64(hip_lib):
     np.testing.assert_allclose(out['pred_matrix'].cpu().numpy(), ref['pred_matrix'].numpy(), rtol=1e-3, atol=1e-4)
     assert out['pairs'].cpu().tolist()[:20] == ref['pairs'][:20]                  # Recall@20 candidates identical
     np.testing.assert_allclose(out['prob'].cpu().numpy()[:20], ref['prob'].numpy()[:20], rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_config5_full_size_64_frames_1080p_properties(hip_lib):
+    """BASELINE config 5 at FULL size -- 64 frames of 1088x1920 (42 840 encoder tokens and 2 040 / 8 160 / 32 640 decoder
+    keys per frame; 2.09 M keys per clip level) -- through size-independent properties: a frame's prediction does not
+    depend on its batch mates (per-frame decoder), and the clip-level temporal attention does not depend on how its
+    keys are split into partial ranges (the same merge the multi-GPU layout uses)."""
+    from openpvsg_amd import ops
+    from openpvsg_amd.model_zoo import panoptic_head_cfg
+    from openpvsg_amd.registry import build_head as bh
+    from openpvsg_amd import blocks, heads  # noqa: F401
+    T = 64
+    shapes = ((272, 480), (136, 240), (68, 120), (34, 60))
+    g = torch.Generator(device=DEV).manual_seed(2)          # 15 GB of features: drawn on the device
+    f = [torch.randn(T, c, *hw, generator=g, device=DEV) for c, hw in zip(CH, shapes)]
+    # (a) per-frame decoder, B = 64
+    h = bh(dict(panoptic_head_cfg(False), train_cfg=None, test_cfg=None)).eval()
+    h.load_state_dict(det_state_dict(h, 4, GAINS))
+    h = h.to(DEV)
+    with torch.no_grad():
+        cls, m, q = h._decode(f, T, 1, all_masks=False)
+        cls1, m1, q1 = h._decode([x[37:38] for x in f], 1, 1, all_masks=False)
+    assert torch.isfinite(m[-1]).all() and m[-1].shape == (T, 100, 272, 480)
+    assert torch.allclose(cls[-1][37], cls1[-1][0], rtol=1e-3, atol=1e-3)
+    assert torch.allclose(q[:, 37], q1[:, 0], rtol=1e-3, atol=1e-3)
+    assert float((m[-1][37] - m1[-1][0]).abs().max()) < 2e-3 * float(m1[-1].abs().max())
+    del h, cls, m, q
+    torch.cuda.empty_cache()
+    # (b) clip-level decoder over T*h*w keys: vary the key split
+    hv = bh(dict(panoptic_head_cfg(True), train_cfg=None, test_cfg=None)).eval()
+    hv.load_state_dict(det_state_dict(hv, 5, GAINS))
+    hv = hv.to(DEV)
+    orig = ops.xattn_num_splits
+    try:
+        with torch.no_grad():
+            cls_a, masks_a, q_a = hv.clip_logits(f, 1, T)
+            ops.xattn_num_splits = lambda B, K: max(1, orig(B, K) // 3)
+            cls_b, masks_b, q_b = hv.clip_logits(f, 1, T)
+    finally:
+        ops.xattn_num_splits = orig
+    assert masks_a.shape == (1, T, 100, 272, 480) and torch.isfinite(masks_a).all()
+    assert torch.allclose(cls_a, cls_b, rtol=1e-3, atol=1e-3) and torch.allclose(q_a, q_b, rtol=1e-3, atol=1e-3)
+    assert float((masks_a - masks_b).abs().max()) < 2e-3 * float(masks_a.abs().max())
