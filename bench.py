@@ -156,6 +156,15 @@ class KernelTimer:
         if name == 'pvsg_center_downsample':
             planes, H, W = a[4:7]
             return 4.0 * planes * H * W * (1 + 21.0 / 64), 0.0
+        if name == 'pvsg_fpn_merge_up2x':
+            planes, h, w = a[5:8]
+            return 4.0 * planes * h * w * 9, 0.0                     # lateral 4 + out 4 + top 1 (x h*w cells)
+        if name == 'pvsg_stem_bn_relu_pool':
+            planes, C, H, W = a[4:8]
+            return 4.0 * planes * (H * W + ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)), 0.0
+        if name == 'pvsg_nchw_to_tokens':
+            B, C, HW = a[4:7]
+            return 8.0 * B * C * HW, 0.0
         return 0.0, 0.0
 
     def summary(self):

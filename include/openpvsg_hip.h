@@ -169,6 +169,26 @@ int pvsg_mask_embed_forward(const float* feat_hwd, const int* pan_low, const int
                             const float* obj_inv_scale, float* out, float* out_normalised, int h, int w, int d,
                             int k, int n_obj, void* stream);
 
+/* ---- pixel-decoder / backbone glue around the library convolutions (HBM streaming) -----------------
+ * [3P] mmdet MSDeformAttnPixelDecoder.forward FPN step:
+ *   out = lateral * scale[plane] + shift[plane] + bilinear_x2(top)      (GroupNorm as per-(image,channel) affine,
+ *   F.interpolate(size = 2x, mode='bilinear', align_corners=False));  lateral/out (planes, 2h, 2w), top (planes, h, w),
+ *   scale/shift (planes) or both NULL. */
+int pvsg_fpn_merge_up2x(const float* lateral, const float* scale, const float* shift, const float* top, float* out,
+                        long long planes, int h, int w, void* stream);
+/* [3P] mmdet ResNet stem: MaxPool2d(3, stride 2, pad 1)(ReLU(BatchNorm_eval(x))), BN as scale[c]/shift[c];
+ *   x (planes = N*C, H, W) -> out (planes, (H-1)/2+1, (W-1)/2+1). */
+int pvsg_stem_bn_relu_pool(const float* x, const float* scale, const float* shift, float* out, long long planes,
+                           int C, int H, int W, void* stream);
+/* pixel-decoder hand-off `feat.flatten(2).transpose(1, 2)` written into a slice of the (B, S, C) token tensor,
+ * with the preceding GroupNorm applied as per-(image,channel) affine (or NULL/NULL):
+ *   dst[b*dst_batch_stride + p*C + c] = src[b, c, p] * scale[b*C+c] + shift[b*C+c]. */
+int pvsg_nchw_to_tokens(const float* src, const float* scale, const float* shift, float* dst, int B, int C, int HW,
+                        long long dst_batch_stride, void* stream);
+/* the inverse (`memory[:, start:start+hw].transpose(1, 2).reshape(B, C, h, w)` made contiguous for the FPN branch):
+ *   dst[b, c, p] = src[b*src_batch_stride + p*C + c]. */
+int pvsg_tokens_to_nchw(const float* src, float* dst, int B, int C, int HW, long long src_batch_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,10 @@ SIGNATURES = {
     'pvsg_affine_act_nchw': [_c_f, _c_f, _c_f, _c_f, _ll, _i, _ll, _i, _c_f],
     'pvsg_minvis_chain': [_c_f, _c_f, _i, _i, _i, _i, _c_f],
     'pvsg_mask_embed_forward': [_c_f] * 7 + [_i] * 5 + [_c_f],
+    'pvsg_fpn_merge_up2x': [_c_f] * 5 + [_ll, _i, _i, _c_f],
+    'pvsg_stem_bn_relu_pool': [_c_f] * 4 + [_ll, _i, _i, _i, _c_f],
+    'pvsg_nchw_to_tokens': [_c_f] * 4 + [_i, _i, _i, _ll, _c_f],
+    'pvsg_tokens_to_nchw': [_c_f, _c_f, _i, _i, _i, _ll, _c_f],
 }
 # entry points that return a value instead of a status code
 VALUE_RETURNING = ('pvsg_xattn_num_splits',)

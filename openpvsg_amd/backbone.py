@@ -106,7 +106,7 @@ class ResNet(BaseModule):
         # convolutions stay plain NCHW MIOpen calls and only the BN/ReLU/residual passes are fused (own kernel).
         if self.norm_eval and x.is_cuda and not torch.is_grad_enabled() and self.fuse_bn_act:
             aff = self._affines()
-            x = F.max_pool2d(ops.affine_act_nchw_(self.conv1(x), *aff['stem']), 3, stride=2, padding=1)
+            x = ops.stem_bn_relu_pool(self.conv1(x), *aff['stem'])      # BN + ReLU + 3x3/2 max-pool in one pass
             outs = []
             for li in range(1, 5):
                 for bi, blk in enumerate(getattr(self, 'layer%d' % li)):

@@ -559,17 +559,30 @@ class MSDeformAttnPixelDecoder(BaseModule):
         t = F.linear(h, fc2.weight).view(B, S, C)
         return ops.add_layernorm(t, x, fc2.bias, layer.norms[1])
 
+    fuse_glue = True
+
     def forward(self, feats):
         B = feats[0].shape[0]
         shapes = [tuple(feats[self.num_input_levels - 1 - i].shape[-2:]) for i in range(self.num_encoder_levels)]
         pos_l, ref, ss, lsi = self._geometry(shapes, feats[0].device)
-        tokens, pos = [], []
-        for i in range(self.num_encoder_levels):
-            f = self.input_convs[i](feats[self.num_input_levels - 1 - i])
-            tokens.append(f.flatten(2).transpose(1, 2))                         # (B, hw, C)
-            pos.append(pos_l[i] + self.level_encoding.weight[i][None, :])
-        x = torch.cat(tokens, 1)
-        pos = torch.cat(pos, 0)[None]                                           # (1, S, C)
+        glue = self.fuse_glue and feats[0].is_cuda and not torch.is_grad_enabled()
+        pos = torch.cat([pos_l[i] + self.level_encoding.weight[i][None, :] for i in range(self.num_encoder_levels)], 0)[None]
+        if glue and not any(m.act for m in self.input_convs):
+            # GroupNorm apply + NCHW -> token transpose of each level in one pass into its slice of x
+            x = feats[0].new_empty((B, sum(h * w for h, w in shapes), self.input_convs[0].conv.out_channels))
+            start = 0
+            for i, (h, w) in enumerate(shapes):
+                m = self.input_convs[i]
+                raw = m.conv(feats[self.num_input_levels - 1 - i])
+                sc, sh = ops.group_norm_affine(raw, m.gn) if m.gn is not None else (None, None)
+                ops.nchw_to_tokens(raw, x, start, sc, sh)
+                start += h * w
+        else:
+            tokens = []
+            for i in range(self.num_encoder_levels):
+                f = self.input_convs[i](feats[self.num_input_levels - 1 - i])
+                tokens.append(f.flatten(2).transpose(1, 2))                     # (B, hw, C)
+            x = torch.cat(tokens, 1)
         for layer in self.encoder.layers:
             # BaseTransformerLayer ('self_attn','norm','ffn','norm') on batch-first tensors
             if self._fusable(layer, x):
@@ -581,16 +594,32 @@ class MSDeformAttnPixelDecoder(BaseModule):
             x = layer.norms[1](x)
         if self.encoder.post_norm is not None:
             x = self.encoder.post_norm(x)
-        outs, start = [], 0
+        outs, start, starts = [], 0, []
         for (h, w) in shapes:
             outs.append(x[:, start:start + h * w].transpose(1, 2).reshape(B, -1, h, w))
+            starts.append(start)
             start += h * w
         for i in range(self.num_input_levels - self.num_encoder_levels - 1, -1, -1):
-            lat = self.lateral_convs[i](feats[i])
             # `outs` are channel-last strided VIEWS of the token tensor (free for the decoder, which wants
             # tokens); the FPN branch wants plain NCHW so that the resize, the add and MIOpen's 3x3 conv
             # (2.2 TFLOP per 32-frame clip) do not run through layout transposes
-            top = outs[-1].contiguous() if self.fpn_nchw else outs[-1]
+            if glue and len(outs) == len(shapes) and x.is_contiguous():
+                top = ops.tokens_to_nchw(x, starts[-1], *shapes[-1])           # tiled transpose of the encoder memory
+            else:
+                top = outs[-1].contiguous() if self.fpn_nchw else outs[-1]
+            lm, om = self.lateral_convs[i], self.output_convs[i]
+            hl, wl = feats[i].shape[-2:]
+            if (glue and lm.gn is not None and not lm.act and om.gn is not None and om.act and
+                    (hl, wl) == (2 * top.shape[-2], 2 * top.shape[-1]) and top.shape[-1] % 2 == 0):
+                # GN(lateral) + x2 bilinear(top) in one pass; GN + ReLU after the 3x3 conv in one in-place pass
+                raw = lm.conv(feats[i])
+                y = ops.fpn_merge_up2x(raw, *ops.group_norm_affine(raw, lm.gn), top.contiguous())
+                o = om.conv(y)
+                sc, sh = ops.group_norm_affine(o, om.gn)
+                ops.affine_act_nchw_(o.view(1, -1, *o.shape[-2:]), sc, sh, relu=True)
+                outs.append(o)
+                continue
+            lat = lm(feats[i])
             y = lat + F.interpolate(top, size=lat.shape[-2:], mode='bilinear', align_corners=False)
-            outs.append(self.output_convs[i](y))
+            outs.append(om(y))
         return self.mask_feature(outs[-1]), outs[:self.num_outs]

@@ -1,0 +1,217 @@
+// HBM-streaming glue around the library convolutions (each replaces 2-4 separate torch passes):
+//
+//  fpn_merge_up2x      [3P] mmdet MSDeformAttnPixelDecoder.forward, FPN step:
+//                        y = GroupNorm(lateral_conv(C2)) + F.interpolate(top, size=2x, bilinear, align_corners=False)
+//                      GroupNorm enters as per-(image, channel) scale/shift; the x2 resize is evaluated in place
+//                      (torch's upsample kernel alone ran at 0.6 TB/s): one read of lateral, a quarter-size read of
+//                      top, one write.
+//  stem_bn_relu_pool   [3P] mmdet ResNet stem: BatchNorm(eval) -> ReLU -> MaxPool2d(3, stride 2, pad 1) in one pass
+//                      (reads the 7x7 conv output once, writes the quarter-size map).
+//  nchw_to_tokens      pixel-decoder hand-off: GroupNorm(input_conv(C_l)).flatten(2).transpose(1,2) written straight
+//                      into its slice of the (B, S, C) token tensor (LDS-tiled transpose; torch's cat of strided
+//                      views ran at 0.6 TB/s).
+#include "common.h"
+
+namespace pvsg {
+
+// thread -> top cell (i, 2j..2j+1): writes the 2x4 output patch rows 2i,2i+1 / cols 4j..4j+3
+__global__ __launch_bounds__(256) void fpn_merge_up2x_kernel(const float* __restrict__ lat,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ top, float* __restrict__ out,
+                                                            int h, int w) {
+  const long long plane = blockIdx.x;
+  const float sc = scale ? scale[plane] : 1.f, sh = shift ? shift[plane] : 0.f;
+  const float* tp = top + plane * (long long)h * w;
+  const float* lp = lat + plane * (long long)h * w * 4;
+  float* op = out + plane * (long long)h * w * 4;
+  const int w2 = w >> 1, W = 2 * w;
+  const int cells = h * w2;
+  for (int t = blockIdx.y * blockDim.x + threadIdx.x; t < cells; t += gridDim.y * blockDim.x) {
+    const int i = t / w2, j = t - i * w2;
+    const int im = max(i - 1, 0), ip = min(i + 1, h - 1);
+    const int c0 = max(2 * j - 1, 0), c1 = 2 * j, c2 = 2 * j + 1, c3 = min(2 * j + 2, w - 1);
+    float r[3][4];
+    const int rows[3] = {im, i, ip};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float* q = tp + (long long)rows[k] * w;
+      r[k][0] = q[c0]; r[k][1] = q[c1]; r[k][2] = q[c2]; r[k][3] = q[c3];
+    }
+    // torch upsample_bilinear2d, scale 0.5, align_corners=False: dst 2a -> (a-1: .25, a: .75) except dst 0 -> (0: 1);
+    // dst 2a+1 -> (a: .75, a+1: .25) with a+1 clamped to the last cell
+    const float wx0a = (j == 0) ? 1.f : 0.25f, wx0b = (j == 0) ? 0.f : 0.75f;   // out col 4j   : taps c0, c1  (c0==c1==0 at j=0)
+    float hx[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      hx[k][0] = (j == 0) ? (1.f * r[k][1] + 0.f * r[k][2]) : (wx0a * r[k][0] + wx0b * r[k][1]);
+      hx[k][1] = 0.75f * r[k][1] + 0.25f * r[k][2];
+      hx[k][2] = 0.25f * r[k][1] + 0.75f * r[k][2];
+      hx[k][3] = 0.75f * r[k][2] + 0.25f * r[k][3];
+    }
+    float4 o0, o1;
+    if (i == 0) {
+      o0 = make_float4(1.f * hx[1][0] + 0.f * hx[2][0], 1.f * hx[1][1] + 0.f * hx[2][1], 1.f * hx[1][2] + 0.f * hx[2][2],
+                       1.f * hx[1][3] + 0.f * hx[2][3]);
+    } else {
+      o0 = make_float4(0.25f * hx[0][0] + 0.75f * hx[1][0], 0.25f * hx[0][1] + 0.75f * hx[1][1],
+                       0.25f * hx[0][2] + 0.75f * hx[1][2], 0.25f * hx[0][3] + 0.75f * hx[1][3]);
+    }
+    o1 = make_float4(0.75f * hx[1][0] + 0.25f * hx[2][0], 0.75f * hx[1][1] + 0.25f * hx[2][1],
+                     0.75f * hx[1][2] + 0.25f * hx[2][2], 0.75f * hx[1][3] + 0.25f * hx[2][3]);
+    const long long b0 = (long long)(2 * i) * W + 4 * j, b1 = b0 + W;
+    const float4 l0 = ld4_stream(lp + b0), l1 = ld4_stream(lp + b1);
+    o0.x += l0.x * sc + sh; o0.y += l0.y * sc + sh; o0.z += l0.z * sc + sh; o0.w += l0.w * sc + sh;
+    o1.x += l1.x * sc + sh; o1.y += l1.y * sc + sh; o1.z += l1.z * sc + sh; o1.w += l1.w * sc + sh;
+    st4(op + b0, o0);
+    st4(op + b1, o1);
+  }
+}
+
+// thread -> output cells (y, 2k), (y, 2k+1): input cols 4k-1 .. 4k+3, rows 2y-1 .. 2y+1
+__global__ __launch_bounds__(256) void stem_bn_relu_pool_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, float* __restrict__ out,
+                                                               int C, int H, int W, int Ho, int Wo, bool vec) {
+  const long long plane = blockIdx.x;
+  const int c = (int)(plane % C);
+  const float sc = scale[c], sh = shift[c];
+  const float* xp = x + plane * (long long)H * W;
+  float* op = out + plane * (long long)Ho * Wo;
+  const int wp = (Wo + 1) >> 1;
+  const int cells = Ho * wp;
+  for (int t = blockIdx.y * blockDim.x + threadIdx.x; t < cells; t += gridDim.y * blockDim.x) {
+    const int y = t / wp, k = t - y * wp;
+    float m0 = 0.f, m1 = 0.f;            // ReLU output is >= 0 and every window holds a valid cell
+    const int x0 = 4 * k;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = 2 * y + dy;
+      if (yy < 0 || yy >= H) continue;
+      const float* q = xp + (long long)yy * W;
+      float v[5];
+      v[0] = (x0 > 0) ? q[x0 - 1] * sc + sh : 0.f;
+      if (vec && x0 + 3 < W) {
+        const float4 f = ld4_stream(q + x0);
+        v[1] = f.x * sc + sh; v[2] = f.y * sc + sh; v[3] = f.z * sc + sh; v[4] = f.w * sc + sh;
+      } else {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) v[1 + d] = (x0 + d < W) ? q[x0 + d] * sc + sh : 0.f;
+      }
+      m0 = fmaxf(m0, fmaxf(v[0], fmaxf(v[1], v[2])));
+      m1 = fmaxf(m1, fmaxf(v[2], fmaxf(v[3], v[4])));
+    }
+    op[(long long)y * Wo + 2 * k] = m0;
+    if (2 * k + 1 < Wo) op[(long long)y * Wo + 2 * k + 1] = m1;
+  }
+}
+
+// src (B, C, HW) -> dst[b, start + p, c] = src[b, c, p] * scale[b*C+c] + shift[b*C+c];  32x32 tiles through LDS
+__global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const float* __restrict__ src,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ dst,
+                                                            int C, int HW, long long dst_batch_stride) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const float* sp = src + ((long long)b * C) * HW;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = c0 + ty + 8 * r, p = p0 + tx;
+    if (c < C && p < HW) {
+      float v = sp[(long long)c * HW + p];
+      if (scale) v = v * scale[(long long)b * C + c] + shift[(long long)b * C + c];
+      tile[ty + 8 * r][tx] = v;
+    }
+  }
+  __syncthreads();
+  float* dp = dst + (long long)b * dst_batch_stride;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int p = p0 + ty + 8 * r, c = c0 + tx;
+    if (c < C && p < HW) dp[(long long)p * C + c] = tile[tx][ty + 8 * r];
+  }
+}
+
+// inverse hand-off: dst[b, c, p] = src[b, start + p, c]  (encoder memory of one level -> NCHW for the FPN branch)
+__global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            int C, int HW, long long src_batch_stride) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* sp = src + (long long)b * src_batch_stride;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int p = p0 + ty + 8 * r, c = c0 + tx;
+    if (c < C && p < HW) tile[ty + 8 * r][tx] = sp[(long long)p * C + c];
+  }
+  __syncthreads();
+  float* dp = dst + ((long long)b * C) * HW;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = c0 + ty + 8 * r, p = p0 + tx;
+    if (c < C && p < HW) dp[(long long)c * HW + p] = tile[tx][ty + 8 * r];
+  }
+}
+
+}  // namespace pvsg
+
+extern "C" int pvsg_fpn_merge_up2x(const float* lateral, const float* scale, const float* shift, const float* top,
+                                   float* out, long long planes, int h, int w, hipStream_t stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(lateral && top && out, "fpn_merge_up2x: null pointer argument");
+  PVSG_REQUIRE((scale == nullptr) == (shift == nullptr), "fpn_merge_up2x: scale and shift come together");
+  PVSG_REQUIRE(planes > 0 && planes < (1LL << 31) && h > 0 && w > 0, "fpn_merge_up2x: bad shape");
+  PVSG_REQUIRE(!(w & 1), "fpn_merge_up2x: the low-resolution width must be even (got %d)", w);
+  PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(lateral) | reinterpret_cast<uintptr_t>(out)) & 15u),
+               "fpn_merge_up2x: 16-byte alignment required");
+  int by = (h * (w / 2) + 255) / 256;
+  if (by > 32) by = 32;
+  hipLaunchKernelGGL(fpn_merge_up2x_kernel, dim3((unsigned)planes, by), dim3(256), 0, stream, lateral, scale, shift, top,
+                     out, h, w);
+  PVSG_LAUNCH_CHECK("fpn_merge_up2x");
+  return PVSG_OK;
+}
+
+extern "C" int pvsg_stem_bn_relu_pool(const float* x, const float* scale, const float* shift, float* out,
+                                      long long planes, int C, int H, int W, hipStream_t stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(x && scale && shift && out, "stem_bn_relu_pool: null pointer argument");
+  PVSG_REQUIRE(planes > 0 && planes < (1LL << 31) && C > 0 && planes % C == 0 && H > 0 && W > 0,
+               "stem_bn_relu_pool: bad shape");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;      // floor((n + 2 - 3) / 2) + 1
+  int by = (Ho * ((Wo + 1) / 2) + 255) / 256;
+  if (by > 64) by = 64;
+  const bool vec = !(W & 3) && !(reinterpret_cast<uintptr_t>(x) & 15u);
+  hipLaunchKernelGGL(stem_bn_relu_pool_kernel, dim3((unsigned)planes, by), dim3(256), 0, stream, x, scale, shift, out, C,
+                     H, W, Ho, Wo, vec);
+  PVSG_LAUNCH_CHECK("stem_bn_relu_pool");
+  return PVSG_OK;
+}
+
+extern "C" int pvsg_nchw_to_tokens(const float* src, const float* scale, const float* shift, float* dst, int B, int C,
+                                   int HW, long long dst_batch_stride, hipStream_t stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(src && dst, "nchw_to_tokens: null pointer argument");
+  PVSG_REQUIRE((scale == nullptr) == (shift == nullptr), "nchw_to_tokens: scale and shift come together");
+  PVSG_REQUIRE(B > 0 && B < 65536 && C > 0 && HW > 0 && dst_batch_stride >= (long long)HW * C, "nchw_to_tokens: bad shape");
+  PVSG_REQUIRE((C + 31) / 32 < 65536, "nchw_to_tokens: too many channels");
+  hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, stream, src, scale,
+                     shift, dst, C, HW, dst_batch_stride);
+  PVSG_LAUNCH_CHECK("nchw_to_tokens");
+  return PVSG_OK;
+}
+
+extern "C" int pvsg_tokens_to_nchw(const float* src, float* dst, int B, int C, int HW, long long src_batch_stride,
+                                   hipStream_t stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(src && dst, "tokens_to_nchw: null pointer argument");
+  PVSG_REQUIRE(B > 0 && B < 65536 && C > 0 && HW > 0 && src_batch_stride >= (long long)HW * C, "tokens_to_nchw: bad shape");
+  PVSG_REQUIRE((C + 31) / 32 < 65536, "tokens_to_nchw: too many channels");
+  hipLaunchKernelGGL(tokens_to_nchw_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, stream, src, dst, C, HW,
+                     src_batch_stride);
+  PVSG_LAUNCH_CHECK("tokens_to_nchw");
+  return PVSG_OK;
+}

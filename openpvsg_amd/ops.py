@@ -334,3 +334,67 @@ def mask_embed(feat_hwd, pan_low, entries, obj_id, obj_inv_scale, normalised=Tru
                   obj_inv_scale.data_ptr(), out.data_ptr(), out_n.data_ptr() if normalised else None, h, w, d, k,
                   int(obj_id.shape[0]), _stream_ptr())
     return out, out_n
+
+
+def group_norm_affine(x, gn):
+    """GroupNorm(x) == x * scale[b,c] + shift[b,c]: the statistics pass only (one read of x).  x (B,C,H,W)."""
+    B, C = x.shape[:2]
+    G = gn.num_groups
+    var, mean = torch.var_mean(x.reshape(B, G, -1), dim=2, correction=0)
+    rstd = torch.rsqrt(var + gn.eps)
+    scale = (rstd[:, :, None] * gn.weight.view(1, G, C // G)).reshape(B * C)
+    shift = (gn.bias.view(1, G, C // G) - mean[:, :, None] * scale.view(B, G, C // G)).reshape(B * C)
+    return scale.contiguous(), shift.contiguous()
+
+
+def fpn_merge_up2x(lateral, scale, shift, top):
+    """lateral * scale[b,c] + shift[b,c] + F.interpolate(top, size=2x, bilinear, align_corners=False).
+    lateral (B,C,2h,2w), top (B,C,h,w) contiguous; scale/shift (B*C) or None."""
+    lat, tp = _chk(lateral, 'lateral'), _chk(top, 'top')
+    B, C, H, W = lat.shape
+    h, w = tp.shape[-2:]
+    if (H, W) != (2 * h, 2 * w) or tp.shape[:2] != (B, C):
+        raise RuntimeError('fpn_merge_up2x: lateral %s is not the x2 of top %s' % (tuple(lat.shape), tuple(tp.shape)))
+    out = torch.empty_like(lat)
+    with torch.cuda.device(lat.device):
+        _lib.call('pvsg_fpn_merge_up2x', lat.data_ptr(), scale.data_ptr() if scale is not None else None,
+                  shift.data_ptr() if shift is not None else None, tp.data_ptr(), out.data_ptr(), B * C, h, w, _stream_ptr())
+    return out
+
+
+def stem_bn_relu_pool(x, scale, shift):
+    """max_pool2d(relu(x * scale[c] + shift[c]), 3, stride 2, padding 1) for x (N,C,H,W)."""
+    x = _chk(x, 'x')
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.call('pvsg_stem_bn_relu_pool', x.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(), N * C, C, H, W,
+                  _stream_ptr())
+    return out
+
+
+def nchw_to_tokens(src, dst, start, scale=None, shift=None):
+    """dst[:, start:start+H*W, :] = (src * scale[b,c] + shift[b,c]).flatten(2).transpose(1, 2);  src (B,C,H,W),
+    dst (B,S,C) contiguous."""
+    s = _chk(src, 'src')
+    B, C, H, W = s.shape
+    if not (dst.is_cuda and dst.is_contiguous() and dst.dtype == torch.float32 and dst.shape[0] == B and dst.shape[2] == C
+            and start + H * W <= dst.shape[1]):
+        raise RuntimeError('nchw_to_tokens: dst %s does not take %s at %d' % (tuple(dst.shape), tuple(s.shape), start))
+    with torch.cuda.device(s.device):
+        _lib.call('pvsg_nchw_to_tokens', s.data_ptr(), scale.data_ptr() if scale is not None else None,
+                  shift.data_ptr() if shift is not None else None, dst.data_ptr() + 4 * start * C, B, C, H * W,
+                  dst.shape[1] * C, _stream_ptr())
+    return dst
+
+
+def tokens_to_nchw(tokens, start, h, w):
+    """tokens[:, start:start+h*w].transpose(1, 2).reshape(B, C, h, w) as a contiguous tensor; tokens (B,S,C)."""
+    t = _chk(tokens, 'tokens')
+    B, S, C = t.shape
+    if start + h * w > S:
+        raise RuntimeError('tokens_to_nchw: %d tokens do not hold [%d, %d)' % (S, start, start + h * w))
+    out = torch.empty((B, C, h, w), device=t.device, dtype=torch.float32)
+    with torch.cuda.device(t.device):
+        _lib.call('pvsg_tokens_to_nchw', t.data_ptr() + 4 * start * C, out.data_ptr(), B, C, h * w, S * C, _stream_ptr())
+    return out

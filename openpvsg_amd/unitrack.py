@@ -72,7 +72,7 @@ class _AppearanceResNet(ResNet):
     def forward(self, x):
         if x.is_cuda and not torch.is_grad_enabled() and self.fuse_bn_act:
             aff = self._affines()
-            x = F.max_pool2d(ops.affine_act_nchw_(self.conv1(x), *aff['stem']), 3, stride=2, padding=1)
+            x = ops.stem_bn_relu_pool(self.conv1(x), *aff['stem'])
             for li in (1, 2, 3):
                 for bi, blk in enumerate(getattr(self, 'layer%d' % li)):
                     x = blk.forward_fused(x, aff[(li, bi)])

@@ -1,0 +1,101 @@
+"""HBM-streaming glue kernels around the library convolutions (csrc/fpn_fuse.hip) against the torch ops they replace."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+DEV = 'cuda'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 32, 23, 40), (1, 64, 5, 6), (3, 32, 1, 2), (2, 32, 92, 160)])
+def test_fpn_merge_up2x_matches_groupnorm_interpolate_add(hip_lib, shape):
+    from openpvsg_amd import ops
+    B, C, h, w = shape
+    g = torch.Generator().manual_seed(h * w)
+    top = torch.randn(B, C, h, w, generator=g).to(DEV)
+    lat = (torch.randn(B, C, 2 * h, 2 * w, generator=g) * 3 + 1).to(DEV)
+    gn = torch.nn.GroupNorm(8, C).to(DEV)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C, generator=g))
+        gn.bias.copy_(torch.randn(C, generator=g))
+        ref = gn(lat) + F.interpolate(top, size=(2 * h, 2 * w), mode='bilinear', align_corners=False)
+        out = ops.fpn_merge_up2x(lat, *ops.group_norm_affine(lat, gn), top)
+        plain = ops.fpn_merge_up2x(lat, None, None, top)
+    assert torch.allclose(out, ref, rtol=1e-5, atol=2e-5)
+    up = F.interpolate(top, size=(2 * h, 2 * w), mode='bilinear', align_corners=False)
+    assert float((plain - lat - up).abs().max()) < 1e-6 * max(1.0, float(lat.abs().max()))
+    with pytest.raises(RuntimeError, match='not the x2'):
+        ops.fpn_merge_up2x(lat[..., :-1].contiguous(), None, None, top)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 64, 368, 640), (1, 8, 7, 9), (2, 4, 10, 13), (1, 3, 1, 1), (1, 4, 2, 5)])
+def test_stem_bn_relu_pool_matches_torch(hip_lib, shape):
+    from openpvsg_amd import ops
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(N, C, H, W, generator=g).to(DEV)
+    sc = (torch.randn(C, generator=g)).to(DEV)            # negative scales included
+    sh = torch.randn(C, generator=g).to(DEV)
+    ref = F.max_pool2d(F.relu(x * sc.view(1, C, 1, 1) + sh.view(1, C, 1, 1)), 3, stride=2, padding=1)
+    out = ops.stem_bn_relu_pool(x, sc, sh)
+    assert out.shape == ref.shape and torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_nchw_to_tokens_and_groupnorm_affine(hip_lib):
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, C = 3, 256
+    gn = torch.nn.GroupNorm(32, C).to(DEV)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C, generator=g))
+        gn.bias.copy_(torch.randn(C, generator=g))
+    shapes = [(23, 40), (5, 7), (46, 80)]
+    S = sum(h * w for h, w in shapes)
+    dst = torch.full((B, S, C), float('nan'), device=DEV)
+    refs, start = [], 0
+    with torch.no_grad():
+        for h, w in shapes:
+            src = (torch.randn(B, C, h, w, generator=g) * 2 - 0.5).to(DEV)
+            ops.nchw_to_tokens(src, dst, start, *ops.group_norm_affine(src, gn))
+            refs.append(gn(src).flatten(2).transpose(1, 2))
+            start += h * w
+        ref = torch.cat(refs, 1)
+        assert torch.allclose(dst, ref, rtol=1e-5, atol=2e-5)
+        raw = torch.randn(B, 48, 9, 11, generator=g).to(DEV)
+        d2 = torch.zeros(B, 120, 48, device=DEV)
+        ops.nchw_to_tokens(raw, d2, 10)
+        assert torch.equal(d2[:, 10:109], raw.flatten(2).transpose(1, 2)) and float(d2[:, :10].abs().sum()) == 0
+        # GN + ReLU as statistics + the in-place affine kernel
+        o = (torch.randn(2, C, 12, 20, generator=g) * 3).to(DEV)
+        want = F.relu(gn(o))
+        sc, sh = ops.group_norm_affine(o, gn)
+        got = ops.affine_act_nchw_(o.clone().view(1, -1, 12, 20), sc, sh, relu=True).view_as(o)
+        assert torch.allclose(got, want, rtol=1e-5, atol=2e-5)
+    with pytest.raises(RuntimeError, match='does not take'):
+        ops.nchw_to_tokens(raw, d2, 30)
+    back = ops.tokens_to_nchw(dst, 23 * 40, 5, 7)
+    assert torch.equal(back, dst[:, 920:955].transpose(1, 2).reshape(B, C, 5, 7))
+    assert torch.equal(ops.tokens_to_nchw(dst, 955, 46, 80), dst[:, 955:].transpose(1, 2).reshape(B, C, 46, 80))
+
+
+@pytest.mark.gpu
+def test_pixel_decoder_glue_path_equals_generic(hip_lib):
+    from openpvsg_amd.model_zoo import panoptic_head_cfg
+    from openpvsg_amd.registry import build_plugin_layer
+    from openpvsg_amd import blocks  # noqa: F401
+    cfg = panoptic_head_cfg(False)['pixel_decoder']
+    pd = build_plugin_layer(dict(cfg, in_channels=[256, 512, 1024, 2048], feat_channels=256, out_channels=256))[1].to(DEV).eval()
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for p in pd.parameters():
+            p.copy_(torch.randn(p.shape, generator=g).to(DEV) * (0.05 if p.dim() > 1 else 0.5))
+        feats = [torch.randn(2, c, *hw, generator=g).to(DEV) for c, hw in zip((256, 512, 1024, 2048), ((48, 80), (24, 40), (12, 20), (6, 10)))]
+        pd.fuse_glue = True
+        mf, mem = pd(feats)
+        pd.fuse_glue = False
+        mf0, mem0 = pd(feats)
+    assert torch.allclose(mf, mf0, rtol=1e-4, atol=1e-4 * float(mf0.abs().max()))
+    for a, b in zip(mem, mem0):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
