@@ -21,13 +21,12 @@ What changes underneath:
 """
 import copy
 
-import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
 from .blocks import BaseModule, ModuleList
-from .config import ConfigDict, _wrap
+from .config import _wrap
 from .registry import (HEADS, build_plugin_layer, build_positional_encoding,
                        build_transformer_layer_sequence)
 

@@ -9,7 +9,6 @@ Detector-level flows of the reference, restated on top of oracle/blocks3p.py + o
 Pinned end-to-end at T=1 by tests/golden/detector_vps_T1.npz.  Parameter names follow the
 reference's checkpoints (backbone.*, panoptic_head.*).
 """
-import torch
 import torch.nn as nn
 
 from . import blocks3p, heads

@@ -1,4 +1,4 @@
-import sys, os, cProfile, pstats
+import sys, cProfile, pstats
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/scripts')
 import torch, kbench
 from openpvsg_amd import unitrack as T

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from oracle import blocks3p, cbuild, relation
-from oracle.detweights import det_input, det_state_dict
+from oracle.detweights import det_state_dict
 from tests.test_msda import make_case
 
 

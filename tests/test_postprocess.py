@@ -9,7 +9,6 @@ import torch
 import torch.nn.functional as F
 
 from oracle import heads as oheads
-from oracle.detweights import det_input
 from tests.synth_inputs import blob_masks, peaky_cls
 
 pytestmark = pytest.mark.gpu
