@@ -142,7 +142,7 @@ class KernelTimer:
             B, Q, K, M, D, NS = a[7:13]
             return B * K * (2.0 * M * D * 4 + (16 if a[3] else 0)) + 4.0 * B * NS * M * Q * (D + 2), 4.0 * B * Q * M * D * K
         if name == 'pvsg_affine_act_nchw':
-            planes, C, HW = a[4:7]
+            planes, C, HW = a[5:8]
             return 4.0 * planes * HW * (3 if a[3] else 2), 0.0
         if name == 'pvsg_msda_fused_forward':
             B, S, M, D, Lq, L, P = a[9:16]

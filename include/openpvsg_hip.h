@@ -147,8 +147,8 @@ int pvsg_add_layernorm(const float* a, const float* b, const float* bias, const 
 
 /* ---- backbone glue: frozen BatchNorm (+ residual) (+ ReLU) in one in-place pass ------------------
  * [3P] mmdet ResNet (norm_eval=True): y = relu(x * scale[c] + shift[c] (+ residual)) over (planes = N*C, HW). */
-int pvsg_affine_act_nchw(float* x, const float* scale, const float* shift, const float* residual,
-                         long long planes, int C, long long HW, int relu, void* stream);
+int pvsg_affine_act_nchw(float* x, const float* scale, const float* shift, const float* residual, float* out,
+                         long long planes, int C, long long HW, int relu, void* stream);   /* out NULL = in place */
 
 /* ---- a9: MinVIS frame-to-frame query matching, whole video in one launch ------
  * Replaces match_from_embds (models/mask2former_vps/mask2former_min_vis.py:244-258: cosine cost, C.cpu(),

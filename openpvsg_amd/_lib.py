@@ -34,7 +34,7 @@ SIGNATURES = {
     'pvsg_panoptic_fuse': [_c_f] * 8 + [_i] * 11 + [ctypes.c_double, _i, _c_f],
     'pvsg_msda_fused_forward': [_c_f, _ll, _c_f, _ll, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _i, _i, _c_f],
     'pvsg_add_layernorm': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _ll, _i, _f, _c_f],
-    'pvsg_affine_act_nchw': [_c_f, _c_f, _c_f, _c_f, _ll, _i, _ll, _i, _c_f],
+    'pvsg_affine_act_nchw': [_c_f, _c_f, _c_f, _c_f, _c_f, _ll, _i, _ll, _i, _c_f],
     'pvsg_minvis_chain': [_c_f, _c_f, _i, _i, _i, _i, _c_f],
     'pvsg_mask_embed_forward': [_c_f] * 7 + [_i] * 5 + [_c_f],
     'pvsg_fpn_merge_up2x': [_c_f] * 5 + [_ll, _i, _i, _c_f],

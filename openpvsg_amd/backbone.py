@@ -3,6 +3,8 @@ selected by configs/mask2former/..._custom_single_video_test.py:14-24.  Stays a 
 (MIOpen) convolution stack: the north-star's hand-written kernels live in the head (SURVEY.md
 section 2, #11).  state_dict keys: conv1, bn1, layer{1-4}.{i}.{conv,bn}{1-3}, downsample.{0,1}.
 Frozen BatchNorm is folded into per-channel scale/shift at first use (inference only)."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -36,16 +38,17 @@ class _Bottleneck(nn.Module):
         out = self.bn3(self.conv3(out))
         return F.relu(out + identity, inplace=True)
 
-    def forward_fused(self, x, aff):
-        """Frozen BN as per-channel affine: BN+ReLU and BN+residual+ReLU are one in-place HIP pass each
-        (csrc/elementwise.hip) behind MIOpen's convolutions."""
+    def forward_fused(self, x, aff, out=None):
+        """Frozen BN as per-channel affine: BN+ReLU and BN+residual+ReLU are one HIP pass each
+        (csrc/elementwise.hip) behind MIOpen's convolutions.  `out`: where the block's result goes (a batch
+        slice of a stage-output tensor) instead of over conv3's own output."""
         if self.downsample is None:
             identity = x
         else:
             identity = ops.affine_act_nchw_(self.downsample[0](x), *aff['ds'], relu=False)
-        out = ops.affine_act_nchw_(self.conv1(x), *aff['bn1'])
-        out = ops.affine_act_nchw_(self.conv2(out), *aff['bn2'])
-        return ops.affine_act_nchw_(self.conv3(out), *aff['bn3'], residual=identity)
+        y = ops.affine_act_nchw_(self.conv1(x), *aff['bn1'])
+        y = ops.affine_act_nchw_(self.conv2(y), *aff['bn2'])
+        return ops.affine_act_nchw_(self.conv3(y), *aff['bn3'], residual=identity, out=out)
 
 
 @BACKBONES.register_module()
@@ -100,20 +103,52 @@ class ResNet(BaseModule):
             self._aff_cache = (ver, d)
         return self._aff_cache[1]
 
+    # The frames of a batch are independent: halves of the batch on two HIP streams let the HBM-bound BN/ReLU
+    # passes of one half run under the MFMA-bound convolutions of the other (59 -> 52 ms per 32 x 720p frames).
+    # Only the backbone does this: torch's F.linear (hipBLASLt) stalls when issued from two side streams.
+    num_streams = int(os.environ.get('PVSG_BACKBONE_STREAMS', '2'))
+
+    def _stage_shapes(self, x):
+        N, _, H, W = x.shape
+        h, w = (H - 1) // 2 + 1, (W - 1) // 2 + 1          # conv1 (7x7 / 2, pad 3)
+        h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1          # max-pool (3x3 / 2, pad 1)
+        shapes = []
+        for li, planes in enumerate((64, 128, 256, 512), 1):
+            if li > 1:
+                h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1  # stride-2 3x3 conv, pad 1
+            shapes.append((N, planes * 4, h, w))
+        return shapes
+
+    def _forward_fused(self, x, aff, outs):
+        """x: a batch slice; outs[li-1]: the matching slice of the stage-output tensors (written in place)."""
+        x = ops.stem_bn_relu_pool(self.conv1(x), *aff['stem'])      # BN + ReLU + 3x3/2 max-pool in one pass
+        for li in range(1, 5):
+            blocks = getattr(self, 'layer%d' % li)
+            for bi, blk in enumerate(blocks):
+                x = blk.forward_fused(x, aff[(li, bi)], out=outs[li - 1] if bi == len(blocks) - 1 else None)
+
     def forward(self, x):
         # Measured on MI355X (32x736x1280 fp32): MIOpen's fused conv+bias+ReLU plans (aten::miopen_convolution_relu
         # / _add_relu) are SLOWER than plain conv (77.9 vs 72.9 ms) and channels_last falls to naive kernels, so the
         # convolutions stay plain NCHW MIOpen calls and only the BN/ReLU/residual passes are fused (own kernel).
         if self.norm_eval and x.is_cuda and not torch.is_grad_enabled() and self.fuse_bn_act:
             aff = self._affines()
-            x = ops.stem_bn_relu_pool(self.conv1(x), *aff['stem'])      # BN + ReLU + 3x3/2 max-pool in one pass
-            outs = []
-            for li in range(1, 5):
-                for bi, blk in enumerate(getattr(self, 'layer%d' % li)):
-                    x = blk.forward_fused(x, aff[(li, bi)])
-                if li - 1 in self.out_indices:
-                    outs.append(x)
-            return tuple(outs)
+            full = [x.new_empty(s) for s in self._stage_shapes(x)]
+            n = min(self.num_streams, x.shape[0]) if not torch.cuda.is_current_stream_capturing() else 1
+            if n <= 1:
+                self._forward_fused(x, aff, full)
+            else:
+                cur = torch.cuda.current_stream()
+                if getattr(self, '_side', None) is None or len(self._side) != n or self._side[0].device != x.device:
+                    self._side = [torch.cuda.Stream(device=x.device) for _ in range(n)]
+                bounds = [x.shape[0] * i // n for i in range(n + 1)]
+                for s, lo, hi in zip(self._side, bounds[:-1], bounds[1:]):
+                    s.wait_stream(cur)
+                    with torch.cuda.stream(s):
+                        self._forward_fused(x[lo:hi], aff, [f[lo:hi] for f in full])
+                for s in self._side:
+                    cur.wait_stream(s)
+            return tuple(full[i] for i in range(4) if i in self.out_indices)
         x = F.max_pool2d(F.relu(self.bn1(self.conv1(x)), inplace=True), 3, stride=2, padding=1)
         outs = []
         for li in range(1, 5):

@@ -286,18 +286,22 @@ def add_layernorm(a, b, bias, norm):
     return out
 
 
-def affine_act_nchw_(x, scale, shift, residual=None, relu=True):
-    """In place: x = relu(x * scale[c] + shift[c] (+ residual)) for x (N,C,H,W) contiguous."""
+def affine_act_nchw_(x, scale, shift, residual=None, relu=True, out=None):
+    """x = relu(x * scale[c] + shift[c] (+ residual)) for x (N,C,H,W) contiguous; in place, or into `out`
+    (same shape, contiguous -- e.g. a batch slice of a larger tensor) which is then returned."""
     if not (x.is_cuda and x.is_contiguous() and x.dtype == torch.float32):
         raise RuntimeError('affine_act_nchw_: needs a contiguous float32 HIP tensor; the MI355X backend has no CPU path')
     N, C, H, W = x.shape
     r = _chk(residual, 'residual') if residual is not None else None
     if r is not None and r.shape != x.shape:
         raise RuntimeError('affine_act_nchw_: residual shape mismatch')
+    if out is not None and not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and out.shape == x.shape):
+        raise RuntimeError('affine_act_nchw_: out must be a contiguous float32 HIP tensor of the same shape')
     with torch.cuda.device(x.device):
         _lib.call('pvsg_affine_act_nchw', x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                  r.data_ptr() if r is not None else None, N * C, C, H * W, int(bool(relu)), _stream_ptr())
-    return x
+                  r.data_ptr() if r is not None else None, out.data_ptr() if out is not None else None,
+                  N * C, C, H * W, int(bool(relu)), _stream_ptr())
+    return x if out is None else out
 
 
 def minvis_chain(embds):
