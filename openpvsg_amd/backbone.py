@@ -107,6 +107,7 @@ class ResNet(BaseModule):
     # passes of one half run under the MFMA-bound convolutions of the other (59 -> 52 ms per 32 x 720p frames).
     # Only the backbone does this: torch's F.linear (hipBLASLt) stalls when issued from two side streams.
     num_streams = int(os.environ.get('PVSG_BACKBONE_STREAMS', '2'))
+    min_stream_batch = 8
 
     def _stage_shapes(self, x):
         N, _, H, W = x.shape
@@ -134,7 +135,9 @@ class ResNet(BaseModule):
         if self.norm_eval and x.is_cuda and not torch.is_grad_enabled() and self.fuse_bn_act:
             aff = self._affines()
             full = [x.new_empty(s) for s in self._stage_shapes(x)]
-            n = min(self.num_streams, x.shape[0]) if not torch.cuda.is_current_stream_capturing() else 1
+            # only where it pays (>= 8 frames): small batches keep the single-stream path
+            n = self.num_streams if (x.shape[0] >= self.min_stream_batch and
+                                     not torch.cuda.is_current_stream_capturing()) else 1
             if n <= 1:
                 self._forward_fused(x, aff, full)
             else:

@@ -23,6 +23,7 @@ b_oa = torch.cat([a.sampling_offsets.bias, a.attention_weights.bias], 0)
 pos_oa = F.linear(pos, w_oa, b_oa)
 w_cat = torch.cat([a.value_proj.weight, w_oa], 0)
 ys = [F.linear(x, w_cat) for x in xs]
+b_cat = torch.zeros(544, device=dev)
 fc1 = layer.ffns[0].layers[0][0]
 
 
@@ -30,6 +31,12 @@ def stage(i):
     x = xs[i]
     if which == 'linear':
         return F.linear(x, w_cat)
+    if which == 'addmm2d':
+        return torch.addmm(b_cat, x.view(B * S, 256), w_cat.t())
+    if which == 'mm2d':
+        return x.view(B * S, 256) @ w_cat.t()
+    if which == 'linear2d':
+        return F.linear(x.view(B * S, 256), w_cat, b_cat)
     if which == 'msda':
         return ops.msda_fused(ys[i], pos_oa, ref2, ss, lsi)
     if which == 'addln':
@@ -46,7 +53,7 @@ with torch.no_grad():
         stage(0); stage(1)
     torch.cuda.synchronize()
     cur = torch.cuda.current_stream()
-    for it in range(3):
+    for it in range(5):
         t = time.perf_counter()
         for i, s in enumerate(streams):
             s.wait_stream(cur)

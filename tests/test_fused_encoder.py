@@ -103,3 +103,28 @@ def test_backbone_fused_bn_act_equals_plain(hip_lib):
         sc = float(r.abs().max())
         np.testing.assert_allclose(u.cpu().numpy(), r.numpy(), rtol=1e-3, atol=1e-4 * sc)
         np.testing.assert_allclose(v.cpu().numpy(), r.numpy(), rtol=1e-3, atol=1e-4 * sc)
+
+
+def test_backbone_two_streams_equal_one_and_odd_sizes(hip_lib):
+    """Batch halves on two HIP streams (>= 8 frames) write the same stage outputs as the single-stream path;
+    odd image sizes go through the fused stem (BN + ReLU + max-pool) and the stage-shape arithmetic."""
+    from openpvsg_amd.backbone import ResNet
+    m = ResNet(depth=50).eval()
+    m.load_state_dict(det_state_dict(m, 9))
+    m = m.to(DEV)
+    for shape in ((9, 3, 96, 128), (8, 3, 70, 101)):
+        x = det_input('img', shape, 3).to(DEV)
+        with torch.no_grad():
+            m.num_streams = 2
+            a = [t.clone() for t in m(x)]
+            m.num_streams = 1
+            b = m(x)
+            m.fuse_bn_act = False
+            c = m(x)
+            m.fuse_bn_act = True
+        assert m._side is not None and len(m._side) == 2
+        for u, v, w in zip(a, b, c):
+            assert u.shape == v.shape == w.shape
+            sc = float(w.abs().max())
+            assert float((u - v).abs().max()) <= 1e-5 * sc        # same kernels on half batches
+            assert float((u - w).abs().max()) <= 1e-4 * sc
