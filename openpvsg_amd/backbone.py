@@ -103,10 +103,13 @@ class ResNet(BaseModule):
             self._aff_cache = (ver, d)
         return self._aff_cache[1]
 
-    # The frames of a batch are independent: halves of the batch on two HIP streams let the HBM-bound BN/ReLU
-    # passes of one half run under the MFMA-bound convolutions of the other (59 -> 52 ms per 32 x 720p frames).
-    # Only the backbone does this: torch's F.linear (hipBLASLt) stalls when issued from two side streams.
-    num_streams = int(os.environ.get('PVSG_BACKBONE_STREAMS', '2'))
+    # The frames of a batch are independent: with PVSG_BACKBONE_STREAMS=2, halves of the batch go to two HIP streams
+    # so that the HBM-bound BN/ReLU passes of one half run under the MFMA-bound convolutions of the other
+    # (59 -> 52 ms per 32 x 720p frames, 186.6 -> 194.0 frames/s end to end).  Off by default: overlapped kernels
+    # cannot be timed one by one (bench.py's per-kernel roofline would read the shared-GPU durations), and only this
+    # MIOpen + streaming-kernel region is safe -- torch GEMMs (rocBLAS / hipBLASLt) issued from two side streams
+    # stall on this stack (scripts/stream_probe4.py).
+    num_streams = int(os.environ.get('PVSG_BACKBONE_STREAMS', '1'))
     min_stream_batch = 8
 
     def _stage_shapes(self, x):
