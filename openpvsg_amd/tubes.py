@@ -180,3 +180,43 @@ def process_feats(query_feat_tubes, d=256):
                 arr[t] = tube[t]['query_feat']
         out[tid] = arr
     return out
+
+
+def process_pairs(pred_relations):
+    """utils/relation_matching.py:445-449: [(subject tube, object tube, relation, spans)] -> [[s, o], ...]."""
+    return [[r[0], r[1]] for r in pred_relations]
+
+
+def process_feats_and_relations(pred_relations, pred_feat_tubes, d=256):
+    """utils/relation_matching.py:452-486: what `relations.pickle` holds for one video --
+    {'feats': {tube id: float64 [T,d]}, 'relations': [{'subject_index','object_index','relation','relation_span (T,)'}]}.
+    A relation's span is the union of its [start, end) ranges, zeroed on frames where either tube is absent, and
+    the relation is dropped when fewer than 3 frames remain.  pred_feat_tubes: {tube id: [per-frame dict or None]}."""
+    T = len(next(iter(pred_feat_tubes.values())))
+    present = {k: np.array([x is not None for x in v]) for k, v in pred_feat_tubes.items()}
+    relations = []
+    for s, o, rel, spans in pred_relations:
+        span = np.zeros(T)
+        for lo, hi in spans:
+            span[lo:hi] = 1
+        span[~present[s]] = 0
+        span[~present[o]] = 0
+        if span.sum() >= 3:
+            relations.append({'subject_index': s, 'object_index': o, 'relation': rel, 'relation_span': span})
+    feats = {}
+    for k, tube in pred_feat_tubes.items():
+        arr = np.zeros([T, d])
+        for t, x in enumerate(tube):
+            if x is not None:
+                arr[t] = x['query_feat']
+        feats[k] = arr
+    return {'feats': feats, 'relations': relations}
+
+
+def write_relations_pickle(work_dir, vid, pred_relations, pred_feat_tubes, d=256):
+    """`<work_dir>/<vid>/relations.pickle`, the file datasets/datasets/pvsg_relation.py:44-46 reads."""
+    path = os.path.join(work_dir, vid, 'relations.pickle')
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, 'wb') as f:
+        pickle.dump(process_feats_and_relations(pred_relations, pred_feat_tubes, d), f)
+    return path

@@ -189,6 +189,8 @@ def test_unitrack_names_resolve_to_backend(compat_path):
     from models.unitrack.model import AppearanceModel, partial_load
     from models.unitrack.multitracker import AssociationTracker
     from models.unitrack.utils import io
+    from utils.relation_matching import (get_pred_mask_tubes_one_video, load_pickle, process_feats,  # noqa: F401
+                                         process_feats_and_relations, process_pairs, save_pickle)
     import openpvsg_amd.unitrack as T
     assert callable(eval_seq) and models.eval_seq is eval_seq and issubclass(MaskAssociationTracker, AssociationTracker)
     assert matching.reconsdot_distance is T.reconsdot_distance and KalmanFilter is T.KalmanFilter and chi2inv95[4] == 9.4877

@@ -4,6 +4,7 @@ import pickle
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 from openpvsg_amd import tubes
@@ -103,3 +104,56 @@ def test_pickle_resolves_through_compat_namespace(tmp_path):
         for k in [k for k in sys.modules if k.split('.')[0] in ('models', 'mmcv', 'mmdet')]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def _ref_relation_matching():
+    """the reference's utils/relation_matching.py (build container only; pycocotools answered by an empty module)"""
+    import importlib.util
+    import sys
+    import types
+    path = '/root/reference/utils/relation_matching.py'
+    if not os.path.exists(path):
+        pytest.skip('reference tree only exists in the build container')
+    saved = {k: sys.modules.get(k) for k in ('pycocotools', 'pycocotools.mask')}
+    pc = types.ModuleType('pycocotools')
+    pc.mask = types.ModuleType('pycocotools.mask')
+    sys.modules.update({'pycocotools': pc, 'pycocotools.mask': pc.mask})
+    try:
+        spec = importlib.util.spec_from_file_location('_ref_relation_matching', path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mod
+
+
+def test_relations_pickle_matches_reference(tmp_path):
+    from openpvsg_amd.tubes import process_feats_and_relations, process_pairs, write_relations_pickle
+    rs = np.random.RandomState(0)
+    T = 12
+    tubes = {}
+    for tid in (3, 7, 8, 11):
+        tubes[tid] = [None if rs.uniform() < 0.3 else {'query_feat': rs.standard_normal(256).astype(np.float32), 'cls_id': tid}
+                      for _ in range(T)]
+    rels = [(3, 7, 5, [(0, 4), (6, 11)]), (7, 8, 2, [(2, 3)]), (11, 3, 40, [(0, 12)]), (8, 11, 1, [(5, 7), (9, 10)])]
+    out = process_feats_and_relations(rels, tubes)
+    assert process_pairs(rels) == [[3, 7], [7, 8], [11, 3], [8, 11]]
+    for r in out['relations']:
+        assert r['relation_span'].sum() >= 3 and r['relation_span'].shape == (T,)
+    path = write_relations_pickle(str(tmp_path), 'vid0', rels, tubes)
+    back = pickle.load(open(path, 'rb'))
+    assert sorted(back['feats']) == [3, 7, 8, 11] and back['feats'][3].dtype == np.float64
+    ref = _ref_relation_matching()
+    want = ref.process_feats_and_relations(rels, tubes)
+    assert ref.process_pairs(rels) == process_pairs(rels)
+    assert sorted(want['feats']) == sorted(out['feats'])
+    for k in want['feats']:
+        np.testing.assert_array_equal(want['feats'][k], out['feats'][k])
+    assert len(want['relations']) == len(out['relations'])
+    for a, b in zip(want['relations'], out['relations']):
+        assert (a['subject_index'], a['object_index'], a['relation']) == (b['subject_index'], b['object_index'], b['relation'])
+        np.testing.assert_array_equal(a['relation_span'], b['relation_span'])
