@@ -169,9 +169,10 @@ def golden_boxes(R):
                         keep=keep, tlwh=tlwh, xyah=xyah)
 
 
-def golden_sequence(R):
+def golden_sequence(R, name='unitrack_sequence.npz', **mots):
     frames, outputs = ips_video()
     cfg = tracker_cfg()
+    cfg.mots.update(mots)
     costs = []
     orig_la = R.matching.linear_assignment
 
@@ -222,7 +223,7 @@ def golden_sequence(R):
     rec['emb0_sum'] = np.array([float(e.double().sum()) for e in embs0])
     rec['emb0_abs'] = np.array([float(e.double().abs().sum()) for e in embs0])
     rec['emb0_big'] = embs0[int(np.argmax([e.shape[-1] for e in embs0]))][0, :8].numpy()
-    np.savez_compressed(os.path.join(OUT, 'unitrack_sequence.npz'), **rec)
+    np.savez_compressed(os.path.join(OUT, name), **rec)
     print('sequence: %d frames, %d tubes, %d cost matrices' % (len(rows), len(tubes), len(costs)))
     for r in rows:
         print(' ', r[0], r[2].tolist(), r[3].tolist())
@@ -235,6 +236,8 @@ def main():
     golden_distance(R)
     golden_boxes(R)
     golden_sequence(R)
+    # motion fused into the appearance cost and Mahalanobis gating on (matching.py:100-113)
+    golden_sequence(R, 'unitrack_sequence_motion.npz', asso_with_motion=True, motion_lambda=0.95, motion_gated=True)
 
 
 if __name__ == '__main__':

@@ -170,10 +170,15 @@ def test_reconsdot_cost_matches_reference_vector(hip_lib):
 
 
 @pytest.mark.gpu
-def test_tracking_sequence_matches_reference_vectors(hip_lib, tmp_path):
+@pytest.mark.parametrize('fixture,mots', [('unitrack_sequence.npz', {}),
+                                          ('unitrack_sequence_motion.npz',
+                                           dict(asso_with_motion=True, motion_lambda=0.95, motion_gated=True))])
+def test_tracking_sequence_matches_reference_vectors(hip_lib, tmp_path, fixture, mots):
     from openpvsg_amd import unitrack as T
     from openpvsg_amd.tubes import read_mots_results, rle_decode
-    g = np.load(os.path.join(G, 'unitrack_sequence.npz'))
+    g = np.load(os.path.join(G, fixture))
+    cfg = tracker_cfg()
+    cfg['mots'].update(mots)
     frames, outputs = ips_video()
     model, _ = _app_model()
     costs, orig = [], T.linear_assignment
@@ -184,7 +189,7 @@ def test_tracking_sequence_matches_reference_vectors(hip_lib, tmp_path):
 
     T.linear_assignment = rec
     try:
-        results, tubes = T.eval_seq(None, tracker_cfg(), outputs, 126, save_root=str(tmp_path), return_results=True,
+        results, tubes = T.eval_seq(None, cfg, outputs, 126, save_root=str(tmp_path), return_results=True,
                                     frames=frames, app_model=model)
     finally:
         T.linear_assignment = orig

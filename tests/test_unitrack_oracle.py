@@ -3,6 +3,7 @@ models/unitrack code (oracle/make_golden_unitrack.py).  CPU only."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import unitrack as U
@@ -74,8 +75,10 @@ def test_third_party_restatements_on_known_answers():
     assert abs(float(U.box_iou(t, torch.tensor([[5., 0., 15., 10.]]))[0, 0]) - 50 / 150) < 1e-7
 
 
-def test_tracking_sequence_matches_reference():
-    g = np.load(os.path.join(G, 'unitrack_sequence.npz'))
+@pytest.mark.parametrize('fixture,cfg', [('unitrack_sequence.npz', {}),
+                                         ('unitrack_sequence_motion.npz', dict(motion_lambda=0.95, motion_gated=True))])
+def test_tracking_sequence_matches_reference(fixture, cfg):
+    g = np.load(os.path.join(G, fixture))
     frames, outputs = ips_video()
     net = U.AppearanceResNet50()
     net.load_state_dict(det_state_dict(net, seed=3))
@@ -88,7 +91,7 @@ def test_tracking_sequence_matches_reference():
 
     U.linear_assignment = rec
     try:
-        results, tubes = U.eval_seq(net, frames, outputs, 126)
+        results, tubes = U.eval_seq(net, frames, outputs, 126, **cfg)
     finally:
         U.linear_assignment = orig
     assert len(results) == int(g['n_frames']) and len(costs) == int(g['n_cost']) and len(tubes) == int(g['n_tubes'])
