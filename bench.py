@@ -257,6 +257,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     torch.backends.cudnn.benchmark = os.environ.get("PVSG_MIOPEN_FIND", "0") == "1"  # exhaustive MIOpen find costs ~5 min per fresh box
+    gemm_table = False
+    if os.environ.get('PVSG_GEMM_TABLE', 'on') != 'off':
+        from openpvsg_amd import tuning
+        gemm_table = tuning.enable()      # pre-selected rocBLAS / hipBLASLt solutions for the clip-size GEMMs (load only)
 
     from openpvsg_amd import build
     if rank == 0 and not os.path.exists(build.lib_path()):
@@ -330,6 +334,7 @@ def main():
                        'frames': T, 'frames_per_gpu': t_local, 'backbone': 'ResNet-50 (reference ships no Swin-B config)',
                        'weights': 'random init seed 0 (cls logits x%g so that some queries pass score>0.8)' % CLS_GAIN,
                        'tubes': int(out['tube_feats'].shape[0]), 'frames_per_step': frames_per_step,
+                       'library_gemm_table': 'openpvsg_amd/tuning/gemm_gfx950.csv (load only)' if gemm_table else 'off',
                        'parallelism': ('%d x 32-frame segments, all-gather of tube records' % world) if weak
                        else ('frame-shard x%d, attention partials merged per layer' % world)},
         }

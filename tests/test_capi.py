@@ -60,3 +60,26 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(_lib.BackendMissingError):
         _lib.load()
+
+
+def test_gemm_table_is_loadable_and_load_only():
+    """openpvsg_amd/tuning: the committed hipBLASLt/rocBLAS selection table carries TunableOp validators and is
+    handed over with tuning switched off (nothing is timed at run time)."""
+    import torch
+    from openpvsg_amd import tuning
+    rows = [r.strip().split(',') for r in open(tuning.TABLE) if r.strip()]
+    assert {r[1] for r in rows if r[0] == 'Validator'} >= {'PT_VERSION', 'GCN_ARCH_NAME', 'ROCBLAS_VERSION', 'HIPBLASLT_VERSION'}
+    ops = [r for r in rows if r[0] != 'Validator']
+    assert len(ops) >= 10 and all(r[0].startswith('Gemm') and r[0].endswith('float_TN') for r in ops)
+    assert any('618240' in r[1] for r in ops)                      # the 32 x 720p encoder shapes
+    if not torch.cuda.is_available():
+        assert tuning.enable() is False              # nothing to configure without a device
+    elif getattr(torch.cuda, 'tunable', None) is not None:
+        was = (torch.cuda.tunable.is_enabled(), torch.cuda.tunable.tuning_is_enabled(), torch.cuda.tunable.get_filename())
+        try:
+            assert tuning.enable() and torch.cuda.tunable.is_enabled() and not torch.cuda.tunable.tuning_is_enabled()
+            assert torch.cuda.tunable.get_filename() == tuning.TABLE
+        finally:
+            torch.cuda.tunable.enable(was[0])
+            torch.cuda.tunable.tuning_enable(was[1])
+            torch.cuda.tunable.set_filename(was[2], insert_device_ordinal=False)
