@@ -70,7 +70,8 @@ def test_gemm_table_is_loadable_and_load_only():
     rows = [r.strip().split(',') for r in open(tuning.TABLE) if r.strip()]
     assert {r[1] for r in rows if r[0] == 'Validator'} >= {'PT_VERSION', 'GCN_ARCH_NAME', 'ROCBLAS_VERSION', 'HIPBLASLT_VERSION'}
     ops = [r for r in rows if r[0] != 'Validator']
-    assert len(ops) >= 10 and all(r[0].startswith('Gemm') and r[0].endswith('float_TN') for r in ops)
+    assert len(ops) >= 10 and all(r[0].startswith('Gemm') and '_float_' in r[0] for r in ops)
+    assert any(r[0].startswith('GemmStridedBatched') for r in ops)    # the backbone's 1x1 convolutions as W @ x[b]
     assert any('618240' in r[1] for r in ops)                      # the 32 x 720p encoder shapes
     if not torch.cuda.is_available():
         assert tuning.enable() is False              # nothing to configure without a device

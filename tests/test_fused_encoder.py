@@ -128,3 +128,27 @@ def test_backbone_two_streams_equal_one_and_odd_sizes(hip_lib):
             sc = float(w.abs().max())
             assert float((u - v).abs().max()) <= 1e-5 * sc        # same kernels on half batches
             assert float((u - w).abs().max()) <= 1e-4 * sc
+
+
+def test_backbone_1x1_convs_as_batched_gemm_equal_miopen(hip_lib):
+    """With the library-GEMM table active the stride-1 1x1 convolutions run as W @ x[b] (torch.bmm, stride-0 weight
+    batch); the stage outputs must equal the MIOpen-convolution path."""
+    from openpvsg_amd import tuning
+    from openpvsg_amd.backbone import ResNet
+    m = ResNet(depth=50).eval()
+    m.load_state_dict(det_state_dict(m, 9))
+    m = m.to(DEV)
+    x = det_input('img', (3, 3, 64, 96), 4).to(DEV)
+    was = (torch.cuda.tunable.is_enabled(), torch.cuda.tunable.tuning_is_enabled(), torch.cuda.tunable.get_filename())
+    try:
+        with torch.no_grad():
+            torch.cuda.tunable.enable(False)
+            a = [t.clone() for t in m(x)]
+            assert tuning.enable()
+            b = m(x)
+    finally:
+        torch.cuda.tunable.enable(was[0])
+        torch.cuda.tunable.tuning_enable(was[1])
+        torch.cuda.tunable.set_filename(was[2], insert_device_ordinal=False)
+    for u, v in zip(a, b):
+        assert float((u - v).abs().max()) <= 1e-4 * float(u.abs().max())
