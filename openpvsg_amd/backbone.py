@@ -14,12 +14,12 @@ from .blocks import BaseModule
 from .registry import BACKBONES
 
 
-def _conv1x1(conv, x):
+def _conv1x1(conv, x, gemm=True):
     """A stride-1 1x1 convolution in NCHW is out[b] = W (Cout x Cin) @ x[b] (Cin x HW).  When the library-GEMM
     selection table is active (openpvsg_amd/tuning) that batched GEMM runs the tabled rocBLAS / hipBLASLt solution:
     22.5 -> 18.8 ms over the ResNet-50's 33 such layers at 32 x 720p (MIOpen issues its own rocBLAS call with the
     default solution; e.g. 256 -> 64 channels at 184x320: 1.19 -> 0.58 ms)."""
-    if conv.stride == (1, 1) and conv.bias is None and x.is_contiguous() and torch.cuda.tunable.is_enabled():
+    if gemm and conv.stride == (1, 1) and conv.bias is None and x.is_contiguous() and torch.cuda.tunable.is_enabled():
         B, cin, H, W = x.shape
         w = conv.weight.view(1, conv.out_channels, cin).expand(B, -1, -1)      # stride-0 batch: no copy
         return torch.bmm(w, x.view(B, cin, H * W)).view(B, -1, H, W)
@@ -50,17 +50,17 @@ class _Bottleneck(nn.Module):
         out = self.bn3(self.conv3(out))
         return F.relu(out + identity, inplace=True)
 
-    def forward_fused(self, x, aff, out=None):
+    def forward_fused(self, x, aff, out=None, gemm=True):
         """Frozen BN as per-channel affine: BN+ReLU and BN+residual+ReLU are one HIP pass each
         (csrc/elementwise.hip) behind MIOpen's convolutions.  `out`: where the block's result goes (a batch
         slice of a stage-output tensor) instead of over conv3's own output."""
         if self.downsample is None:
             identity = x
         else:
-            identity = ops.affine_act_nchw_(_conv1x1(self.downsample[0], x), *aff['ds'], relu=False)
-        y = ops.affine_act_nchw_(_conv1x1(self.conv1, x), *aff['bn1'])
+            identity = ops.affine_act_nchw_(_conv1x1(self.downsample[0], x, gemm), *aff['ds'], relu=False)
+        y = ops.affine_act_nchw_(_conv1x1(self.conv1, x, gemm), *aff['bn1'])
         y = ops.affine_act_nchw_(self.conv2(y), *aff['bn2'])
-        return ops.affine_act_nchw_(_conv1x1(self.conv3, y), *aff['bn3'], residual=identity, out=out)
+        return ops.affine_act_nchw_(_conv1x1(self.conv3, y, gemm), *aff['bn3'], residual=identity, out=out)
 
 
 @BACKBONES.register_module()
@@ -135,13 +135,13 @@ class ResNet(BaseModule):
             shapes.append((N, planes * 4, h, w))
         return shapes
 
-    def _forward_fused(self, x, aff, outs):
+    def _forward_fused(self, x, aff, outs, gemm=True):
         """x: a batch slice; outs[li-1]: the matching slice of the stage-output tensors (written in place)."""
         x = ops.stem_bn_relu_pool(self.conv1(x), *aff['stem'])      # BN + ReLU + 3x3/2 max-pool in one pass
         for li in range(1, 5):
             blocks = getattr(self, 'layer%d' % li)
             for bi, blk in enumerate(blocks):
-                x = blk.forward_fused(x, aff[(li, bi)], out=outs[li - 1] if bi == len(blocks) - 1 else None)
+                x = blk.forward_fused(x, aff[(li, bi)], out=outs[li - 1] if bi == len(blocks) - 1 else None, gemm=gemm)
 
     def forward(self, x):
         # Measured on MI355X (32x736x1280 fp32): MIOpen's fused conv+bias+ReLU plans (aten::miopen_convolution_relu
@@ -163,7 +163,8 @@ class ResNet(BaseModule):
                 for s, lo, hi in zip(self._side, bounds[:-1], bounds[1:]):
                     s.wait_stream(cur)
                     with torch.cuda.stream(s):
-                        self._forward_fused(x[lo:hi], aff, [f[lo:hi] for f in full])
+                        # torch GEMMs issued from two side streams stall on this stack: convolutions only here
+                        self._forward_fused(x[lo:hi], aff, [f[lo:hi] for f in full], gemm=False)
                 for s in self._side:
                     cur.wait_stream(s)
             return tuple(full[i] for i in range(4) if i in self.out_indices)
