@@ -156,6 +156,9 @@ class KernelTimer:
         if name == 'pvsg_center_downsample':
             planes, H, W = a[4:7]
             return 4.0 * planes * H * W * (1 + 21.0 / 64), 0.0
+        if name == 'pvsg_conv1x1_affine':
+            B, Cout, Cin, HW = a[6:10]
+            return 4.0 * B * HW * (Cin + Cout * (2 if a[4] else 1)), 2.0 * B * HW * Cin * Cout
         if name == 'pvsg_fpn_merge_up2x':
             planes, h, w = a[5:8]
             return 4.0 * planes * h * w * 9, 0.0                     # lateral 4 + out 4 + top 1 (x h*w cells)
@@ -360,7 +363,8 @@ def main():
             dom = max((k for k in agg if agg[k]['bytes'] > 0), key=lambda k: agg[k]['ms'])
             d = agg[dom]
             per = d['ms'] / d['calls']
-            mfma_bound = dom.startswith(('pvsg_mask_logits', 'pvsg_attn_mask_bits', 'pvsg_masked_xattn'))
+            # the roof that binds = the larger ideal time (bytes / HBM peak vs flops / f32 matrix peak) over its launches
+            mfma_bound = d['flops'] / (F32_MFMA_PEAK_TF * 1e12) > d['bytes'] / (HBM_PEAK_GBS * 1e9)
             traffic = None
             tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
             if os.path.exists(tpath):

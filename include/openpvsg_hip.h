@@ -189,6 +189,13 @@ int pvsg_nchw_to_tokens(const float* src, const float* scale, const float* shift
  *   dst[b, c, p] = src[b*src_batch_stride + p*C + c]. */
 int pvsg_tokens_to_nchw(const float* src, float* dst, int B, int C, int HW, long long src_batch_stride, void* stream);
 
+/* [3P] mmdet ResNet bottleneck tail (norm_eval): out = relu(BN(conv1x1(x)) + identity) in one pass, for the layers
+ * whose 1x1 GEMM is HBM-bound (Cin <= 256):  out[b] = act((W (Cout x Cin) @ x[b] (Cin x HW)) * scale[c] + shift[c]
+ * (+ residual[b])).  Requires Cout % 32 == 0, Cin % 16 == 0, Cin <= 256, HW % 4 == 0; residual NULL = none. */
+int pvsg_conv1x1_affine(const float* weight, const float* x, const float* scale, const float* shift,
+                        const float* residual, float* out, int B, int Cout, int Cin, long long HW, int relu,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

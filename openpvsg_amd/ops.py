@@ -402,3 +402,30 @@ def tokens_to_nchw(tokens, start, h, w):
     with torch.cuda.device(t.device):
         _lib.call('pvsg_tokens_to_nchw', t.data_ptr() + 4 * start * C, out.data_ptr(), B, C, h * w, S * C, _stream_ptr())
     return out
+
+
+def conv1x1_affine_supported(cout, cin, hw):
+    return cout % 32 == 0 and cin % 16 == 0 and cin <= 256 and hw % 4 == 0
+
+
+def conv1x1_affine(x, weight, scale, shift, residual=None, relu=True, out=None):
+    """act(conv1x1(x, weight) * scale[c] + shift[c] (+ residual)) in one pass (csrc/conv1x1.hip).
+    x (B,Cin,H,W), weight (Cout,Cin,1,1) or (Cout,Cin); out: optional contiguous (B,Cout,H,W) destination."""
+    x = _chk(x, 'x')
+    B, Cin, H, W = x.shape
+    w = _chk(weight.reshape(weight.shape[0], -1), 'weight')
+    Cout = w.shape[0]
+    if w.shape[1] != Cin or not conv1x1_affine_supported(Cout, Cin, H * W):
+        raise RuntimeError('conv1x1_affine: unsupported shape Cout=%d Cin=%d HW=%d' % (Cout, Cin, H * W))
+    r = _chk(residual, 'residual') if residual is not None else None
+    if out is None:
+        out = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32)
+    elif not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (B, Cout, H, W)):
+        raise RuntimeError('conv1x1_affine: out must be a contiguous float32 HIP tensor (B,Cout,H,W)')
+    if r is not None and r.shape != out.shape:
+        raise RuntimeError('conv1x1_affine: residual shape mismatch')
+    with torch.cuda.device(x.device):
+        _lib.call('pvsg_conv1x1_affine', w.data_ptr(), x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                  r.data_ptr() if r is not None else None, out.data_ptr(), B, Cout, Cin, H * W, int(bool(relu)),
+                  _stream_ptr())
+    return out
