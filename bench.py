@@ -368,7 +368,10 @@ def main():
             traffic = None
             tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(dom.split('[')[0], {}).get('hbm_bytes_per_launch_T%d' % t_local)
+                ent = json.load(open(tpath)).get(dom.split('[')[0], {})
+                traffic = ent.get('hbm_bytes_per_launch_T%d' % t_local)
+                if traffic is None and ent.get('ratio_to_algorithmic'):       # kernels whose launches differ in shape
+                    traffic = ent['ratio_to_algorithmic'] * d['bytes'] / d['calls']
             if mfma_bound:
                 ach = d['flops'] / d['calls'] / per / 1e9
                 line['roofline'] = dict(kernel=dom, bound='mfma', achieved=ach, peak=F32_MFMA_PEAK_TF,
