@@ -136,6 +136,130 @@ __global__ __launch_bounds__(512) void conv1x1_affine_kernel(
   }
 }
 
+// Same tile scheme with the x operand four K-blocks ahead (Cin % 64 == 0): a K-block is 32 MFMAs (~0.4 us) per wave
+// but an HBM round trip under load is ~2 us, so with a one-block look-ahead the wave waits on memory in every block
+// and matrix time and memory time add up instead of overlapping.  Here a ring of four blocks (16 float4 per lane) is
+// always in flight; the ring rolls over into the wave's NEXT tile, so the pipe stays fed across tiles too.
+template <int CMT>
+__global__ __launch_bounds__(512) void conv1x1_affine_deep_kernel(
+    const float* __restrict__ Wt, const float* __restrict__ X, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ residual, float* __restrict__ out, int Cout, int Cin,
+    int HW, int relu, int mw, int mgroups, int wgs_per_bm) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  const int bm = blockIdx.x / wgs_per_bm;
+  const int wg = blockIdx.x - bm * wgs_per_bm;
+  const int b = bm / mgroups, mg = bm - b * mgroups;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j16 = lane & 15, g = lane >> 4;
+  const int rows = mw * (CMT * 16);
+  const int mbase = mg * rows;
+  {
+    const float* Wp = Wt + (long long)mbase * Cin;
+    const int total = rows * Cin;
+    const int panel = CMT * 16 * Cin;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const int q = i / Cin, c = i - q * Cin;
+      const int mi = q / (CMT * 16), ql = q - mi * (CMT * 16);
+      const int kb = c >> 4, cc = c & 15;
+      const int ln = (cc & 3) * 16 + (ql & 15);
+      wlds[mi * panel + (((kb * CMT + (ql >> 4)) * 64 + ln) << 2) + (cc >> 2)] = Wp[i];
+    }
+  }
+  __syncthreads();
+  const int ppw = 8 / mw;
+  const int mi = wave % mw, pj = wave / mw;
+  const float* wl = wlds + mi * (CMT * 16 * Cin);
+  const int m0 = mbase + mi * (CMT * 16);
+  const int ntiles = (HW + 63) >> 6;
+  const int nkb = Cin >> 4;
+  const float* Xb = X + (long long)b * Cin * HW + (long long)g * HW;
+  float sc[CMT][4], sh[CMT][4];
+#pragma unroll
+  for (int qt = 0; qt < CMT; ++qt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sc[qt][r] = scale[m0 + qt * 16 + g * 4 + r];
+      sh[qt][r] = shift[m0 + qt * 16 + g * 4 + r];
+    }
+  const int stride = wgs_per_bm * ppw;
+  int tile = wg * ppw + pj;
+  float4 bq[4][4];
+  {
+    const int n = tile * 64 + 4 * j16;
+    const bool valid = tile < ntiles && n + 3 < HW;
+    const float* Fp = Xb + (valid ? n : 0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        bq[u][s] = valid ? ld4(Fp + (long long)(u * 16 + 4 * s) * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (; tile < ntiles; tile += stride) {
+    const int n = tile * 64 + 4 * j16;
+    const bool valid = n + 3 < HW;
+    const float* Fp = Xb + (valid ? n : 0);
+    const int nn = (tile + stride) * 64 + 4 * j16;
+    const bool nvalid = tile + stride < ntiles && nn + 3 < HW;
+    const float* Fn = Xb + (nvalid ? nn : 0);
+    const long long base = ((long long)b * Cout + m0 + g * 4) * HW + (valid ? n : 0);
+    float4 rr[CMT][4];
+    if (residual) {
+#pragma unroll
+      for (int qt = 0; qt < CMT; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          rr[qt][r] = valid ? ld4_stream(residual + base + (long long)(qt * 16 + r) * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    f32x4 acc[CMT][4];
+#pragma unroll
+    for (int qt = 0; qt < CMT; ++qt)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) acc[qt][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb4 = 0; kb4 < nkb; kb4 += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kb = kb4 + u;
+        float4 a[CMT];
+#pragma unroll
+        for (int qt = 0; qt < CMT; ++qt)
+          a[qt] = *reinterpret_cast<const float4*>(&wl[((kb * CMT + qt) * 64 + lane) << 2]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float b0 = bq[u][s].x, b1 = bq[u][s].y, b2 = bq[u][s].z, b3 = bq[u][s].w;
+#pragma unroll
+          for (int qt = 0; qt < CMT; ++qt) {
+            const float av = (s == 0) ? a[qt].x : (s == 1) ? a[qt].y : (s == 2) ? a[qt].z : a[qt].w;
+            acc[qt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[qt][0], 0, 0, 0);
+            acc[qt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[qt][1], 0, 0, 0);
+            acc[qt][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2, acc[qt][2], 0, 0, 0);
+            acc[qt][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b3, acc[qt][3], 0, 0, 0);
+          }
+        }
+        // refill this ring slot: four K-blocks ahead, rolling over into the next tile
+        const int nk = kb + 4;
+        const bool cur = nk < nkb;
+        const float* src = cur ? Fp + (long long)(nk * 16) * HW : Fn + (long long)((nk - nkb) * 16) * HW;
+        const bool ok = cur ? valid : nvalid;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bq[u][s] = ok ? ld4(src + (long long)(4 * s) * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int qt = 0; qt < CMT; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float s1 = sc[qt][r], s0 = sh[qt][r];
+          float4 v = make_float4(acc[qt][0][r] * s1 + s0, acc[qt][1][r] * s1 + s0, acc[qt][2][r] * s1 + s0,
+                                 acc[qt][3][r] * s1 + s0);
+          if (residual) { v.x += rr[qt][r].x; v.y += rr[qt][r].y; v.z += rr[qt][r].z; v.w += rr[qt][r].w; }
+          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          st4(out + base + (long long)(qt * 16 + r) * HW, v);
+        }
+    }
+  }
+}
+
 }  // namespace pvsg
 
 extern "C" int pvsg_conv1x1_affine(const float* weight, const float* x, const float* scale, const float* shift,
@@ -165,13 +289,14 @@ extern "C" int pvsg_conv1x1_affine(const float* weight, const float* x, const fl
   if (wgs < 1) wgs = 1;
   const size_t lds = (size_t)mw * prow * Cin * sizeof(float);
   PVSG_REQUIRE(lds <= 128 * 1024, "conv1x1_affine: weight panel does not fit LDS");
-  const auto kern = conv1x1_affine_kernel<CMT>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  const bool deep = (Cin % 64) == 0;
+  const auto kern = deep ? conv1x1_affine_deep_kernel<CMT> : conv1x1_affine_kernel<CMT>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[deep]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        128 * 1024);
     if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "conv1x1_affine: LDS attribute: %s", hipGetErrorString(e));
-    attr_set = true;
+    attr_set[deep] = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(B * mgroups * wgs)), dim3(512), lds, stream, weight, x, scale, shift, residual,
                      out, Cout, Cin, (int)HW, relu, mw, mgroups, wgs);
