@@ -58,9 +58,10 @@ def parse():
     ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'off'])
     ap.add_argument('--cpu-frames', type=int, default=4)
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
-                    help='N>1: weak = one 32-frame clip (segment of a longer video) per GPU, tube records all-gathered; '
-                         'strong = ONE clip sharded by frame, attention partials merged across GPUs every layer')
+    ap.add_argument('--scaling', default='strong', choices=['weak', 'strong'],
+                    help='N>1: strong (default, BASELINE config 4) = ONE 32-frame clip sharded by frame, 32/N frames per '
+                         'GPU, attention partials merged across GPUs every decoder layer; weak = one 32-frame segment '
+                         'of a longer video per GPU, tube records all-gathered')
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL over xGMI); gloo only for same-device logic tests')
     ap.add_argument('--graph', action='store_true', help='replay backbone+head as one hipGraph (experimental)')
     ap.add_argument('--checksum', action='store_true', help='add a result checksum (sharding-invariance check)')
@@ -247,9 +248,31 @@ def cpu_baseline_and_parity(det_gpu, rel_gpu, pipe, args, dev):
     return base, parity
 
 
+def self_spawn(args):
+    """`python bench.py --gpus N` with no launcher around it: re-exec under torch.distributed.run with one
+    rank per GPU (the reference's launcher does the same for tools/test.py:186-190 `init_dist`)
+    and hand its exit code back.  The ranks then find WORLD_SIZE / RANK / LOCAL_RANK in the environment."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_spawn(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
@@ -257,6 +280,9 @@ def main():
         dist.init_process_group(args.backend, init_method='env://')
     if os.environ.get('PVSG_ONE_DEVICE') == '1':   # logic test: every rank on GPU 0 (gloo backend)
         local = 0
+    elif torch.cuda.device_count() <= local:
+        raise SystemExit('bench.py: rank %d needs cuda:%d but this node shows %d GPUs'
+                         % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     torch.backends.cudnn.benchmark = os.environ.get("PVSG_MIOPEN_FIND", "0") == "1"  # exhaustive MIOpen find costs ~5 min per fresh box

@@ -122,13 +122,28 @@ int pvsg_pair_score_forward(const float* sub_feats, const float* obj_feats, cons
  *   kept_idx / kept_score / kept_class (K)   queries with label != background and score > thr, in
  *                                            query order; score = softmax max (fusion_head.py:117-120)
  *   panoptic (T, ih, iw) int32; seg_id (T, K) int32 (-1 = dropped, else class + 1000*instance)
- *   owner_ws (T*ih*iw) bytes, counter_ws (T*3*128) int32: scratch
- *   (H, W) = batch_input_shape, (ih, iw) = img_shape crop; second resize to ori_shape NOT included */
+ *   panoptic (T, oh, ow) int32; owner_ws (T*oh*ow) bytes, counter_ws (T*3*128) int32: scratch
+ *   (H, W) = batch_input_shape, (ih, iw) = img_shape crop, (oh, ow) = ori_shape: the second resize under
+ *   rescale=True (mask2former_fusion_head.py:376-383) is composed with the first one per output pixel;
+ *   pass (oh, ow) = (ih, iw) when rescale is off */
 int pvsg_panoptic_fuse(const float* mask_logits, const int* kept_idx, const float* kept_score,
                        const int* kept_class, int* panoptic, int* seg_id, unsigned char* owner_ws,
                        int* counter_ws, int T, int Q, int K, int h, int w, int H, int W, int ih, int iw,
-                       int num_things, int num_classes, double iou_thr, int filter_low_score,
-                       void* stream);
+                       int oh, int ow, int num_things, int num_classes, double iou_thr,
+                       int filter_low_score, void* stream);
+
+/* ---- a8 (instance branch): instance_postprocess without the (Q,H,W) float tensor ----------------
+ * Replaces the per-query mask work of MaskFormerFusionHeadCustom.instance_postprocess,
+ * models/mask2former/mask2former_fusion_head.py:192-242 (`mask_pred[query_indices]`, `> 0`, sigmoid-weighted
+ * mask score, mask2bbox) on the same composed up-sample / crop / resize as pvsg_panoptic_fuse.
+ *   mask_logits (T, Q, h, w); sel_idx (n) query index of each selected (query, class) entry, shared by the
+ *   frames, or (T, n) with sel_per_frame = 1 (per-frame top-k re-selection, mask2former_vps/mask2former.py:196-200)
+ *   masks (T, n, oh, ow) bytes 0/1 = resized logit > 0, or NULL (statistics only)
+ *   stat_sum (T, n) float64 = sum over the mask of sigmoid(logit)
+ *   stat_box (T, n, 5) int32 = {pixel count, min x, min y, max x, max y} (count 0: empty mask) */
+int pvsg_instance_masks(const float* mask_logits, const int* sel_idx, unsigned char* masks, double* stat_sum,
+                        int* stat_box, int T, int Q, int n, int sel_per_frame, int h, int w, int H, int W,
+                        int ih, int iw, int oh, int ow, void* stream);
 
 /* ---- a1/a2 fused forms used inside the pixel decoder ------------------------------------------
  * pvsg_msda_fused_forward: [3P] MultiScaleDeformableAttention.forward steps 4-6 (softmax over the

@@ -22,6 +22,11 @@
 //   3 paint      panoptic[y,x] = ok[owner] && (conf || !filter) ? seg_id[owner] : num_classes.
 // The up-sampling arithmetic is ATen's upsample_bilinear2d (align_corners=False): src = (dst+0.5)*in/out
 // - 0.5 clamped at 0, i1 = min(i0+1, in-1), and the same association of the four products.
+// With rescale=True and ori_shape != img_shape the reference resizes the cropped maps a second time
+// (mask2former_fusion_head.py:376-383); pan_owner_2stage_kernel composes both resizes per output pixel
+// (4 stage-2 taps, each a 4-tap stage-1 interpolation of the stride-4 logits: 16 source taps), so that
+// case never materialises (Q,H,W) either.  pvsg_instance_masks does the same for instance_postprocess
+// (mask2former_fusion_head.py:192-242): binary masks, mask-quality sums and boxes of the selected queries.
 #include "common.h"
 
 namespace pvsg {
@@ -179,6 +184,157 @@ __global__ __launch_bounds__(256) void pan_owner_x4_kernel(
   }
 }
 
+// ATen's source index for one output coordinate of a bilinear resize in -> out (align_corners=False,
+// no scale_factor: scale = in/out in float).
+struct Tap { int i0; int ip; float l0, l1; };
+__device__ __forceinline__ Tap bilinear_tap(int dst, int in, int out) {
+  const float scale = (float)in / (float)out;
+  float f = scale * ((float)dst + 0.5f) - 0.5f;
+  f = f < 0.f ? 0.f : f;
+  int i0 = (int)f;
+  i0 = i0 > in - 1 ? in - 1 : i0;
+  Tap t;
+  t.i0 = i0;
+  t.ip = (i0 < in - 1) ? 1 : 0;
+  t.l1 = f - (float)i0;
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+
+// Both resizes composed: output pixel (oy,ox) of the (oh,ow) map <- bilinear over the (ih,iw) crop of the
+// (H,W) map <- bilinear over the (h,w) stride-4 logits.
+struct Tap2 {
+  int r[4], c[4];          // source rows / columns: (stage-2 tap a) x (stage-1 tap)
+  float ly[4], lx[4];      // stage-1 weights per (a, tap)
+  float Ly0, Ly1, Lx0, Lx1;
+};
+__device__ __forceinline__ Tap2 make_tap2(int oy, int ox, int h, int w, int H, int W, int ih, int iw, int oh, int ow) {
+  Tap2 t;
+  const Tap ty = bilinear_tap(oy, ih, oh), tx = bilinear_tap(ox, iw, ow);
+  t.Ly0 = ty.l0; t.Ly1 = ty.l1; t.Lx0 = tx.l0; t.Lx1 = tx.l1;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const Tap sy = bilinear_tap(ty.i0 + a * ty.ip, h, H), sx = bilinear_tap(tx.i0 + a * tx.ip, w, W);
+    t.r[2 * a] = sy.i0; t.r[2 * a + 1] = sy.i0 + sy.ip; t.ly[2 * a] = sy.l0; t.ly[2 * a + 1] = sy.l1;
+    t.c[2 * a] = sx.i0; t.c[2 * a + 1] = sx.i0 + sx.ip; t.lx[2 * a] = sx.l0; t.lx[2 * a + 1] = sx.l1;
+  }
+  return t;
+}
+__device__ __forceinline__ float sample2(const float* __restrict__ p, int w, const Tap2& t) {
+  float v[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float* r0 = p + (long long)t.r[2 * a] * w;
+      const float* r1 = p + (long long)t.r[2 * a + 1] * w;
+      v[a][b] = t.ly[2 * a] * (t.lx[2 * b] * r0[t.c[2 * b]] + t.lx[2 * b + 1] * r0[t.c[2 * b + 1]]) +
+                t.ly[2 * a + 1] * (t.lx[2 * b] * r1[t.c[2 * b]] + t.lx[2 * b + 1] * r1[t.c[2 * b + 1]]);
+    }
+  return t.Ly0 * (t.Lx0 * v[0][0] + t.Lx1 * v[0][1]) + t.Ly1 * (t.Lx0 * v[1][0] + t.Lx1 * v[1][1]);
+}
+
+__global__ __launch_bounds__(256) void pan_owner_2stage_kernel(
+    const float* __restrict__ logits, const int* __restrict__ kept_idx, const float* __restrict__ kept_score,
+    unsigned char* __restrict__ owner_out, int* __restrict__ counters, int Q, int K, int h, int w,
+    int H, int W, int ih, int iw, int oh, int ow) {
+  __shared__ int s_area[MAXK], s_orig[MAXK], s_region_conf[MAXK];
+  __shared__ int s_idx[MAXK];
+  __shared__ float s_score[MAXK];
+  const int t = blockIdx.z;
+  for (int k = threadIdx.x; k < MAXK; k += blockDim.x) {
+    s_area[k] = 0; s_orig[k] = 0; s_region_conf[k] = 0;
+    if (k < K) { s_idx[k] = kept_idx[k]; s_score[k] = kept_score[k]; }
+  }
+  __syncthreads();
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const bool inside = x < ow && y < oh;
+  const Tap2 tp = make_tap2(inside ? y : 0, inside ? x : 0, h, w, H, W, ih, iw, oh, ow);
+  const float* base = logits + (long long)t * Q * h * w;
+  float best = -1.f, pown = 0.f;
+  int own = 0;
+  const int lane = threadIdx.x & 63;
+  for (int k = 0; k < K; ++k) {
+    const float v = inside ? sample2(base + (long long)s_idx[k] * h * w, w, tp) : 0.f;
+    const float prob = 1.f / (1.f + expf(-v));
+    const float sc = s_score[k] * prob;
+    if (sc > best) { best = sc; own = k; pown = prob; }
+    const unsigned long long conf = __ballot(inside && prob >= 0.5f);
+    if (lane == 0 && conf) atomicAdd(&s_orig[k], __popcll(conf));
+  }
+  if (inside) {
+    const bool c = pown >= 0.5f;
+    atomicAdd(&s_area[own], 1);
+    if (c) atomicAdd(&s_region_conf[own], 1);
+    owner_out[((long long)t * oh + y) * ow + x] = (unsigned char)(own | (c ? 0x80 : 0));
+  }
+  __syncthreads();
+  int* ct = counters + (long long)t * 3 * MAXK;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    if (s_area[k]) atomicAdd(ct + k, s_area[k]);
+    if (s_orig[k]) atomicAdd(ct + MAXK + k, s_orig[k]);
+    if (s_region_conf[k]) atomicAdd(ct + 2 * MAXK + k, s_region_conf[k]);
+  }
+}
+
+// instance_postprocess (mask2former_fusion_head.py:192-242) for n selected queries of T frames: the binary
+// mask `logit > 0` at output resolution, sum(sigmoid * binary), count(binary) and the box of the binary mask.
+//   stat_sum (T,n) float64, stat_box (T,n,5) int32 = {count, min x, min y, max x, max y}
+__global__ void inst_init_kernel(double* __restrict__ stat_sum, int* __restrict__ stat_box, int n, int big) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  stat_sum[i] = 0.0;
+  int* b = stat_box + 5ll * i;
+  b[0] = 0; b[1] = big; b[2] = big; b[3] = -1; b[4] = -1;
+}
+
+__global__ __launch_bounds__(256) void inst_masks_kernel(
+    const float* __restrict__ logits, const int* __restrict__ sel_idx, unsigned char* __restrict__ masks,
+    double* __restrict__ stat_sum, int* __restrict__ stat_box, int Q, int n, int sel_per_frame, int h, int w,
+    int H, int W, int ih, int iw, int oh, int ow) {
+  __shared__ double s_sum[4];
+  __shared__ int s_box[4][5];
+  const int e = blockIdx.z % n, t = blockIdx.z / n;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const bool inside = x < ow && y < oh;
+  const Tap2 tp = make_tap2(inside ? y : 0, inside ? x : 0, h, w, H, W, ih, iw, oh, ow);
+  const float* p = logits + ((long long)t * Q + sel_idx[sel_per_frame ? t * n + e : e]) * h * w;
+  const float v = inside ? sample2(p, w, tp) : -1.f;
+  const bool on = inside && v > 0.f;
+  if (masks && inside) masks[(((long long)t * n + e) * oh + y) * ow + x] = on ? 1 : 0;
+  double sg = on ? (double)(1.f / (1.f + expf(-v))) : 0.0;
+  int cnt = on ? 1 : 0, x0 = on ? x : 0x7fffffff, y0 = on ? y : 0x7fffffff, x1 = on ? x : -1, y1 = on ? y : -1;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    sg += __shfl_xor(sg, off);
+    cnt += __shfl_xor(cnt, off);
+    x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
+    x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
+  }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_sum[wv] = sg; s_box[wv][0] = cnt; s_box[wv][1] = x0; s_box[wv][2] = y0; s_box[wv][3] = x1; s_box[wv][4] = y1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; ++i) {
+      s_sum[0] += s_sum[i]; s_box[0][0] += s_box[i][0];
+      s_box[0][1] = min(s_box[0][1], s_box[i][1]); s_box[0][2] = min(s_box[0][2], s_box[i][2]);
+      s_box[0][3] = max(s_box[0][3], s_box[i][3]); s_box[0][4] = max(s_box[0][4], s_box[i][4]);
+    }
+    if (s_box[0][0]) {
+      const long long o = (long long)t * n + e;
+      atomicAdd(stat_sum + o, s_sum[0]);
+      int* b = stat_box + 5 * o;
+      atomicAdd(b, s_box[0][0]);
+      atomicMin(b + 1, s_box[0][1]); atomicMin(b + 2, s_box[0][2]);
+      atomicMax(b + 3, s_box[0][3]); atomicMax(b + 4, s_box[0][4]);
+    }
+  }
+}
+
 __global__ void pan_decide_kernel(const int* __restrict__ counters, const int* __restrict__ kept_class,
                                   int* __restrict__ seg_id, int K, int num_things, double iou_thr,
                                   int filter_low) {
@@ -224,19 +380,23 @@ __global__ __launch_bounds__(256) void pan_paint_kernel(const unsigned char* __r
 extern "C" int pvsg_panoptic_fuse(const float* mask_logits, const int* kept_idx, const float* kept_score,
                                   const int* kept_class, int* panoptic, int* seg_id,
                                   unsigned char* owner_ws, int* counter_ws, int T, int Q, int K, int h,
-                                  int w, int H, int W, int ih, int iw, int num_things, int num_classes,
-                                  double iou_thr, int filter_low_score, hipStream_t stream) {
+                                  int w, int H, int W, int ih, int iw, int oh, int ow, int num_things,
+                                  int num_classes, double iou_thr, int filter_low_score, hipStream_t stream) {
   using namespace pvsg;
   PVSG_REQUIRE(mask_logits && panoptic && owner_ws && counter_ws, "panoptic_fuse: null pointer argument");
-  PVSG_REQUIRE(T > 0 && Q > 0 && h > 0 && w > 0 && H > 0 && W > 0 && ih > 0 && iw > 0 && ih <= H && iw <= W,
-               "panoptic_fuse: bad geometry (h=%d w=%d H=%d W=%d ih=%d iw=%d)", h, w, H, W, ih, iw);
+  PVSG_REQUIRE(T > 0 && Q > 0 && h > 0 && w > 0 && H > 0 && W > 0 && ih > 0 && iw > 0 && ih <= H && iw <= W &&
+                   oh > 0 && ow > 0,
+               "panoptic_fuse: bad geometry (h=%d w=%d H=%d W=%d ih=%d iw=%d oh=%d ow=%d)", h, w, H, W, ih, iw, oh, ow);
   PVSG_REQUIRE(K >= 0 && K <= MAXK - 1, "panoptic_fuse: at most %d kept queries (got %d)", MAXK - 1, K);
   PVSG_REQUIRE(K == 0 || (kept_idx && kept_score && kept_class && seg_id), "panoptic_fuse: null kept-query tables");
-  const long long npix = (long long)ih * iw;
+  const long long npix = (long long)oh * ow;
   hipError_t e = hipMemsetAsync(counter_ws, 0, (size_t)T * 3 * MAXK * sizeof(int), stream);
   if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "panoptic_fuse: memset: %s", hipGetErrorString(e));
   if (K > 0) {
-    if (H == 4 * h && W == 4 * w)
+    if (oh != ih || ow != iw)
+      hipLaunchKernelGGL(pan_owner_2stage_kernel, dim3((ow + 63) / 64, (oh + 3) / 4, T), dim3(256), 0, stream,
+                         mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, H, W, ih, iw, oh, ow);
+    else if (H == 4 * h && W == 4 * w)
       hipLaunchKernelGGL(pan_owner_x4_kernel, dim3((w + 1 + 31) / 32, (h + 1 + 7) / 8, T), dim3(256), 0, stream,
                          mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, ih, iw);
     else
@@ -252,5 +412,26 @@ extern "C" int pvsg_panoptic_fuse(const float* mask_logits, const int* kept_idx,
   hipLaunchKernelGGL(pan_paint_kernel, dim3((unsigned)nb, T), dim3(256), 0, stream, owner_ws, seg_id,
                      panoptic, K, npix, num_classes, filter_low_score);
   PVSG_LAUNCH_CHECK("panoptic_fuse(paint)");
+  return PVSG_OK;
+}
+
+extern "C" int pvsg_instance_masks(const float* mask_logits, const int* sel_idx, unsigned char* masks,
+                                   double* stat_sum, int* stat_box, int T, int Q, int n, int sel_per_frame,
+                                   int h, int w, int H, int W, int ih, int iw, int oh, int ow,
+                                   hipStream_t stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(mask_logits && stat_sum && stat_box, "instance_masks: null pointer argument");
+  PVSG_REQUIRE(T > 0 && Q > 0 && n >= 0 && h > 0 && w > 0 && H > 0 && W > 0 && ih > 0 && iw > 0 && ih <= H &&
+                   iw <= W && oh > 0 && ow > 0,
+               "instance_masks: bad geometry (h=%d w=%d H=%d W=%d ih=%d iw=%d oh=%d ow=%d)", h, w, H, W, ih, iw, oh, ow);
+  PVSG_REQUIRE((long long)T * n <= 65535, "instance_masks: T*n = %lld exceeds the grid limit 65535", (long long)T * n);
+  if (n == 0) return PVSG_OK;
+  PVSG_REQUIRE(sel_idx, "instance_masks: null selection table");
+  hipLaunchKernelGGL(inst_init_kernel, dim3((T * n + 255) / 256), dim3(256), 0, stream, stat_sum, stat_box, T * n,
+                     0x7fffffff);
+  PVSG_LAUNCH_CHECK("instance_masks(init)");
+  hipLaunchKernelGGL(inst_masks_kernel, dim3((ow + 63) / 64, (oh + 3) / 4, T * n), dim3(256), 0, stream,
+                     mask_logits, sel_idx, masks, stat_sum, stat_box, Q, n, sel_per_frame, h, w, H, W, ih, iw, oh, ow);
+  PVSG_LAUNCH_CHECK("instance_masks");
   return PVSG_OK;
 }

@@ -22,6 +22,13 @@ from .config import _wrap
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 
 
+def encode_mask_results(mask_results):
+    """[3P] mmdet.core.encode_mask_results: per-class lists of binary masks -> lists of COCO RLE dicts
+    (only reached with num_stuff_classes == 0, the video-instance flavour; tubes.rle_encode is the codec)."""
+    from .tubes import rle_encode
+    return [[rle_encode(np.asarray(m, dtype=np.uint8)) for m in per_cls] for per_cls in mask_results]
+
+
 def bbox2result(bboxes, labels, num_classes):
     """[3P] mmdet.core.bbox2result."""
     if bboxes.shape[0] == 0:
@@ -66,21 +73,82 @@ class _Base(BaseModule):
         raise NotImplementedError('training is outside the MI355X inference hot path')
 
     @staticmethod
-    def _finish(res, num_things, keep_device=False):
+    def _ins_to_host(labels, bboxes, binm, num_things):
+        """(labels (n,), boxes (n,5|6), masks (n,H,W) bool) -> (bbox2result lists, per-class lists of numpy masks)
+        (mask2former.py:172-181, mask2former_vps/mask2former.py:201-206)."""
+        bbox_results = bbox2result(bboxes, labels, num_things)
+        masks_np = binm.detach().cpu().numpy()
+        mask_results = [[] for _ in range(num_things)]
+        for j, lab in enumerate(labels.tolist()):
+            mask_results[lab].append(masks_np[j])
+        return bbox_results, mask_results
+
+    @classmethod
+    def _finish(cls, res, num_things, keep_device=False):
         """Device -> host conversion of one image's result (mask2former.py:165-186)."""
         if 'pan_results' in res and not keep_device:
             res['pan_results'] = res['pan_results'].detach().cpu().numpy()
         if 'query_feats' in res and not keep_device:
             res['query_feats'] = {k: [x.detach().cpu().numpy() for x in v] for k, v in res['query_feats'].items()}
         if 'ins_results' in res:
-            labels, bboxes, binm = res['ins_results']
-            bbox_results = bbox2result(bboxes, labels, num_things)
-            masks_np = binm.detach().cpu().numpy()
-            mask_results = [[] for _ in range(num_things)]
-            for j, lab in enumerate(labels.tolist()):
-                mask_results[lab].append(masks_np[j])
-            res['ins_results'] = bbox_results, mask_results
+            res['ins_results'] = cls._ins_to_host(*res['ins_results'], num_things)
         return res
+
+    @staticmethod
+    def _video_ins_to_host(labels, bboxes, binm, num_things, order=None, top=10):
+        """mask2former_vps/mask2former.py:188-206: 1-based instance id in front of the box, sort by score,
+        keep the best `top`, then the default instance-segmentation format."""
+        n = bboxes.shape[0]
+        if order is None:
+            ids = torch.arange(n, dtype=bboxes.dtype, device=bboxes.device)[:, None] + 1
+            bboxes = torch.cat([ids, bboxes], dim=1)
+            inds = torch.argsort(bboxes[:, -1], descending=True)[:top]
+            labels, bboxes, binm = labels[inds], bboxes[inds], binm[inds]
+        else:                      # already sorted / truncated by fusion.instance_fused(top=...)
+            bboxes = torch.cat([order.to(bboxes.dtype)[:, None] + 1, bboxes], dim=1)
+        return _Base._ins_to_host(labels, bboxes, binm, num_things)
+
+    def _fused_ok(self, metas, rescale):
+        """The fused post-processing kernels apply whenever the frames handed over share one geometry
+        (batch_input_shape, img_shape and -- under rescale -- ori_shape); instance_on and the second
+        resize to ori_shape are handled by the kernels (pvsg_panoptic_fuse, pvsg_instance_masks)."""
+        cfg = self.panoptic_fusion_head.test_cfg
+        if cfg.get('semantic_on', False):
+            return False
+        key = {(tuple(m['batch_input_shape'][:2]), tuple(m['img_shape'][:2]),
+                tuple(m['ori_shape'][:2]) if rescale else None) for m in metas}
+        return len(key) == 1
+
+    def _fused_frames(self, cls, masks4, embds, meta, rescale, video):
+        """cls (Q,classes+1) shared by the T frames of masks4 (T,Q,h,w); embds (Q,C) query features.
+        -> list of T host-side result dicts, or None when the kept set exceeds the kernel's capacity."""
+        fusion = self.panoptic_fusion_head
+        cfg = fusion.test_cfg
+        T = masks4.shape[0]
+        ori = meta['ori_shape'] if rescale else None
+        out = [dict() for _ in range(T)]
+        if cfg.get('panoptic_on', True):
+            if not fusion.fused_capacity_ok(cls):
+                return None
+            pan, seg, keep = fusion.panoptic_fused(cls, masks4, meta['batch_input_shape'], meta['img_shape'], ori)
+            kf_np = embds[keep].detach().cpu().numpy()
+            pan_np, seg_l = pan.cpu().numpy(), seg.tolist()
+            for t in range(T):
+                qd = {}
+                for i, sid in enumerate(seg_l[t]):
+                    if sid >= 0:   # video: (C,) rows; image: (1,C) as the reference's query_feat_k
+                        qd.setdefault(sid, []).append(kf_np[i] if video else kf_np[i][None])
+                out[t].update(pan_results=pan_np[t], query_feats=qd)
+        if cfg.get('instance_on', False):
+            ins = fusion.instance_fused(cls, masks4, meta['batch_input_shape'], meta['img_shape'], ori,
+                                        top=10 if video else None)
+            for t in range(T):
+                if video:
+                    labels, boxes, binm, order = ins[t]
+                    out[t]['ins_results'] = self._video_ins_to_host(labels, boxes, binm, self.num_things_classes, order)
+                else:
+                    out[t]['ins_results'] = self._ins_to_host(*ins[t], self.num_things_classes)
+        return out
 
 
 @DETECTORS.register_module()
@@ -93,28 +161,14 @@ class Mask2FormerCustom(_Base):
             meta['batch_input_shape'] = tuple(imgs.shape[-2:])
         return self.simple_test(imgs, img_metas, **kwargs)
 
-    def _fused_ok(self, metas, rescale):
-        """Fused up-sample + panoptic kernel applies when the map is produced at img_shape (no second
-        resize to a different ori_shape) and only panoptic output is requested."""
-        cfg = self.panoptic_fusion_head.test_cfg
-        if cfg.get('instance_on', False) or cfg.get('semantic_on', False) or not cfg.get('panoptic_on', True):
-            return False
-        return all((not rescale) or tuple(m['ori_shape'][:2]) == tuple(m['img_shape'][:2]) for m in metas)
-
     def simple_test(self, imgs, img_metas, rescale=False, **kwargs):
         feats = self.extract_feat(imgs)
-        if self.fused_postprocess and self._fused_ok(img_metas, rescale) and len(img_metas) == 1:
+        if self.fused_postprocess and len(img_metas) == 1 and self._fused_ok(img_metas, rescale):
             # one image per call (the reference's own limit, SURVEY.md section 3.1 quirk)
-            head, fusion = self.panoptic_head, self.panoptic_fusion_head
-            cls_list, mask_list, q = head._decode(feats, 1, 1, all_masks=False)
-            pan, seg, keep = fusion.panoptic_fused(cls_list[-1][0], mask_list[-1], img_metas[0]['batch_input_shape'],
-                                                   img_metas[0]['img_shape'])
-            kf = q[:, 0][keep]
-            qd = {}
-            for i, sid in enumerate(seg[0].tolist()):
-                if sid >= 0:
-                    qd.setdefault(sid, []).append(kf[i][None])      # (1, C) as the reference's query_feat_k
-            return [self._finish(dict(pan_results=pan[0], query_feats=qd), self.num_things_classes)]
+            cls_list, mask_list, q = self.panoptic_head._decode(feats, 1, 1, all_masks=False)
+            res = self._fused_frames(cls_list[-1][0], mask_list[-1], q[:, 0], img_metas[0], rescale, video=False)
+            if res is not None:
+                return [r['ins_results'] for r in res] if self.num_stuff_classes == 0 else res
         cls, masks, qf = self.panoptic_head.simple_test_with_query(feats, img_metas, **kwargs)
         results = self.panoptic_fusion_head.simple_test_with_query(cls, masks, qf, img_metas, rescale=rescale,
                                                                    **kwargs)
@@ -160,35 +214,23 @@ class Mask2FormerVideoCustom(_Base):
         bs, T = ref_img.shape[:2]
         feats = self.extract_feat(ref_img.reshape((bs * T,) + tuple(ref_img.shape[2:])))
         flat_metas = [m for per_video in ref_img_metas for m in per_video]
-        if (self.inference_mode == 'clip' and self.fused_postprocess and bs == 1 and
-                Mask2FormerCustom._fused_ok(self, flat_metas, rescale) and
-                len({tuple(m['img_shape'][:2]) for m in flat_metas}) == 1):
-            # all frames of the clip share the class logits -> one fused up-sample + panoptic launch set
-            head, fusion = self.panoptic_head, self.panoptic_fusion_head
-            cls, masks4, q = head.clip_logits(feats, 1, T)
-            pan, seg, keep = fusion.panoptic_fused(cls[0], masks4[0], flat_metas[0]['batch_input_shape'],
-                                                   flat_metas[0]['img_shape'])
-            kf = q[:, 0][keep]
-            pan_np, seg_l = pan.cpu().numpy(), seg.tolist()
-            kf_np = kf.detach().cpu().numpy()
-            out = []
-            for t in range(T):
-                qd = {}
-                for i, sid in enumerate(seg_l[t]):
-                    if sid >= 0:
-                        qd.setdefault(sid, []).append(kf_np[i])
-                out.append(dict(pan_results=pan_np[t], query_feats=qd))
-            return [out]
+        fused = self.fused_postprocess and bs == 1 and self._fused_ok(flat_metas, rescale)
+        head = self.panoptic_head
+        masks4 = None
         if self.inference_mode == 'clip':
-            cls, masks, q = self.panoptic_head.simple_test_with_query(feats, ref_img_metas, **kwargs)
-            logits, embds = cls, q.permute(1, 0, 2)                    # (bs,Q,C+1), (bs,Q,C)
+            if fused:
+                # all frames of the clip share the class logits -> one fused post-processing launch set
+                cls, masks4, q = head.clip_logits(feats, 1, T)
+                logits, embds, masks4 = cls, q.permute(1, 0, 2), masks4[0]
+            else:
+                cls, masks, q = head.simple_test_with_query(feats, ref_img_metas, **kwargs)
+                logits, embds = cls, q.permute(1, 0, 2)                    # (bs,Q,C+1), (bs,Q,C)
         else:
             if bs != 1:
                 raise NotImplementedError('per-frame VPS inference runs one video per call (as shipped)')
             # Shipped flow: one head call per frame (mask2former.py:136-143) + MinVIS chaining (:146-165).
             # Frames are independent inside the head, so they run as ONE batch of T; the matching chain
             # over the T frames is one on-device launch (ops.minvis_chain) instead of T-1 host LAPs.
-            head = self.panoptic_head
             cls_list, mask_list, qq = head._decode(feats, T, 1, all_masks=False)
             cls_t, masks4 = cls_list[-1], mask_list[-1][:, 0]                 # (T,Q,C+1), (T,Q,h,w)
             embds_t = qq.permute(1, 0, 2).contiguous()                        # (T,Q,C)
@@ -197,21 +239,14 @@ class Mask2FormerVideoCustom(_Base):
             logits = cls_t[ar, perm].mean(0, keepdim=True)                    # (1,Q,C+1)
             embds = embds_t[ar, perm].mean(0, keepdim=True)                   # (1,Q,C)
             masks4 = masks4[ar, perm]                                         # (T,Q,h,w) on frame-0 slots
-            if (self.fused_postprocess and Mask2FormerCustom._fused_ok(self, flat_metas, rescale) and
-                    len({tuple(m['img_shape'][:2]) for m in flat_metas}) == 1):
-                fusion = self.panoptic_fusion_head
-                pan, seg, keep = fusion.panoptic_fused(logits[0], masks4, flat_metas[0]['batch_input_shape'],
-                                                       flat_metas[0]['img_shape'])
-                kf_np = embds[0][keep].detach().cpu().numpy()
-                pan_np, seg_l = pan.cpu().numpy(), seg.tolist()
-                out = []
-                for t in range(T):
-                    qd = {}
-                    for i, sid in enumerate(seg_l[t]):
-                        if sid >= 0:
-                            qd.setdefault(sid, []).append(kf_np[i])
-                    out.append(dict(pan_results=pan_np[t], query_feats=qd))
+        if fused and masks4 is not None:
+            out = self._fused_frames(logits[0], masks4, embds[0], flat_metas[0], rescale, video=True)
+            if out is not None:
+                if self.num_stuff_classes == 0:
+                    for r in out:
+                        r['ins_results'] = (r['ins_results'][0], encode_mask_results(r['ins_results'][1]))
                 return [out]
+        if masks4 is not None:
             h, w = flat_metas[0]['batch_input_shape'][:2]
             masks = torch.nn.functional.interpolate(masks4, size=(h, w), mode='bilinear',
                                                     align_corners=False).unsqueeze(0)   # (1,T,Q,H,W)
@@ -226,9 +261,9 @@ class Mask2FormerVideoCustom(_Base):
                 if 'query_feats' in r:
                     r['query_feats'] = {k: [x.detach().cpu().numpy() for x in v] for k, v in r['query_feats'].items()}
                 if 'ins_results' in r:
-                    labels, bboxes, binm = r['ins_results']
-                    ids = torch.arange(len(bboxes), dtype=bboxes.dtype, device=bboxes.device)[:, None] + 1
-                    r['ins_results'] = labels, torch.cat([ids, bboxes], dim=1), binm
+                    r['ins_results'] = self._video_ins_to_host(*r['ins_results'], self.num_things_classes)
+                    if self.num_stuff_classes == 0:
+                        r['ins_results'] = (r['ins_results'][0], encode_mask_results(r['ins_results'][1]))
                 results[b].append(r)
         return results
 

@@ -84,17 +84,23 @@ class MaskFormerFusionHeadCustom(BaseModule):
         seg = torch.where(paint, seg_id[owner].to(torch.int32), seg)
         return seg, seg_id
 
-    def panoptic_fused(self, mask_cls, mask_logits4, batch_input_shape, img_shape):
+    def panoptic_fused(self, mask_cls, mask_logits4, batch_input_shape, img_shape, ori_shape=None):
         """Fused path (postprocess.hip): class decision here, everything per-pixel in the kernel.
         mask_cls (Q,classes+1); mask_logits4 (T,Q,h,w) stride-4 logits of T frames that share the
-        class logits -> (panoptic (T,ih,iw) int32, seg_id (T,K) int32, keep (Q,) bool)."""
+        class logits; ori_shape = the `rescale=True` target (fusion_head.py:376-383) or None
+        -> (panoptic (T,oh,ow) int32, seg_id (T,K) int32, keep (Q,) bool)."""
         scores, labels, keep = self.panoptic_select(mask_cls)
         idx = keep.nonzero()[:, 0]
         pan, seg = ops.panoptic_fuse(mask_logits4, idx, scores[idx], labels[idx], batch_input_shape,
                                      img_shape[:2], self.num_things_classes, self.num_classes,
                                      self.test_cfg.get('iou_thr', 0.8),
-                                     self.test_cfg.get('filter_low_score', False))
+                                     self.test_cfg.get('filter_low_score', False),
+                                     ori_hw=None if ori_shape is None else ori_shape[:2])
         return pan, seg, keep
+
+    def fused_capacity_ok(self, mask_cls):
+        """The fused kernel keeps its kept-query tables in LDS (<= 127 queries)."""
+        return int(self.panoptic_select(mask_cls)[2].sum()) <= ops.PANOPTIC_FUSE_MAX_KEPT
 
     def panoptic_postprocess_with_query(self, mask_cls, mask_pred, query_feats):
         """mask_cls (Q,classes+1), mask_pred (Q,H,W) logits, query_feats (Q,...) ->
@@ -131,6 +137,45 @@ class MaskFormerFusionHeadCustom(BaseModule):
         det = top_scores * mask_score
         boxes = torch.cat([mask2bbox(binary), det[:, None]], dim=-1)
         return top_labels, boxes, binary
+
+    def instance_select(self, mask_cls):
+        """fusion_head.py:207-225: the top-k (query, class) pairs, things only ->
+        (class scores (n,), labels (n,), query index (n,))."""
+        max_per_image = self.test_cfg.get('max_per_image', 100)
+        scores = F.softmax(mask_cls, dim=-1)[:, :-1]
+        top_scores, top_idx = scores.flatten(0, 1).topk(max_per_image, sorted=False)
+        top_labels = top_idx % self.num_classes
+        thing = top_labels < self.num_things_classes
+        return top_scores[thing], top_labels[thing], (top_idx // self.num_classes)[thing]
+
+    @staticmethod
+    def _instance_boxes(cls_scores, ssum, sbox):
+        """mask-quality rescoring + mask2bbox from the kernel's statistics -> (T,n,5) [x0,y0,x1,y1,score]."""
+        cnt = sbox[..., 0].to(torch.float32)
+        mask_score = ssum.to(torch.float32) / (cnt + 1e-6)
+        det = cls_scores[None] * mask_score
+        box = torch.stack([sbox[..., 1], sbox[..., 2], sbox[..., 3] + 1, sbox[..., 4] + 1], -1).to(torch.float32)
+        box = torch.where((sbox[..., 0] > 0)[..., None], box, torch.zeros_like(box))
+        return torch.cat([box, det[..., None]], -1)
+
+    def instance_fused(self, mask_cls, mask_logits4, batch_input_shape, img_shape, ori_shape=None, top=None):
+        """instance_postprocess for T frames sharing the class logits, from the stride-4 logits
+        (pvsg_instance_masks: no (Q,H,W) float tensor).  -> per frame (labels, boxes (n,5), masks (n,oh,ow) bool);
+        top = k keeps the k best-scoring instances of each frame, best first
+        (mask2former_vps/mask2former.py:196-200), and only those masks are produced."""
+        scores, labels, qidx = self.instance_select(mask_cls)
+        ori = None if ori_shape is None else ori_shape[:2]
+        T = mask_logits4.shape[0]
+        if top is None:
+            masks, ssum, sbox = ops.instance_masks(mask_logits4, qidx, batch_input_shape, img_shape[:2], ori)
+            boxes = self._instance_boxes(scores, ssum, sbox)
+            return [(labels, boxes[t], masks[t]) for t in range(T)]
+        _, ssum, sbox = ops.instance_masks(mask_logits4, qidx, batch_input_shape, img_shape[:2], ori, want_masks=False)
+        boxes = self._instance_boxes(scores, ssum, sbox)                       # (T,n,5)
+        order = torch.argsort(boxes[..., -1], dim=1, descending=True)[:, :top]    # (T,k)
+        masks, _, _ = ops.instance_masks(mask_logits4, qidx[order], batch_input_shape, img_shape[:2], ori)
+        ar = torch.arange(T, device=order.device)[:, None]
+        return [(labels[order[t]], boxes[ar, order][t], masks[t], order[t]) for t in range(T)]
 
     # ---- drivers ----------------------------------------------------------------------------------
     def simple_test_with_query(self, mask_cls_results, mask_pred_results, query_feats, img_metas,

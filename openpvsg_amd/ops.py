@@ -222,11 +222,12 @@ def pair_score(sub_feats, obj_feats, W1, b1, w2, b2, return_tokens=False, W1T=No
 
 
 def panoptic_fuse(mask_logits, kept_idx, kept_score, kept_class, out_hw, crop_hw, num_things,
-                  num_classes, iou_thr=0.8, filter_low_score=False):
-    """Fused x4 up-sampling + panoptic fusion for T frames sharing one kept-query set.
+                  num_classes, iou_thr=0.8, filter_low_score=False, ori_hw=None):
+    """Fused up-sampling (+ crop + optional second resize to `ori_hw`) + panoptic fusion for T frames
+    sharing one kept-query set.
 
     mask_logits (T,Q,h,w) stride-4 logits; kept_* (K,) in query order ->
-    (panoptic (T,ih,iw) int32, seg_id (T,K) int32 with -1 for dropped queries)."""
+    (panoptic (T,oh,ow) int32, seg_id (T,K) int32 with -1 for dropped queries)."""
     x = _chk(mask_logits, 'mask_logits')
     if x.dim() != 4:
         raise RuntimeError('panoptic_fuse: mask_logits must be (T,Q,h,w)')
@@ -234,10 +235,11 @@ def panoptic_fuse(mask_logits, kept_idx, kept_score, kept_class, out_hw, crop_hw
     K = int(kept_idx.numel())
     H, W = int(out_hw[0]), int(out_hw[1])
     ih, iw = int(crop_hw[0]), int(crop_hw[1])
+    oh, ow = (ih, iw) if ori_hw is None else (int(ori_hw[0]), int(ori_hw[1]))
     dev = x.device
-    pan = torch.empty((T, ih, iw), device=dev, dtype=torch.int32)
+    pan = torch.empty((T, oh, ow), device=dev, dtype=torch.int32)
     seg = torch.empty((T, K), device=dev, dtype=torch.int32)
-    owner = torch.empty((T * ih * iw,), device=dev, dtype=torch.uint8)
+    owner = torch.empty((T * oh * ow,), device=dev, dtype=torch.uint8)
     counters = torch.empty((T * 3 * 128,), device=dev, dtype=torch.int32)
     if K:
         ki = _chk(kept_idx.to(torch.int32), 'kept_idx', torch.int32)
@@ -249,9 +251,40 @@ def panoptic_fuse(mask_logits, kept_idx, kept_score, kept_class, out_hw, crop_hw
     with torch.cuda.device(dev):
         _lib.call('pvsg_panoptic_fuse', x.data_ptr(), ptrs[0], ptrs[1], ptrs[2], pan.data_ptr(),
                   seg.data_ptr() if K else None, owner.data_ptr(), counters.data_ptr(), T, Q, K, h, w, H, W,
-                  ih, iw, int(num_things), int(num_classes), float(iou_thr), int(bool(filter_low_score)),
+                  ih, iw, oh, ow, int(num_things), int(num_classes), float(iou_thr), int(bool(filter_low_score)),
                   _stream_ptr())
     return pan, seg
+
+
+PANOPTIC_FUSE_MAX_KEPT = 127   # kept-query tables of postprocess.hip live in LDS (MAXK - 1)
+
+
+def instance_masks(mask_logits, sel_idx, out_hw, crop_hw, ori_hw=None, want_masks=True):
+    """instance_postprocess mask work (fusion_head.py:207-240) for n selected queries (sel_idx (n,) shared by the frames, or (T,n)) of T frames on the
+    composed up-sample / crop / resize.  -> (masks (T,n,oh,ow) bool or None, sigmoid sums (T,n) float64,
+    box stats (T,n,5) int32 = count, min x, min y, max x, max y)."""
+    x = _chk(mask_logits, 'mask_logits')
+    if x.dim() != 4:
+        raise RuntimeError('instance_masks: mask_logits must be (T,Q,h,w)')
+    T, Q, h, w = x.shape
+    per_frame = sel_idx.dim() == 2
+    if per_frame and sel_idx.shape[0] != T:
+        raise RuntimeError('instance_masks: per-frame selection must be (T,n)')
+    n = int(sel_idx.shape[-1])
+    H, W = int(out_hw[0]), int(out_hw[1])
+    ih, iw = int(crop_hw[0]), int(crop_hw[1])
+    oh, ow = (ih, iw) if ori_hw is None else (int(ori_hw[0]), int(ori_hw[1]))
+    dev = x.device
+    masks = torch.empty((T, n, oh, ow), device=dev, dtype=torch.uint8) if want_masks else None
+    ssum = torch.zeros((T, n), device=dev, dtype=torch.float64)
+    sbox = torch.zeros((T, n, 5), device=dev, dtype=torch.int32)
+    if n:
+        si = _chk(sel_idx.to(torch.int32), 'sel_idx', torch.int32)
+        with torch.cuda.device(dev):
+            _lib.call('pvsg_instance_masks', x.data_ptr(), si.data_ptr(),
+                      masks.data_ptr() if masks is not None else None, ssum.data_ptr(), sbox.data_ptr(),
+                      T, Q, n, int(per_frame), h, w, H, W, ih, iw, oh, ow, _stream_ptr())
+    return (masks.view(torch.bool) if masks is not None else None), ssum, sbox
 
 
 def msda_fused(y, pos_oa, ref_points, spatial_shapes, level_start_index, num_heads=8, num_levels=3,

@@ -19,6 +19,7 @@ Reference sites restated here:
 import math
 from collections import defaultdict
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -264,6 +265,24 @@ def fusion_simple_test_with_query(mask_cls_results, mask_pred_results, query_fea
                                                       test_cfg.get('max_per_image', 100))
         results.append(res)
     return results
+
+
+def video_ins_results(labels, bboxes, binm, num_things, top=10):
+    """mask2former_vps/mask2former.py:188-206: 1-based instance id in front of each box, sort by score,
+    keep the best `top`, then (bbox2result lists [3P], per-class lists of numpy masks)."""
+    ids = torch.arange(len(bboxes), dtype=bboxes.dtype)[:, None] + 1
+    bboxes = torch.cat([ids, bboxes], dim=1)
+    inds = torch.argsort(bboxes[:, -1], descending=True)
+    labels, bboxes, binm = labels[inds][:top], bboxes[inds][:top], binm[inds][:top]
+    if bboxes.shape[0] == 0:
+        bbox_results = [np.zeros((0, bboxes.shape[1]), dtype=np.float32) for _ in range(num_things)]
+    else:
+        b, lab = bboxes.numpy(), labels.numpy()
+        bbox_results = [b[lab == i, :] for i in range(num_things)]
+    mask_results = [[] for _ in range(num_things)]
+    for j, lab in enumerate(labels.tolist()):
+        mask_results[lab].append(binm[j].numpy())
+    return bbox_results, mask_results
 
 
 # ----------------------------------------------------------------------------------------------

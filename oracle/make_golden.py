@@ -290,7 +290,7 @@ def synth_feats(nimg, seed):
             for i, (c, hw) in enumerate(zip(HEAD_CFG['in_channels'], FEAT_SHAPES))]
 
 
-def gen_head(HEADS):
+def load_head_modules():
     ips = load_by_path('ref_m2f_head', 'models/mask2former/mask2former_head.py')
     load_by_path('models.mask2former_vps.utils', 'models/mask2former_vps/utils.py',
                  'models.mask2former_vps')
@@ -300,6 +300,11 @@ def gen_head(HEADS):
                  'models/mask2former_vps/maskformer_video_head.py', 'models.mask2former_vps')
     vid = load_by_path('models.mask2former_vps.mask2former_video_head',
                        'models/mask2former_vps/mask2former_video_head.py', 'models.mask2former_vps')
+    return ips, vid
+
+
+def gen_head(HEADS):
+    ips, vid = load_head_modules()
 
     def trace(head, fwd_head_name):
         rec = {'am': []}
@@ -456,6 +461,107 @@ def gen_detector(HEADS, DETECTORS):
         else np.zeros((0, 256), np.float32)
     np.savez_compressed(os.path.join(OUT, 'detector_vps_T1.npz'), seed=seed, T=T, pan=pans,
                         ids0=np.array(ids[0], dtype=np.int64), feat0=feat0)
+    # same detector with instance_on=True (as both shipped configs set it) and a second resize to ori_shape:
+    # pins the `ins_results` conversion of mask2former_vps/mask2former.py:188-206 (id column, score sort,
+    # top-10, bbox2result / per-class mask lists) and the rescale branch of the fusion head
+    model.panoptic_fusion_head.test_cfg = to_attr(dict(test_cfg, instance_on=True))
+    metas = [[dict(batch_input_shape=(64, 96), img_shape=(60, 90, 3), ori_shape=(45, 70, 3)) for _ in range(T)]]
+    with torch.no_grad():
+        results = model.simple_test(None, None, img, metas, rescale=True)
+    r0 = results[0][0]
+    bbox_results, mask_results = r0['ins_results']
+    cls_of, boxes, areas, packed = [], [], [], []
+    for c in range(115):
+        for j in range(bbox_results[c].shape[0]):
+            cls_of.append(c)
+            boxes.append(bbox_results[c][j])
+            areas.append(int(mask_results[c][j].sum()))
+            packed.append(np.packbits(mask_results[c][j].astype(np.uint8)))
+    print('detector vps (instance_on, ori 45x70): %d instances kept' % len(cls_of))
+    np.savez_compressed(os.path.join(OUT, 'detector_vps_T1_ins.npz'), seed=seed, T=T,
+                        pan=np.stack([results[0][t]['pan_results'] for t in range(T)]),
+                        ids0=np.array(sorted(r0['query_feats'].keys()), dtype=np.int64),
+                        ins_cls=np.array(cls_of, dtype=np.int64),
+                        ins_boxes=np.stack(boxes) if boxes else np.zeros((0, 6), np.float32),
+                        ins_area=np.array(areas, dtype=np.int64),
+                        ins_masks_packed=np.stack(packed) if packed else np.zeros((0, 0), np.uint8))
+
+
+def gen_tubes():
+    """concat_seq (models/mask2former_vps/utils.py:20-89) + write_mots_results (models/unitrack/utils/io.py:14-36)
+    run from the reference's own files.  cv2 / the tracking visualiser / the timer are inert stand-ins; the COCO
+    run-length codec ([3P] pycocotools, absent) is the repository's restatement -- so this pins the record
+    STRUCTURE (ids by first appearance, 1-based frames, `frame id cid h w rle` lines, SimpleTracker tubes with None
+    for absent frames), not pycocotools' strings."""
+    import pickle
+    import tempfile
+    from openpvsg_amd import tubes as ptubes
+    from tests.synth_inputs import tube_outputs
+
+    def mod(name):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+
+    cv2 = mod('cv2')
+    cv2.imread = lambda *a, **k: None
+    cv2.imwrite = lambda *a, **k: True
+    mu = mod('pycocotools.mask')
+
+    def encode(arr):
+        r = ptubes.rle_encode(np.asarray(arr))
+        r['counts'] = r['counts'].encode('ascii')
+        return r
+    mu.encode = encode
+    mod('pycocotools').mask = mu
+    log = mod('models.unitrack.utils.log')
+    log.logger = types.SimpleNamespace(info=lambda *a, **k: None)
+
+    class Timer:
+        average_time = 0.0
+
+        def tic(self):
+            pass
+
+        def toc(self):
+            pass
+    mod('models.unitrack.utils.meter').Timer = Timer
+    mod('models.unitrack.utils.visualize').plot_tracking = lambda *a, **k: None
+    mod('models.unitrack.data')
+    load_by_path('models.unitrack.data.query_feat_tracklet', 'models/unitrack/data/query_feat_tracklet.py')
+    sys.modules['models.unitrack.data'].query_feat_tracklet = sys.modules['models.unitrack.data.query_feat_tracklet']
+    io = load_by_path('models.unitrack.utils.io', 'models/unitrack/utils/io.py')
+    sys.modules['models.unitrack.utils'].io = io
+    sys.modules['models.unitrack.utils'].visualize = sys.modules['models.unitrack.utils.visualize']
+    sys.modules['models.unitrack.utils'].log = log
+    if 'models.mask2former_vps' not in sys.modules:
+        pkg = mod('models.mask2former_vps')
+        pkg.__path__ = [os.path.join(REF, 'models', 'mask2former_vps')]
+    ut = load_by_path('models.mask2former_vps.utils', 'models/mask2former_vps/utils.py', 'models.mask2former_vps')
+    save = {}
+    for case in (0, 1):
+        outs = tube_outputs(case)
+        with tempfile.TemporaryDirectory() as d:
+            root = os.path.join(d, '0001_4164158586')
+            ut.concat_seq(outs, root)
+            txt = open(os.path.join(root, 'quantitive', 'masks.txt'), 'rb').read()
+            with open(os.path.join(root, 'query_feats.pickle'), 'rb') as f:
+                tb = pickle.load(f)
+        T = len(outs)
+        present = np.array([[x is not None for x in t.qf_tube] for t in tb], dtype=bool).reshape(len(tb), T)
+        feats = np.zeros((len(tb), T, 256), np.float32)
+        cls = np.full((len(tb), T), -1, np.int64)
+        for i, t in enumerate(tb):
+            for j, x in enumerate(t.qf_tube):
+                if x is not None:
+                    feats[i, j] = x['query_feat']
+                    cls[i, j] = x['cls_id']
+                    assert x['query_feat'].dtype == np.float32 and sorted(x.keys()) == ['cls_id', 'query_feat']
+        save.update({'c%d_masks_txt' % case: np.frombuffer(txt, dtype=np.uint8),
+                     'c%d_track_ids' % case: np.array([t.track_id for t in tb], dtype=np.int64),
+                     'c%d_present' % case: present, 'c%d_feats' % case: feats, 'c%d_cls' % case: cls})
+        print('tubes case', case, 'tracks', [t.track_id for t in tb], 'masks.txt bytes', len(txt))
+    np.savez_compressed(os.path.join(OUT, 'tubes_concat_seq.npz'), **save)
 
 
 def gen_relation():
@@ -551,11 +657,21 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    gen_relation()
+    only = set(sys.argv[1:])          # e.g. `python -m oracle.make_golden detector tubes`; nothing = everything
+
+    def want(name):
+        return not only or name in only
+    if want('relation'):
+        gen_relation()
     HEADS, DETECTORS, POSENC = install_stubs()
-    gen_head(HEADS)
-    gen_fusion(HEADS)
-    gen_detector(HEADS, DETECTORS)
+    if want('head') or want('detector'):
+        gen_head(HEADS) if want('head') else load_head_modules()
+    if want('fusion') or want('detector'):
+        gen_fusion(HEADS) if want('fusion') else load_by_path('ref_fusion_head', 'models/mask2former/mask2former_fusion_head.py')
+    if want('detector'):
+        gen_detector(HEADS, DETECTORS)
+    if want('tubes'):
+        gen_tubes()
     print('golden fixtures written to', OUT)
 
 

@@ -60,8 +60,13 @@ class VPSDetectorOracle(nn.Module):
                 logits, masks[:, t], embds, [ref_img_metas[b][t] for b in range(bs)],
                 self.num_things, self.num_stuff, self.test_cfg, rescale=rescale)
             for b in range(len(res)):
+                self._finish(res[b])
                 results[b].append(res[b])
         return results
+
+    def _finish(self, r):
+        if 'ins_results' in r:      # mask2former_vps/mask2former.py:188-206
+            r['ins_results'] = heads.video_ins_results(*r['ins_results'], self.num_things)
 
     def clip_forward(self, ref_img, batch_input_shape):
         """Clip-level path: all T frames' keys attended jointly (T*h*w keys)."""
@@ -79,5 +84,6 @@ class VPSDetectorOracle(nn.Module):
                 cls, masks[:, t], embds, [ref_img_metas[b][t] for b in range(bs)],
                 self.num_things, self.num_stuff, self.test_cfg, rescale=rescale)
             for b in range(len(res)):
+                self._finish(res[b])
                 results[b].append(res[b])
         return results

@@ -98,3 +98,42 @@ def reconsdot_case(d=64, seed=21):
     det[0] = torch.cat([trk[0][:, :, :30] + 0.05 * det[0][:, :, :30], det[0][:, :, 30:]], 2)
     det[3] = trk[2][:, :, :17] + 0.1 * det[3]
     return trk, det
+
+
+def tube_outputs(case):
+    """Per-frame VPS detector outputs as tools/prepare_query_tube_vps.py hands them to concat_seq:
+    [[{'pan_results': (H,W) int32 ndarray, 'query_feats': {segment id: [tensor (256,), ...]}}], ...].
+    case 0: 6 frames, a thing that leaves and returns, a stuff segment entering late with two queries, an empty
+    frame; case 1: 4 frames 720p-like aspect (90x160), three things of one class with ids 1005/2005/3005, one of
+    them present in a single frame, long runs (RLE continuation characters)."""
+    rs = np.random.RandomState(40 + case)
+    outs = []
+    if case == 0:
+        T, H, W = 6, 32, 48
+        for t in range(T):
+            pan = np.full((H, W), 126, np.int32)
+            qf = {}
+            if t not in (2, 4):
+                pan[2 + t:12 + t, 3:17] = 1005
+                qf[1005] = [torch.from_numpy(rs.standard_normal(256).astype(np.float32))]
+            if t >= 1 and t != 4:
+                pan[18:30, 20 + t:40 + t] = 120
+                qf[120] = [torch.from_numpy(rs.standard_normal(256).astype(np.float32)), torch.zeros(256)]
+            if t == 3:
+                pan[0:3, 40:48] = 2007
+                qf[2007] = [torch.from_numpy(rs.standard_normal(256).astype(np.float64))]   # float64 -> float32 cast
+            outs.append([dict(pan_results=pan, query_feats=qf)])
+        return outs
+    T, H, W = 4, 90, 160
+    for t in range(T):
+        pan = np.full((H, W), 126, np.int32)
+        qf = {}
+        for inst, (y, x, hh, ww) in enumerate(((5, 5 + 7 * t, 40, 50), (50, 100 - 9 * t, 35, 55), (0, 150, 90, 10)), 1):
+            if inst == 3 and t != 1:
+                continue
+            sid = 5 + 1000 * inst
+            pan[y:y + hh, x:x + ww] = sid
+            pan[y + 3:y + 6, x + 3:x + 9] = 126            # a hole: more runs per column
+            qf[sid] = [torch.from_numpy(rs.standard_normal(256).astype(np.float32))]
+        outs.append([dict(pan_results=pan, query_feats=qf)])
+    return outs

@@ -215,6 +215,57 @@ def test_ips_detector_vs_oracle(hip_lib):
     assert sorted(res['query_feats'].keys()) == sorted(ref['query_feats'].keys())
     labels_ref = ref['ins_results'][0].numpy()
     assert sum(len(x) for x in res['ins_results'][1]) == len(labels_ref)
+    # shipped test_cfg has instance_on=True and this case resizes to ori_shape: both now run in the fused kernels
+    bbox_results, mask_results = res['ins_results']
+    rl, rb, rm = (x.numpy() for x in ref['ins_results'])
+    for c in range(115):
+        sel = rl == c
+        assert bbox_results[c].shape[0] == int(sel.sum())
+        if sel.any():
+            oa, ob = np.argsort(-bbox_results[c][:, 4]), np.argsort(-rb[sel][:, 4])
+            np.testing.assert_allclose(bbox_results[c][oa][:, :4], rb[sel][ob][:, :4], atol=1.0)
+            np.testing.assert_allclose(bbox_results[c][oa][:, 4], rb[sel][ob][:, 4], rtol=1e-3, atol=1e-4)
+            ma, mb = np.stack(mask_results[c])[oa], rm[sel][ob]
+            assert ma.shape[1:] == (45, 70) and (ma != mb).mean() < 2e-3
+
+
+def test_vps_detector_instance_on_and_rescale_vs_reference_golden(hip_lib, golden_dir):
+    """Unmodified shipped test_cfg (instance_on=True, per-frame mode) with ori_shape != img_shape against the
+    REFERENCE detector's own output: fused two-resize panoptic map + `ins_results` in the reference's format
+    (id column, score-sorted top-10, bbox2result lists, per-class numpy masks; mask2former_vps/mask2former.py:188-206)."""
+    g = np.load(os.path.join(golden_dir, 'detector_vps_T1_ins.npz'))
+    seed, T = int(g['seed']), int(g['T'])
+    m = build_detector(True, seed, {'cls_embed.weight': 40.0})
+    assert m.panoptic_fusion_head.test_cfg.get('instance_on') is True and m.inference_mode == 'per_frame'
+    img = det_input('clip', (1, T, 3, 64, 96), seed).to(DEV)
+    meta = dict(img_shape=(60, 90, 3), ori_shape=(45, 70, 3))
+    from openpvsg_amd import ops
+    calls = []
+    orig = ops._lib.call
+    ops._lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    try:
+        res = m.forward(img=None, img_metas=None, return_loss=False, rescale=True, ref_img=img,
+                        ref_img_metas=[[dict(meta) for _ in range(T)]])
+    finally:
+        ops._lib.call = orig
+    assert 'pvsg_panoptic_fuse' in calls and 'pvsg_instance_masks' in calls      # the fused kernels ran
+    r0 = res[0][0]
+    assert r0['pan_results'].shape == (45, 70) and (r0['pan_results'] != g['pan'][0]).mean() < 1e-3
+    assert sorted(r0['query_feats'].keys()) == list(g['ids0'])
+    bbox_results, mask_results = r0['ins_results']
+    assert len(bbox_results) == 115 and len(mask_results) == 115
+    cls_of = [c for c in range(115) for _ in range(bbox_results[c].shape[0])]
+    assert cls_of == list(g['ins_cls'])
+    boxes = np.concatenate([b for b in bbox_results if b.shape[0]])
+    np.testing.assert_allclose(boxes[:, 1:5], g['ins_boxes'][:, 1:5], atol=1.0)
+    np.testing.assert_allclose(boxes[:, 5], g['ins_boxes'][:, 5], rtol=1e-3, atol=1e-4)
+    # the id column is the 1-based position in instance_postprocess' list, whose order is torch.topk(sorted=False)'s
+    # (implementation-defined, differs between the CPU and the HIP topk): distinct positions within 1..max_per_image
+    ids = boxes[:, 0]
+    assert len(set(ids.tolist())) == len(ids) and ids.min() >= 1 and ids.max() <= 100 and (ids == ids.round()).all()
+    masks = np.stack([mm for c in range(115) for mm in mask_results[c]])
+    ref = np.unpackbits(g['ins_masks_packed'], axis=1)[:, :45 * 70].reshape(-1, 45, 70).astype(bool)
+    assert (masks != ref).mean() < 1e-3
 
 
 REL_CASES = [('rel_s1_N4_T8.npz', ('transformer', 'vanilla')), ('rel_s2_N8_T16.npz', ('transformer', 'filter', 'conv')),

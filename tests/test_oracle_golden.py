@@ -113,6 +113,31 @@ def test_detector_vps_T1(golden_dir):
         np.testing.assert_allclose(f0, g['feat0'], rtol=1e-3, atol=1e-3)
 
 
+def test_detector_vps_T1_instance_on_and_rescale(golden_dir):
+    """The shipped test_cfg (instance_on=True) with ori_shape != img_shape: the reference's own `ins_results`
+    (id column, score sort, top-10, per-class lists) and the doubly resized panoptic map."""
+    from oracle import pipeline
+    g = _load(golden_dir, 'detector_vps_T1_ins.npz')
+    seed, T = int(g['seed']), int(g['T'])
+    model = pipeline.VPSDetectorOracle(test_cfg=dict(pipeline.DEFAULT_TEST_CFG, instance_on=True)).eval()
+    model.load_state_dict(det_state_dict(model, seed, {'cls_embed.weight': 40.0}))
+    img = det_input('clip', (1, T, 3, 64, 96), seed)
+    meta = dict(batch_input_shape=(64, 96), img_shape=(60, 90, 3), ori_shape=(45, 70, 3))
+    with torch.no_grad():
+        r0 = model.simple_test(img, [[meta] * T], rescale=True)[0][0]
+    assert (r0['pan_results'].numpy() != g['pan'][0]).mean() < 1e-3
+    assert sorted(r0['query_feats'].keys()) == list(g['ids0'])
+    bbox_results, mask_results = r0['ins_results']
+    cls_of = [c for c in range(115) for _ in range(bbox_results[c].shape[0])]
+    assert cls_of == list(g['ins_cls'])
+    boxes = np.concatenate([b for b in bbox_results if b.shape[0]]) if cls_of else np.zeros((0, 6), np.float32)
+    np.testing.assert_allclose(boxes[:, 0], g['ins_boxes'][:, 0])                      # instance ids
+    np.testing.assert_allclose(boxes[:, 1:5], g['ins_boxes'][:, 1:5], atol=1.0)
+    np.testing.assert_allclose(boxes[:, 5], g['ins_boxes'][:, 5], rtol=1e-3, atol=1e-4)
+    areas = [int(m.sum()) for c in range(115) for m in mask_results[c]]
+    assert np.abs(np.array(areas) - g['ins_area']).max() <= max(2, 1e-3 * g['ins_area'].max())
+
+
 REL_CASES = [('rel_s1_N4_T8.npz', ('transformer', 'vanilla')),
              ('rel_s2_N8_T16.npz', ('transformer', 'filter', 'conv')),
              ('rel_s3_N17_T33.npz', ('transformer',)), ('rel_s4_N2_T5.npz', ('vanilla',)),

@@ -157,3 +157,39 @@ def test_relations_pickle_matches_reference(tmp_path):
     for a, b in zip(want['relations'], out['relations']):
         assert (a['subject_index'], a['object_index'], a['relation']) == (b['subject_index'], b['object_index'], b['relation'])
         np.testing.assert_array_equal(a['relation_span'], b['relation_span'])
+
+
+@pytest.mark.parametrize('case', [0, 1])
+def test_concat_seq_equals_reference_records(tmp_path, golden_dir, case):
+    """tests/golden/tubes_concat_seq.npz holds what the REFERENCE's concat_seq + write_mots_results wrote for
+    tests.synth_inputs.tube_outputs(case) (oracle/make_golden.py gen_tubes): masks.txt byte for byte, and the
+    SimpleTracker tubes of query_feats.pickle (track ids by first appearance, None for absent frames, float32
+    features, class ids)."""
+    from tests.synth_inputs import tube_outputs
+    g = np.load(os.path.join(golden_dir, 'tubes_concat_seq.npz'))
+    p = 'c%d_' % case
+    outs = tube_outputs(case)
+    tb, _ = tubes.concat_seq(outs, str(tmp_path))
+    assert open(os.path.join(str(tmp_path), 'quantitive', 'masks.txt'), 'rb').read() == g[p + 'masks_txt'].tobytes()
+    with open(os.path.join(str(tmp_path), 'query_feats.pickle'), 'rb') as f:
+        tb2 = pickle.load(f)
+    for tubeset in (tb, tb2):
+        assert [t.track_id for t in tubeset] == list(g[p + 'track_ids'])
+        for i, t in enumerate(tubeset):
+            assert len(t.qf_tube) == len(outs)
+            assert [x is not None for x in t.qf_tube] == list(g[p + 'present'][i])
+            for j, x in enumerate(t.qf_tube):
+                if x is not None:
+                    assert sorted(x.keys()) == ['cls_id', 'query_feat'] and x['query_feat'].dtype == np.float32
+                    assert x['cls_id'] == g[p + 'cls'][i, j]
+                    np.testing.assert_array_equal(x['query_feat'], g[p + 'feats'][i, j])
+    # masks.txt read back (utils/relation_matching.py:65-105 form) reproduces every segment mask
+    back = tubes.read_mots_results(os.path.join(str(tmp_path), 'quantitive', 'masks.txt'))
+    object_list = []
+    for t, o in enumerate(outs):
+        for sid in o[0]['query_feats']:
+            if sid not in object_list:
+                object_list.append(sid)
+            tid = object_list.index(sid) + 1
+            m = [d[t] for d in back[tid]['mask'] if t in d][0]
+            assert (m == (o[0]['pan_results'] == sid)).all()
