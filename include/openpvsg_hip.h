@@ -101,6 +101,47 @@ int pvsg_masked_xattn_partial(const float* q_proj, const float* k_proj, const fl
 int pvsg_xattn_combine(const float* part_o, const float* part_ml, float* out, int B, int Q, int M,
                        int D, int NS, void* stream);
 
+/* ---- a4/a5 + query side of a3: the Q-row part of a decoder layer in two launches -----------------
+ * Replaces, per layer of [3P] mmdet DetrTransformerDecoderLayer (operation_order cross_attn, norm, self_attn,
+ * norm, ffn, norm) as driven by models/mask2former/mask2former_head.py:457-470 and
+ * models/mask2former_vps/mask2former_video_head.py:435-452: the cross-attention out_proj + identity + LayerNorm,
+ * the self-attention over the queries ([3P] mmcv MultiheadAttention -> nn.MultiheadAttention), the FFN + LayerNorms,
+ * and the query side of forward_head (mask2former_head.py:375-381: post_norm, cls_embed, mask_embed), plus the
+ * next layer's cross-attention query projection -- about 35 library launches on 100 rows per layer.
+ * Weights are given in MFMA-fragment order: packed = pvsg_pack_rows_weight(W (N, K) row-major), size
+ * roundup16(N) * K floats, prepared once per checkpoint.  Built for 256 dims, 8 heads, Q <= 128,
+ * FFN width a multiple of 512, <= 128 class outputs (PVSG_ERR_UNSUPPORTED otherwise). */
+typedef struct pvsg_decoder_layer {
+  const float *xo_w, *xo_b;         /* attentions.0.attn.out_proj  packed (256,256), bias */
+  const float *n0_g, *n0_b;         /* norms.0 */
+  const float *sa_in_w, *sa_in_b;   /* attentions.1.attn.in_proj   packed (768,256), bias (768) */
+  const float *sa_out_w, *sa_out_b; /* attentions.1.attn.out_proj */
+  const float *n1_g, *n1_b;         /* norms.1 */
+  const float *f1_w, *f1_b;         /* ffns.0.layers.0.0           packed (F,256), bias (F) */
+  const float *f2_w, *f2_b;         /* ffns.0.layers.1             packed (256,F), bias (256) */
+  const float *n2_g, *n2_b;         /* norms.2 */
+  int embed_dims, num_heads, ffn_dim;
+} pvsg_decoder_layer;
+typedef struct pvsg_decoder_head {
+  const float *pn_g, *pn_b;         /* transformer_decoder.post_norm */
+  const float *cls_w, *cls_b;       /* cls_embed                   packed (num_cls_out,256), bias */
+  const float *m0_w, *m0_b, *m1_w, *m1_b, *m2_w, *m2_b;   /* mask_embed.0 / .2 / .4 */
+  int num_cls_out;
+} pvsg_decoder_head;
+int pvsg_pack_rows_weight(const float* W, float* packed, int N, int K, void* stream);
+/* x1 = LN0(attn_core Wo^T + bo + query);  qkv (B*Q, 768) = [((x1+pos) Wq^T + bq)/sqrt(32) | (x1+pos) Wk^T + bk | x1 Wv^T + bv]
+ *   attn_core (B, Q, 256) = pvsg_xattn_combine output; query (B, Q, 256) layer input; query_pos (Q, 256) */
+int pvsg_decoder_rows_pre(const pvsg_decoder_layer* layer, const float* attn_core, const float* query,
+                          const float* query_pos, float* x1, float* qkv, int B, int Q, void* stream);
+/* query_out = LN2(FFN(x2) + x2), x2 = LN1(selfattn(qkv) Wo^T + bo + x1);  cls_out (B*Q, num_cls_out) and
+ * mask_embed_out (B*Q, 256) from post_norm(query_out);  next_q_out = ((query_out + pos) Wq'^T + bq')/sqrt(32) for the
+ * next layer's cross-attention (next_q_w packed (256,256); NULL = last layer).
+ * layer == NULL: head part only on x1 = the initial queries (the forward_head call before layer 0). */
+int pvsg_decoder_rows_post(const pvsg_decoder_layer* layer, const pvsg_decoder_head* head, const float* next_q_w,
+                           const float* next_q_b, const float* x1, const float* qkv, const float* query_pos,
+                           float* query_out, float* cls_out, float* mask_embed_out, float* next_q_out, int B,
+                           int Q, void* stream);
+
 /* ---- a11: pairwise relation proposal scorer -------------------------------------------------
  * Replaces models/relation_head/base.py:49-62 PairProposalNetwork.forward (N^2 Python loop).
  *   sub_feats, obj_feats (N, T, 256)  encoder outputs; tokens = max over T (base.py:50-51)

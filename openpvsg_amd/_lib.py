@@ -18,6 +18,21 @@ _i = ctypes.c_int
 _f = ctypes.c_float
 _ll = ctypes.c_longlong
 
+
+
+class DecoderLayer(ctypes.Structure):
+    """pvsg_decoder_layer (include/openpvsg_hip.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        'xo_w', 'xo_b', 'n0_g', 'n0_b', 'sa_in_w', 'sa_in_b', 'sa_out_w', 'sa_out_b', 'n1_g', 'n1_b',
+        'f1_w', 'f1_b', 'f2_w', 'f2_b', 'n2_g', 'n2_b')] + [('embed_dims', _i), ('num_heads', _i), ('ffn_dim', _i)]
+
+
+class DecoderHead(ctypes.Structure):
+    """pvsg_decoder_head (include/openpvsg_hip.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        'pn_g', 'pn_b', 'cls_w', 'cls_b', 'm0_w', 'm0_b', 'm1_w', 'm1_b', 'm2_w', 'm2_b')] + [('num_cls_out', _i)]
+
+
 # name -> argtypes; must list every function include/openpvsg_hip.h declares
 # (tests/test_capi.py cross-checks this table against the header).
 SIGNATURES = {
@@ -29,6 +44,9 @@ SIGNATURES = {
     'pvsg_xattn_num_splits': [_i, _ll],
     'pvsg_masked_xattn_partial': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _ll, _i, _i, _i, _c_f],
     'pvsg_xattn_combine': [_c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _c_f],
+    'pvsg_pack_rows_weight': [_c_f, _c_f, _i, _i, _c_f],
+    'pvsg_decoder_rows_pre': [ctypes.POINTER(DecoderLayer), _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _c_f],
+    'pvsg_decoder_rows_post': [ctypes.POINTER(DecoderLayer), ctypes.POINTER(DecoderHead)] + [_c_f] * 9 + [_i, _i, _c_f],
     'pvsg_pair_prepare_weights': [_c_f, _c_f, _i, _i, _c_f],
     'pvsg_pair_score_forward': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _c_f],
     'pvsg_panoptic_fuse': [_c_f] * 8 + [_i] * 13 + [ctypes.c_double, _i, _c_f],

@@ -1,0 +1,525 @@
+// The query-row side of a Mask2Former transformer-decoder layer in two launches.
+//
+// Replaces, per decoder layer ([3P] mmdet DetrTransformerDecoderLayer with operation_order
+// ('cross_attn','norm','self_attn','norm','ffn','norm'), driven from
+// models/mask2former/mask2former_head.py:457-470 / models/mask2former_vps/mask2former_video_head.py:435-452):
+//   cross-attention out_proj + identity + LayerNorm                      (after pvsg_xattn_combine)
+//   self-attention over the Q=100 queries (in_proj, softmax(QK^T)V, out_proj) + identity + LayerNorm
+//   FFN 256 -> 2048 -> 256 (+ReLU) + identity + LayerNorm
+// and the query-side half of forward_head (mask2former_head.py:375-381 / video_head.py:340-343):
+//   post_norm LayerNorm, cls_embed, the 3-layer mask_embed MLP,
+// plus the NEXT layer's cross-attention query projection ((q + query_pos) Wq^T + bq) / sqrt(32).
+//
+// Why: with Q = 100 rows these are ~35 tiny library GEMM / elementwise launches per layer (about 0.6 ms per
+// layer, 5.5 ms per clip regardless of the clip length -- the fixed cost that caps frame-sharded scaling).
+// Here a workgroup owns 16 query rows of one batch element and walks the whole chain with the activations in
+// LDS; every GEMM is  X[16 x K] . W^T  on v_mfma_f32_16x16x4_f32 (exact f32), the weights streamed from L2
+// in MFMA-fragment order (pvsg_pack_rows_weight: one contiguous 1 KiB per wave load).  The only cross-row
+// step, self-attention, needs the K/V projections of all 100 rows, hence two kernels:
+//   decoder_rows_pre   out_proj + LN, self-attention in_proj (q scaled, k, v)            -> x1, qkv
+//   decoder_rows_post  self-attention, out_proj + LN, FFN + LN, post_norm, cls / mask embeddings, next q
+// `decoder_rows_post` with no layer runs the head part only (the forward_head call on the initial queries).
+#include "common.h"
+
+#include "../../include/openpvsg_hip.h"
+
+namespace pvsg {
+
+constexpr int DR_THREADS = 512;           // 8 waves: 8 heads in the attention step, 8 column groups in the GEMMs
+constexpr int DR_C = 256;                 // embed dims (8 heads x 32)
+constexpr int DR_LD = DR_C + 4;           // LDS row stride: rows 16 B apart mod 256 B -> conflict-free b128 reads
+constexpr int DR_FC = 512;                // FFN hidden chunk held in LDS
+constexpr int DR_LDH = DR_FC + 4;
+constexpr int DR_MAXQ = 128;
+
+__global__ void pack_rows_weight_kernel(const float* __restrict__ W, float* __restrict__ P, int N, int K,
+                                        long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+  const long long rest = i >> 8;
+  const int nkc = K >> 4;
+  const int kc = (int)(rest % nkc), tile = (int)(rest / nkc);
+  const int n = tile * 16 + (lane & 15), k = kc * 16 + 4 * (lane >> 4) + j;
+  P[i] = n < N ? W[(long long)n * K + k] : 0.f;
+}
+
+// acc[i] += X[16 x (16*nkc)] . W^T for column tiles t0 + i (packed weights, k chunks kc0 .. kc0+nkc-1 of a
+// weight with `wkc` chunks per tile).  A fragment: lane (r = lane&15, g = lane>>4) holds X[r][16kc + 4g + j],
+// B fragment: W[16t + r][16kc + 4g + j] -- the k index of MFMA step j is 4g + j on both sides.
+template <int NT, int NKC, int DEPTH>
+__device__ __forceinline__ void rows_gemm(const float* __restrict__ xl, int ld, const float* __restrict__ wp,
+                                          int wkc, int kc0, int t0, f32x4 (&acc)[NT], int lane) {
+  // The weights come from L2 / Infinity Cache (0.5 - 2 us away) while one k chunk is only NT x 128 matrix cycles:
+  // DEPTH chunks of B fragments are kept in flight in a register ring (fully unrolled: static ring indices).
+  const float* xa = xl + (lane & 15) * ld + 4 * (lane >> 4);
+  const float* wb = wp + ((long long)t0 * wkc + kc0) * 256 + lane * 4;
+  const long long tstride = (long long)wkc * 256;
+  float4 ring[DEPTH][NT];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) ring[d][i] = ld4(wb + i * tstride + d * 256);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc) {
+    const float4 a = *reinterpret_cast<const float4*>(xa + kc * 16);
+    float4 cur[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) cur[i] = ring[kc % DEPTH][i];
+    if (kc + DEPTH < NKC) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) ring[kc % DEPTH][i] = ld4(wb + i * tstride + (kc + DEPTH) * 256);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, cur[i].x, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, cur[i].y, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, cur[i].z, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, cur[i].w, acc[i], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);     // keep the ring as written: loads of chunk kc+DEPTH stay behind chunk kc's
+  }
+}
+
+// all-reduce over the 64 lanes in the VALU: DPP quad / row permutations for the first four steps,
+// v_permlane16_swap / v_permlane32_swap for the last two (no LDS crossbar round trips).
+template <bool MAX>
+__device__ __forceinline__ float wave_allreduce(float v) {
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
+  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
+  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xf, 0xf, false)));  // row_half_mirror
+  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x140, 0xf, 0xf, false)));  // row_mirror
+  unsigned u = __float_as_uint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = op(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  u = __float_as_uint(v);
+  auto b2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return op(__uint_as_float(b2[0]), __uint_as_float(b2[1]));
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[NT]) {
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// LayerNorm over the 256 columns of the 16 LDS rows of `x` (two-pass statistics like ATen), 32 threads per row.
+// out_a / out_b: LDS destinations (either may be null); add_b: optional (16 x 256, row stride 256... see use)
+// row-wise addend for out_b (query_pos); g_out: optional global destination (row pointer of row 0, stride 256).
+__device__ __forceinline__ void rows_layernorm(const float* __restrict__ x, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, float eps, float* out_a,
+                                               float* out_b, const float* __restrict__ add_b,
+                                               float* __restrict__ g_out, int valid_rows) {
+  const int r = threadIdx.x >> 5, c0 = (threadIdx.x & 31) * 8;
+  const float4 v0 = *reinterpret_cast<const float4*>(x + r * DR_LD + c0);
+  const float4 v1 = *reinterpret_cast<const float4*>(x + r * DR_LD + c0 + 4);
+  float s = (v0.x + v0.y) + (v0.z + v0.w) + (v1.x + v1.y) + (v1.z + v1.w);
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s * (1.f / DR_C);
+  float d[8] = {v0.x - mean, v0.y - mean, v0.z - mean, v0.w - mean, v1.x - mean, v1.y - mean, v1.z - mean, v1.w - mean};
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q += d[i] * d[i];
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q * (1.f / DR_C) + eps);
+  const float4 g0 = ld4(gamma + c0), g1 = ld4(gamma + c0 + 4), b0 = ld4(beta + c0), b1 = ld4(beta + c0 + 4);
+  float4 y0 = make_float4(d[0] * rstd * g0.x + b0.x, d[1] * rstd * g0.y + b0.y, d[2] * rstd * g0.z + b0.z,
+                          d[3] * rstd * g0.w + b0.w);
+  float4 y1 = make_float4(d[4] * rstd * g1.x + b1.x, d[5] * rstd * g1.y + b1.y, d[6] * rstd * g1.z + b1.z,
+                          d[7] * rstd * g1.w + b1.w);
+  if (out_a) {
+    *reinterpret_cast<float4*>(out_a + r * DR_LD + c0) = y0;
+    *reinterpret_cast<float4*>(out_a + r * DR_LD + c0 + 4) = y1;
+  }
+  if (g_out && r < valid_rows) {
+    st4(g_out + (long long)r * DR_C + c0, y0);
+    st4(g_out + (long long)r * DR_C + c0 + 4, y1);
+  }
+  if (out_b) {
+    if (add_b && r < valid_rows) {
+      const float4 p0 = ld4(add_b + (long long)r * DR_C + c0), p1 = ld4(add_b + (long long)r * DR_C + c0 + 4);
+      y0.x += p0.x; y0.y += p0.y; y0.z += p0.z; y0.w += p0.w;
+      y1.x += p1.x; y1.y += p1.y; y1.z += p1.z; y1.w += p1.w;
+    }
+    *reinterpret_cast<float4*>(out_b + r * DR_LD + c0) = y0;
+    *reinterpret_cast<float4*>(out_b + r * DR_LD + c0 + 4) = y1;
+  }
+}
+
+// 16 x 256 tile of a (rows, 256) global tensor -> LDS (zeros past `valid_rows`)
+__device__ __forceinline__ void load_tile(float* dst, const float* __restrict__ src, int valid_rows) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = threadIdx.x + it * DR_THREADS;     // float4 index in the 16 x 64 grid
+    const int r = idx >> 6, c = (idx & 63) * 4;
+    const float4 v = r < valid_rows ? ld4(src + (long long)r * DR_C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(dst + r * DR_LD + c) = v;
+  }
+}
+
+// epilogue of a 256-column GEMM: out[r][c] = act(acc + bias[c] (+ res[r][c])) into LDS
+template <int NT>
+__device__ __forceinline__ void store_tiles_lds(const f32x4 (&acc)[NT], int t0, const float* __restrict__ bias,
+                                                const float* res, int ldres, float* out, int ldo, int col_off,
+                                                bool relu, int lane) {
+  const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int col = (t0 + i) * 16 + j;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * g + e;
+      float v = acc[i][e] + bv;
+      if (res) v += res[r * ldres + col - col_off];
+      if (relu) v = fmaxf(v, 0.f);
+      out[r * ldo + col - col_off] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pre: x1 = LN(core Wo^T + bo + query);  qkv = [ ((x1+pos) Wq^T + bq) * scale | (x1+pos) Wk^T + bk | x1 Wv^T + bv ]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DR_THREADS) void decoder_rows_pre_kernel(
+    pvsg_decoder_layer L, const float* __restrict__ core, const float* __restrict__ query,
+    const float* __restrict__ qpos, float* __restrict__ x1, float* __restrict__ qkv, int Q, int tiles_per_b,
+    float scale, float eps) {
+  __shared__ __attribute__((aligned(16))) float xa[16 * DR_LD], xb[16 * DR_LD], xc[16 * DR_LD];
+  const int b = blockIdx.x / tiles_per_b, tile = blockIdx.x - b * tiles_per_b;
+  const int q0 = tile * 16;
+  const int valid = min(16, Q - q0);
+  const long long row0 = (long long)b * Q + q0;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  load_tile(xa, core + row0 * DR_C, valid);
+  load_tile(xc, query + row0 * DR_C, valid);
+  __syncthreads();
+  {
+    f32x4 acc[2];
+    zero_acc(acc);
+    rows_gemm<2, 16, 8>(xa, DR_LD, L.xo_w, 16, 0, w * 2, acc, lane);
+    store_tiles_lds<2>(acc, w * 2, L.xo_b, xc, DR_LD, xb, DR_LD, 0, false, lane);
+  }
+  __syncthreads();
+  // xa <- x1, xc <- x1 + pos, global x1
+  rows_layernorm(xb, L.n0_g, L.n0_b, eps, xa, xc, qpos + (long long)q0 * DR_C, x1 + row0 * DR_C, valid);
+  __syncthreads();
+  const int g = lane >> 4, j = lane & 15;
+  {
+    f32x4 acc[4];
+    zero_acc(acc);
+    rows_gemm<4, 16, 4>(xc, DR_LD, L.sa_in_w, 16, 0, w * 4, acc, lane);      // q | k columns 0..511
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = (w * 4 + i) * 16 + j;
+      const float bv = L.sa_in_b[col];
+      const float sc = col < DR_C ? scale : 1.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        if (r < valid) qkv[(row0 + r) * (3 * DR_C) + col] = (acc[i][e] + bv) * sc;
+      }
+    }
+  }
+  {
+    f32x4 acc[2];
+    zero_acc(acc);
+    rows_gemm<2, 16, 8>(xa, DR_LD, L.sa_in_w, 16, 0, 32 + w * 2, acc, lane);  // v columns 512..767
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int col = (32 + w * 2 + i) * 16 + j;
+      const float bv = L.sa_in_b[col];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        if (r < valid) qkv[(row0 + r) * (3 * DR_C) + col] = acc[i][e] + bv;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// post
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
+    pvsg_decoder_layer L, pvsg_decoder_head Hd, int has_layer, const float* __restrict__ next_q_w,
+    const float* __restrict__ next_q_b, const float* __restrict__ x1, const float* __restrict__ qkv,
+    const float* __restrict__ qpos, float* __restrict__ query_out, float* __restrict__ cls_out,
+    float* __restrict__ emb_out, float* __restrict__ next_q_out, int Q, int tiles_per_b, float scale, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xa = smem;                       // [16][DR_LD]
+  float* xb = xa + 16 * DR_LD;
+  float* xc = xb + 16 * DR_LD;
+  float* big = xc + 16 * DR_LD;           // attention probabilities [8][128][16]  /  FFN hidden chunk [16][DR_LDH]
+  const int b = blockIdx.x / tiles_per_b, tile = blockIdx.x - b * tiles_per_b;
+  const int q0 = tile * 16;
+  const int valid = min(16, Q - q0);
+  const long long row0 = (long long)b * Q + q0;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+
+  if (has_layer) {
+    // ---- self-attention: wave = head ---------------------------------------------------------
+    load_tile(xc, x1 + row0 * DR_C, valid);                    // x1 tile (identity of the self-attention)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {                           // scaled q rows of the tile -> xb
+      const int idx = threadIdx.x + it * DR_THREADS;
+      const int r = idx >> 6, c = (idx & 63) * 4;
+      const float4 v = r < valid ? ld4(qkv + (row0 + r) * (3 * DR_C) + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(xb + r * DR_LD + c) = v;
+    }
+    __syncthreads();
+    {
+      const int h = w;
+      float* pm = big + h * (DR_MAXQ * 16);
+      const float* kvb = qkv + (long long)b * Q * (3 * DR_C);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {                 // raw scores S[key][r] -> pm (private to this wave)
+        const int key = p * 64 + lane;
+        const bool kv = key < Q;
+        float kr[32];
+        const float* kp = kvb + (long long)(kv ? key : 0) * (3 * DR_C) + DR_C + h * 32;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float4 t = ld4(kp + 4 * i);
+          kr[4 * i] = t.x; kr[4 * i + 1] = t.y; kr[4 * i + 2] = t.z; kr[4 * i + 3] = t.w;
+        }
+#pragma unroll 2
+        for (int r = 0; r < 16; ++r) {
+          const float* qr = xb + r * DR_LD + h * 32;
+          float s = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(qr + 4 * i);     // broadcast read
+            s += t.x * kr[4 * i] + t.y * kr[4 * i + 1] + t.z * kr[4 * i + 2] + t.w * kr[4 * i + 3];
+          }
+          pm[key * 16 + r] = kv ? s : -INFINITY;
+        }
+      }
+#pragma unroll 4
+      for (int r = 0; r < 16; ++r) {                // softmax over the keys of row r (lanes = keys)
+        const float s0 = pm[lane * 16 + r], s1 = pm[(64 + lane) * 16 + r];
+        const float m = wave_allreduce<true>(fmaxf(s0, s1));
+        const float e0 = __expf(s0 - m), e1 = __expf(s1 - m);
+        const float inv = 1.f / wave_allreduce<false>(e0 + e1);
+        pm[lane * 16 + r] = e0 * inv;
+        pm[(64 + lane) * 16 + r] = e1 * inv;
+      }
+      // P . V : lane = (d, key half)
+      const int d = lane & 31, half = lane >> 5;
+      float o16[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o16[r] = 0.f;
+      const int kend = min(64, Q - half * 64);
+      const float* vcol = kvb + 2 * DR_C + h * 32 + d;
+#pragma unroll 1
+      for (int k8 = 0; k8 < 64; k8 += 8) {           // 8 value rows in flight per step (uniform trip count)
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int kk = k8 + u;
+          v8[u] = kk < kend ? vcol[(long long)(half * 64 + kk) * (3 * DR_C)] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float* pr = pm + (half * 64 + k8 + u) * 16;     // rows past Q hold zeros
+          const float v = v8[u];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(pr + 4 * i);
+            o16[4 * i] += t.x * v; o16[4 * i + 1] += t.y * v; o16[4 * i + 2] += t.z * v; o16[4 * i + 3] += t.w * v;
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float t = o16[r] + __shfl_xor(o16[r], 32);
+        if (half == 0) xa[r * DR_LD + h * 32 + d] = t;
+      }
+    }
+    __syncthreads();
+    // ---- out_proj + identity + LN -> x2 (xa) -------------------------------------------------
+    {
+      f32x4 acc[2];
+      zero_acc(acc);
+      rows_gemm<2, 16, 8>(xa, DR_LD, L.sa_out_w, 16, 0, w * 2, acc, lane);
+      store_tiles_lds<2>(acc, w * 2, L.sa_out_b, xc, DR_LD, xb, DR_LD, 0, false, lane);
+    }
+    __syncthreads();
+    rows_layernorm(xb, L.n1_g, L.n1_b, eps, xa, nullptr, nullptr, nullptr, valid);
+    __syncthreads();
+    // ---- FFN in hidden chunks of 512 -----------------------------------------------------------
+    {
+      f32x4 yacc[2];
+      zero_acc(yacc);
+      const int nchunk = L.ffn_dim / DR_FC, wkc2 = L.ffn_dim >> 4;
+      for (int c = 0; c < nchunk; ++c) {
+        {
+          f32x4 acc[4];
+          zero_acc(acc);
+          rows_gemm<4, 16, 4>(xa, DR_LD, L.f1_w, 16, 0, c * 32 + w * 4, acc, lane);
+          store_tiles_lds<4>(acc, c * 32 + w * 4, L.f1_b, nullptr, 0, big, DR_LDH, c * DR_FC, true, lane);
+        }
+        __syncthreads();
+        rows_gemm<2, DR_FC / 16, 8>(big, DR_LDH, L.f2_w, wkc2, c * (DR_FC / 16), w * 2, yacc, lane);
+        __syncthreads();
+      }
+      store_tiles_lds<2>(yacc, w * 2, L.f2_b, xa, DR_LD, xb, DR_LD, 0, false, lane);
+    }
+    __syncthreads();
+    // x3 -> xc (+ global), x3 + pos -> xb is done below after the head reads
+    rows_layernorm(xb, L.n2_g, L.n2_b, eps, xc, nullptr, nullptr, query_out + row0 * DR_C, valid);
+    __syncthreads();
+  } else {
+    load_tile(xc, x1 + row0 * DR_C, valid);                    // head only: x1 carries the queries
+    __syncthreads();
+  }
+  // ---- forward_head, query side: p = post_norm(x3) -> xa; xb <- x3 + pos (for the next q projection) ----
+  rows_layernorm(xc, Hd.pn_g, Hd.pn_b, eps, xa, nullptr, nullptr, nullptr, valid);
+  {
+    const int r = threadIdx.x >> 5, c0 = (threadIdx.x & 31) * 8;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      float4 v = *reinterpret_cast<const float4*>(xc + r * DR_LD + c0 + 4 * hh);
+      if (r < valid) {
+        const float4 p = ld4(qpos + (long long)(q0 + r) * DR_C + c0 + 4 * hh);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+      }
+      *reinterpret_cast<float4*>(xb + r * DR_LD + c0 + 4 * hh) = v;
+    }
+  }
+  __syncthreads();
+  {  // class logits: one column tile per wave (classes + 1 <= 128)
+    f32x4 acc[1];
+    zero_acc(acc);
+    rows_gemm<1, 16, 8>(xa, DR_LD, Hd.cls_w, 16, 0, w, acc, lane);
+    const int col = w * 16 + j;
+    if (col < Hd.num_cls_out) {
+      const float bv = Hd.cls_b[col];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        if (r < valid) cls_out[(row0 + r) * Hd.num_cls_out + col] = acc[0][e] + bv;
+      }
+    }
+  }
+  if (next_q_w) {  // next layer's cross-attention query: ((x3 + pos) Wq^T + bq) * scale
+    f32x4 acc[2];
+    zero_acc(acc);
+    rows_gemm<2, 16, 8>(xb, DR_LD, next_q_w, 16, 0, w * 2, acc, lane);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int col = (w * 2 + i) * 16 + j;
+      const float bv = next_q_b[col];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        if (r < valid) next_q_out[(row0 + r) * DR_C + col] = (acc[i][e] + bv) * scale;
+      }
+    }
+  }
+  {  // mask_embed MLP: xa -> (relu) xc -> (relu) xb -> global
+    f32x4 acc[2];
+    zero_acc(acc);
+    rows_gemm<2, 16, 8>(xa, DR_LD, Hd.m0_w, 16, 0, w * 2, acc, lane);
+    __syncthreads();                                        // xb (next-q operand) and xc no longer read
+    store_tiles_lds<2>(acc, w * 2, Hd.m0_b, nullptr, 0, xc, DR_LD, 0, true, lane);
+    __syncthreads();
+    zero_acc(acc);
+    rows_gemm<2, 16, 8>(xc, DR_LD, Hd.m1_w, 16, 0, w * 2, acc, lane);
+    store_tiles_lds<2>(acc, w * 2, Hd.m1_b, nullptr, 0, xb, DR_LD, 0, true, lane);
+    __syncthreads();
+    zero_acc(acc);
+    rows_gemm<2, 16, 8>(xb, DR_LD, Hd.m2_w, 16, 0, w * 2, acc, lane);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int col = (w * 2 + i) * 16 + j;
+      const float bv = Hd.m2_b[col];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        if (r < valid) emb_out[(row0 + r) * DR_C + col] = acc[i][e] + bv;
+      }
+    }
+  }
+}
+
+constexpr size_t DR_POST_LDS = (size_t)(3 * 16 * DR_LD + 8 * DR_MAXQ * 16) * sizeof(float);
+static_assert(8 * DR_MAXQ * 16 >= 16 * DR_LDH, "FFN chunk must fit in the attention scratch");
+
+}  // namespace pvsg
+
+extern "C" int pvsg_pack_rows_weight(const float* W, float* packed, int N, int K, void* stream_) {
+  using namespace pvsg;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PVSG_REQUIRE(W && packed, "pack_rows_weight: null pointer argument");
+  PVSG_REQUIRE(N > 0 && K > 0 && K % 16 == 0, "pack_rows_weight: K must be a positive multiple of 16 (N=%d K=%d)", N, K);
+  const long long total = (long long)((N + 15) / 16) * 16 * K;
+  hipLaunchKernelGGL(pack_rows_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, W, packed,
+                     N, K, total);
+  PVSG_LAUNCH_CHECK("pack_rows_weight");
+  return PVSG_OK;
+}
+
+static int check_layer(const pvsg_decoder_layer* L, const char* who) {
+  using namespace pvsg;
+  PVSG_REQUIRE(L->xo_w && L->xo_b && L->n0_g && L->n0_b && L->sa_in_w && L->sa_in_b && L->sa_out_w && L->sa_out_b &&
+                   L->n1_g && L->n1_b && L->f1_w && L->f1_b && L->f2_w && L->f2_b && L->n2_g && L->n2_b,
+               "%s: null pointer in pvsg_decoder_layer", who);
+  if (L->embed_dims != DR_C || L->num_heads != 8 || L->ffn_dim <= 0 || L->ffn_dim % DR_FC)
+    return set_err(PVSG_ERR_UNSUPPORTED, "%s: built for 256 dims, 8 heads, FFN width a multiple of %d (got %d/%d/%d)",
+                   who, DR_FC, L->embed_dims, L->num_heads, L->ffn_dim);
+  return PVSG_OK;
+}
+
+extern "C" int pvsg_decoder_rows_pre(const pvsg_decoder_layer* layer, const float* attn_core, const float* query,
+                                     const float* query_pos, float* x1, float* qkv, int B, int Q,
+                                     void* stream_) {
+  using namespace pvsg;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PVSG_REQUIRE(layer && attn_core && query && query_pos && x1 && qkv, "decoder_rows_pre: null pointer argument");
+  PVSG_REQUIRE(B > 0 && Q > 0, "decoder_rows_pre: non-positive dimension");
+  if (Q > DR_MAXQ) return set_err(PVSG_ERR_UNSUPPORTED, "decoder_rows_pre: at most %d queries (got %d)", DR_MAXQ, Q);
+  if (int rc = check_layer(layer, "decoder_rows_pre")) return rc;
+  const int tiles = (Q + 15) / 16;
+  hipLaunchKernelGGL(decoder_rows_pre_kernel, dim3(B * tiles), dim3(DR_THREADS), 0, stream, *layer, attn_core, query,
+                     query_pos, x1, qkv, Q, tiles, 0.17677669529663687f, 1e-5f);
+  PVSG_LAUNCH_CHECK("decoder_rows_pre");
+  return PVSG_OK;
+}
+
+extern "C" int pvsg_decoder_rows_post(const pvsg_decoder_layer* layer, const pvsg_decoder_head* head,
+                                      const float* next_q_w, const float* next_q_b, const float* x1,
+                                      const float* qkv, const float* query_pos, float* query_out, float* cls_out,
+                                      float* mask_embed_out, float* next_q_out, int B, int Q, void* stream_) {
+  using namespace pvsg;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PVSG_REQUIRE(head && x1 && query_pos && cls_out && mask_embed_out, "decoder_rows_post: null pointer argument");
+  PVSG_REQUIRE(!layer || (qkv && query_out), "decoder_rows_post: a layer needs qkv and query_out");
+  PVSG_REQUIRE((next_q_w == nullptr) == (next_q_b == nullptr) && (!next_q_w || next_q_out),
+               "decoder_rows_post: next_q_w / next_q_b / next_q_out go together");
+  PVSG_REQUIRE(B > 0 && Q > 0, "decoder_rows_post: non-positive dimension");
+  PVSG_REQUIRE(head->pn_g && head->pn_b && head->cls_w && head->cls_b && head->m0_w && head->m0_b && head->m1_w &&
+                   head->m1_b && head->m2_w && head->m2_b, "decoder_rows_post: null pointer in pvsg_decoder_head");
+  if (Q > DR_MAXQ) return set_err(PVSG_ERR_UNSUPPORTED, "decoder_rows_post: at most %d queries (got %d)", DR_MAXQ, Q);
+  if (head->num_cls_out <= 0 || head->num_cls_out > 128)
+    return set_err(PVSG_ERR_UNSUPPORTED, "decoder_rows_post: 1..128 class outputs (got %d)", head->num_cls_out);
+  pvsg_decoder_layer L;
+  memset(&L, 0, sizeof(L));
+  if (layer) {
+    if (int rc = check_layer(layer, "decoder_rows_post")) return rc;
+    L = *layer;
+  }
+  const int tiles = (Q + 15) / 16;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decoder_rows_post_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)DR_POST_LDS);
+  hipLaunchKernelGGL(decoder_rows_post_kernel, dim3(B * tiles), dim3(DR_THREADS), DR_POST_LDS, stream, L, *head,
+                     layer ? 1 : 0, next_q_w, next_q_b, x1, qkv, query_pos, query_out, cls_out, mask_embed_out,
+                     next_q_out, Q, tiles, 0.17677669529663687f, 1e-5f);
+  PVSG_LAUNCH_CHECK("decoder_rows_post");
+  return PVSG_OK;
+}

@@ -277,7 +277,8 @@ __global__ __launch_bounds__(1024) void xattn_combine_kernel(const float* __rest
 
 extern "C" int pvsg_xattn_num_splits(int B, long long K) {
   long long ns = (256 + B - 1) / B;
-  const long long maxs = (K + 255) / 256;
+  const long long maxs = (K + 63) / 64;     // down to two 32-key tiles per workgroup: short key ranges (few frames
+                                            // per GPU, self-attention) are latency-bound, spread them over the CUs
   if (ns > maxs) ns = maxs;
   if (ns < 1) ns = 1;
   return (int)ns;

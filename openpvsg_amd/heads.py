@@ -20,17 +20,107 @@ What changes underneath:
     pack -- bit-exact w.r.t. the resized logits.
 """
 import copy
+import os
 
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import _lib, ops
 from .blocks import BaseModule, ModuleList
 from .config import _wrap
 from .registry import (HEADS, build_plugin_layer, build_positional_encoding,
                        build_transformer_layer_sequence)
 
 FAST_ORDER = ('cross_attn', 'norm', 'self_attn', 'norm', 'ffn', 'norm')
+
+
+class DecoderRows:
+    """Packed weights + C structs of the decoder's query-row kernels (csrc/decoder_rows.hip): the
+    out_proj / norm / self-attention / FFN / norm chain of every DetrTransformerDecoderLayer and the query
+    side of forward_head (post_norm, cls_embed, mask_embed), two launches per layer instead of ~35 library
+    calls on 100 rows.  Built once per checkpoint: `signature` notices in-place loads / device moves."""
+
+    @staticmethod
+    def supported(head):
+        from .blocks import FFN, MultiheadAttention
+        dec = head.transformer_decoder
+        if os.environ.get('PVSG_DECODER_ROWS', 'on') == 'off' or dec.post_norm is None:
+            return False
+        if head.decoder_embed_dims != 256 or head.num_heads != 8 or head.num_queries > 128 or head.num_classes + 1 > 128:
+            return False
+        me = head.mask_embed
+        if not (len(me) == 5 and all(isinstance(me[i], nn.Linear) for i in (0, 2, 4)) and me[4].out_features == 256):
+            return False
+        for layer in dec.layers:
+            if layer.operation_order != FAST_ORDER or len(layer.ffns) != 1:
+                return False
+            ffn = layer.ffns[0]
+            if not (isinstance(ffn, FFN) and ffn.add_identity and len(ffn.layers) == 3 and
+                    isinstance(ffn.layers[1], nn.Linear) and ffn.layers[1].in_features % 512 == 0):
+                return False
+            if not all(isinstance(a, MultiheadAttention) and a.attn.in_proj_weight is not None for a in layer.attentions):
+                return False
+        return True
+
+    @staticmethod
+    def _params(head):
+        yield from head.transformer_decoder.parameters()
+        yield from head.cls_embed.parameters()
+        yield from head.mask_embed.parameters()
+
+    @classmethod
+    def signature(cls, head):
+        return tuple((p.data_ptr(), p._version) for p in cls._params(head))
+
+    def __init__(self, head):
+        self.sig = self.signature(head)
+        self.keep = []                       # packed tensors / contiguous views the structs point to
+
+        def pk(w):
+            t = ops.pack_rows_weight(w)
+            self.keep.append(t)
+            return t.data_ptr()
+
+        def raw(t):
+            t = t.detach().contiguous()
+            self.keep.append(t)
+            return t.data_ptr()
+
+        C = 256
+        self.layers, self.next_q = [], []
+        for layer in head.transformer_decoder.layers:
+            xa, sa, ffn = layer.attentions[0].attn, layer.attentions[1].attn, layer.ffns[0]
+            f1, f2 = ffn.layers[0][0], ffn.layers[1]
+            n0, n1, n2 = layer.norms
+            st = _lib.DecoderLayer(
+                xo_w=pk(xa.out_proj.weight), xo_b=raw(xa.out_proj.bias), n0_g=raw(n0.weight), n0_b=raw(n0.bias),
+                sa_in_w=pk(sa.in_proj_weight), sa_in_b=raw(sa.in_proj_bias), sa_out_w=pk(sa.out_proj.weight),
+                sa_out_b=raw(sa.out_proj.bias), n1_g=raw(n1.weight), n1_b=raw(n1.bias),
+                f1_w=pk(f1.weight), f1_b=raw(f1.bias), f2_w=pk(f2.weight), f2_b=raw(f2.bias),
+                n2_g=raw(n2.weight), n2_b=raw(n2.bias), embed_dims=C, num_heads=8, ffn_dim=f1.out_features)
+            self.layers.append(st)
+            wq = ops.pack_rows_weight(xa.in_proj_weight[:C])
+            bq = xa.in_proj_bias[:C].detach().contiguous()
+            self.next_q.append((wq, bq))
+        pn, me = head.transformer_decoder.post_norm, head.mask_embed
+        self.num_cls_out = head.cls_embed.out_features
+        self.head = _lib.DecoderHead(
+            pn_g=raw(pn.weight), pn_b=raw(pn.bias), cls_w=pk(head.cls_embed.weight), cls_b=raw(head.cls_embed.bias),
+            m0_w=pk(me[0].weight), m0_b=raw(me[0].bias), m1_w=pk(me[2].weight), m1_b=raw(me[2].bias),
+            m2_w=pk(me[4].weight), m2_b=raw(me[4].bias), num_cls_out=self.num_cls_out)
+
+    def start(self, q, q_pos):
+        """forward_head's query side on the initial queries + layer 0's cross-attention query."""
+        _, cls, emb, nq = ops.decoder_rows_post(None, self.head, self.next_q[0] if self.layers else None, q, None,
+                                                q_pos, self.num_cls_out)
+        return cls, emb, nq
+
+    def layer(self, i, attn_core, q, q_pos):
+        """layer i after its cross-attention core -> (new queries, class logits, mask embeddings, next layer's q)."""
+        x1, qkv = ops.decoder_rows_pre(self.layers[i], attn_core, q, q_pos)
+        nxt = self.next_q[i + 1] if i + 1 < len(self.layers) else None
+        return ops.decoder_rows_post(self.layers[i], self.head, nxt, x1, qkv, q_pos, self.num_cls_out)
 
 
 class _Mask2FormerHeadBase(BaseModule):
@@ -85,11 +175,8 @@ class _Mask2FormerHeadBase(BaseModule):
                 nn.init.xavier_normal_(p)
 
     # ---- one `forward_head` step ----------------------------------------------------------------
-    def _head_step(self, q, mask_features, lows, level, want_logits, need_mask=True):
-        """q (B,Q,C) -> cls (B,Q,classes+1), mask logits or None, ops.AttnMask for `level` or None."""
-        x = self.transformer_decoder.post_norm(q)
-        cls_pred = self.cls_embed(x)
-        emb = self.mask_embed(x)
+    def _mask_step(self, emb, mask_features, lows, level, want_logits, need_mask=True):
+        """mask embeddings (B,Q,C) -> mask logits or None, ops.AttnMask for `level` or None."""
         logits = ops.mask_logits(emb, mask_features) if (want_logits or lows is None) else None
         mask = None
         if need_mask:
@@ -106,7 +193,27 @@ class _Mask2FormerHeadBase(BaseModule):
                 mask = ops.attn_mask_pack(low)
             if self.mask_sync is not None:
                 mask = self.mask_sync(mask)   # frame-sharded clip: OR the per-query flags over ranks
-        return cls_pred, (logits if want_logits else None), mask
+        return (logits if want_logits else None), mask
+
+    def _head_step(self, q, mask_features, lows, level, want_logits, need_mask=True):
+        """q (B,Q,C) -> cls (B,Q,classes+1), mask logits or None, ops.AttnMask for `level` or None."""
+        x = self.transformer_decoder.post_norm(q)
+        cls_pred = self.cls_embed(x)
+        emb = self.mask_embed(x)
+        logits, mask = self._mask_step(emb, mask_features, lows, level, want_logits, need_mask)
+        return cls_pred, logits, mask
+
+    def _rows(self):
+        """DecoderRows for the current weights, or None when the generic module path has to run."""
+        if getattr(self, '_rows_ok', None) is None:
+            self._rows_ok = DecoderRows.supported(self)
+        if not self._rows_ok or not self.query_feat.weight.is_cuda:
+            return None
+        st = getattr(self, '_rows_state', None)
+        if st is None or st.sig != DecoderRows.signature(self):
+            with torch.no_grad():
+                st = self._rows_state = DecoderRows(self)
+        return st
 
     def forward_head(self, decoder_out, mask_feature, attn_mask_target_size):
         """Reference signature (head.py:355): decoder_out (Q,B,C) -> cls_pred, mask_pred and the
@@ -152,9 +259,30 @@ class _Mask2FormerHeadBase(BaseModule):
             d2, d4, d8 = ops.center_downsample(mf)
             lows = {0: d8, 1: d4, 2: d2}
         q = self.query_feat.weight[None].expand(B, -1, -1).contiguous()
-        q_pos = self.query_embed.weight[None]
         cls_list, mask_list = [], []
         n_layers = self.num_transformer_decoder_layers
+        rows = self._rows()
+        if rows is not None:
+            # query rows through csrc/decoder_rows.hip: two launches per layer (+ mask bits, attention, merge)
+            q_pos2 = self.query_embed.weight
+            cls_pred, emb, qproj = rows.start(q, q_pos2)
+            logits, mask = self._mask_step(emb, mf, lows, 0, all_masks or n_layers == 0)
+            cls_list.append(cls_pred)
+            mask_list.append(logits)
+            for i in range(n_layers):
+                lvl = i % L
+                attn = self.transformer_decoder.layers[i].attentions[0]
+                kp, vp = attn.project_kv(k_in[lvl], v_in[lvl])
+                part = ops.masked_xattn_partial(qproj, kp, vp, mask, self.num_heads)
+                core = ops.xattn_combine(*part) if self.partial_combine is None else self.partial_combine(*part)
+                q, cls_pred, emb, qproj = rows.layer(i, core, q, q_pos2)
+                last = i == n_layers - 1
+                logits, mask = self._mask_step(emb, mf, lows, (i + 1) % L, all_masks or last,
+                                               need_mask=not last or all_masks)
+                cls_list.append(cls_pred)
+                mask_list.append(logits)
+            return cls_list, mask_list, q.transpose(0, 1)
+        q_pos = self.query_embed.weight[None]
         cls_pred, logits, mask = self._head_step(q, mf, lows, 0, all_masks or n_layers == 0)
         cls_list.append(cls_pred)
         mask_list.append(logits)

@@ -5,6 +5,8 @@ dtype / shape -> RuntimeError), allocates the output with torch (device memory +
 torch's), and calls the C ABI with raw device pointers on torch's CURRENT HIP stream.
 Nothing here computes on the CPU; a CPU tensor is an error.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -462,3 +464,47 @@ def conv1x1_affine(x, weight, scale, shift, residual=None, relu=True, out=None):
                   r.data_ptr() if r is not None else None, out.data_ptr(), B, Cout, Cin, H * W, int(bool(relu)),
                   _stream_ptr())
     return out
+
+
+# ---- decoder query rows (decoder_rows.hip) ---------------------------------------------------------
+def pack_rows_weight(W):
+    """(N,K) Linear weight -> MFMA-fragment order (roundup16(N)*K,), once per checkpoint."""
+    W = _chk(W.detach(), 'W')
+    N, K = W.shape
+    out = torch.empty((((N + 15) // 16) * 16 * K,), device=W.device, dtype=torch.float32)
+    with torch.cuda.device(W.device):
+        _lib.call('pvsg_pack_rows_weight', W.data_ptr(), out.data_ptr(), N, K, _stream_ptr())
+    return out
+
+
+def decoder_rows_pre(layer_struct, attn_core, query, query_pos):
+    """x1 = LN(attn_core Wo^T + bo + query); qkv = self-attention in_proj of x1 (q scaled). (B,Q,256) -> x1, qkv (B,Q,768)."""
+    core, q, pos = _chk(attn_core, 'attn_core'), _chk(query, 'query'), _chk(query_pos, 'query_pos')
+    B, Q, C = q.shape
+    x1 = torch.empty_like(q)
+    qkv = torch.empty((B, Q, 3 * C), device=q.device, dtype=torch.float32)
+    with torch.cuda.device(q.device):
+        _lib.call('pvsg_decoder_rows_pre', ctypes.byref(layer_struct), core.data_ptr(), q.data_ptr(), pos.data_ptr(),
+                  x1.data_ptr(), qkv.data_ptr(), B, Q, _stream_ptr())
+    return x1, qkv
+
+
+def decoder_rows_post(layer_struct, head_struct, next_q, x1, qkv, query_pos, num_cls_out):
+    """Self-attention + FFN + norms (layer_struct None: skipped, x1 = the queries) and the query side of
+    forward_head; next_q = (packed Wq, bq) of the next layer's cross-attention or None.
+    -> query_out (B,Q,256) or None, cls (B,Q,num_cls_out), mask_embed (B,Q,256), next_q (B,Q,256) or None."""
+    x1, pos = _chk(x1, 'x1'), _chk(query_pos, 'query_pos')
+    B, Q, C = x1.shape
+    dev = x1.device
+    q_out = torch.empty_like(x1) if layer_struct is not None else None
+    cls = torch.empty((B, Q, num_cls_out), device=dev, dtype=torch.float32)
+    emb = torch.empty_like(x1)
+    nq = torch.empty_like(x1) if next_q is not None else None
+    with torch.cuda.device(dev):
+        _lib.call('pvsg_decoder_rows_post', ctypes.byref(layer_struct) if layer_struct is not None else None,
+                  ctypes.byref(head_struct), next_q[0].data_ptr() if next_q is not None else None,
+                  next_q[1].data_ptr() if next_q is not None else None, x1.data_ptr(),
+                  _chk(qkv, 'qkv').data_ptr() if qkv is not None else None, pos.data_ptr(),
+                  q_out.data_ptr() if q_out is not None else None, cls.data_ptr(), emb.data_ptr(),
+                  nq.data_ptr() if nq is not None else None, B, Q, _stream_ptr())
+    return q_out, cls, emb, nq

@@ -1,0 +1,162 @@
+"""csrc/decoder_rows.hip (query-row side of a decoder layer, C ABI) against a plain PyTorch fp32 statement of the
+same ops (nn.MultiheadAttention, F.layer_norm, F.linear) and against the generic module path of the head."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from oracle.detweights import det_input, det_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _head(video, seed, gains=None):
+    from openpvsg_amd import blocks, heads  # noqa: F401
+    from openpvsg_amd.model_zoo import mask2former_r50_model_cfg, panoptic_head_cfg
+    from openpvsg_amd.registry import build_head
+    cfg = panoptic_head_cfg(video)
+    cfg.update(train_cfg=None, test_cfg=mask2former_r50_model_cfg(video)['test_cfg'])
+    h = build_head(cfg).eval()
+    sd = det_state_dict(h, seed, gains or {'cls_embed.weight': 12.0})
+    # non-trivial norm parameters and biases (the deterministic initialiser leaves LayerNorm at 1 / 0)
+    g = torch.Generator().manual_seed(seed)
+    for k in sd:
+        if 'norm' in k and k.endswith('weight'):
+            sd[k] = 1.0 + 0.2 * torch.randn(sd[k].shape, generator=g)
+        elif k.endswith('bias') and ('transformer_decoder' in k or 'mask_embed' in k or 'cls_embed' in k):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+    h.load_state_dict(sd)
+    return h.to(DEV)
+
+
+def _torch_layer(head, i, core, q, q_pos):
+    """One decoder layer after the cross-attention core, and the head's query side, in plain torch."""
+    layer = head.transformer_decoder.layers[i]
+    xa, sa = layer.attentions[0].attn, layer.attentions[1].attn
+    x1 = layer.norms[0](q + xa.out_proj(core))
+    qk = (x1 + q_pos).transpose(0, 1)
+    att = sa(qk, qk, x1.transpose(0, 1), need_weights=False)[0].transpose(0, 1)
+    x2 = layer.norms[1](x1 + att)
+    ffn = layer.ffns[0]
+    y = ffn.layers[1](F.relu(ffn.layers[0][0](x2)))
+    x3 = layer.norms[2](x2 + y)
+    return x1, x3
+
+
+def _torch_head_side(head, x3, q_pos, next_layer):
+    p = head.transformer_decoder.post_norm(x3)
+    cls, emb = head.cls_embed(p), head.mask_embed(p)
+    nq = None
+    if next_layer is not None:
+        a = head.transformer_decoder.layers[next_layer].attentions[0].attn
+        nq = F.linear(x3 + q_pos, a.in_proj_weight[:256], a.in_proj_bias[:256]) * 32 ** -0.5
+    return cls, emb, nq
+
+
+@pytest.mark.parametrize('B,Q', [(1, 100), (3, 100), (2, 37), (1, 128), (5, 16)])
+def test_rows_kernels_vs_torch(hip_lib, B, Q):
+    from openpvsg_amd.heads import DecoderRows
+    head = _head(True, 11)
+    rows = DecoderRows(head)
+    core = det_input('core', (B, Q, 256), 1).to(DEV)
+    q = det_input('q', (B, Q, 256), 2).to(DEV)
+    q_pos = det_input('pos', (Q, 256), 3).to(DEV)
+    with torch.no_grad():
+        for i in (0, 4, 8):
+            x1_ref, x3_ref = _torch_layer(head, i, core, q, q_pos[None])
+            nxt = i + 1 if i + 1 < 9 else None
+            cls_ref, emb_ref, nq_ref = _torch_head_side(head, x3_ref, q_pos[None], nxt)
+            x3, cls, emb, nq = rows.layer(i, core, q, q_pos)
+            tol = dict(rtol=2e-4, atol=2e-4)
+            np.testing.assert_allclose(x3.cpu().numpy(), x3_ref.cpu().numpy(), **tol)
+            np.testing.assert_allclose(cls.cpu().numpy(), cls_ref.cpu().numpy(), **tol)
+            np.testing.assert_allclose(emb.cpu().numpy(), emb_ref.cpu().numpy(), **tol)
+            if nxt is None:
+                assert nq is None
+            else:
+                np.testing.assert_allclose(nq.cpu().numpy(), nq_ref.cpu().numpy(), **tol)
+        # head-only form on the initial queries
+        cls, emb, nq = rows.start(q, q_pos)
+        cls_ref, emb_ref, nq_ref = _torch_head_side(head, q, q_pos[None], 0)
+        np.testing.assert_allclose(cls.cpu().numpy(), cls_ref.cpu().numpy(), rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(emb.cpu().numpy(), emb_ref.cpu().numpy(), rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(nq.cpu().numpy(), nq_ref.cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_pre_kernel_outputs(hip_lib):
+    """x1 and the self-attention in-projection (scaled q | k | v) of decoder_rows_pre on their own."""
+    from openpvsg_amd import ops
+    from openpvsg_amd.heads import DecoderRows
+    head = _head(False, 12)
+    rows = DecoderRows(head)
+    B, Q = 2, 100
+    core, q = det_input('core', (B, Q, 256), 4).to(DEV), det_input('q', (B, Q, 256), 5).to(DEV)
+    q_pos = det_input('pos', (Q, 256), 6).to(DEV)
+    layer = head.transformer_decoder.layers[3]
+    with torch.no_grad():
+        x1, qkv = ops.decoder_rows_pre(rows.layers[3], core, q, q_pos)
+        x1_ref = layer.norms[0](q + layer.attentions[0].attn.out_proj(core))
+        sa = layer.attentions[1].attn
+        W, b = sa.in_proj_weight, sa.in_proj_bias
+        ref = torch.cat([F.linear(x1_ref + q_pos, W[:256], b[:256]) * 32 ** -0.5,
+                         F.linear(x1_ref + q_pos, W[256:512], b[256:512]), F.linear(x1_ref, W[512:], b[512:])], -1)
+    np.testing.assert_allclose(x1.cpu().numpy(), x1_ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(qkv.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('video,T', [(False, 2), (True, 3)])
+def test_decode_rows_path_equals_module_path(hip_lib, video, T, monkeypatch):
+    """Whole decoder: the query-row kernels vs the generic module path (library GEMMs), all 10 predictions."""
+    from tests.test_modules_gpu import feats
+    head = _head(video, 13)
+    f = [x.to(DEV) for x in feats(T, 13)]
+    B, Tn = (1, T) if video else (T, 1)
+    with torch.no_grad():
+        assert head._rows() is not None
+        a = head._decode(f, B, Tn, all_masks=True, exact_masks=True)
+        fast = head._decode(f, B, Tn, all_masks=False)
+        head._rows_ok = False                      # generic path
+        b = head._decode(f, B, Tn, all_masks=True, exact_masks=True)
+        slow = head._decode(f, B, Tn, all_masks=False)
+    for x, y in zip(a[0], b[0]):
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-3, atol=1e-3)
+    for x, y in zip(a[1], b[1]):
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(a[2].cpu().numpy(), b[2].cpu().numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(fast[0][-1].cpu().numpy(), slow[0][-1].cpu().numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(fast[1][-1].cpu().numpy(), slow[1][-1].cpu().numpy(), rtol=1e-3, atol=1e-3)
+
+
+def test_rows_state_follows_weight_updates(hip_lib):
+    """load_state_dict (in place) and a device move both invalidate the packed weights."""
+    head = _head(False, 14)
+    st = head._rows()
+    assert head._rows() is st
+    q = det_input('q', (1, 100, 256), 7).to(DEV)
+    q_pos = det_input('pos', (100, 256), 8).to(DEV)
+    with torch.no_grad():
+        c1 = st.start(q, q_pos)[0].clone()
+    sd = {k: v.clone() for k, v in head.state_dict().items()}
+    sd['cls_embed.bias'] += 1.0
+    sd['cls_embed.weight'] *= 2.0                # packed copy: only a rebuilt state sees this
+    head.load_state_dict(sd)
+    st2 = head._rows()
+    assert st2 is not st
+    with torch.no_grad():
+        c2 = st2.start(q, q_pos)[0]
+        ref = head.cls_embed(head.transformer_decoder.post_norm(q))
+    np.testing.assert_allclose(c2.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-4)
+    assert float((c2 - c1).abs().max()) > 0.5
+
+
+def test_unsupported_shapes_report(hip_lib):
+    import ctypes
+    from openpvsg_amd import _lib
+    lay = _lib.DecoderLayer(embed_dims=256, num_heads=8, ffn_dim=2048)
+    one = ctypes.c_void_p(16)
+    rc = hip_lib.pvsg_decoder_rows_pre(ctypes.byref(lay), one, one, one, one, one, 1, 100, None)
+    assert rc == 1 and b'null pointer in pvsg_decoder_layer' in hip_lib.pvsg_last_error()
+    rc = hip_lib.pvsg_decoder_rows_pre(ctypes.byref(lay), one, one, one, one, one, 1, 200, None)
+    assert rc == 2 and b'at most 128 queries' in hip_lib.pvsg_last_error()

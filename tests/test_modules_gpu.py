@@ -489,13 +489,37 @@ def test_config2_ips_720p_batch_independence(hip_lib):
     g = torch.Generator().manual_seed(0)
     shapes = ((184, 320), (92, 160), (46, 80), (23, 40))
     f3 = [torch.randn(3, c, *hw, generator=g).to(DEV) for c, hw in zip(CH, shapes)]
+    # record every layer's attention-mask bits: the decoder is a chain of hard thresholds (sigmoid < 0.5), and the
+    # B=3 / B=1 runs differ by float rounding (different key-range splits, library GEMM shapes), so a logit within
+    # ~1e-5 of zero may flip a bit and legitimately change everything after it.  A batch-index bug, in contrast,
+    # shows up as O(1) differences from the first layer on.
+    rec = []
+    orig = h._mask_step
+
+    def spy(emb, mf, lows, level, want_logits, need_mask=True):
+        out = orig(emb, mf, lows, level, want_logits, need_mask)
+        rec[-1].append(None if out[1] is None else out[1].bits.clone())
+        return out
+    h._mask_step = spy
     with torch.no_grad():
-        cls3, m3, q3 = h._decode(f3, 3, 1, all_masks=False)
-        cls1, m1, q1 = h._decode([f[1:2] for f in f3], 1, 1, all_masks=False)
-    assert torch.allclose(cls3[-1][1], cls1[-1][0], rtol=1e-3, atol=1e-3)
-    assert torch.allclose(q3[:, 1], q1[:, 0], rtol=1e-3, atol=1e-3)
-    sc = float(m1[-1].abs().max())
-    assert float((m3[-1][1] - m1[-1][0]).abs().max()) < 2e-3 * sc
+        rec.append([])
+        cls3, m3, q3 = h._decode(f3, 3, 1, all_masks=True)
+        rec.append([])
+        cls1, m1, q1 = h._decode([f[1:2] for f in f3], 1, 1, all_masks=True)
+    h._mask_step = orig
+    flips = [int((a[1] != b[0]).any(-1).sum()) for a, b in zip(rec[0], rec[1]) if a is not None]
+    keys = [int(b[0].shape[0]) for b in rec[1] if b is not None]
+    assert len(flips) >= 9 and all(fl <= max(1, k // 2000) for fl, k in zip(flips, keys)), flips   # rare near-zero logits only
+    first = next((i for i, fl in enumerate(flips) if fl), len(flips))       # prediction i+1 is the first to see a flip
+    for i in range(min(first + 1, 10)):
+        assert torch.allclose(cls3[i][1], cls1[i][0], rtol=1e-3, atol=1e-3), i
+        sc = float(m1[i].abs().max())
+        assert float((m3[i][1] - m1[i][0]).abs().max()) < 1e-3 * sc, i
+    if first == len(flips):
+        assert torch.allclose(q3[:, 1], q1[:, 0], rtol=1e-3, atol=1e-3)
+    # after a flip the runs still agree to the size of one key's contribution
+    assert float((cls3[-1][1] - cls1[-1][0]).abs().max()) < 5e-2
+    assert float((m3[-1][1] - m1[-1][0]).abs().max()) < 5e-2 * float(m1[-1].abs().max())
 
 
 def test_config5_sizes_1080p_and_relation_N100_T64(hip_lib):
