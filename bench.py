@@ -5,14 +5,20 @@ One "step" = one pass of the hot path over one synthetic clip already resident i
   ResNet-50 -> MSDeformAttn pixel decoder -> clip-level masked-attention decoder (keys = T*h*w)
   -> last-layer mask logits -> per-frame x4 up-sampling + panoptic fusion -> tube assembly ->
   relation head (object encoders, N^2 pair scorer, top-100 pairs, temporal transformer).
-N > 1 (default --scaling weak): every rank runs the same step on its own 32-frame segment of a longer video
-(per-GPU work fixed); the per-frame segment records and kept query features are all-gathered (RCCL) and the
-relation head scores tubes over all N*32 frames.  --scaling strong shards ONE clip by frame instead
-(attention partials merged across ranks every decoder layer).
+N > 1 (default --scaling strong = BASELINE config 4): ONE 32-frame clip sharded by frame, 32/N frames per GPU; the
+attention partials are merged across the ranks every decoder layer and the per-frame segment records are
+all-gathered (RCCL) before tube assembly.  `python bench.py --gpus N` without a launcher re-executes itself under
+torch.distributed.run with N ranks.  --scaling weak gives every rank its own 32-frame segment of a longer video.
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around every C-ABI
-launch of the timed steps; `cpu_baseline` times the CPU oracle (oracle/, "port") on a bounded
-sample of the same workload on this box's host cores.
+Prints ONE JSON line (rank 0):
+  roofline            dominant HAND-WRITTEN kernel (by time), HIP events around every C-ABI launch of the timed steps
+  roofline_step       the whole step against the f32 matrix peak: algorithmic FLOP (library ops counted by
+                      torch.utils.flop_counter on one extra untimed step + the hand-written kernels' own counts)
+                      / 157.3 TF / ms_per_step, with the hand-written / other (library + gaps) time split
+  cpu_baseline        the CPU oracle (oracle/, kind "port") on a bounded sample of the same workload on this box's
+                      host cores: 1 warm-up + `--cpu-reps` timed repetitions (`--cpu-full`: also the full clip, minutes)
+  sub_benchmarks      relation head at N in {32,64,100} tubes and fused post-processing at K in {10,30} kept
+                      queries (SURVEY.md section 8d / BASELINE.md section 2)
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -56,7 +62,14 @@ def parse():
     ap.add_argument('--height', type=int, default=720)
     ap.add_argument('--width', type=int, default=1280)
     ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'off'])
-    ap.add_argument('--cpu-frames', type=int, default=4)
+    ap.add_argument('--cpu-frames', type=int, default=2, help='frames of the bounded CPU-oracle sample')
+    ap.add_argument('--cpu-reps', type=int, default=3, help='timed repetitions of the CPU sample after 1 warm-up')
+    ap.add_argument('--cpu-full', action='store_true', help='also time the oracle on the full clip (minutes)')
+    ap.add_argument('--head-outputs', default='synthetic', choices=['synthetic', 'model'],
+                    help='synthetic: class logits / mask-logit offsets with a controlled keep count (--keep) are applied '
+                         'to the head outputs so that ~--keep tubes reach the relation head; model: raw random-init outputs')
+    ap.add_argument('--keep', type=int, default=32)
+    ap.add_argument('--sub-benchmarks', default='on', choices=['on', 'off'])
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--scaling', default='strong', choices=['weak', 'strong'],
                     help='N>1: strong (default, BASELINE config 4) = ONE 32-frame clip sharded by frame, 32/N frames per '
@@ -80,6 +93,35 @@ def make_clip(T, H, W, seed=0):
     out = torch.zeros(T, 3, Hp, Wp)
     out[:, :, :H, :W] = img
     return out, (Hp, Wp)
+
+
+def synthetic_head_outputs(T, h4, w4, num_queries=100, num_classes=126, n_keep=32, seed=0, t0=0, T_total=None):
+    """Controlled keep-count (random-init weights give flat class logits and noise-like masks,
+    so `score > 0.8` + the area filter of mask2former_fusion_head.py:139-169 would leave ~2 segments and the relation
+    head would be timed on 2 tubes).  -> class logits (1,Q,classes+1) with `n_keep` confident queries (two thirds
+    things, one third stuff) and additive mask-logit offsets (T,Q,h4,w4): +/-40 on a drifting rectangle per kept
+    query (some absent in some frames), 0 for the others.  The decoder's own outputs are still computed and the
+    offsets are ADDED to its mask logits inside the timed step."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    T_total = T_total or T
+    cls = torch.randn(1, num_queries, num_classes + 1, generator=g)
+    cls[..., num_classes] += 8.0                                   # background for everyone ...
+    kept = torch.randperm(num_queries, generator=g)[:n_keep]
+    off = torch.zeros(T, num_queries, h4, w4)
+    gy, gx = 4, (n_keep + 3) // 4
+    for i, q in enumerate(kept.tolist()):
+        c = int(torch.randint(0, 115, (1,), generator=g)) if i % 3 else int(torch.randint(115, num_classes, (1,), generator=g))
+        cls[0, q, c] += 20.0                                       # ... except the kept ones
+        ch, cw = h4 // gy, w4 // gx
+        y0, x0 = (i // gx) * ch, (i % gx) * cw
+        for t in range(T):
+            tt = t0 + t
+            off[t, q] = -40.0
+            if (tt + 3 * i) % 11 == 0 and i % 4 == 1:              # leaves for a frame now and then
+                continue
+            dy, dx = (tt * (1 + i % 3)) % max(1, ch // 3), (tt * (1 + i % 2)) % max(1, cw // 3)
+            off[t, q, y0 + dy // 2: y0 + ch - ch // 6, x0 + dx // 2: x0 + cw - cw // 6] = 40.0
+    return cls, off
 
 
 def build_models(seed=0):
@@ -166,6 +208,18 @@ class KernelTimer:
         if name == 'pvsg_stem_bn_relu_pool':
             planes, C, H, W = a[4:8]
             return 4.0 * planes * (H * W + ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)), 0.0
+        if name == 'pvsg_decoder_rows_pre':
+            B, Q = a[6:8]
+            return 4.0 * (256 * 256 + 768 * 256) + 4.0 * B * Q * 256 * 6, 2.0 * B * Q * 256 * (256 + 768)
+        if name == 'pvsg_decoder_rows_post':
+            B, Q = a[11:13]
+            w_head = 128 * 256 + 3 * 256 * 256 + (256 * 256 if a[2] else 0)
+            w_layer = (256 * 256 + 2 * 256 * 2048) if a[0] is not None else 0
+            att = 4.0 * B * Q * Q * 256 if a[0] is not None else 0.0
+            return 4.0 * (w_head + w_layer) + 4.0 * B * Q * 256 * 6, 2.0 * B * Q * (w_head + w_layer) + att
+        if name == 'pvsg_xattn_combine':
+            B, Q, M, D, NS = a[3:8]
+            return 4.0 * B * NS * M * Q * (D + 2) + 4.0 * B * Q * M * D, 0.0
         if name == 'pvsg_nchw_to_tokens':
             B, C, HW = a[4:7]
             return 8.0 * B * C * HW, 0.0
@@ -187,13 +241,15 @@ class KernelTimer:
         return agg
 
 
-def cpu_baseline_and_parity(det_gpu, rel_gpu, pipe, args, dev):
-    """Oracle (CPU restatement of the reference algorithm) on a bounded sample: a `cpu_frames`-frame
-    720p clip through the same clip-level flow + relation head; also compares the product's panoptic
-    maps with the oracle's on that sample."""
+def cpu_baseline_and_parity(det_gpu, rel_gpu, pipe, args, dev, frames, reps, check=True):
+    """Oracle (CPU restatement of the reference algorithm, oracle/) on a bounded sample: a `frames`-frame 720p clip
+    through the same clip-level flow + relation head, 1 warm-up + `reps` timed repetitions; also compares the
+    product's panoptic maps / pair matrix with the oracle's on that sample."""
+    import numpy as np
+    import torch.nn.functional as F
     from oracle import pipeline as opipe
     from oracle import relation as orel
-    T = args.cpu_frames
+    T = frames
     ncpu = host_cores()
     torch.set_num_threads(ncpu)
     clip, (Hp, Wp) = make_clip(T, args.height, args.width)
@@ -206,29 +262,61 @@ def cpu_baseline_and_parity(det_gpu, rel_gpu, pipe, args, dev):
                                 if n in orl[k].state_dict()})
     meta = dict(batch_input_shape=(Hp, Wp), img_shape=(args.height, args.width, 3),
                 ori_shape=(args.height, args.width, 3))
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        res = o.clip_test(clip[None], [[meta] * T], rescale=True)[0]
-        # tubes exactly as the product assembles them, then the reference's relation flow
-        order, frames = [], []
-        for t in range(T):
-            frames.append(res[t]['query_feats'])
-            for sid in res[t]['query_feats']:
-                if sid not in order:
-                    order.append(sid)
-        feats = torch.zeros(len(order), T, 256)
-        for t in range(T):
-            for sid, lst in frames[t].items():
-                feats[order.index(sid), t] = lst[0].reshape(-1)
-        rel_out = None
-        if len(order) >= 2:
-            rel_out = orel.evaluate_video(orl['se'], orl['oe'], orl['pp'], orl['rm'], feats, [], 100)
-    cpu_s = time.perf_counter() - t0
+    syn = None
+    if args.head_outputs == 'synthetic':
+        syn = synthetic_head_outputs(T, Hp // 4, Wp // 4, n_keep=args.keep, T_total=T)
+
+    def run():
+        with torch.no_grad():
+            cls, masks, q = o.clip_forward(clip[None], (Hp, Wp))          # masks (1,T,Q,H,W): already up-sampled
+            if syn is not None:                                          # same controlled head outputs as the product
+                cls = syn[0]
+                masks = masks + F.interpolate(syn[1], size=(Hp, Wp), mode='bilinear', align_corners=False)[None]
+            embds = q.permute(1, 0, 2)
+            res = []
+            for t in range(T):
+                res.append(opipe.heads.fusion_simple_test_with_query(cls, masks[:, t], embds, [meta], o.num_things,
+                                                                      o.num_stuff, o.test_cfg, rescale=True)[0])
+            # tubes exactly as the product assembles them, then the reference's relation flow
+            order, fr = [], []
+            for t in range(T):
+                fr.append(res[t]['query_feats'])
+                for sid in res[t]['query_feats']:
+                    if sid not in order:
+                        order.append(sid)
+            feats = torch.zeros(len(order), T, 256)
+            for t in range(T):
+                for sid, lst in fr[t].items():
+                    feats[order.index(sid), t] = lst[0].reshape(-1)
+            rel_out = None
+            if len(order) >= 2:
+                rel_out = orel.evaluate_video(orl['se'], orl['oe'], orl['pp'], orl['rm'], feats, [], 100)
+        return res, order, rel_out
+
+    run()                                                                # warm-up
+    times = []
+    for _ in range(max(1, reps)):
+        t0 = time.perf_counter()
+        res, order, rel_out = run()
+        times.append(time.perf_counter() - t0)
+    cpu_s = sum(times) / len(times)
+    base = dict(value=T / cpu_s, unit='frames/s', cores=ncpu, kind='port',
+                sample='%d-frame 720p clip, clip-level VPS forward + fusion + relation head (oracle/, torch CPU fp32, '
+                       '%d threads): 1 warm-up + %d timed runs, %.1f s each (min %.1f, max %.1f)'
+                       % (T, torch.get_num_threads(), len(times), cpu_s, min(times), max(times)),
+                seconds_per_run=times)
+    if not check:
+        return base, None
     # product on the same sample
-    out = pipe(clip.to(dev), (Hp, Wp), (args.height, args.width))
+    saved = pipe.head_override
+    if syn is not None:
+        pipe.head_override = make_override(syn, dev)
+    try:
+        out = pipe(clip.to(dev), (Hp, Wp), (args.height, args.width))
+    finally:
+        pipe.head_override = saved
     torch.cuda.synchronize()
     a = out['pan_results'].cpu().numpy()
-    import numpy as np
     b = np.stack([res[t]['pan_results'].numpy() for t in range(T)])
     ids = (set(np.unique(a)) | set(np.unique(b))) - {126}
     inter = sum(((a == i) & (b == i)).sum() for i in ids)
@@ -242,10 +330,93 @@ def cpu_baseline_and_parity(det_gpu, rel_gpu, pipe, args, dev):
             if pm_a.shape == rel_out['pred_matrix'].shape else None
         pa = out['relation']['pairs'].cpu().tolist()
         parity['top20_pairs_equal'] = pa[:20] == rel_out['pairs'][:20]
-    base = dict(value=T / cpu_s, unit='frames/s', cores=ncpu, kind='port',
-                sample='%d-frame 720p clip, clip-level VPS forward + fusion + relation head (oracle/, torch CPU '
-                       'fp32, %d threads), %.1f s' % (T, torch.get_num_threads(), cpu_s))
     return base, parity
+
+
+def make_override(syn, dev):
+    cls_syn, off = syn[0].to(dev), syn[1].to(dev)
+
+    def override(cls, masks4):
+        masks4 = masks4.add_(off[None]) if masks4.shape[1:] == off.shape else masks4 + off[None]
+        return cls_syn, masks4
+    return override
+
+
+def fastpath_bit_flip_rate(head, feats, T):
+    """Fast path (attention-mask bits from down-sampled features, einsum(E, resize(F))) vs the reference order
+    (resize(einsum(E, F)) then threshold) on the LAST layer's mask embeddings, per decoder level, at the bench size."""
+    import torch.nn.functional as F
+    from openpvsg_amd import ops
+    rec = {}
+    orig = head._mask_step
+
+    def spy(emb, mf, lows, level, want_logits, need_mask=True):
+        rec['emb'], rec['mf'], rec['lows'] = emb, mf, lows
+        return orig(emb, mf, lows, level, want_logits, need_mask)
+    head._mask_step = spy
+    try:
+        with torch.no_grad():
+            head.clip_logits(feats, 1, T)
+    finally:
+        head._mask_step = orig
+    emb, mf, lows = rec['emb'], rec['mf'], rec['lows']
+    out = {}
+    if lows is None:
+        return None
+    with torch.no_grad():
+        logits = ops.mask_logits(emb, mf)                                  # (1,T,Q,H/4,W/4)
+        for lvl in range(3):
+            fast = ops.attn_mask_from_lowres_feature(emb, lows[lvl]).bits
+            size = tuple(lows[lvl].shape[-2:])
+            low = F.interpolate(logits.flatten(0, 1), size, mode='bilinear', align_corners=False).unflatten(0, (1, T))
+            exact = ops.attn_mask_pack(low).bits
+            x = (fast ^ exact).view(torch.uint8)
+            flips = int(sum(int(((x >> k) & 1).sum()) for k in range(8)))
+            out['level%d' % lvl] = dict(keys=int(fast.shape[1]), flipped_bits=flips,
+                                        rate=flips / (fast.shape[1] * emb.shape[1]))
+    return out
+
+
+def sub_benchmarks(det, rel, pipe, args, dev, iters=20):
+    """relation head on synthetic tubes N(0,1) [N,T,256] for N in {32,64,100}; fused
+    post-processing (x4 up-sampling + panoptic fusion of one clip) with K in {10,30} kept queries."""
+    from openpvsg_amd.relation import relation_forward
+    from tests.synth_inputs import blob_masks, peaky_cls
+    out = {}
+    T = args.frames
+    g = torch.Generator().manual_seed(7)
+
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / iters
+
+    with torch.no_grad():
+        for N in (32, 64, 100):
+            feats = torch.randn(N, T, 256, generator=g).to(dev)
+            ms = timeit(lambda: relation_forward(rel['subject_encoder'], rel['object_encoder'], rel['pair_model'],
+                                                 rel['relation_model'], feats, 100))
+            ms_pair = timeit(lambda: rel['pair_model'](feats, feats))
+            out['relation_head_N%d_T%d' % (N, T)] = dict(ms=ms, videos_per_s=1e3 / ms, pair_scorer_us=ms_pair * 1e3)
+        fusion = det.panoptic_fusion_head
+        Hp, Wp = (args.height + 31) // 32 * 32, (args.width + 31) // 32 * 32
+        for K in (10, 30):
+            cls, conf = peaky_cls(100, 126, K, 3)
+            one = blob_masks(100, Hp // 4, Wp // 4, conf, 5)
+            logits4 = one[None].repeat(T, 1, 1, 1).to(dev)
+            cls = cls.to(dev)
+            ms = timeit(lambda: fusion.panoptic_fused(cls, logits4, (Hp, Wp), (args.height, args.width)))
+            kept = int(fusion.panoptic_select(cls)[2].sum())
+            out['postprocess_K%d' % K] = dict(ms=ms, frames_per_s=T * 1e3 / ms, kept=kept,
+                                              algorithmic_GB=(4.0 * T * kept * (Hp // 4) * (Wp // 4) + 5.0 * T * args.height * args.width) / 1e9)
+    return out
 
 
 def self_spawn(args):
@@ -317,6 +488,10 @@ def main():
         clip_local = clip[t0:t0 + t_local].to(dev)       # resident in HBM before the timed region
     group = None
     frames_per_step = T * world if weak else T
+    if args.head_outputs == 'synthetic':
+        syn = synthetic_head_outputs(t_local, Hp // 4, Wp // 4, n_keep=args.keep, seed=rank if weak else 0,
+                                     t0=0 if weak else t0, T_total=T)
+        pipe.head_override = make_override(syn, dev)
 
     timer = KernelTimer()
     if not args.no_kernel_timing and rank == 0:
@@ -347,13 +522,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # one extra UNTIMED step under torch's flop counter: algorithmic flops of the library ops (mm / addmm / bmm /
+    # convolution); the hand-written kernels' own counts come from KernelTimer.work
+    lib_flops = None
+    try:
+        from torch.utils.flop_counter import FlopCounterMode
+        n0 = len(timer.records)
+        timer.enabled = bool(timer.records)
+        with FlopCounterMode(display=False) as fc:
+            step()
+        torch.cuda.synchronize()
+        timer.enabled = False
+        hw_flops_one = sum(KernelTimer.work(n, a)[1] for n, a, _, _ in timer.records[n0:])
+        del timer.records[n0:]
+        lib_flops = float(fc.get_total_flops())
+    except Exception:
+        timer.enabled = False
+        hw_flops_one = None
+    if world > 1:
+        dist.barrier()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         fps = frames_per_step * args.steps / elapsed
         line = {
             'metric': 'frames/sec for 720p 32-frame VPS+relation forward',
             'value': fps, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak' if (weak or world == 1) else 'strong',
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'Mask2Former-VPS R50 clip-level forward, %d frames %dx%d (padded %dx%d), '
@@ -361,7 +556,13 @@ def main():
                                    'tube assembly, relation head (TemporalTransformer, top-100 pairs)'
                                    % (T, args.height, args.width, Hp, Wp),
                        'frames': T, 'frames_per_gpu': t_local, 'backbone': 'ResNet-50 (reference ships no Swin-B config)',
-                       'weights': 'random init seed 0 (cls logits x%g so that some queries pass score>0.8)' % CLS_GAIN,
+                       'weights': 'random init seed 0',
+                       'head_outputs': ('synthetic class logits + additive mask-logit offsets, %d confident queries '
+                                        '(BASELINE.md section 2: controlled keep count; random-init outputs keep ~2 segments)'
+                                        % args.keep) if args.head_outputs == 'synthetic' else
+                       'model (cls logits x%g so that some queries pass score>0.8)' % CLS_GAIN,
+                       'test_cfg': 'instance_on=False, inference_mode=clip (the shipped configs set instance_on=True and '
+                                   'run per-frame; scripts/ips_pipeline_bench.py measures that flavour)',
                        'tubes': int(out['tube_feats'].shape[0]), 'frames_per_step': frames_per_step,
                        'library_gemm_table': 'openpvsg_amd/tuning/gemm_gfx950.csv (load only)' if gemm_table else 'off',
                        'parallelism': ('%d x 32-frame segments, all-gather of tube records' % world) if weak
@@ -386,18 +587,30 @@ def main():
                                TFLOPs=d['flops'] / d['calls'] / per / 1e9 if per > 0 and d['flops'] else None,
                                ms_per_step=d['ms'] / args.steps)
             line['kernels'] = kern
+            hw_ms = sum(d['ms'] for d in agg.values()) / args.steps
+            if lib_flops is not None and hw_flops_one is not None:
+                f0 = lib_flops + hw_flops_one                 # this rank's share of the step
+                ideal_ms = f0 / (F32_MFMA_PEAK_TF * 1e12) * 1e3
+                line['roofline_step'] = dict(
+                    bound='mfma', algorithmic_TFLOP_per_step=f0 * world / 1e12, library_TFLOP_per_gpu=lib_flops / 1e12,
+                    handwritten_TFLOP_per_gpu=hw_flops_one / 1e12, peak=F32_MFMA_PEAK_TF, unit='TFLOP/s per GPU',
+                    achieved=f0 / (ms_per_step * 1e-3) / 1e12, frac=ideal_ms / ms_per_step, ideal_ms_per_step=ideal_ms,
+                    handwritten_kernel_ms_per_step=hw_ms, other_ms_per_step=ms_per_step - hw_ms,
+                    note='rank 0; other = library kernels (MIOpen / rocBLAS / hipBLASLt / ATen) + launch gaps + host syncs')
             dom = max((k for k in agg if agg[k]['bytes'] > 0), key=lambda k: agg[k]['ms'])
             d = agg[dom]
             per = d['ms'] / d['calls']
             # the roof that binds = the larger ideal time (bytes / HBM peak vs flops / f32 matrix peak) over its launches
             mfma_bound = d['flops'] / (F32_MFMA_PEAK_TF * 1e12) > d['bytes'] / (HBM_PEAK_GBS * 1e9)
+            # HBM-side bytes per launch from the PMC passes of scripts/pmc_traffic.py (FETCH_SIZE / WRITE_SIZE in
+            # separate rocprofv3 runs of THIS bench at T=32, gfx950 read correction applied), keyed by C-ABI entry;
+            # null when the file has no entry for this kernel / clip length
             traffic = None
             tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
             if os.path.exists(tpath):
                 ent = json.load(open(tpath)).get(dom.split('[')[0], {})
-                traffic = ent.get('hbm_bytes_per_launch_T%d' % t_local)
-                if traffic is None and ent.get('ratio_to_algorithmic'):       # kernels whose launches differ in shape
-                    traffic = ent['ratio_to_algorithmic'] * d['bytes'] / d['calls']
+                if ent.get('frames') == t_local:
+                    traffic = ent.get('hbm_bytes_per_launch')
             if mfma_bound:
                 ach = d['flops'] / d['calls'] / per / 1e9
                 line['roofline'] = dict(kernel=dom, bound='mfma', achieved=ach, peak=F32_MFMA_PEAK_TF,
@@ -430,12 +643,23 @@ def main():
                 else:
                     named.append(dict(kernel=k, bound='launch-latency', avg_launch_us=per_ms * 1e3))
             line['roofline_named_kernels'] = named
+        if world == 1 and args.sub_benchmarks == 'on':
+            try:
+                line['sub_benchmarks'] = sub_benchmarks(det, rel, pipe, args, dev)
+                feats = det.extract_feat(clip_local)
+                line['fastpath_mask_bit_flip_rate'] = fastpath_bit_flip_rate(det.panoptic_head, feats, T)
+                del feats
+            except Exception as e:
+                line['sub_benchmarks'] = dict(failed=repr(e))
         if args.cpu_baseline != 'off' and world == 1:
             try:
-                base, parity = cpu_baseline_and_parity(det, rel, pipe, args, dev)
+                base, parity = cpu_baseline_and_parity(det, rel, pipe, args, dev, args.cpu_frames, args.cpu_reps)
                 line['cpu_baseline'] = base
                 line['parity_on_cpu_sample'] = parity
                 line['speedup_vs_cpu_baseline'] = fps / base['value']
+                if args.cpu_full:
+                    full, _ = cpu_baseline_and_parity(det, rel, pipe, args, dev, T, 1, check=False)
+                    line['cpu_baseline_full_clip'] = full
             except Exception as e:  # the bench line must still be printed
                 line['cpu_baseline'] = dict(value=None, unit='frames/s', cores=host_cores(), kind='port',
                                             sample='failed: %r' % (e,))

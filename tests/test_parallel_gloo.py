@@ -110,3 +110,31 @@ def test_merge_reference_handles_empty_ranges():
     ml[:, 2, ..., 1] = 4.0
     out = parallel.merge_partials_reference(o, ml)
     assert torch.allclose(out, torch.full_like(out, 1.0))
+
+
+def test_bench_gpus_flag_self_spawns_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` with no launcher around it must re-execute itself under torch.distributed.run
+    with N ranks (tools/test.py:186-190 leaves that to its launcher script); with WORLD_SIZE set it must not."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '2'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen['cmd']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '4' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-4:] == ['--gpus', '4', '--steps', '2'] and seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    # a launcher's WORLD_SIZE that disagrees with --gpus is an error, not a silent 1-GPU run
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert 'WORLD_SIZE=2' in str(e.value.code)

@@ -86,3 +86,29 @@ def test_two_rank_clip_equals_single_process(hip_lib, tmp_path):
             np.testing.assert_allclose(p['pm'].numpy(), ref['relation']['pred_matrix'].cpu().numpy(), rtol=1e-3, atol=1e-4)
     pan = torch.cat([p['pan'] for p in sorted(parts, key=lambda d: d['t0'])]).numpy()
     assert (pan != ref['pan_results'].cpu().numpy()).mean() < 2e-3
+
+
+def test_bench_gpus_2_runs_two_ranks_on_the_frame_sharded_clip(hip_lib):
+    """`python bench.py --gpus 2` (no launcher) on the one-GPU box: PVSG_ONE_DEVICE=1 puts both ranks on cuda:0 and
+    gloo carries the exchanges; the printed line must say n_gpus 2 / strong scaling / 2 frames per GPU, and the
+    sharded clip must reproduce the single-process results (tube ids, query / pair sums)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ['--frames', '4', '--height', '64', '--width', '96', '--steps', '1', '--warmup', '1', '--cpu-baseline', 'off',
+              '--sub-benchmarks', 'off', '--checksum', '--keep', '6']
+    env = dict(os.environ, PVSG_ONE_DEVICE='1', PVSG_GEMM_TABLE='off')
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + extra + common, env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    two = run(['--gpus', '2', '--backend', 'gloo'])
+    one = run([])
+    assert two['n_gpus'] == 2 and two['scaling'] == 'strong' and two['config']['frames_per_gpu'] == 2
+    assert one['n_gpus'] == 1 and one['config']['frames_per_gpu'] == 4
+    assert two['checksum']['tube_ids'] == one['checksum']['tube_ids'] and len(one['checksum']['tube_ids']) >= 2
+    assert abs(two['checksum']['query_sum'] - one['checksum']['query_sum']) < 1e-2 * max(1.0, abs(one['checksum']['query_sum']))
+    assert abs(two['checksum']['tube_feat_sum'] - one['checksum']['tube_feat_sum']) < 1e-2 * max(1.0, abs(one['checksum']['tube_feat_sum']))
