@@ -52,12 +52,12 @@ def test_head_forward_vs_reference_golden(hip_lib, golden_dir, name, video, T):
         cls_f, mask_f, qf = h.simple_test_with_query(f, metas)
     for j, li in enumerate(g['layers']):
         np.testing.assert_allclose(cls_list[li].cpu().numpy(), g['cls'][j], rtol=1e-3, atol=1e-3)
-        np.testing.assert_allclose(mask_list[li].cpu().numpy(), g['mask'][j], rtol=1e-3, atol=2e-3)
+        np.testing.assert_allclose(mask_list[li].cpu().numpy(), g['mask'][j], rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(q.cpu().numpy(), g['query'], rtol=1e-3, atol=1e-3)
     # fast path (bits from down-sampled features, only the last layer's logits) == reference outputs
     np.testing.assert_allclose(cls_f.cpu().numpy(), g['final_cls'], rtol=1e-3, atol=1e-3)
     samp = mask_f[:, ::7, ::5, ::5] if not video else mask_f[:, :, ::7, ::5, ::5]
-    np.testing.assert_allclose(samp.cpu().numpy(), g['final_mask_sample'], rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(samp.cpu().numpy(), g['final_mask_sample'], rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(qf.cpu().numpy(), g['final_query'], rtol=1e-3, atol=1e-3)
 
 
@@ -68,11 +68,17 @@ def test_forward_head_mask_bits_match_reference(hip_lib, golden_dir):
     with torch.no_grad():
         mf, mems = h.pixel_decoder(f)
         q0 = h.query_feat.weight.unsqueeze(1)
-        _, _, am = h.forward_head(q0, mf, mems[0].shape[-2:])
-    bits = np.packbits(am[0].cpu().numpy(), axis=-1)
-    assert (bits != g['am_first']).mean() < 0.01
+        _, logits, am = h.forward_head(q0, mf, mems[0].shape[-2:])
+        low = torch.nn.functional.interpolate(logits, mems[0].shape[-2:], mode='bilinear', align_corners=False)
+    ours = am[0].cpu().numpy()                                           # (Q, K) bool, True = blocked
+    ref = np.unpackbits(g['am_first'], axis=-1)[:, :ours.shape[1]].astype(bool)
+    # a bit is the hard decision `logit < 0`: it may differ from the reference's only where the resized logit is
+    # within the 1e-3 parity tolerance of the threshold; everywhere else it must be identical
+    near = np.abs(low[0].flatten(1).cpu().numpy()) < 1e-3
+    assert not ((ours != ref) & ~near).any()
+    assert (ours != ref).sum() <= near.sum()
     pop = am[0].sum(-1).cpu().numpy()
-    assert np.abs(pop - g['am_popcount'][0]).max() <= 1
+    assert np.abs(pop - g['am_popcount'][0]).max() <= max(1, int(near.sum(1).max()))
 
 
 def test_fusion_vs_reference_golden(hip_lib, golden_dir):
