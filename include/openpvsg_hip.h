@@ -198,6 +198,16 @@ int pvsg_msda_fused_forward(const float* value, long long value_row_stride, cons
                             long long oa_row_stride, const float* pos_oa, const float* ref_points,
                             const int64_t* spatial_shapes, const int64_t* level_start_index, float* out,
                             int B, int S, int M, int D, int Lq, int L, int P, void* stream);
+/* pvsg_msda_proj_ln_forward: the same sampling + [3P] MultiScaleDeformableAttention.forward steps 7-8 (output_proj,
+ * + identity) + the BaseTransformerLayer norm that follows, in one launch:
+ *   out = LayerNorm_256(identity + MSDA(...) Wo^T + bo);  wo_packed = pvsg_pack_rows_weight(output_proj.weight (256,256)),
+ *   identity / out (B*Lq, 256).  The 256x256 projection runs on the matrix cores under the texture-bound gather. */
+int pvsg_msda_proj_ln_forward(const float* value, long long value_row_stride, const float* oa,
+                              long long oa_row_stride, const float* pos_oa, const float* ref_points,
+                              const int64_t* spatial_shapes, const int64_t* level_start_index,
+                              const float* wo_packed, const float* wo_bias, const float* identity,
+                              const float* gamma, const float* beta, float* out, int B, int S, int M, int D, int Lq,
+                              int L, int P, float eps, void* stream);
 int pvsg_add_layernorm(const float* a, const float* b, const float* bias, const float* gamma,
                        const float* beta, float* out, long long rows, int C, float eps, void* stream);
 

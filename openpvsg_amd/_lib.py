@@ -52,6 +52,7 @@ SIGNATURES = {
     'pvsg_panoptic_fuse': [_c_f] * 8 + [_i] * 13 + [ctypes.c_double, _i, _c_f],
     'pvsg_instance_masks': [_c_f] * 5 + [_i] * 12 + [_c_f],
     'pvsg_msda_fused_forward': [_c_f, _ll, _c_f, _ll, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _i, _i, _c_f],
+    'pvsg_msda_proj_ln_forward': [_c_f, _ll, _c_f, _ll] + [_c_f] * 10 + [_i] * 7 + [_f, _c_f],
     'pvsg_add_layernorm': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _ll, _i, _f, _c_f],
     'pvsg_affine_act_nchw': [_c_f, _c_f, _c_f, _c_f, _c_f, _ll, _i, _ll, _i, _c_f],
     'pvsg_minvis_chain': [_c_f, _c_f, _i, _i, _i, _i, _c_f],

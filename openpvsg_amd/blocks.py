@@ -18,6 +18,7 @@ internally.  Nothing here runs on CPU tensors (ops.py raises).
 """
 import copy
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -523,6 +524,10 @@ class MSDeformAttnPixelDecoder(BaseModule):
         return self._geom[key]
 
     fuse_encoder = True
+    # msda_proj_ln (sampling + output_proj + identity + LayerNorm in one kernel): correct, but measured no faster than
+    # msda_fused + library GEMM + add_layernorm (2.94 vs 1.82 + ~0.7 + 0.38 ms per layer at 32 x 720p: with 128 VGPRs /
+    # 66 KB LDS only 16 waves per CU gather, and the matrix phase does not hide under them) -> opt-in
+    fuse_out_proj = os.environ.get('PVSG_MSDA_PROJ_LN', 'off') == 'on'
     fpn_nchw = True
 
     def _fusable(self, layer, x):
@@ -549,9 +554,18 @@ class MSDeformAttnPixelDecoder(BaseModule):
         w_cat = torch.cat([a.value_proj.weight, w_oa], 0)                      # (544, 256)
         b_cat = torch.cat([a.value_proj.bias, torch.zeros_like(b_oa)], 0)
         y = F.linear(x, w_cat, b_cat)                                          # (B, S, 544)
-        core = ops.msda_fused(y, pos_oa, ref2d, ss, lsi)
-        t = F.linear(core, a.output_proj.weight)
-        x = ops.add_layernorm(t, x, a.output_proj.bias, layer.norms[0])
+        if MSDeformAttnPixelDecoder.fuse_out_proj:
+            # sampling + output_proj + identity + LayerNorm in one kernel (projection on the matrix cores under the
+            # texture-bound gather); the packed weight is rebuilt when the parameter changes
+            w = a.output_proj.weight
+            ver = (w.data_ptr(), w._version)
+            if getattr(a, '_wo_packed_ver', None) != ver:
+                a._wo_packed, a._wo_packed_ver = ops.pack_rows_weight(w), ver
+            x = ops.msda_proj_ln(y, pos_oa, ref2d, ss, lsi, a._wo_packed, a.output_proj.bias, x, layer.norms[0])
+        else:
+            core = ops.msda_fused(y, pos_oa, ref2d, ss, lsi)
+            t = F.linear(core, a.output_proj.weight)
+            x = ops.add_layernorm(t, x, a.output_proj.bias, layer.norms[0])
         ffn = layer.ffns[0]
         fc1, fc2 = ffn.layers[0][0], ffn.layers[1]
         B, S, C = x.shape

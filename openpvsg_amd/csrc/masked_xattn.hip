@@ -24,6 +24,10 @@
 // 64 TF (41 % of the f32 matrix peak); a variant loading fragments straight from HBM into registers
 // measured 0.72 ms -- both are limited by the QK -> softmax -> PV dependency inside a wave at 2 waves
 // per SIMD, not by the loads.
+// Tried and measured slower (round 2, 471 040 keys, 0.755 ms baseline): (a) 16 waves per workgroup, wave = (head,
+// half of the query tiles), 128 VGPRs -> 4 waves/SIMD: 1.006 ms (31 spilled VGPRs, K/V fragments read twice, an
+// eighth padding tile); (b) rescaling O only when a wave vote says the running maximum moved + b128 mask reads:
+// 1.03 ms (the wave-uniform branches stop the compiler from interleaving one tile's soft-max with the MFMAs).
 // Ranges are combined by `xattn_combine_kernel` (log-sum-exp merge); the same partial format is
 // what ranks exchange when a clip's frames are sharded over GPUs (openpvsg_amd/parallel.py).
 #include "common.h"
@@ -304,8 +308,11 @@ extern "C" int pvsg_masked_xattn_partial(const float* q_proj, const float* k_pro
   // ranges past the end are legal: they publish (m=-inf, l=0, o=0) and the merge skips them
   chunk = (chunk + TK - 1) / TK * TK;
   const size_t lds = (size_t)2 * XLDS_TILE_FLOATS * sizeof(float);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_partial_lds_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // once per process (the attribute belongs to the function, not to a device or a launch)
+  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_partial_lds_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr_rc != hipSuccess)
+    return set_err(PVSG_ERR_HIP, "masked_xattn_partial: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(attr_rc));
   hipLaunchKernelGGL(xattn_partial_lds_kernel, dim3(B * NS), dim3(512), lds, stream, q_proj, k_proj, v_proj,
                      mask_bits, mask_flags, part_o, part_ml, Q, K, NS, chunk);
   PVSG_LAUNCH_CHECK("masked_xattn_partial");

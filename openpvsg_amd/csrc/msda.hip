@@ -213,20 +213,16 @@ extern "C" int pvsg_ms_deform_attn_forward(const float* value, const int64_t* sp
 namespace pvsg {
 
 template <int L, int P>
-__global__ __launch_bounds__(256) void msda_fused_m8d32(
-    const float* __restrict__ value, long long value_stride, const float* __restrict__ oa,
-    long long oa_stride, const float* __restrict__ pos_oa, const float* __restrict__ ref,
-    const long long* __restrict__ shapes, const long long* __restrict__ lsi, float* __restrict__ out,
-    int S, int Lq, long long nq_total, unsigned nblk) {
+__device__ __forceinline__ float4 msda_sample_query(const float* __restrict__ value, long long value_stride,
+                                                    const float* __restrict__ oa, long long oa_stride,
+                                                    const float* __restrict__ pos_oa, const float* __restrict__ ref,
+                                                    const long long* __restrict__ shapes,
+                                                    const long long* __restrict__ lsi, int S, int Lq, long long gq,
+                                                    int lane) {
   constexpr int M = 8, D = 32, LP = L * P;
-  const unsigned lb = xcd_contiguous_block(blockIdx.x, nblk);
-  const long long gq = (long long)lb * 4 + (threadIdx.x >> 6);
-  if (gq >= nq_total) return;
-  const int lane = threadIdx.x & 63;
   const int m = lane >> 3, c4 = lane & 7;
   const int b = (int)(gq / Lq);
   const int q = (int)(gq - (long long)b * Lq);
-
   const float* offp = oa + gq * oa_stride + m * (LP * 2);
   const float* logp = oa + gq * oa_stride + M * LP * 2 + m * LP;
   const float* poff = pos_oa ? pos_oa + (long long)q * (M * LP * 3) + m * (LP * 2) : nullptr;
@@ -244,7 +240,6 @@ __global__ __launch_bounds__(256) void msda_fused_m8d32(
     if (plog) { const float4 u = ld4(plog + 4 * i); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
     aw[4 * i] = t.x; aw[4 * i + 1] = t.y; aw[4 * i + 2] = t.z; aw[4 * i + 3] = t.w;
   }
-  // softmax over the head's L*P logits
   float mx = aw[0];
 #pragma unroll
   for (int i = 1; i < LP; ++i) mx = fmaxf(mx, aw[i]);
@@ -254,13 +249,12 @@ __global__ __launch_bounds__(256) void msda_fused_m8d32(
   const float inv = 1.f / sum;
   const float rx = ref[2 * q], ry = ref[2 * q + 1];
   const float* vbase = value + (long long)b * S * value_stride + m * D + c4 * 4;
-
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int l = 0; l < L; ++l) {
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
     const float* vl = vbase + lsi[l] * value_stride;
-    const float invW = 1.f / (float)W, invH = 1.f / (float)H;   // wave-uniform reciprocals
+    const float invW = 1.f / (float)W, invH = 1.f / (float)H;
     float4 v[P][4];
     float cw[P][4];
 #pragma unroll
@@ -297,7 +291,141 @@ __global__ __launch_bounds__(256) void msda_fused_m8d32(
       acc.x += a * s.x; acc.y += a * s.y; acc.z += a * s.z; acc.w += a * s.w;
     }
   }
-  st4_stream(out + gq * (M * D) + m * D + c4 * 4, acc);
+  return acc;
+}
+
+template <int L, int P>
+__global__ __launch_bounds__(256) void msda_fused_m8d32(
+    const float* __restrict__ value, long long value_stride, const float* __restrict__ oa,
+    long long oa_stride, const float* __restrict__ pos_oa, const float* __restrict__ ref,
+    const long long* __restrict__ shapes, const long long* __restrict__ lsi, float* __restrict__ out,
+    int S, int Lq, long long nq_total, unsigned nblk) {
+  const unsigned lb = xcd_contiguous_block(blockIdx.x, nblk);
+  const long long gq = (long long)lb * 4 + (threadIdx.x >> 6);
+  if (gq >= nq_total) return;
+  const int lane = threadIdx.x & 63;
+  const float4 acc = msda_sample_query<L, P>(value, value_stride, oa, oa_stride, pos_oa, ref, shapes, lsi, S, Lq, gq, lane);
+  st4_stream(out + gq * 256 + lane * 4, acc);            // lane = (head, 4-channel quad): column 4*lane
+}
+
+// ------------------------------------------------------------------------------------------------
+// msda_proj_ln: the whole attention half of an encoder layer after the projection GEMM,
+//   out = LayerNorm( identity + ( MSDA(value, offsets, logits) Wo^T + bo ) )
+// i.e. mmcv MultiScaleDeformableAttention.forward steps 4-8 + BaseTransformerLayer's first norm in ONE launch.
+// The sampling is bound by the texture path (profiles/r01_msda_pmc.txt: TA busy 98 %), the 256x256 output
+// projection by the matrix pipe: a workgroup gathers 64 queries into LDS (8 waves x 8 queries, lane = (head,
+// 4-channel quad) as in msda_fused_m8d32), multiplies the 64x256 tile by Wo^T on v_mfma_f32_16x16x4_f32 with the
+// weight fragments streamed from L2 (packed by pvsg_pack_rows_weight, 4 KB per query), adds bias + identity and
+// normalises the rows.  Two workgroups share a CU (66.5 KB LDS each), so one's matrix phase runs under the
+// other's gather.  Removes per layer: the 633 MB sampled-output round trip, the library GEMM launch and the
+// add_layernorm pass (another 1.9 GB).
+// ------------------------------------------------------------------------------------------------
+constexpr int MP_ROWS = 64, MP_LD = 260, MP_THREADS = 512;
+
+template <bool MAX>
+__device__ __forceinline__ float msda_wave_allreduce(float v) {
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xf, 0xf, false)));
+  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xf, 0xf, false)));
+  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xf, 0xf, false)));
+  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x140, 0xf, 0xf, false)));
+  unsigned u = __float_as_uint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = op(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  u = __float_as_uint(v);
+  auto b2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return op(__uint_as_float(b2[0]), __uint_as_float(b2[1]));
+}
+
+template <int L, int P>
+__global__ __launch_bounds__(MP_THREADS, 4) void msda_proj_ln_kernel(
+    const float* __restrict__ value, long long value_stride, const float* __restrict__ oa, long long oa_stride,
+    const float* __restrict__ pos_oa, const float* __restrict__ ref, const long long* __restrict__ shapes,
+    const long long* __restrict__ lsi, const float* __restrict__ wo, const float* __restrict__ wo_bias,
+    const float* __restrict__ identity, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ out, int S, int Lq, long long nq_total, unsigned ntiles, float eps) {
+  __shared__ __attribute__((aligned(16))) float xs[MP_ROWS * MP_LD];
+  const unsigned tile = xcd_contiguous_block(blockIdx.x, ntiles);
+  const long long q0 = (long long)tile * MP_ROWS;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // ---- phase 1: gather (wave w -> rows 8w .. 8w+7) ----------------------------------------------------
+#pragma unroll 1
+  for (int i = 0; i < 8; ++i) {
+    const int r = w * 8 + i;
+    const long long gq = q0 + r;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gq < nq_total)
+      acc = msda_sample_query<L, P>(value, value_stride, oa, oa_stride, pos_oa, ref, shapes, lsi, S, Lq, gq, lane);
+    *reinterpret_cast<float4*>(xs + r * MP_LD + lane * 4) = acc;       // lane = (head, quad) -> column 4*lane
+  }
+  __syncthreads();
+  // ---- phase 2: Y = X Wo^T, wave w -> column tiles 2w, 2w+1, all four row tiles ----------------------------
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) { acc[rt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  {
+    constexpr int DEPTH = 4;
+    const float* xa = xs + (lane & 15) * MP_LD + 4 * (lane >> 4);
+    const float* wb = wo + (long long)(2 * w) * 16 * 256 + lane * 4;     // [tile][kc][lane][4], 16 k chunks per tile
+    float4 ring[DEPTH][2];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) { ring[d][0] = ld4(wb + d * 256); ring[d][1] = ld4(wb + 16 * 256 + d * 256); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kc = 0; kc < 16; ++kc) {
+      float4 a[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) a[rt] = *reinterpret_cast<const float4*>(xa + rt * 16 * MP_LD + kc * 16);
+      const float4 b0 = ring[kc % DEPTH][0], b1 = ring[kc % DEPTH][1];
+      if (kc + DEPTH < 16) {
+        ring[kc % DEPTH][0] = ld4(wb + (kc + DEPTH) * 256);
+        ring[kc % DEPTH][1] = ld4(wb + 16 * 256 + (kc + DEPTH) * 256);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].x, b0.x, acc[rt][0], 0, 0, 0);
+        acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].x, b1.x, acc[rt][1], 0, 0, 0);
+        acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].y, b0.y, acc[rt][0], 0, 0, 0);
+        acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].y, b1.y, acc[rt][1], 0, 0, 0);
+        acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].z, b0.z, acc[rt][0], 0, 0, 0);
+        acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].z, b1.z, acc[rt][1], 0, 0, 0);
+        acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].w, b0.w, acc[rt][0], 0, 0, 0);
+        acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].w, b1.w, acc[rt][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();                                                   // every wave is done reading X
+  {
+    const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int col = (2 * w + c) * 16 + j;
+      const float bv = wo_bias ? wo_bias[col] : 0.f;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xs[(rt * 16 + 4 * g + e) * MP_LD + col] = acc[rt][c][e] + bv;
+    }
+  }
+  __syncthreads();
+  // ---- phase 3: + identity, LayerNorm, coalesced row stores (wave w -> rows 8w .. 8w+7) ------------------------
+  const float4 gm = ld4(gamma + lane * 4), bt = ld4(beta + lane * 4);
+#pragma unroll 2
+  for (int i = 0; i < 8; ++i) {
+    const int r = w * 8 + i;
+    const long long gq = q0 + r;
+    if (gq >= nq_total) break;
+    float4 x = *reinterpret_cast<const float4*>(xs + r * MP_LD + lane * 4);
+    const float4 idv = ld4_stream(identity + gq * 256 + lane * 4);
+    x.x += idv.x; x.y += idv.y; x.z += idv.z; x.w += idv.w;
+    const float mean = msda_wave_allreduce<false>(x.x + x.y + x.z + x.w) * (1.f / 256.f);
+    const float dx = x.x - mean, dy = x.y - mean, dz = x.z - mean, dw = x.w - mean;
+    const float var = msda_wave_allreduce<false>(dx * dx + dy * dy + dz * dz + dw * dw) * (1.f / 256.f);
+    const float rstd = rsqrtf(var + eps);
+    st4_stream(out + gq * 256 + lane * 4,
+               make_float4(dx * rstd * gm.x + bt.x, dy * rstd * gm.y + bt.y, dz * rstd * gm.z + bt.z, dw * rstd * gm.w + bt.w));
+  }
 }
 
 // out = LayerNorm(a + b + bias) * gamma + beta over the last dim C = 256; one wave per row.
@@ -352,6 +480,36 @@ extern "C" int pvsg_msda_fused_forward(const float* value, long long value_row_s
                      oa_row_stride, pos_oa, ref_points, reinterpret_cast<const long long*>(spatial_shapes),
                      reinterpret_cast<const long long*>(level_start_index), out, S, Lq, nq, nblk);
   PVSG_LAUNCH_CHECK("msda_fused_forward");
+  return PVSG_OK;
+}
+
+extern "C" int pvsg_msda_proj_ln_forward(const float* value, long long value_row_stride, const float* oa,
+                                         long long oa_row_stride, const float* pos_oa, const float* ref_points,
+                                         const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                         const float* wo_packed, const float* wo_bias, const float* identity,
+                                         const float* gamma, const float* beta, float* out, int B, int S, int M,
+                                         int D, int Lq, int L, int P, float eps, hipStream_t stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(value && oa && ref_points && spatial_shapes && level_start_index && wo_packed && identity && gamma &&
+                   beta && out, "msda_proj_ln_forward: null pointer argument");
+  PVSG_REQUIRE(B > 0 && S > 0 && Lq > 0, "msda_proj_ln_forward: non-positive dimension");
+  if (M != 8 || D != 32 || L != 3 || P != 4)
+    return set_err(PVSG_ERR_UNSUPPORTED, "msda_proj_ln_forward: built for M=8 D=32 L=3 P=4 (got %d %d %d %d)", M, D, L, P);
+  PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(oa) |
+                  reinterpret_cast<uintptr_t>(pos_oa) | reinterpret_cast<uintptr_t>(out) |
+                  reinterpret_cast<uintptr_t>(wo_packed) | reinterpret_cast<uintptr_t>(identity) |
+                  reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15u) &&
+               !(value_row_stride & 3) && !(oa_row_stride & 3) && value_row_stride >= M * D,
+               "msda_proj_ln_forward: 16-byte alignment / row strides multiple of 4 floats required");
+  const long long nq = (long long)B * Lq;
+  const long long nt = (nq + MP_ROWS - 1) / MP_ROWS;
+  PVSG_REQUIRE(nt < (1ll << 31), "msda_proj_ln_forward: too many queries");
+  hipLaunchKernelGGL((msda_proj_ln_kernel<3, 4>), dim3((unsigned)nt), dim3(MP_THREADS), 0, stream, value,
+                     value_row_stride, oa, oa_row_stride, pos_oa, ref_points,
+                     reinterpret_cast<const long long*>(spatial_shapes),
+                     reinterpret_cast<const long long*>(level_start_index), wo_packed, wo_bias, identity, gamma, beta,
+                     out, S, Lq, nq, (unsigned)nt, eps);
+  PVSG_LAUNCH_CHECK("msda_proj_ln_forward");
   return PVSG_OK;
 }
 

@@ -308,6 +308,28 @@ def msda_fused(y, pos_oa, ref_points, spatial_shapes, level_start_index, num_hea
     return out
 
 
+def msda_proj_ln(y, pos_oa, ref_points, spatial_shapes, level_start_index, wo_packed, wo_bias, identity, norm,
+                 num_heads=8, num_levels=3, num_points=4):
+    """LayerNorm(identity + MSDA(y) Wo^T + bo): msda_fused + output_proj + residual + norm in one launch.
+    wo_packed = pack_rows_weight(output_proj.weight); identity (B,S,256); norm an nn.LayerNorm(256)."""
+    y = _chk(y, 'y')
+    B, S, W = y.shape
+    C = W - num_heads * num_levels * num_points * 3
+    pos = _chk(pos_oa, 'pos_oa') if pos_oa is not None else None
+    ref = _chk(ref_points, 'ref_points')
+    ss = _chk(spatial_shapes, 'spatial_shapes', torch.int64)
+    lsi = _chk(level_start_index, 'level_start_index', torch.int64)
+    idt = _chk(identity, 'identity')
+    out = torch.empty((B, S, C), device=y.device, dtype=torch.float32)
+    with torch.cuda.device(y.device):
+        _lib.call('pvsg_msda_proj_ln_forward', y.data_ptr(), W, y.data_ptr() + 4 * C, W,
+                  pos.data_ptr() if pos is not None else None, ref.data_ptr(), ss.data_ptr(), lsi.data_ptr(),
+                  wo_packed.data_ptr(), wo_bias.data_ptr() if wo_bias is not None else None, idt.data_ptr(),
+                  norm.weight.data_ptr(), norm.bias.data_ptr(), out.data_ptr(), B, S, num_heads, C // num_heads, S,
+                  num_levels, num_points, float(norm.eps), _stream_ptr())
+    return out
+
+
 def add_layernorm(a, b, bias, norm):
     """LayerNorm(a + b + bias) with `norm` an nn.LayerNorm(256): residual add + norm in one pass."""
     a = _chk(a, 'a')

@@ -81,6 +81,18 @@ def test_msda_fused_equals_oracle(hip_lib, B, h0w0, scale):
     a = ops.msda_fused(y.to(DEV), pos_oa.to(DEV), ref.to(DEV), ss.to(DEV), lsi.to(DEV))
     sc = float(expect.abs().max())
     np.testing.assert_allclose(a.cpu().numpy(), expect.numpy(), rtol=1e-4, atol=2e-5 * sc)
+    # the same sampling with the output projection + identity + LayerNorm fused behind it (msda_proj_ln), against
+    # the oracle's samples pushed through plain torch: Linear, add, layer_norm (incl. a partial last 64-query tile)
+    wo, bo = det_input('wo', (256, 256), 5, 0.08), det_input('bo', (256,), 6, 0.1)
+    idt = det_input('identity', (B, S, 256), 7)
+    norm = torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        norm.weight.copy_(1.0 + 0.2 * det_input('g', (256,), 8))
+        norm.bias.copy_(0.1 * det_input('b', (256,), 9))
+        want = norm(idt + torch.nn.functional.linear(expect, wo, bo))
+        got = ops.msda_proj_ln(y.to(DEV), pos_oa.to(DEV), ref.to(DEV), ss.to(DEV), lsi.to(DEV),
+                               ops.pack_rows_weight(wo.to(DEV)), bo.to(DEV), idt.to(DEV), norm.to(DEV))
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
 
 
 def test_backbone_fused_bn_act_equals_plain(hip_lib):
