@@ -70,6 +70,7 @@ def parse():
                          'to the head outputs so that ~--keep tubes reach the relation head; model: raw random-init outputs')
     ap.add_argument('--keep', type=int, default=32)
     ap.add_argument('--sub-benchmarks', default='on', choices=['on', 'off'])
+    ap.add_argument('--no-flop-count', action='store_true', help='skip the extra untimed flop-counting step (profiling runs)')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--scaling', default='strong', choices=['weak', 'strong'],
                     help='N>1: strong (default, BASELINE config 4) = ONE 32-frame clip sharded by frame, 32/N frames per '
@@ -158,8 +159,8 @@ class KernelTimer:
         timer = self
 
         def timed(name, *args):
-            if not timer.enabled:
-                return orig(name, *args)
+            if not timer.enabled or torch.cuda.is_current_stream_capturing():
+                return orig(name, *args)          # launches being captured into a hipGraph cannot carry timing events
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             orig(name, *args)
@@ -457,6 +458,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     torch.backends.cudnn.benchmark = os.environ.get("PVSG_MIOPEN_FIND", "0") == "1"  # exhaustive MIOpen find costs ~5 min per fresh box
+    # deterministic MIOpen kernels (no split-K atomics): the step becomes bitwise reproducible run to run
+    torch.backends.cudnn.deterministic = os.environ.get('PVSG_DETERMINISTIC', '1') == '1'
     gemm_table = False
     if os.environ.get('PVSG_GEMM_TABLE', 'on') != 'off':
         from openpvsg_amd import tuning
@@ -524,8 +527,10 @@ def main():
 
     # one extra UNTIMED step under torch's flop counter: algorithmic flops of the library ops (mm / addmm / bmm /
     # convolution); the hand-written kernels' own counts come from KernelTimer.work
-    lib_flops = None
+    lib_flops = hw_flops_one = None
     try:
+        if args.no_flop_count:
+            raise RuntimeError('skipped')
         from torch.utils.flop_counter import FlopCounterMode
         n0 = len(timer.records)
         timer.enabled = bool(timer.records)

@@ -8,6 +8,8 @@ frames = None -> zeros in utils/relation_matching.py:431-444), written to query_
 tools/rel_test.py:33-66 then scores relations on `feats [N,T,256]`.
 Here the same records stay on the GPU: kept segment ids per frame -> tube index -> `feats`.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -16,10 +18,15 @@ from . import parallel
 
 def assemble_tubes(seg_ids, kept_feats, num_frames):
     """seg_ids: list over frames of (K_t,) int64 tensors (-1 = dropped), kept_feats: list of (K_t,C)
-    -> (tube_ids (N,) sorted by first appearance, feats (N,T,C) with zeros where absent)."""
+    -> (tube_ids (N,) sorted by first appearance, feats (N,T,C) with zeros where absent).
+    One device->host transfer (the segment ids), one host->device transfer (the scatter indices)."""
     dev = kept_feats[0].device if kept_feats else torch.device('cpu')
     C = kept_feats[0].shape[-1] if kept_feats else 256
-    host = [s.tolist() for s in seg_ids]                    # one small transfer per frame
+    same_k = len({int(s.numel()) for s in seg_ids}) <= 1
+    if seg_ids and same_k:
+        host = torch.stack([s.reshape(-1) for s in seg_ids]).tolist()       # the one sync of the stage
+    else:
+        host = [s.tolist() for s in seg_ids]
     order = []
     seen = set()
     for ids in host:
@@ -29,15 +36,28 @@ def assemble_tubes(seg_ids, kept_feats, num_frames):
                 order.append(sid)
     index = {sid: i for i, sid in enumerate(order)}
     feats = torch.zeros((len(order), num_frames, C), dtype=torch.float32, device=dev)
+    rows, ts, cols = [], [], []
     for t, ids in enumerate(host):
         first = {}
         for k, sid in enumerate(ids):
             if sid >= 0 and sid not in first:               # `feat[0]` of the id's list (utils.py:48)
                 first[sid] = k
-        if first:
-            rows = torch.tensor([index[s] for s in first], device=dev)
-            cols = torch.tensor(list(first.values()), device=dev)
-            feats[rows, t] = kept_feats[t][cols]
+        for sid, k in first.items():
+            rows.append(index[sid])
+            ts.append(t)
+            cols.append(k)
+    if rows:
+        shared = all(f is kept_feats[0] for f in kept_feats)                 # clip mode: one kept set for all frames
+        idx = torch.tensor([rows, ts, cols], dtype=torch.long, device=dev)
+        if shared:
+            feats[idx[0], idx[1]] = kept_feats[0][idx[2]]
+        else:
+            offs, tot = [], 0
+            for f in kept_feats:
+                offs.append(tot)
+                tot += f.shape[0]
+            flat = torch.cat(kept_feats, 0)
+            feats[idx[0], idx[1]] = flat[idx[2] + torch.tensor(offs, dtype=torch.long, device=dev)[idx[1]]]
     return torch.tensor(order, dtype=torch.long, device=dev), feats
 
 
@@ -57,6 +77,10 @@ class PVSGPipeline(torch.nn.Module):
         # benchmarks only: callable (cls, masks4) -> (cls, masks4) applied to the head's outputs before fusion
         # (synthetic class logits / mask-logit offsets with a controlled keep count)
         self.head_override = None
+        # the relation head is ~100 launches of microsecond kernels behind the host sync of tube assembly: replayed as
+        # one hipGraph per (N tubes, T frames) shape (second time a shape is seen); PVSG_RELATION_GRAPH=off disables
+        self.relation_graph = os.environ.get('PVSG_RELATION_GRAPH', 'on') != 'off'
+        self._rel_graphs, self._rel_seen = {}, {}
 
     def _graphed_forward(self, clip):
         """backbone + pixel decoder + decoder (about 2 000 launches, static shapes, no host sync) replayed as
@@ -96,6 +120,45 @@ class PVSGPipeline(torch.nn.Module):
         # the graph's output buffers are overwritten by the next replay: hand out copies of the small ones
         # (masks4, 0.75 GB at 32 x 720p, is consumed by the fusion kernels of this same call)
         return cls.clone(), masks4, q.clone()
+
+    def _relation(self, feats):
+        from .relation import relation_forward
+
+        def run(x):
+            return relation_forward(self.subject_encoder, self.object_encoder, self.pair_model, self.relation_model,
+                                    x, self.num_top_pairs)
+        if not self.relation_graph or not feats.is_cuda or torch.cuda.is_current_stream_capturing():
+            return run(feats)
+        key = (tuple(feats.shape), str(feats.device))
+        ent = self._rel_graphs.get(key)
+        if ent is None:
+            self._rel_seen[key] = self._rel_seen.get(key, 0) + 1
+            if self._rel_seen[key] < 2:
+                return run(feats)                      # first sighting of this shape: eager (also warms the libraries)
+            try:
+                static_in = feats.clone()
+                side = torch.cuda.Stream(device=feats.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    run(static_in)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = run(static_in)
+                ent = (graph, static_in, static_out)
+            except Exception as e:
+                import warnings
+                warnings.warn('hipGraph capture of the relation head failed (%r); running eagerly' % (e,))
+                ent = False
+            if len(self._rel_graphs) >= 16:                  # bounded: tube counts vary from clip to clip
+                self._rel_graphs.pop(next(iter(self._rel_graphs)))
+            self._rel_graphs[key] = ent
+        if ent is False:
+            return run(feats)
+        graph, static_in, static_out = ent
+        static_in.copy_(feats)
+        graph.replay()
+        return {k: v.clone() for k, v in static_out.items()}     # small tensors; the static ones are reused next replay
 
     @torch.no_grad()
     def vps_clip(self, clip, batch_input_shape, img_shape=None, total_frames=None, group=None, solo=False):
@@ -182,6 +245,5 @@ class PVSGPipeline(torch.nn.Module):
         tube_ids, feats = assemble_tubes(seg_ids, k_feats, T)
         rel = None
         if feats.shape[0] >= 2:
-            rel = relation_forward(self.subject_encoder, self.object_encoder, self.pair_model,
-                                   self.relation_model, feats, self.num_top_pairs)
+            rel = self._relation(feats)
         return dict(pan_results=pans, tube_ids=tube_ids, tube_feats=feats, relation=rel, cls=cls, query=q)

@@ -33,7 +33,7 @@ def run_pass(counter, frames, workdir):
     out = os.path.join(workdir, counter)
     cmd = ['rocprofv3', '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', out, '--',
            sys.executable, os.path.join(ROOT, 'bench.py'), '--frames', str(frames), '--steps', '1', '--warmup', '1',
-           '--cpu-baseline', 'off', '--sub-benchmarks', 'off', '--no-kernel-timing']
+           '--cpu-baseline', 'off', '--sub-benchmarks', 'off', '--no-kernel-timing', '--no-flop-count']
     env = dict(os.environ, TMPDIR='/tmp')
     subprocess.run(cmd, cwd='/tmp', env=env, check=True, stdout=subprocess.DEVNULL)
     files = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
@@ -77,7 +77,7 @@ def main():
                           hbm_read_bytes_per_launch=fk * 1024 * 2, hbm_write_bytes_per_launch=wk * 1024,
                           hbm_bytes_per_launch=fk * 1024 * 2 + wk * 1024)
     out['_source'] = dict(commands=[cmd_f, cmd_w], note='mean over every launch of the kernel in a 1 warm-up + 1 timed '
-                          '+ 1 flop-count step run; kernels with several shapes per step (conv1x1, affine, xattn) are '
+                          'step run; kernels with several shapes per step (conv1x1, affine, xattn) are '
                           'per-launch means over those shapes')
     json.dump(out, open(a.out, 'w'), indent=1)
     if a.keep_csv:
