@@ -53,6 +53,20 @@ class ModuleList(BaseModule, nn.ModuleList):
 # ------------------------------------------------------------------------------------------------
 # positional encodings (cached per shape: the padding mask is all-False on this path)
 # ------------------------------------------------------------------------------------------------
+class _ShapeCache(dict):
+    """Shape-keyed cache with a bound: inputs of varying size (keep_ratio resizing) must not grow it forever;
+    the oldest entry goes first."""
+
+    def __init__(self, limit=16):
+        super().__init__()
+        self.limit = limit
+
+    def __setitem__(self, k, v):
+        if k not in self and len(self) >= self.limit:
+            del self[next(iter(self))]
+        super().__setitem__(k, v)
+
+
 def _interleave_sin_cos(p):
     return torch.stack((p[..., 0::2].sin(), p[..., 1::2].cos()), dim=-1).flatten(-2)
 
@@ -66,7 +80,7 @@ class SinePositionalEncoding(BaseModule):
         super().__init__(init_cfg)
         self.num_feats, self.temperature, self.normalize = num_feats, temperature, normalize
         self.scale, self.eps, self.offset = scale, eps, offset
-        self._cache = {}
+        self._cache = _ShapeCache()
 
     def grid(self, h, w, device):
         """(2*num_feats, h, w) encoding of an unpadded h x w map (batch independent)."""
@@ -101,7 +115,7 @@ class SinePositionalEncoding3D(BaseModule):
         super().__init__(init_cfg)
         self.num_feats, self.temperature, self.normalize = num_feats, temperature, normalize
         self.scale, self.eps, self.offset = scale, eps, offset
-        self._cache = {}
+        self._cache = _ShapeCache()
 
     def grid(self, T, h, w, device, t0=0, t_total=None):
         """(T, 2*num_feats, h, w) for frames t0..t0+T-1 of a clip of t_total frames (frame shards on
@@ -486,7 +500,7 @@ class MSDeformAttnPixelDecoder(BaseModule):
                                                 norm_cfg=norm_cfg, act=act_cfg is not None))
         self.mask_feature = nn.Conv2d(feat_channels, out_channels, 1)
         self.num_outs = num_outs
-        self._geom = {}
+        self._geom = _ShapeCache()
 
     def init_weights(self):
         for m in list(self.input_convs) + list(self.lateral_convs) + list(self.output_convs):

@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 // ---- status codes shared with include/openpvsg_hip.h ----------------------
 #define PVSG_OK 0
 #define PVSG_ERR_INVALID_ARG 1
@@ -60,6 +62,18 @@ __device__ __forceinline__ void st4_stream(float* p, float4 v) {
   typedef float v4 __attribute__((ext_vector_type(4)));
   v4 t = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(t, reinterpret_cast<v4*>(p));
+}
+
+// Dynamic LDS above 64 KB needs an opt-in per kernel function; done once per (function, device) -- one `done` mask per
+// call site, bit = device ordinal.  Racing threads at worst set the same value twice.
+inline hipError_t ensure_dynamic_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -291,12 +291,10 @@ extern "C" int pvsg_conv1x1_affine(const float* weight, const float* x, const fl
   PVSG_REQUIRE(lds <= 128 * 1024, "conv1x1_affine: weight panel does not fit LDS");
   const bool deep = (Cin % 64) == 0;
   const auto kern = deep ? conv1x1_affine_deep_kernel<CMT> : conv1x1_affine_kernel<CMT>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[deep]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       128 * 1024);
+  static std::atomic<unsigned long long> attr_done[2];
+  {
+    const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 128 * 1024, attr_done[deep]);
     if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "conv1x1_affine: LDS attribute: %s", hipGetErrorString(e));
-    attr_set[deep] = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(B * mgroups * wgs)), dim3(512), lds, stream, weight, x, scale, shift, residual,
                      out, Cout, Cin, (int)HW, relu, mw, mgroups, wgs);

@@ -515,8 +515,11 @@ extern "C" int pvsg_decoder_rows_post(const pvsg_decoder_layer* layer, const pvs
     L = *layer;
   }
   const int tiles = (Q + 15) / 16;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decoder_rows_post_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)DR_POST_LDS);
+  static std::atomic<unsigned long long> attr_done;
+  {
+    const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&decoder_rows_post_kernel), (int)DR_POST_LDS, attr_done);
+    if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "decoder_rows_post: LDS attribute: %s", hipGetErrorString(e));
+  }
   hipLaunchKernelGGL(decoder_rows_post_kernel, dim3(B * tiles), dim3(DR_THREADS), DR_POST_LDS, stream, L, *head,
                      layer ? 1 : 0, next_q_w, next_q_b, x1, qkv, query_pos, query_out, cls_out, mask_embed_out,
                      next_q_out, Q, tiles, 0.17677669529663687f, 1e-5f);

@@ -259,6 +259,8 @@ __global__ __launch_bounds__(256) void center_downsample_kernel(const float* __r
   }
 }
 
+constexpr size_t MASK_GEMM_MAX_LDS = (size_t)(320 / 16) * QT * 64 * 4 * sizeof(float);   // C <= 320 (checked by the callers)
+
 static int launch_cfg(int B, int T, int N, int* tiles_per_img, int* wgs_per_b) {
   *tiles_per_img = (N + TILE_N - 1) / TILE_N;
   const long long ntiles = (long long)T * *tiles_per_img;
@@ -287,14 +289,16 @@ extern "C" int pvsg_mask_logits_forward(const float* mask_embed, const float* ma
   launch_cfg(B, T, N, &tpi, &wpb);
   const size_t lds = (size_t)(C / 16) * QT * 64 * 4 * sizeof(float);
   if (vec) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_gemm_kernel<MODE_LOGITS, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static std::atomic<unsigned long long> attr_done_1;
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(&mask_gemm_kernel<MODE_LOGITS, true>), (int)MASK_GEMM_MAX_LDS, attr_done_1) != hipSuccess)
+      return set_err(PVSG_ERR_HIP, "mask_gemm: cannot reserve %zu bytes of LDS", lds);
     hipLaunchKernelGGL((mask_gemm_kernel<MODE_LOGITS, true>), dim3(B * wpb), dim3(512), lds, stream,
                        mask_embed, mask_feature, out, (uint32_t*)nullptr, (uint32_t*)nullptr, Q, C, N,
                        T, tpi, wpb);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_gemm_kernel<MODE_LOGITS, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static std::atomic<unsigned long long> attr_done_2;
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(&mask_gemm_kernel<MODE_LOGITS, false>), (int)MASK_GEMM_MAX_LDS, attr_done_2) != hipSuccess)
+      return set_err(PVSG_ERR_HIP, "mask_gemm: cannot reserve %zu bytes of LDS", lds);
     hipLaunchKernelGGL((mask_gemm_kernel<MODE_LOGITS, false>), dim3(B * wpb), dim3(512), lds, stream,
                        mask_embed, mask_feature, out, (uint32_t*)nullptr, (uint32_t*)nullptr, Q, C, N,
                        T, tpi, wpb);
@@ -320,13 +324,15 @@ extern "C" int pvsg_attn_mask_bits_forward(const float* mask_embed, const float*
   launch_cfg(B, T, N, &tpi, &wpb);
   const size_t lds = (size_t)(C / 16) * QT * 64 * 4 * sizeof(float);
   if (vec) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_gemm_kernel<MODE_BITS, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static std::atomic<unsigned long long> attr_done_3;
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(&mask_gemm_kernel<MODE_BITS, true>), (int)MASK_GEMM_MAX_LDS, attr_done_3) != hipSuccess)
+      return set_err(PVSG_ERR_HIP, "mask_gemm: cannot reserve %zu bytes of LDS", lds);
     hipLaunchKernelGGL((mask_gemm_kernel<MODE_BITS, true>), dim3(B * wpb), dim3(512), lds, stream,
                        mask_embed, feature_lowres, (float*)nullptr, bits, flags, Q, C, N, T, tpi, wpb);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_gemm_kernel<MODE_BITS, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static std::atomic<unsigned long long> attr_done_4;
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(&mask_gemm_kernel<MODE_BITS, false>), (int)MASK_GEMM_MAX_LDS, attr_done_4) != hipSuccess)
+      return set_err(PVSG_ERR_HIP, "mask_gemm: cannot reserve %zu bytes of LDS", lds);
     hipLaunchKernelGGL((mask_gemm_kernel<MODE_BITS, false>), dim3(B * wpb), dim3(512), lds, stream,
                        mask_embed, feature_lowres, (float*)nullptr, bits, flags, Q, C, N, T, tpi, wpb);
   }

@@ -308,11 +308,12 @@ extern "C" int pvsg_masked_xattn_partial(const float* q_proj, const float* k_pro
   // ranges past the end are legal: they publish (m=-inf, l=0, o=0) and the merge skips them
   chunk = (chunk + TK - 1) / TK * TK;
   const size_t lds = (size_t)2 * XLDS_TILE_FLOATS * sizeof(float);
-  // once per process (the attribute belongs to the function, not to a device or a launch)
-  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_partial_lds_kernel),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (attr_rc != hipSuccess)
-    return set_err(PVSG_ERR_HIP, "masked_xattn_partial: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(attr_rc));
+  static std::atomic<unsigned long long> attr_done;
+  {
+    const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&xattn_partial_lds_kernel), (int)lds, attr_done);
+    if (e != hipSuccess)
+      return set_err(PVSG_ERR_HIP, "masked_xattn_partial: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+  }
   hipLaunchKernelGGL(xattn_partial_lds_kernel, dim3(B * NS), dim3(512), lds, stream, q_proj, k_proj, v_proj,
                      mask_bits, mask_flags, part_o, part_ml, Q, K, NS, chunk);
   PVSG_LAUNCH_CHECK("masked_xattn_partial");

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void minvis_chain_kernel(const float* __restri
                                                           int* __restrict__ perm_out, int T, int Q, int C) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* cost = sm;                         // [Q][Q]  rows = target slot j, cols = current query i
-  float* ncur = cost + Q * Q;               // [Q] 1/|cur_i|
+  float* ncur = cost + ((Q * Q + 1) & ~1);  // [Q] 1/|cur_i|  (cost region rounded to 8 bytes: `u` below is float64)
   float* ntgt = ncur + MQ;                  // [Q] 1/|tgt_j|
   double* u = reinterpret_cast<double*>(ntgt + MQ);   // [Q+1] row potentials (1-based)
   int* pprev = reinterpret_cast<int*>(u + MQ + 1);    // [Q] previous frame's permutation
@@ -144,7 +144,7 @@ extern "C" int pvsg_minvis_chain(const float* embds, int* perm, int V, int T, in
   PVSG_REQUIRE(V > 0 && T > 0 && Q > 0 && C > 0, "minvis_chain: non-positive dimension");
   if (Q > MQ || (C & 3) || (reinterpret_cast<uintptr_t>(embds) & 15u))
     return set_err(PVSG_ERR_UNSUPPORTED, "minvis_chain: needs Q <= 128, C %% 4 == 0, 16-byte aligned embeddings (Q=%d C=%d)", Q, C);
-  const size_t lds = (size_t)Q * Q * 4 + 2 * MQ * 4 + (MQ + 1) * 8 + 2 * MQ * 4 + 16;
+  const size_t lds = (size_t)((Q * Q + 1) & ~1) * 4 + 2 * MQ * 4 + (MQ + 1) * 8 + 2 * MQ * 4 + 16;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&minvis_chain_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(minvis_chain_kernel, dim3(V), dim3(256), lds, stream, embds, perm, T, Q, C);

@@ -136,6 +136,11 @@ class _Mask2FormerHeadBase(BaseModule):
         self.num_things_classes, self.num_stuff_classes = num_things_classes, num_stuff_classes
         self.num_classes = num_things_classes + num_stuff_classes
         self.num_queries = num_queries
+        if num_queries > ops.MAX_QUERIES:
+            # fail at construction, not at the first forward (mask GEMM / masked attention keep all queries of a key
+            # tile in registers: 7 row tiles of 16)
+            raise ValueError('num_queries=%d: the HIP mask-projection and masked-attention kernels are built for at most '
+                             '%d queries (INTEGRATION.md, "Built-in limits")' % (num_queries, ops.MAX_QUERIES))
         self.num_transformer_feat_level = num_transformer_feat_level
         self.num_heads = transformer_decoder.transformerlayers.attn_cfgs.num_heads
         self.num_transformer_decoder_layers = transformer_decoder.num_layers

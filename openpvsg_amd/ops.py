@@ -258,6 +258,7 @@ def panoptic_fuse(mask_logits, kept_idx, kept_score, kept_class, out_hw, crop_hw
     return pan, seg
 
 
+MAX_QUERIES = 112              # mask_gemm.hip / masked_xattn.hip: 7 query tiles of 16
 PANOPTIC_FUSE_MAX_KEPT = 127   # kept-query tables of postprocess.hip live in LDS (MAXK - 1)
 
 

@@ -108,3 +108,15 @@ def test_product_refuses_cpu_forward():
     with pytest.raises(RuntimeError, match='no CPU path'):
         with torch.no_grad():
             h.simple_test_with_query(feats, [dict(batch_input_shape=(32, 36))])
+
+
+def test_unsupported_num_queries_fails_at_construction():
+    """A config the HIP kernels cannot serve (more than 112 queries) is rejected when the head is BUILT, with a clear
+    message, not at the first forward."""
+    import pytest
+    from openpvsg_amd import blocks, heads  # noqa: F401
+    from openpvsg_amd.model_zoo import panoptic_head_cfg
+    from openpvsg_amd.registry import build_head
+    cfg = dict(panoptic_head_cfg(False), train_cfg=None, test_cfg=None, num_queries=200)
+    with pytest.raises(ValueError, match='at most 112 queries'):
+        build_head(cfg)

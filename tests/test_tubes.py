@@ -193,3 +193,91 @@ def test_concat_seq_equals_reference_records(tmp_path, golden_dir, case):
             tid = object_list.index(sid) + 1
             m = [d[t] for d in back[tid]['mask'] if t in d][0]
             assert (m == (o[0]['pan_results'] == sid)).all()
+
+
+@pytest.mark.gpu
+def test_device_tubes_to_files_to_relation_evaluate(hip_lib, tmp_path):
+    """SURVEY section 8f row 2 end to end on the GPU: clip-level VPS forward -> device tube assembly (pipeline.py) and,
+    from the SAME per-frame results, the reference's file route: concat_seq -> masks.txt + query_feats.pickle ->
+    process_feats -> relations.pickle -> PVSGRelationDataset -> DataLoader -> relation.evaluate (tools/rel_test.py).
+    Both routes must see the same tubes and select the same pairs."""
+    import json
+    from oracle.detweights import det_state_dict
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from openpvsg_amd import relation as prel
+    from openpvsg_amd.pipeline import PVSGPipeline
+    dev = torch.device('cuda:0')
+    det, rel = bench.build_models(0)
+    for i, m in enumerate(rel.values()):
+        m.load_state_dict(det_state_dict(m, 30 + i))
+    det = det.to(dev)
+    rel = {k: v.to(dev) for k, v in rel.items()}
+    pipe = PVSGPipeline(det, rel['subject_encoder'], rel['object_encoder'], rel['pair_model'], rel['relation_model']).eval()
+    pipe.relation_graph = False
+    T, H, W = 6, 128, 192
+    clip, (Hp, Wp) = bench.make_clip(T, H, W)
+    syn = bench.synthetic_head_outputs(T, Hp // 4, Wp // 4, n_keep=12)
+    pipe.head_override = bench.make_override(syn, dev)
+    out = pipe(clip.to(dev), (Hp, Wp), (H, W))
+    N = out['tube_feats'].shape[0]
+    assert N >= 6 and out['relation'] is not None
+    # the per-frame records a detector hands to concat_seq (tools/prepare_query_tube_vps.py:244-256)
+    kept_feats = out['query'][:, 0][pipe._last_keep]
+    pan_np = out['pan_results'].cpu().numpy()
+    # segment id of every kept query in every frame: the fusion kernel again on the same head outputs
+    frames = []
+    fused_seg = det.panoptic_fusion_head.panoptic_fused(out['cls'][0], _masks_for(pipe, det, clip.to(dev), T) + syn[1].to(dev),
+                                                        (Hp, Wp), (H, W))[1].tolist()
+    for t in range(T):
+        qd = {}
+        for k, sid in enumerate(fused_seg[t]):
+            if sid >= 0:
+                qd.setdefault(sid, []).append(kept_feats[k])
+        frames.append([dict(pan_results=pan_np[t], query_feats=qd)])
+    tb, _ = tubes.concat_seq(frames, str(tmp_path / 'vid0'))
+    feats_file = tubes.process_feats(pickle.load(open(tmp_path / 'vid0' / 'query_feats.pickle', 'rb')))
+    # 1. same tubes on both routes (ids by first appearance, zeros where absent)
+    assert len(tb) == N and sorted(feats_file) == list(range(1, N + 1))
+    dev_feats = out['tube_feats'].cpu().numpy()
+    for i in range(N):
+        np.testing.assert_allclose(feats_file[i + 1], dev_feats[i], rtol=0, atol=0)
+    back = tubes.read_mots_results(str(tmp_path / 'vid0' / 'quantitive' / 'masks.txt'))
+    tid_of = {int(s): i + 1 for i, s in enumerate(out['tube_ids'].tolist())}
+    for t in range(T):
+        for sid in frames[t][0]['query_feats']:
+            m = [d[t] for d in back[tid_of[sid]]['mask'] if t in d][0]
+            assert (m.astype(bool) == (pan_np[t] == sid)).all()
+    # 2. relations.pickle -> dataset -> evaluate
+    gts = [(1, 2, 3, [[0, T]]), (2, 1, 5, [[1, 4]]), (3, 1, 7, [[0, 2]])]            # the last one spans < 3 frames: dropped
+    tube_dict = {t.track_id: t.qf_tube for t in tb}
+    tubes.write_relations_pickle(str(tmp_path / 'wd'), 'v1', gts, tube_dict)
+    anno = dict(split=dict(vidor=dict(val=['v1']), epic_kitchen=dict(val=[]), ego4d=dict(val=[])),
+                objects=dict(thing=['a'], stuff=['b']), relations=[str(i) for i in range(57)], data=[dict(video_id='v1')])
+    (tmp_path / 'pvsg.json').write_text(json.dumps(anno))
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'openpvsg_amd', 'compat')
+    sys.path.insert(0, compat)
+    try:
+        for k in [k for k in sys.modules if k.split('.')[0] == 'datasets']:
+            del sys.modules[k]
+        from datasets import PVSGRelationDataset
+    finally:
+        sys.path.remove(compat)
+    ds = PVSGRelationDataset(str(tmp_path / 'pvsg.json'), 'val', str(tmp_path / 'wd'))
+    item = ds[0]
+    assert item['feats'].shape == (N, T, 256) and len(item['relations']) == 2
+    loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False)
+    final, prl = prel.evaluate(rel['subject_encoder'], rel['object_encoder'], rel['pair_model'], rel['relation_model'],
+                               loader, 100, ds.relations, dev, verbose=False)
+    assert set(final) == {20, 50, 100} and 0.0 <= prl[0] <= 1.0
+    # the file route feeds the relation head the same tensor, so it must pick the same pairs
+    with torch.no_grad():
+        again = prel.relation_forward(rel['subject_encoder'], rel['object_encoder'], rel['pair_model'], rel['relation_model'],
+                                      torch.as_tensor(item['feats']).float().to(dev), 100)
+    assert again['pairs'].tolist() == out['relation']['pairs'].tolist()
+    np.testing.assert_allclose(again['pred_matrix'].cpu().numpy(), out['relation']['pred_matrix'].cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def _masks_for(pipe, det, clip, T):
+    with torch.no_grad():
+        return det.panoptic_head.clip_logits(det.extract_feat(clip), 1, T)[1][0]
