@@ -100,6 +100,16 @@ int pvsg_masked_xattn_partial(const float* q_proj, const float* k_proj, const fl
                               void* stream);
 int pvsg_xattn_combine(const float* part_o, const float* part_ml, float* out, int B, int Q, int M,
                        int D, int NS, void* stream);
+/* Frame-sharded clip (BASELINE config 4): ONE message per decoder layer and rank.
+ * pvsg_xattn_merge_local: a rank's NS key-range partials -> one packed record per batch element,
+ *   packed (B, REC) floats, REC = M*Q*(D+2) + 4 = [o (M,Q,D) un-normalised | (m, l) (M,Q,2) | the rank's 128 flag bits];
+ *   mask_flags (B,4) = "query has an unblocked key among this rank's keys" (NULL: no mask).
+ * pvsg_xattn_combine_packed: packed (R, B, REC) = the all-gathered records of R ranks -> out (B, Q, M*D).  A rank whose
+ *   keys are all blocked for a query attended unmasked (the reset of mask2former_head.py:453-454 is decided by the whole
+ *   clip); its contribution counts only if every rank reported the query blocked -- no flag exchange before the attention. */
+int pvsg_xattn_merge_local(const float* part_o, const float* part_ml, const uint32_t* mask_flags, float* packed,
+                           int B, int Q, int M, int D, int NS, void* stream);
+int pvsg_xattn_combine_packed(const float* packed, float* out, int R, int B, int Q, int M, int D, void* stream);
 
 /* ---- a4/a5 + query side of a3: the Q-row part of a decoder layer in two launches -----------------
  * Replaces, per layer of [3P] mmdet DetrTransformerDecoderLayer (operation_order cross_attn, norm, self_attn,

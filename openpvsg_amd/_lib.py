@@ -44,6 +44,8 @@ SIGNATURES = {
     'pvsg_xattn_num_splits': [_i, _ll],
     'pvsg_masked_xattn_partial': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _ll, _i, _i, _i, _c_f],
     'pvsg_xattn_combine': [_c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _c_f],
+    'pvsg_xattn_merge_local': [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _c_f],
+    'pvsg_xattn_combine_packed': [_c_f, _c_f, _i, _i, _i, _i, _i, _c_f],
     'pvsg_pack_rows_weight': [_c_f, _c_f, _i, _i, _c_f],
     'pvsg_decoder_rows_pre': [ctypes.POINTER(DecoderLayer), _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _c_f],
     'pvsg_decoder_rows_post': [ctypes.POINTER(DecoderLayer), ctypes.POINTER(DecoderHead)] + [_c_f] * 9 + [_i, _i, _c_f],

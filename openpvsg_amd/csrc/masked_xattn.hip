@@ -277,6 +277,68 @@ __global__ __launch_bounds__(1024) void xattn_combine_kernel(const float* __rest
   }
 }
 
+// ---- frame-sharded clips: one message per decoder layer and rank -------------------------------------------------------
+// A rank's key ranges are merged locally into ONE un-normalised partial per (batch, head, query) and packed with the
+// rank's 128-bit "this query has an unblocked key among MY keys" flags into a record of M*Q*(D+2) + 4 floats
+// (108.8 KB at M=8, Q=100, D=32); the records of all ranks are all-gathered and merged by xattn_combine_packed.
+// The all-blocked reset of mask2former_head.py:453-454 is a property of the WHOLE clip: a rank whose keys are all
+// blocked for a query attends unmasked (its kernel cannot know the other ranks' bits); the merge keeps that
+// contribution only if EVERY rank reported the query blocked -- so no flag exchange is needed before the attention.
+__global__ __launch_bounds__(256) void xattn_merge_local_kernel(const float* __restrict__ part_o,
+                                                               const float* __restrict__ part_ml,
+                                                               const uint32_t* __restrict__ flags,
+                                                               float* __restrict__ packed, int Q, int NS, int rec) {
+  constexpr int D = 32, M = 8;
+  const int b = blockIdx.y, q = blockIdx.x;
+  const int hd = threadIdx.x, h = hd >> 5, d = hd & 31;
+  float m = -INFINITY, num = 0.f, den = 0.f;
+  for (int s = 0; s < NS; ++s) {
+    const long long slot = ((long long)b * NS + s) * M + h;
+    const float2 ml = *reinterpret_cast<const float2*>(part_ml + (slot * Q + q) * 2);
+    if (ml.x == -INFINITY) continue;
+    const float ov = part_o[(slot * Q + q) * D + d];
+    const float mn = fmaxf(m, ml.x);
+    const float a = __expf(m - mn), w = __expf(ml.x - mn);
+    num = num * a + w * ov;
+    den = den * a + w * ml.y;
+    m = mn;
+  }
+  float* r = packed + (long long)b * rec;
+  r[((long long)h * Q + q) * D + d] = num;
+  if (d == 0) *reinterpret_cast<float2*>(r + (long long)M * Q * D + ((long long)h * Q + q) * 2) = make_float2(m, den);
+  if (q == 0 && hd < 4)
+    reinterpret_cast<uint32_t*>(r + (long long)M * Q * (D + 2))[hd] = flags ? flags[b * 4 + hd] : 0xffffffffu;
+}
+
+__global__ __launch_bounds__(256) void xattn_combine_packed_kernel(const float* __restrict__ packed,
+                                                                  float* __restrict__ out, int R, int B, int Q, int rec) {
+  constexpr int D = 32, M = 8;
+  const int b = blockIdx.y, q = blockIdx.x;
+  const int hd = threadIdx.x, h = hd >> 5, d = hd & 31;
+  // does any rank see an unblocked key for this query?
+  bool any = false;
+  for (int r = 0; r < R; ++r) {
+    const uint32_t* fl = reinterpret_cast<const uint32_t*>(packed + ((long long)r * B + b) * rec + (long long)M * Q * (D + 2));
+    any = any || ((fl[q >> 5] >> (q & 31)) & 1u);
+  }
+  float m = -INFINITY, num = 0.f, den = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const float* rp = packed + ((long long)r * B + b) * rec;
+    const uint32_t* fl = reinterpret_cast<const uint32_t*>(rp + (long long)M * Q * (D + 2));
+    const bool mine = (fl[q >> 5] >> (q & 31)) & 1u;
+    if (any && !mine) continue;                     // this rank attended unmasked for a query that is not reset
+    const float2 ml = *reinterpret_cast<const float2*>(rp + (long long)M * Q * D + ((long long)h * Q + q) * 2);
+    if (ml.x == -INFINITY) continue;
+    const float ov = rp[((long long)h * Q + q) * D + d];
+    const float mn = fmaxf(m, ml.x);
+    const float a = __expf(m - mn), w = __expf(ml.x - mn);
+    num = num * a + w * ov;
+    den = den * a + w * ml.y;
+    m = mn;
+  }
+  out[((long long)b * Q + q) * (M * D) + hd] = num / den;
+}
+
 }  // namespace pvsg
 
 extern "C" int pvsg_xattn_num_splits(int B, long long K) {
@@ -329,5 +391,32 @@ extern "C" int pvsg_xattn_combine(const float* part_o, const float* part_ml, flo
     return set_err(PVSG_ERR_UNSUPPORTED, "xattn_combine: built for 8 heads x 32 dims");
   hipLaunchKernelGGL(xattn_combine_kernel, dim3(Q, B), dim3(1024), 0, stream, part_o, part_ml, out, Q, NS);
   PVSG_LAUNCH_CHECK("xattn_combine");
+  return PVSG_OK;
+}
+
+extern "C" int pvsg_xattn_merge_local(const float* part_o, const float* part_ml, const uint32_t* mask_flags,
+                                      float* packed, int B, int Q, int M, int D, int NS, hipStream_t stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(part_o && part_ml && packed, "xattn_merge_local: null pointer argument");
+  PVSG_REQUIRE(B > 0 && Q > 0 && NS > 0, "xattn_merge_local: non-positive dimension");
+  if (M != 8 || D != 32 || Q > 128)
+    return set_err(PVSG_ERR_UNSUPPORTED, "xattn_merge_local: built for 8 heads x 32 dims, Q<=128");
+  const int rec = M * Q * (D + 2) + 4;
+  hipLaunchKernelGGL(xattn_merge_local_kernel, dim3(Q, B), dim3(256), 0, stream, part_o, part_ml, mask_flags, packed, Q,
+                     NS, rec);
+  PVSG_LAUNCH_CHECK("xattn_merge_local");
+  return PVSG_OK;
+}
+
+extern "C" int pvsg_xattn_combine_packed(const float* packed, float* out, int R, int B, int Q, int M, int D,
+                                         hipStream_t stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(packed && out, "xattn_combine_packed: null pointer argument");
+  PVSG_REQUIRE(R > 0 && B > 0 && Q > 0, "xattn_combine_packed: non-positive dimension");
+  if (M != 8 || D != 32 || Q > 128)
+    return set_err(PVSG_ERR_UNSUPPORTED, "xattn_combine_packed: built for 8 heads x 32 dims, Q<=128");
+  const int rec = M * Q * (D + 2) + 4;
+  hipLaunchKernelGGL(xattn_combine_packed_kernel, dim3(Q, B), dim3(256), 0, stream, packed, out, R, B, Q, rec);
+  PVSG_LAUNCH_CHECK("xattn_combine_packed");
   return PVSG_OK;
 }

@@ -279,7 +279,7 @@ class _Mask2FormerHeadBase(BaseModule):
                 attn = self.transformer_decoder.layers[i].attentions[0]
                 kp, vp = attn.project_kv(k_in[lvl], v_in[lvl])
                 part = ops.masked_xattn_partial(qproj, kp, vp, mask, self.num_heads)
-                core = ops.xattn_combine(*part) if self.partial_combine is None else self.partial_combine(*part)
+                core = ops.xattn_combine(*part) if self.partial_combine is None else self.partial_combine(*part, mask)
                 q, cls_pred, emb, qproj = rows.layer(i, core, q, q_pos2)
                 last = i == n_layers - 1
                 logits, mask = self._mask_step(emb, mf, lows, (i + 1) % L, all_masks or last,
@@ -296,8 +296,8 @@ class _Mask2FormerHeadBase(BaseModule):
             if layer.operation_order != FAST_ORDER:
                 raise NotImplementedError('decoder operation_order %s' % (layer.operation_order,))
             lvl = i % L
-            q = layer.attentions[0].attend_bqc(q + q_pos, k_in[lvl], v_in[lvl], mask, q,
-                                               combine=self.partial_combine)
+            comb = None if self.partial_combine is None else (lambda po, pml, m=mask: self.partial_combine(po, pml, m))
+            q = layer.attentions[0].attend_bqc(q + q_pos, k_in[lvl], v_in[lvl], mask, q, combine=comb)
             q = layer.norms[0](q)
             qk = q + q_pos
             q = layer.attentions[1].attend_bqc(qk, qk, q, None, q)

@@ -182,6 +182,32 @@ def xattn_combine(part_o, part_ml):
     return out
 
 
+def xattn_merge_local(part_o, part_ml, mask=None):
+    """This rank's key-range partials -> one packed record per batch element (B, M*Q*(D+2)+4): un-normalised
+    output, (max, sum), and the rank's local 'has an unblocked key' flags -- the per-layer message of a
+    frame-sharded clip."""
+    po, pml = _chk(part_o, 'part_o'), _chk(part_ml, 'part_ml')
+    B, NS, M, Q, D = po.shape
+    packed = torch.empty((B, M * Q * (D + 2) + 4), device=po.device, dtype=torch.float32)
+    with torch.cuda.device(po.device):
+        _lib.call('pvsg_xattn_merge_local', po.data_ptr(), pml.data_ptr(),
+                  mask.flags.data_ptr() if mask is not None else None, packed.data_ptr(), B, Q, M, D, NS, _stream_ptr())
+    return packed
+
+
+def xattn_combine_packed(packed, num_queries, num_heads=8, head_dim=32):
+    """(R, B, REC) all-gathered records -> (B, Q, M*D); see pvsg_xattn_combine_packed for the reset rule."""
+    p = _chk(packed, 'packed')
+    R, B, rec = p.shape
+    if rec != num_heads * num_queries * (head_dim + 2) + 4:
+        raise RuntimeError('xattn_combine_packed: record length %d does not match Q=%d' % (rec, num_queries))
+    out = torch.empty((B, num_queries, num_heads * head_dim), device=p.device, dtype=torch.float32)
+    with torch.cuda.device(p.device):
+        _lib.call('pvsg_xattn_combine_packed', p.data_ptr(), out.data_ptr(), R, B, num_queries, num_heads, head_dim,
+                  _stream_ptr())
+    return out
+
+
 def masked_xattn(q_proj, k_proj, v_proj, mask=None, num_heads=8):
     return xattn_combine(*masked_xattn_partial(q_proj, k_proj, v_proj, mask, num_heads))
 

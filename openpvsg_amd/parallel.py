@@ -4,11 +4,12 @@ over xGMI on ROCm; 'gloo' in the CPU tests).
 The reference is data-parallel only (tools/test.py:244-252).  The north-star shards ONE clip by
 frame: backbone, pixel decoder, mask projection and post-processing are per-frame and stay local;
 two exchanges exist, both tiny and latency-bound:
-  1. clip-level masked attention: every rank streams its frames' keys and publishes the
-     un-normalised partial (o, m, l) per query and head (13.6 KB/head); `all_gather` + the same
-     log-sum-exp merge kernel that joins key ranges on one GPU.  The per-query "has an unblocked
-     key" flags are OR-ed over ranks first (the reset of mask2former_head.py:453-454 is a global
-     property of the clip).
+  1. clip-level masked attention, ONE message per decoder layer: every rank streams its frames' keys, merges its
+     own key ranges locally and publishes one record = the un-normalised partial (o, m, l) per query and head +
+     its 128 LOCAL "this query has an unblocked key among my keys" flag bits (108.8 KB); `all_gather`, then the
+     merge kernel.  The all-blocked reset of mask2former_head.py:453-454 is a property of the whole clip: a rank
+     that sees a query fully blocked attends unmasked, and the merge counts that contribution only if EVERY rank
+     reported the query blocked -- so nothing has to be exchanged before the attention kernel runs.
   2. tube assembly before relation scoring: `all_gather` of the per-frame records
      (segment id per query per frame, + per-frame queries/logits in per-frame mode).
 Messages are <= a few MB: one direct all-gather over the 7 xGMI links, no ring tuning needed.
@@ -30,11 +31,18 @@ def shard_frames(num_frames, rank, world):
 
 
 def all_gather_cat(t, dim=0, group=None):
-    """all_gather of equally-shaped tensors, concatenated along `dim` (rank order)."""
+    """all_gather of equally-shaped tensors, concatenated along `dim` (rank order).  RCCL: one
+    `all_gather_into_tensor` straight into the result (no per-rank staging tensors, no torch.cat launch)."""
     if not is_dist(group):
         return t
     world = dist.get_world_size(group)
     t = t.contiguous()
+    if dist.get_backend(group) == 'nccl':
+        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=group)
+        if dim == 0:
+            return out.flatten(0, 1)
+        return torch.cat(list(out.unbind(0)), dim=dim)
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t, group=group)
     return torch.cat(out, dim=dim)
@@ -66,8 +74,40 @@ def merge_partials_reference(part_o, part_ml):
     return out.permute(0, 2, 1, 3).reshape(B, Q, M * D)
 
 
+def pack_record_reference(part_o, part_ml, flags):
+    """Pure-torch statement of xattn_merge_local_kernel: (B,NS,M,Q,D)/(B,NS,M,Q,2) + flags (B,4) int32 ->
+    packed (B, M*Q*(D+2)+4) float32 (flag words bit-cast), for the CPU/gloo tests."""
+    B, NS, M, Q, D = part_o.shape
+    m, l = part_ml[..., 0], part_ml[..., 1]
+    mstar = m.max(dim=1, keepdim=True).values
+    w = torch.where(torch.isinf(m) & (m < 0), torch.zeros_like(m), torch.exp(m - torch.where(torch.isinf(mstar), torch.zeros_like(mstar), mstar)))
+    num = (w[..., None] * part_o).sum(1)                    # (B,M,Q,D)
+    den = (w * l).sum(1)                                   # (B,M,Q)
+    ml = torch.stack([mstar[:, 0], den], -1)               # (B,M,Q,2)
+    fl = flags.to(torch.int32).view(torch.float32)
+    return torch.cat([num.reshape(B, -1), ml.reshape(B, -1), fl.reshape(B, 4)], 1)
+
+
+def merge_records_reference(packed, Q, M=8, D=32):
+    """Pure-torch statement of xattn_combine_packed_kernel on (R,B,REC) gathered records -> (B,Q,M*D)."""
+    R, B, rec = packed.shape
+    o = packed[..., :M * Q * D].reshape(R, B, M, Q, D)
+    ml = packed[..., M * Q * D:M * Q * (D + 2)].reshape(R, B, M, Q, 2)
+    fl = packed[..., M * Q * (D + 2):].contiguous().view(torch.int32)                       # (R,B,4)
+    q = torch.arange(Q)
+    mine = ((fl[..., q // 32] >> (q % 32)) & 1).bool()                                     # (R,B,Q)
+    use = mine | ~mine.any(0, keepdim=True)                                               # reset only if blocked on every rank
+    m = torch.where(use[:, :, None, :], ml[..., 0], torch.full_like(ml[..., 0], float('-inf')))
+    part_o = o.permute(1, 0, 2, 3, 4)
+    part_ml = torch.stack([m, ml[..., 1]], -1).permute(1, 0, 2, 3, 4)
+    return merge_partials_reference(part_o, part_ml)
+
+
 class ClipShard:
-    """Wires a Mask2FormerVideoHead for a frame-sharded clip: flags OR + partial all-gather."""
+    """Wires a Mask2FormerVideoHead for a frame-sharded clip.  One exchange per decoder layer: every rank merges its
+    key ranges locally (ops.xattn_merge_local), the 108.8 KB records (partial + the rank's LOCAL mask flags) are
+    all-gathered, and ops.xattn_combine_packed applies the clip-wide all-blocked reset while merging -- the attention
+    kernel runs on local flags, no flag exchange precedes it."""
 
     def __init__(self, head, total_frames, group=None):
         self.head, self.group = head, group
@@ -76,16 +116,13 @@ class ClipShard:
         self.t0, self.t_local = shard_frames(total_frames, self.rank, self.world)
         head.clip_frame_offset, head.clip_total_frames = self.t0, total_frames
         head.partial_combine = self.combine
-        head.mask_sync = self.sync_mask
+        head.mask_sync = None
 
-    def sync_mask(self, mask):
-        if mask is not None:
-            mask.flags = or_flags(mask.flags, self.group)
-        return mask
-
-    def combine(self, part_o, part_ml):
+    def combine(self, part_o, part_ml, mask=None):
         from . import ops
-        return ops.xattn_combine(all_gather_cat(part_o, 1, self.group), all_gather_cat(part_ml, 1, self.group))
+        rec = ops.xattn_merge_local(part_o, part_ml, mask)                 # (B, REC)
+        allrec = all_gather_cat(rec[None], 0, self.group)                  # (R, B, REC): the layer's one message
+        return ops.xattn_combine_packed(allrec, part_o.shape[3], part_o.shape[2], part_o.shape[4])
 
     def release(self):
         self.head.partial_combine = None

@@ -70,6 +70,17 @@ def _worker(rank, world, port, tmp):
     s = torch.einsum('bmqd,bmkd->bmqk', q, k).masked_fill(eff[:, None], float('-inf'))
     full = torch.einsum('bmqk,bmkd->bmqd', s.softmax(-1), v).permute(0, 2, 1, 3).reshape(B, Q, M * D)
     assert torch.allclose(merged, full, rtol=1e-5, atol=1e-6)
+    # ---- the product's exchange: ONE message per layer, attention on LOCAL flags, reset decided by the merge -------------
+    local_honor = torch.tensor([[(int(words[0, qq // 32]) >> (qq % 32)) & 1 for qq in range(Q)]]).bool()
+    lo, lml = partial_attention(q, k[:, :, ks], v[:, :, ks], blocked[:, :, ks], local_honor)   # locally blocked -> unmasked
+    rec = parallel.pack_record_reference(lo, lml, words)
+    allrec = parallel.all_gather_cat(rec[None], 0)                          # (R, B, REC)
+    assert allrec.shape == (world, B, M * Q * (D + 2) + 4)
+    merged2 = parallel.merge_records_reference(allrec, Q, M, D)
+    assert torch.allclose(merged2, full, rtol=1e-5, atol=1e-6)
+    # query 5 is blocked on rank 0 only: rank 0 attended unmasked, and that contribution must have been dropped
+    if rank == 0:
+        assert not local_honor[0, 5] and lml[0, 0, 0, 5, 1] > 0
     # ---- tube records: every rank rebuilds the same tubes -----------------------------------------
     ids_all = torch.tensor([[1005, 120, -1], [1005, -1, 2007], [-1, 120, 2007], [1005, 120, 2007]])
     feats = torch.arange(3 * 8, dtype=torch.float32).view(3, 8)

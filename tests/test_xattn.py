@@ -99,3 +99,41 @@ def test_large_key_count_rows_sum_to_one(hip_lib):
     mask = ops.attn_mask_pack(low)
     out = ops.masked_xattn(q, k, v, mask, 8)
     assert torch.allclose(out, torch.ones_like(out), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('R', [2, 3])
+def test_one_message_per_layer_exchange_equals_single_device(hip_lib, R):
+    """Frame-sharded clip, R emulated ranks: every rank attends on its LOCAL mask flags (no flag exchange), merges
+    its key ranges into one packed record (pvsg_xattn_merge_local) and the gathered records are merged with the
+    clip-wide reset rule (pvsg_xattn_combine_packed).  Must equal the single-device masked attention, including
+    queries blocked on some ranks only, on every rank (reset), and with no mask; and the torch statements of the two
+    kernels (parallel.pack_record_reference / merge_records_reference) must agree with them."""
+    from openpvsg_amd import ops, parallel
+    B, Q, T, hw = 2, 100, 6, (5, 8)
+    K = T * hw[0] * hw[1]
+    q, k, v = (det_input(n, s, 17).to(DEV) for n, s in (('q', (B, Q, 256)), ('k', (B, K, 256)), ('v', (B, K, 256))))
+    low = det_input('low', (B, T, Q, hw[0], hw[1]), 18)
+    low[:, :, 3] = -1.0                       # query 3: blocked on every frame -> reset, attends everything
+    low[:, :T // R, 5] = -1.0                 # query 5: blocked on the first rank's frames only
+    low[0, :, 7] = -1.0
+    low[0, T - 1, 7, 0, 0] = 1.0              # query 7 (batch 0): a single allowed key, on the last rank
+    full = ops.masked_xattn(q * 0.2, k, v, ops.attn_mask_pack(low.to(DEV)), 8)
+    per = T // R
+    recs, recs_ref = [], []
+    for r in range(R):
+        ks = slice(r * per * hw[0] * hw[1], (r + 1) * per * hw[0] * hw[1])
+        m = ops.attn_mask_pack(low[:, r * per:(r + 1) * per].contiguous().to(DEV))        # local bits AND local flags
+        po, pml = ops.masked_xattn_partial(q * 0.2, k[:, ks].contiguous(), v[:, ks].contiguous(), m, 8, num_splits=2 + r)
+        recs.append(ops.xattn_merge_local(po, pml, m))
+        recs_ref.append(parallel.pack_record_reference(po.cpu(), pml.cpu(), m.flags.cpu()))
+    allrec = torch.stack(recs)                                                           # what all_gather hands back
+    out = ops.xattn_combine_packed(allrec, Q)
+    assert torch.allclose(out, full, rtol=1e-4, atol=1e-5)
+    ref = parallel.merge_records_reference(torch.stack(recs_ref), Q)
+    assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(allrec.cpu().numpy()[..., :-4], torch.stack(recs_ref).numpy()[..., :-4], rtol=1e-4, atol=1e-5)
+    assert (allrec.cpu()[..., -4:].contiguous().view(torch.int32) == torch.stack(recs_ref)[..., -4:].contiguous().view(torch.int32)).all()
+    # no mask at all (self-attention style): flags default to all-ones
+    po, pml = ops.masked_xattn_partial(q * 0.2, k, v, None, 8, num_splits=3)
+    one = ops.xattn_combine_packed(ops.xattn_merge_local(po, pml, None)[None], Q)
+    assert torch.allclose(one, ops.xattn_combine(po, pml), rtol=1e-5, atol=1e-6)
