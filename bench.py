@@ -535,7 +535,10 @@ def main():
         n0 = len(timer.records)
         timer.enabled = bool(timer.records)
         with FlopCounterMode(display=False) as fc:
-            step()
+            if world > 1:      # same local compute without the exchanges: no collective runs under the dispatch mode
+                pipe(clip_local, (Hp, Wp), (args.height, args.width), total_frames=T, group=group, shard='none')
+            else:
+                step()
         torch.cuda.synchronize()
         timer.enabled = False
         hw_flops_one = sum(KernelTimer.work(n, a)[1] for n, a, _, _ in timer.records[n0:])
