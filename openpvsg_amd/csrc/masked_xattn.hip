@@ -27,7 +27,12 @@
 // Tried and measured slower (round 2, 471 040 keys, 0.755 ms baseline): (a) 16 waves per workgroup, wave = (head,
 // half of the query tiles), 128 VGPRs -> 4 waves/SIMD: 1.006 ms (31 spilled VGPRs, K/V fragments read twice, an
 // eighth padding tile); (b) rescaling O only when a wave vote says the running maximum moved + b128 mask reads:
-// 1.03 ms (the wave-uniform branches stop the compiler from interleaving one tile's soft-max with the MFMAs).
+// 1.03 ms; (c) one wave per SIMD (4-wave workgroups, 256 VGPRs + 170 AccVGPRs), S^T double / triple buffered so that
+// P.V(i-1) and S^T(i+1) are issued between the soft-max instructions of sub-tile i (sched_group_barrier pipeline,
+// verified in the ISA): 0.97-1.10 ms.  Reading of (a)-(c): the f32-input MFMA runs at the f32 VECTOR rate on the same
+// SIMD units (cdna_hip_programming.md, "FP32-input MFMA"), so soft-max VALU work does not hide under it whatever the
+// interleave or the wave count -- only fewer non-MFMA instructions per key would help (457 VALU + 35 exp + 183 SALU
+// per 112 MFMA today).
 // Ranges are combined by `xattn_combine_kernel` (log-sum-exp merge); the same partial format is
 // what ranks exchange when a clip's frames are sharded over GPUs (openpvsg_amd/parallel.py).
 #include "common.h"
