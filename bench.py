@@ -619,17 +619,20 @@ def main():
                 ent = json.load(open(tpath)).get(dom.split('[')[0], {})
                 if ent.get('frames') == t_local:
                     traffic = ent.get('hbm_bytes_per_launch')
+            scope = ('dominant HAND-WRITTEN kernel by time (HIP events around the C-ABI launches); the largest kernels of '
+                     'the step are library GEMMs / convolutions -- roofline_step covers the whole step')
             if mfma_bound:
                 ach = d['flops'] / d['calls'] / per / 1e9
                 line['roofline'] = dict(kernel=dom, bound='mfma', achieved=ach, peak=F32_MFMA_PEAK_TF,
                                         unit='TFLOP/s', frac=ach / F32_MFMA_PEAK_TF, traffic=traffic,
-                                        avg_launch_ms=per, launches_per_step=d['calls'] / args.steps)
+                                        avg_launch_ms=per, launches_per_step=d['calls'] / args.steps,
+                                        algorithmic_bytes_per_launch=d['bytes'] / d['calls'], scope=scope)
             else:
                 ach = d['bytes'] / d['calls'] / per / 1e6
                 line['roofline'] = dict(kernel=dom, bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
                                         frac=ach / HBM_PEAK_GBS, traffic=traffic, avg_launch_ms=per,
                                         launches_per_step=d['calls'] / args.steps,
-                                        algorithmic_bytes_per_launch=d['bytes'] / d['calls'])
+                                        algorithmic_bytes_per_launch=d['bytes'] / d['calls'], scope=scope)
             # the four kernels the north-star names, each against its own roof (same HIP-event data)
             named = []
             for key, bound in (('pvsg_msda_fused_forward', 'hbm'), ('pvsg_ms_deform_attn_forward', 'hbm'),
