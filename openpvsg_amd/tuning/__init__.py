@@ -1,7 +1,7 @@
 """Library-GEMM selection for the clip-size shapes of the path (hipBLASLt / rocBLAS solution per shape).
 
 PyTorch's TunableOp timed every rocBLAS / hipBLASLt solution for the fp32 GEMMs `bench.py` issues at
-32 x 720p frames (encoder projections 618 240 x 256 -> 544 / 256 / 1024, FFN 1024 -> 256, decoder K/V projections
+32 x 720p frames (and, round 2, at 16 / 8 / 4 frames: what a rank holds when the clip is sharded over 2 / 4 / 8 GPUs) (encoder projections 618 240 x 256 -> 544 / 256 / 1024, FFN 1024 -> 256, decoder K/V projections
 at 29 440 / 117 760 / 471 040 keys, the backbone's stride-1 1x1 convolutions as batched W @ x[b], ...) and the winners are stored in `gemm_gfx950.csv` (`scripts/tune_gemms.sh`
 regenerates it, ~140 s).  `enable()` only LOADS that table: no tuning happens at run time, shapes that are not in it
 and library versions that do not match the file's validators fall back to PyTorch's default choice.
