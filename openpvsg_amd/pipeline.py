@@ -103,7 +103,7 @@ class PVSGPipeline(torch.nn.Module):
                         run(static_in)
                 torch.cuda.current_stream().wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                     static_out = run(static_in)
                 entry = (graph, static_in, static_out)
             except Exception as e:   # capture unsupported for some op: stay eager, say so once
@@ -143,7 +143,8 @@ class PVSGPipeline(torch.nn.Module):
                     run(static_in)
                 torch.cuda.current_stream().wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # thread_local: CUDA calls of other threads (RCCL's watchdog polls events) must not invalidate the capture
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                     static_out = run(static_in)
                 ent = (graph, static_in, static_out)
             except Exception as e:
