@@ -33,9 +33,12 @@
 // SIMD units (cdna_hip_programming.md, "FP32-input MFMA"), so soft-max VALU work does not hide under it whatever the
 // interleave or the wave count -- only fewer non-MFMA instructions per key would help (457 VALU + 35 exp + 183 SALU
 // per 112 MFMA today).
+// (d, adopted = LEAN) stale reference maximum + per-lane sums + log2-domain logits: half the VALU instructions, 0.733 ms;
+// (e) with the soft-max removed the kernel takes 0.46 ms: the rest is the latency of the QK -> soft-max -> PV chain.
 // Ranges are combined by `xattn_combine_kernel` (log-sum-exp merge); the same partial format is
 // what ranks exchange when a clip's frames are sharded over GPUs (openpvsg_amd/parallel.py).
 #include "common.h"
+#include <stdlib.h>
 
 namespace pvsg {
 
@@ -73,6 +76,7 @@ __device__ __forceinline__ float group_sum4(float v) {
 constexpr int TK = 32;                                   // keys per LDS tile
 constexpr int XLDS_TILE_FLOATS = TK * 256 * 2 + TK * 4;  // K rows + V rows + mask words (as floats)
 
+template <bool LEAN>
 __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
     const float* __restrict__ qp, const float* __restrict__ kp, const float* __restrict__ vp,
     const uint32_t* __restrict__ bits, const uint32_t* __restrict__ flags, float* __restrict__ part_o,
@@ -102,6 +106,10 @@ __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
         const float4 a = ld4(p), c = ld4(p + 4);
         qf[qt][0] = a.x; qf[qt][1] = a.y; qf[qt][2] = a.z; qf[qt][3] = a.w;
         qf[qt][4] = c.x; qf[qt][5] = c.y; qf[qt][6] = c.z; qf[qt][7] = c.w;
+        if (LEAN) {        // logits in the log2 domain: exp2 without the per-element multiply
+#pragma unroll
+          for (int i = 0; i < 8; ++i) qf[qt][i] *= 1.4426950408889634f;
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) qf[qt][i] = 0.f;
@@ -176,39 +184,86 @@ __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
       bool kvalid[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) kvalid[r] = kt + sub * 16 + g * 4 + r < k1;
-      // ---- mask + online softmax (per query column) ---------------------------------------------------------
+      if constexpr (LEAN) {
+        // ---- lean online soft-max.  The f32 MFMA runs at the vector rate on the same SIMD, so every VALU instruction
+        // here adds to the kernel's time.  The reference maximum `mrun` is allowed to go STALE: p = 2^(s - mrun) with
+        // s - mrun <= 10 cannot overflow, so as long as no lane sees a logit more than 10 above its reference the
+        // sub-tile needs no cross-group max, no exp for alpha and no rescale of O; the partial sums stay per lane and
+        // are reduced over the four lane groups once, at the end.  One wave vote per 16 keys picks the path.
+        float tl[XQT];
+        bool need = false;
 #pragma unroll
-      for (int qt = 0; qt < XQT; ++qt) {
-        const bool hq = (honor >> qt) & 1u;
-        const int sh = (qt & 1) * 16 + j;
-        float sv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // mask word of this key for query tile qt, read on demand from the LDS copy
-          const uint32_t w = hq ? tm[(sub * 16 + g * 4 + r) * 4 + (qt >> 1)] : 0u;
-          const bool masked = !kvalid[r] || ((w >> sh) & 1u);
-          sv[r] = masked ? -INFINITY : st[qt][r];
-        }
-        const float tmax = group_max4(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
-        const float mnew = fmaxf(mrun[qt], tmax);
-        float alpha = 1.f, psum = 0.f;
-        if (mnew == -INFINITY) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) st[qt][r] = 0.f;
-        } else {
-          alpha = __expf(mrun[qt] - mnew);
+        for (int qt = 0; qt < XQT; ++qt) {
+          const bool hq = (honor >> qt) & 1u;
+          const int sh = (qt & 1) * 16 + j;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = __expf(sv[r] - mnew);
+            const uint32_t w = hq ? tm[(sub * 16 + g * 4 + r) * 4 + (qt >> 1)] : 0u;
+            const bool masked = !kvalid[r] || ((w >> sh) & 1u);
+            st[qt][r] = masked ? -INFINITY : st[qt][r];
+          }
+          tl[qt] = fmaxf(fmaxf(st[qt][0], st[qt][1]), fmaxf(st[qt][2], st[qt][3]));
+          need = need || (tl[qt] > mrun[qt] + 10.f);
+        }
+        if (__ballot(need) != 0ull) {
+          // rare path: new common reference per query column (the same in all four lane groups), rescale O and l
+#pragma unroll
+          for (int qt = 0; qt < XQT; ++qt) {
+            const float mnew = fmaxf(mrun[qt], group_max4(tl[qt]));
+            const float alpha = (mnew == -INFINITY) ? 1.f : exp2f(mrun[qt] - mnew);
+            lrun[qt] *= alpha;
+            o[qt][0] *= alpha;
+            o[qt][1] *= alpha;
+            mrun[qt] = mnew;
+          }
+        }
+#pragma unroll
+        for (int qt = 0; qt < XQT; ++qt) {
+          const float mref = (mrun[qt] == -INFINITY) ? 0.f : mrun[qt];      // nothing unblocked yet: every p = 2^-inf = 0
+          float psum = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = exp2f(st[qt][r] - mref);
             st[qt][r] = p;
             psum += p;
           }
+          lrun[qt] += psum;                                                  // per-lane partial: groups merged at the end
         }
-        psum = group_sum4(psum);
-        lrun[qt] = lrun[qt] * alpha + psum;
-        mrun[qt] = mnew;
-        o[qt][0] *= alpha;
-        o[qt][1] *= alpha;
+      } else {
+        // ---- mask + online softmax (per query column) ---------------------------------------------------------
+  #pragma unroll
+        for (int qt = 0; qt < XQT; ++qt) {
+          const bool hq = (honor >> qt) & 1u;
+          const int sh = (qt & 1) * 16 + j;
+          float sv[4];
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // mask word of this key for query tile qt, read on demand from the LDS copy
+            const uint32_t w = hq ? tm[(sub * 16 + g * 4 + r) * 4 + (qt >> 1)] : 0u;
+            const bool masked = !kvalid[r] || ((w >> sh) & 1u);
+            sv[r] = masked ? -INFINITY : st[qt][r];
+          }
+          const float tmax = group_max4(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
+          const float mnew = fmaxf(mrun[qt], tmax);
+          float alpha = 1.f, psum = 0.f;
+          if (mnew == -INFINITY) {
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) st[qt][r] = 0.f;
+          } else {
+            alpha = __expf(mrun[qt] - mnew);
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float p = __expf(sv[r] - mnew);
+              st[qt][r] = p;
+              psum += p;
+            }
+          }
+          psum = group_sum4(psum);
+          lrun[qt] = lrun[qt] * alpha + psum;
+          mrun[qt] = mnew;
+          o[qt][0] *= alpha;
+          o[qt][1] *= alpha;
+        }
       }
       // ---- O^T += V^T . P^T (V fragments from LDS right before use) ---------------------------------------------
 #pragma unroll
@@ -235,7 +290,9 @@ __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
       float* op = part_o + (slot * Q + q) * D + g * 8;
       st4(op, make_float4(o[qt][0][0], o[qt][1][0], o[qt][0][1], o[qt][1][1]));
       st4(op + 4, make_float4(o[qt][0][2], o[qt][1][2], o[qt][0][3], o[qt][1][3]));
-      if (g == 0) *reinterpret_cast<float2*>(part_ml + (slot * Q + q) * 2) = make_float2(mrun[qt], lrun[qt]);
+      float mo = mrun[qt], lo = lrun[qt];
+      if (LEAN) { lo = group_sum4(lo); mo *= 0.6931471805599453f; }        // log2 domain -> natural, -inf stays -inf
+      if (g == 0) *reinterpret_cast<float2*>(part_ml + (slot * Q + q) * 2) = make_float2(mo, lo);
     }
   }
 }
@@ -377,12 +434,19 @@ extern "C" int pvsg_masked_xattn_partial(const float* q_proj, const float* k_pro
   const size_t lds = (size_t)2 * XLDS_TILE_FLOATS * sizeof(float);
   static std::atomic<unsigned long long> attr_done;
   {
-    const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&xattn_partial_lds_kernel), (int)lds, attr_done);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&xattn_partial_lds_kernel<true>), (int)lds, attr_done);
+    static std::atomic<unsigned long long> attr_done2;
+    if (e == hipSuccess) e = ensure_dynamic_lds(reinterpret_cast<const void*>(&xattn_partial_lds_kernel<false>), (int)lds, attr_done2);
     if (e != hipSuccess)
       return set_err(PVSG_ERR_HIP, "masked_xattn_partial: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(xattn_partial_lds_kernel, dim3(B * NS), dim3(512), lds, stream, q_proj, k_proj, v_proj,
-                     mask_bits, mask_flags, part_o, part_ml, Q, K, NS, chunk);
+  static const bool lean = []() { const char* e = getenv("PVSG_XATTN_LEAN"); return !(e && e[0] == '0'); }();
+  if (lean)
+    hipLaunchKernelGGL(xattn_partial_lds_kernel<true>, dim3(B * NS), dim3(512), lds, stream, q_proj, k_proj, v_proj,
+                       mask_bits, mask_flags, part_o, part_ml, Q, K, NS, chunk);
+  else
+    hipLaunchKernelGGL(xattn_partial_lds_kernel<false>, dim3(B * NS), dim3(512), lds, stream, q_proj, k_proj, v_proj,
+                       mask_bits, mask_flags, part_o, part_ml, Q, K, NS, chunk);
   PVSG_LAUNCH_CHECK("masked_xattn_partial");
   return PVSG_OK;
 }
