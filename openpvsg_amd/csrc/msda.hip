@@ -437,21 +437,33 @@ __global__ __launch_bounds__(256) void add_layernorm256_kernel(
   const float4 g = ld4(gamma + lane * 4), be = ld4(beta + lane * 4);
   float4 bi = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias) bi = ld4(bias + lane * 4);
-  for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
-    float4 x = ld4(a + row * 256 + lane * 4);
-    if (b) { const float4 y = ld4(b + row * 256 + lane * 4); x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w; }
-    x.x += bi.x; x.y += bi.y; x.z += bi.z; x.w += bi.w;
-    float s = x.x + x.y + x.z + x.w;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    const float mean = s * (1.f / 256.f);
-    const float dx = x.x - mean, dy = x.y - mean, dz = x.z - mean, dw = x.w - mean;
-    float v = dx * dx + dy * dy + dz * dz + dw * dw;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    const float rstd = rsqrtf(v * (1.f / 256.f) + eps);
-    st4(out + row * 256 + lane * 4,
-        make_float4(dx * rstd * g.x + be.x, dy * rstd * g.y + be.y, dz * rstd * g.z + be.z, dw * rstd * g.w + be.w));
+  // two rows per wave and iteration (independent load / reduce chains); the row reductions run in the VALU (DPP +
+  // permlane swaps) instead of twelve ds_bpermute round trips per row; streaming (touched-once) loads and stores
+  const long long stride = (long long)gridDim.x * 8;
+  for (long long row = (long long)blockIdx.x * 8 + (threadIdx.x >> 6) * 2; row < rows; row += stride) {
+    const bool two = row + 1 < rows;
+    float4 x0 = ld4_stream(a + row * 256 + lane * 4);
+    float4 x1 = two ? ld4_stream(a + (row + 1) * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b) {
+      const float4 y0 = ld4_stream(b + row * 256 + lane * 4);
+      const float4 y1 = two ? ld4_stream(b + (row + 1) * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      x0.x += y0.x; x0.y += y0.y; x0.z += y0.z; x0.w += y0.w;
+      x1.x += y1.x; x1.y += y1.y; x1.z += y1.z; x1.w += y1.w;
+    }
+    x0.x += bi.x; x0.y += bi.y; x0.z += bi.z; x0.w += bi.w;
+    x1.x += bi.x; x1.y += bi.y; x1.z += bi.z; x1.w += bi.w;
+    const float m0 = msda_wave_allreduce<false>((x0.x + x0.y) + (x0.z + x0.w)) * (1.f / 256.f);
+    const float m1 = msda_wave_allreduce<false>((x1.x + x1.y) + (x1.z + x1.w)) * (1.f / 256.f);
+    const float d0x = x0.x - m0, d0y = x0.y - m0, d0z = x0.z - m0, d0w = x0.w - m0;
+    const float d1x = x1.x - m1, d1y = x1.y - m1, d1z = x1.z - m1, d1w = x1.w - m1;
+    const float v0 = msda_wave_allreduce<false>((d0x * d0x + d0y * d0y) + (d0z * d0z + d0w * d0w));
+    const float v1 = msda_wave_allreduce<false>((d1x * d1x + d1y * d1y) + (d1z * d1z + d1w * d1w));
+    const float r0 = rsqrtf(v0 * (1.f / 256.f) + eps), r1 = rsqrtf(v1 * (1.f / 256.f) + eps);
+    st4_stream(out + row * 256 + lane * 4,
+               make_float4(d0x * r0 * g.x + be.x, d0y * r0 * g.y + be.y, d0z * r0 * g.z + be.z, d0w * r0 * g.w + be.w));
+    if (two)
+      st4_stream(out + (row + 1) * 256 + lane * 4,
+                 make_float4(d1x * r1 * g.x + be.x, d1y * r1 * g.y + be.y, d1z * r1 * g.z + be.z, d1w * r1 * g.w + be.w));
   }
 }
 
@@ -523,7 +535,7 @@ extern "C" int pvsg_add_layernorm(const float* a, const float* b, const float* b
   PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out) |
                   reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(gamma) |
                   reinterpret_cast<uintptr_t>(beta)) & 15u), "add_layernorm: 16-byte alignment required");
-  long long nb = (rows + 3) / 4;
+  long long nb = (rows + 7) / 8;
   if (nb > 256 * 16) nb = 256 * 16;
   hipLaunchKernelGGL(add_layernorm256_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a, b, bias, gamma, beta,
                      out, rows, eps);
