@@ -221,6 +221,9 @@ class KernelTimer:
         if name == 'pvsg_xattn_combine':
             B, Q, M, D, NS = a[3:8]
             return 4.0 * B * NS * M * Q * (D + 2) + 4.0 * B * Q * M * D, 0.0
+        if name == 'pvsg_decoder_kv_inputs':
+            frames, hw, C = a[5:8]
+            return 16.0 * frames * hw * C, 0.0                       # tokens + pe read, value + key written
         if name == 'pvsg_nchw_to_tokens':
             B, C, HW = a[4:7]
             return 8.0 * B * C * HW, 0.0

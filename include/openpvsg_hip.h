@@ -265,6 +265,14 @@ int pvsg_nchw_to_tokens(const float* src, const float* scale, const float* shift
  *   dst[b, c, p] = src[b*src_batch_stride + p*C + c]. */
 int pvsg_tokens_to_nchw(const float* src, float* dst, int B, int C, int HW, long long src_batch_stride, void* stream);
 
+/* decoder key / value inputs of one level (mask2former_head.py:421-436, mask2former_video_head.py:392-410): from the
+ * encoder's token tensor (frames, S, 256) whose rows start .. start+hw of every frame are level l,
+ *   v_out[f*hw + p] = tokens[f, start + p] + level_embed;   k_out = v_out + pos_enc[(f*hw + p) % pe_rows]
+ * `tokens` points at row `start` of frame 0; frame_stride = S*256 floats; pos_enc (pe_rows, 256) with pe_rows = frames*hw
+ * (3-D encoding of a clip) or hw (2-D encoding shared by the frames of a batch). */
+int pvsg_decoder_kv_inputs(const float* tokens, const float* level_embed, const float* pos_enc, float* v_out, float* k_out,
+                           long long frames, int hw, int C, long long frame_stride, long long pe_rows, void* stream);
+
 /* [3P] mmdet ResNet bottleneck tail (norm_eval): out = relu(BN(conv1x1(x)) + identity) in one pass, for the layers
  * whose 1x1 GEMM is HBM-bound (Cin <= 256):  out[b] = act((W (Cout x Cin) @ x[b] (Cin x HW)) * scale[c] + shift[c]
  * (+ residual[b])).  Requires Cout % 32 == 0, Cin % 16 == 0, Cin <= 256, HW % 4 == 0; residual NULL = none. */

@@ -63,6 +63,7 @@ SIGNATURES = {
     'pvsg_stem_bn_relu_pool': [_c_f] * 4 + [_ll, _i, _i, _i, _c_f],
     'pvsg_nchw_to_tokens': [_c_f] * 4 + [_i, _i, _i, _ll, _c_f],
     'pvsg_tokens_to_nchw': [_c_f, _c_f, _i, _i, _i, _ll, _c_f],
+    'pvsg_decoder_kv_inputs': [_c_f] * 5 + [_ll, _i, _i, _ll, _ll, _c_f],
     'pvsg_conv1x1_affine': [_c_f] * 6 + [_i, _i, _i, _ll, _i, _c_f],
 }
 # entry points that return a value instead of a status code

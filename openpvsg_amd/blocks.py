@@ -627,6 +627,9 @@ class MSDeformAttnPixelDecoder(BaseModule):
             outs.append(x[:, start:start + h * w].transpose(1, 2).reshape(B, -1, h, w))
             starts.append(start)
             start += h * w
+        # the encoder memory as ONE token tensor + where each returned level lives in it: lets the head build the
+        # decoder's key / value inputs in one pass per level (ops.decoder_kv_inputs) instead of gather copy + 2 adds
+        self.last_tokens = (x, tuple(starts[:self.num_outs]), tuple(shapes[:self.num_outs])) if x.is_contiguous() else None
         for i in range(self.num_input_levels - self.num_encoder_levels - 1, -1, -1):
             # `outs` are channel-last strided VIEWS of the token tensor (free for the decoder, which wants
             # tokens); the FPN branch wants plain NCHW so that the resize, the add and MIOpen's 3x3 conv

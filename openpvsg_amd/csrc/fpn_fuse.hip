@@ -156,6 +156,28 @@ __global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const float* __rest
   }
 }
 
+// Decoder key / value inputs of one level (mask2former_head.py:421-436 / mask2former_video_head.py:392-410):
+//   value = memory_l.flatten(2).permute(..) + level_embed[l],  key = value + positional_encoding_l
+// straight from the encoder's token tensor (frames x S x C, level l = rows start .. start+hw of every frame): one pass
+// that writes both tensors (the torch form is a strided gather copy + two adds = 7 tensor passes instead of 4).
+__global__ __launch_bounds__(256) void decoder_kv_inputs_kernel(const float* __restrict__ tokens,
+                                                               const float* __restrict__ level_embed,
+                                                               const float* __restrict__ pe, float* __restrict__ v_out,
+                                                               float* __restrict__ k_out, long long rows, int hw,
+                                                               long long frame_stride, long long pe_rows) {
+  const int lane = threadIdx.x & 63;
+  const float4 le = ld4(level_embed + lane * 4);
+  for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
+    const long long t = r / hw, p = r - t * hw;
+    float4 x = ld4_stream(tokens + t * frame_stride + p * 256 + lane * 4);
+    x.x += le.x; x.y += le.y; x.z += le.z; x.w += le.w;
+    st4(v_out + r * 256 + lane * 4, x);
+    const float4 e = ld4(pe + (r % pe_rows) * 256 + lane * 4);
+    x.x += e.x; x.y += e.y; x.z += e.z; x.w += e.w;
+    st4(k_out + r * 256 + lane * 4, x);
+  }
+}
+
 }  // namespace pvsg
 
 extern "C" int pvsg_fpn_merge_up2x(const float* lateral, const float* scale, const float* shift, const float* top,
@@ -213,5 +235,25 @@ extern "C" int pvsg_tokens_to_nchw(const float* src, float* dst, int B, int C, i
   hipLaunchKernelGGL(tokens_to_nchw_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, stream, src, dst, C, HW,
                      src_batch_stride);
   PVSG_LAUNCH_CHECK("tokens_to_nchw");
+  return PVSG_OK;
+}
+
+extern "C" int pvsg_decoder_kv_inputs(const float* tokens, const float* level_embed, const float* pos_enc, float* v_out,
+                                      float* k_out, long long frames, int hw, int C, long long frame_stride,
+                                      long long pe_rows, hipStream_t stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(tokens && level_embed && pos_enc && v_out && k_out, "decoder_kv_inputs: null pointer argument");
+  PVSG_REQUIRE(frames > 0 && hw > 0 && pe_rows > 0 && frame_stride >= (long long)hw * C, "decoder_kv_inputs: bad shape");
+  if (C != 256) return set_err(PVSG_ERR_UNSUPPORTED, "decoder_kv_inputs: built for 256 channels (got %d)", C);
+  PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(tokens) | reinterpret_cast<uintptr_t>(level_embed) |
+                  reinterpret_cast<uintptr_t>(pos_enc) | reinterpret_cast<uintptr_t>(v_out) |
+                  reinterpret_cast<uintptr_t>(k_out)) & 15u) && !(frame_stride & 3),
+               "decoder_kv_inputs: 16-byte alignment required");
+  const long long rows = frames * hw;
+  long long nb = (rows + 3) / 4;
+  if (nb > 256 * 16) nb = 256 * 16;
+  hipLaunchKernelGGL(decoder_kv_inputs_kernel, dim3((unsigned)nb), dim3(256), 0, stream, tokens, level_embed, pos_enc,
+                     v_out, k_out, rows, hw, frame_stride, pe_rows);
+  PVSG_LAUNCH_CHECK("decoder_kv_inputs");
   return PVSG_OK;
 }

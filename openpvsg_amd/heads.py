@@ -208,6 +208,23 @@ class _Mask2FormerHeadBase(BaseModule):
         logits, mask = self._mask_step(emb, mask_features, lows, level, want_logits, need_mask)
         return cls_pred, logits, mask
 
+    def _pe_tokens(self, T, h, w, dev):
+        """Decoder positional encoding of one level in token (key) order, cached per shape: the encodings depend on the
+        geometry only, and re-laying (T,C,h,w) out as (T*h*w,C) every forward is a full pass over the level."""
+        cache = self.__dict__.setdefault('_pe_tok_cache', {})
+        key = (T if self.video else 0, h, w, str(dev), self.clip_frame_offset, self.clip_total_frames)
+        pe = cache.get(key)
+        if pe is None:
+            if self.video:
+                g = self.decoder_positional_encoding.grid(T, h, w, dev, self.clip_frame_offset, self.clip_total_frames)
+                pe = g.flatten(2).permute(0, 2, 1).reshape(T * h * w, -1).contiguous()
+            else:
+                pe = self.decoder_positional_encoding.grid(h, w, dev).flatten(1).t().contiguous()
+            if len(cache) >= 16:
+                cache.pop(next(iter(cache)))
+            cache[key] = pe
+        return pe
+
     def _rows(self):
         """DecoderRows for the current weights, or None when the generic module path has to run."""
         if getattr(self, '_rows_ok', None) is None:
@@ -241,18 +258,22 @@ class _Mask2FormerHeadBase(BaseModule):
         L = self.num_transformer_feat_level
         dev = mask_features.device
         k_in, v_in, sizes = [], [], {}
+        tokens = getattr(self.pixel_decoder, 'last_tokens', None)
         for i in range(L):
-            mem = self.decoder_input_projs[i](memories[i])
-            h, w = mem.shape[-2:]
+            h, w = memories[i].shape[-2:]
             sizes[i] = (h, w)
+            pe = self._pe_tokens(T, h, w, dev)                       # (T*h*w, C) video / (h*w, C) image, key order (t, y, x)
+            if (tokens is not None and mask_features.is_cuda and isinstance(self.decoder_input_projs[i], nn.Identity) and
+                    C == 256 and tokens[0].shape[0] == B * T and tokens[2][i] == (h, w) and
+                    memories[i].data_ptr() == tokens[0].data_ptr() + 4 * tokens[1][i] * C):
+                # one pass from the encoder's token tensor: value = tokens + level_embed, key = value + pe
+                v, k = ops.decoder_kv_inputs(tokens[0], tokens[1][i], h * w, self.level_embed.weight[i].detach(), pe)
+                v_in.append(v.view(B, T * h * w, C))
+                k_in.append(k.view(B, T * h * w, C))
+                continue
+            mem = self.decoder_input_projs[i](memories[i])
             tok = mem.reshape(B, T, C, h * w).permute(0, 1, 3, 2).reshape(B, T * h * w, C)
             v = tok + self.level_embed.weight[i][None, None, :]
-            if self.video:
-                pe = self.decoder_positional_encoding.grid(T, h, w, dev, self.clip_frame_offset,
-                                                           self.clip_total_frames)
-                pe = pe.flatten(2).permute(0, 2, 1).reshape(T * h * w, C)
-            else:
-                pe = self.decoder_positional_encoding.grid(h, w, dev).flatten(1).t()
             v_in.append(v)
             k_in.append(v + pe[None])
         self._level_sizes = sizes

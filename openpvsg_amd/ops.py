@@ -515,6 +515,21 @@ def conv1x1_affine(x, weight, scale, shift, residual=None, relu=True, out=None):
     return out
 
 
+def decoder_kv_inputs(tokens, start, hw, level_embed, pos_enc):
+    """tokens (F,S,256) encoder memory, level rows start..start+hw -> value input (F*hw,256) = tokens + level_embed and
+    key input = value + pos_enc, pos_enc (F*hw,256) or (hw,256); one pass, both outputs."""
+    x, le, pe = _chk(tokens, 'tokens'), _chk(level_embed, 'level_embed'), _chk(pos_enc, 'pos_enc')
+    Fr, S, C = x.shape
+    if pe.shape[0] not in (Fr * hw, hw) or pe.shape[1] != C or start + hw > S:
+        raise RuntimeError('decoder_kv_inputs: inconsistent shapes')
+    v = torch.empty((Fr * hw, C), device=x.device, dtype=torch.float32)
+    k = torch.empty_like(v)
+    with torch.cuda.device(x.device):
+        _lib.call('pvsg_decoder_kv_inputs', x.data_ptr() + 4 * start * C, le.data_ptr(), pe.data_ptr(), v.data_ptr(),
+                  k.data_ptr(), Fr, hw, C, S * C, pe.shape[0], _stream_ptr())
+    return v, k
+
+
 # ---- decoder query rows (decoder_rows.hip) ---------------------------------------------------------
 def pack_rows_weight(W):
     """(N,K) Linear weight -> MFMA-fragment order (roundup16(N)*K,), once per checkpoint."""

@@ -26,7 +26,7 @@ ENTRY = [('msda_fused', 'pvsg_msda_fused_forward'), ('msda_fwd', 'pvsg_ms_deform
          ('decoder_rows_post', 'pvsg_decoder_rows_post'), ('decoder_rows_pre', 'pvsg_decoder_rows_pre'),
          ('pan_owner', 'pvsg_panoptic_fuse'), ('fpn_merge_up2x', 'pvsg_fpn_merge_up2x'),
          ('stem_bn_relu_pool', 'pvsg_stem_bn_relu_pool'), ('nchw_to_tokens', 'pvsg_nchw_to_tokens'),
-         ('tokens_to_nchw', 'pvsg_tokens_to_nchw'), ('pair_', 'pvsg_pair_score_forward')]
+         ('tokens_to_nchw', 'pvsg_tokens_to_nchw'), ('decoder_kv_inputs', 'pvsg_decoder_kv_inputs'), ('pair_', 'pvsg_pair_score_forward')]
 
 
 def run_pass(counter, frames, workdir):

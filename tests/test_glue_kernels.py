@@ -99,3 +99,20 @@ def test_pixel_decoder_glue_path_equals_generic(hip_lib):
     assert torch.allclose(mf, mf0, rtol=1e-4, atol=1e-4 * float(mf0.abs().max()))
     for a, b in zip(mem, mem0):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('F_,S,start,hw,video', [(3, 50, 7, 12, True), (4, 161, 0, 161, False), (2, 40, 30, 10, True)])
+def test_decoder_kv_inputs(hip_lib, F_, S, start, hw, video):
+    """value = tokens + level_embed, key = value + pe in one pass (mask2former_head.py:421-436), 3-D (per frame) and
+    2-D (shared) encodings, vs the torch statement."""
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(F_, S, 256, generator=g).to(DEV)
+    le = torch.randn(256, generator=g).to(DEV)
+    pe = torch.randn((F_ * hw) if video else hw, 256, generator=g).to(DEV)
+    v, k = ops.decoder_kv_inputs(x, start, hw, le, pe)
+    tok = x[:, start:start + hw].reshape(F_ * hw, 256)
+    v_ref = tok + le[None]
+    k_ref = v_ref + (pe if video else pe.repeat(F_, 1))
+    assert torch.equal(v, v_ref) and torch.equal(k, k_ref)
