@@ -129,7 +129,11 @@ class PVSGPipeline(torch.nn.Module):
                                     x, self.num_top_pairs)
         if not self.relation_graph or not feats.is_cuda or torch.cuda.is_current_stream_capturing():
             return run(feats)
-        key = (tuple(feats.shape), str(feats.device))
+        # the graph bakes in parameter ADDRESSES and derived buffers (the pair scorer's transposed W1): any weight change,
+        # in place or by swapping modules, gets a new graph
+        sig = tuple((p.data_ptr(), p._version) for m in (self.subject_encoder, self.object_encoder, self.pair_model, self.relation_model)
+                    for p in m.parameters())
+        key = (tuple(feats.shape), str(feats.device), hash(sig))
         ent = self._rel_graphs.get(key)
         if ent is None:
             self._rel_seen[key] = self._rel_seen.get(key, 0) + 1

@@ -112,3 +112,30 @@ def test_bench_gpus_2_runs_two_ranks_on_the_frame_sharded_clip(hip_lib):
     assert two['checksum']['tube_ids'] == one['checksum']['tube_ids'] and len(one['checksum']['tube_ids']) >= 2
     assert abs(two['checksum']['query_sum'] - one['checksum']['query_sum']) < 1e-2 * max(1.0, abs(one['checksum']['query_sum']))
     assert abs(two['checksum']['tube_feat_sum'] - one['checksum']['tube_feat_sum']) < 1e-2 * max(1.0, abs(one['checksum']['tube_feat_sum']))
+
+
+def test_relation_graph_replay_equals_eager_and_follows_weight_updates(hip_lib):
+    """PVSGPipeline replays the relation head as a hipGraph from the second sighting of a (tubes, frames) shape: same
+    results as eager, results are copies (valid after the next call), and a weight update invalidates the graph."""
+    from openpvsg_amd.relation import relation_forward
+    pipe = _build()
+    assert pipe.relation_graph
+    g = torch.Generator().manual_seed(5)
+    feats = [torch.randn(9, 6, 256, generator=g).cuda() for _ in range(3)]
+    mods = (pipe.subject_encoder, pipe.object_encoder, pipe.pair_model, pipe.relation_model)
+    with torch.no_grad():
+        outs = [pipe._relation(f) for f in feats]                      # eager, capture + replay, replay
+        refs = [relation_forward(*mods, f, 100) for f in feats]
+    assert len(pipe._rel_graphs) == 1 and next(iter(pipe._rel_graphs.values())) is not False
+    for o, r in zip(outs, refs):
+        assert o['pairs'].tolist() == r['pairs'].tolist()
+        assert torch.allclose(o['pred_matrix'], r['pred_matrix'], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(o['prob'], r['prob'], rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+        pipe.pair_model.pair_ffn[0].weight.mul_(1.5)                     # in place: new version, same address
+        o2 = pipe._relation(feats[0])                                   # first sighting of the new signature: eager
+        o3 = pipe._relation(feats[0])                                   # captured again
+        r2 = relation_forward(*mods, feats[0], 100)
+    assert torch.allclose(o2['pred_matrix'], r2['pred_matrix'], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(o3['pred_matrix'], r2['pred_matrix'], rtol=1e-5, atol=1e-6)
+    assert not torch.allclose(o3['pred_matrix'], refs[0]['pred_matrix'], atol=1e-3)
