@@ -2,14 +2,16 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle.detweights import det_state_dict
 from openpvsg_amd.model_zoo import panoptic_head_cfg
 from openpvsg_amd.registry import build_head as bh
 from openpvsg_amd import blocks, heads  # noqa
 DEV = 'cuda:0'
 CH = (256, 512, 1024, 2048)
+torch.manual_seed(4)
 h = bh(dict(panoptic_head_cfg(False), train_cfg=None, test_cfg=None)).eval()
-h.load_state_dict(det_state_dict(h, 4, {'cls_embed.weight': 12.0}))
+h.init_weights()
+with torch.no_grad():
+    h.cls_embed.weight.mul_(12.0)
 h = h.to(DEV)
 g = torch.Generator().manual_seed(0)
 shapes = ((184, 320), (92, 160), (46, 80), (23, 40))

@@ -12,7 +12,7 @@ dev = torch.device('cuda:0')
 from openpvsg_amd import tuning
 from openpvsg_amd.pipeline import PVSGPipeline
 tuning.enable()
-torch.backends.cudnn.deterministic = True
+torch.backends.cudnn.deterministic = os.environ.get('PVSG_DETERMINISTIC', '1') == '1'
 det, rel = bench.build_models(0)
 det = det.to(dev)
 rel = {k: m.to(dev) for k, m in rel.items()}
