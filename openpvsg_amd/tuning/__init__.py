@@ -20,5 +20,7 @@ def enable(table=TABLE):
         return False
     t.enable(True)
     t.tuning_enable(False)
+    if hasattr(t, 'write_file_on_exit'):
+        t.write_file_on_exit(False)          # load only: N ranks must not rewrite the tracked table at exit
     t.set_filename(table, insert_device_ordinal=False)
     return True

@@ -32,3 +32,10 @@ evs = sorted([e for e in prof.events() if e.device_type == torch.autograd.Device
 for i, e in enumerate(evs):
     if 'emset' in e.name and e.device_time > 200:
         print('memset %.0f us  after %s  before %s' % (e.device_time, evs[i - 1].name[:70], evs[i + 1].name[:70] if i + 1 < len(evs) else '-'))
+print('--- elementwise / reduction ATen ops by GPU time ---')
+rows = [r for r in prof.key_averages(group_by_input_shape=True)
+        if r.key in ('aten::add', 'aten::add_', 'aten::copy_', 'aten::var_mean', 'aten::mul', 'aten::cat', 'aten::clone', 'aten::contiguous',
+                     'aten::sub', 'aten::div', 'aten::index', 'aten::index_put_', 'aten::zeros', 'aten::fill_', 'aten::sigmoid', 'aten::softmax')]
+rows.sort(key=lambda r: -r.self_device_time_total)
+for r in rows[:25]:
+    print('ELT %8.1f us  x%-3d %-16s %s' % (r.self_device_time_total, r.count, r.key, str(r.input_shapes)[:150]))
