@@ -280,6 +280,17 @@ int pvsg_conv1x1_affine(const float* weight, const float* x, const float* scale,
                         const float* residual, float* out, int B, int Cout, int Cin, long long HW, int relu,
                         void* stream);
 
+/* [3P] 3x3 / stride 1 / pad 1 convolution (NCHW f32) as Winograd F(2x2,3x3) on the f32 matrix cores, replacing the
+ * library call behind mmdet ResNet Bottleneck.conv2 -> bn2 -> relu and the pixel decoder's FPN output convolutions
+ * (mmdet MSDeformAttnPixelDecoder.output_convs[i].conv):
+ *   y[n, co] = act( conv3x3(x[n], w[co]) * scale[co] + shift[co] )      scale == shift == NULL: no affine
+ * `u_packed` = 16 * Cin * Cout floats written by pvsg_conv3x3_winograd_pack from the (Cout, Cin, 3, 3) weight (once per
+ * weight; U = G g G^T in f64, stored in the kernel's operand order).  Requires Cin % 8 == 0, Cout % 64 == 0, even W,
+ * Cin*H*W < 2^31; other shapes return PVSG_ERR_UNSUPPORTED (the caller keeps its library convolution for those). */
+int pvsg_conv3x3_winograd_pack(const float* weight, float* u_packed, int Cin, int Cout, void* stream);
+int pvsg_conv3x3_winograd(const float* x, const float* u_packed, const float* scale, const float* shift, float* y,
+                          int N, int Cin, int Cout, int H, int W, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

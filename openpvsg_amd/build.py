@@ -18,6 +18,9 @@ ARCH = 'gfx950'
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 CFLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC',
           '-Wall', '-Wno-unused-function']
+# per-file additions.  winograd3x3: packed-f32 VALU (v_pk_add_f32 built by the SLP vectoriser, with the v_movs that feed
+# it) beside f32 MFMAs costs issue slots the scalar adds do not.
+EXTRA_CFLAGS = {'winograd3x3.hip': ['-fno-slp-vectorize']}
 
 
 def lib_path():
@@ -49,7 +52,7 @@ def build_hip_lib(force=False, verbose=True):
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC] + CFLAGS + ['-c', s, '-o', o]
+        cmd = [HIPCC] + CFLAGS + EXTRA_CFLAGS.get(os.path.basename(s), []) + ['-c', s, '-o', o]
         if verbose:
             print('[build]', ' '.join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -515,6 +515,44 @@ def conv1x1_affine(x, weight, scale, shift, residual=None, relu=True, out=None):
     return out
 
 
+def conv3x3_winograd_supported(cout, cin, h, w):
+    return cin % 8 == 0 and cout % 64 == 0 and w % 2 == 0 and cin * h * w < 2 ** 31
+
+
+def conv3x3_winograd_pack(weight):
+    """(Cout,Cin,3,3) -> the 16*Cin*Cout transformed weights in the operand order of csrc/winograd3x3.hip (once per weight)."""
+    w = _chk(weight, 'weight')
+    Cout, Cin = w.shape[:2]
+    if tuple(w.shape[2:]) != (3, 3) or not conv3x3_winograd_supported(Cout, Cin, 2, 2):
+        raise RuntimeError('conv3x3_winograd_pack: unsupported weight shape %s' % (tuple(w.shape),))
+    u = torch.empty(16 * Cin * Cout, device=w.device, dtype=torch.float32)
+    with torch.cuda.device(w.device):
+        _lib.call('pvsg_conv3x3_winograd_pack', w.data_ptr(), u.data_ptr(), Cin, Cout, _stream_ptr())
+    return u
+
+
+def conv3x3_winograd(x, u_packed, cout, scale=None, shift=None, relu=False, out=None):
+    """act(conv3x3(x, w, stride 1, pad 1) * scale[c] + shift[c]) with w given as conv3x3_winograd_pack(w)
+    (csrc/winograd3x3.hip).  x (N,Cin,H,W); scale/shift None = no affine."""
+    x = _chk(x, 'x')
+    N, Cin, H, W = x.shape
+    u = _chk(u_packed, 'u_packed')
+    if u.numel() != 16 * Cin * cout or not conv3x3_winograd_supported(cout, Cin, H, W):
+        raise RuntimeError('conv3x3_winograd: unsupported shape Cout=%d Cin=%d H=%d W=%d' % (cout, Cin, H, W))
+    if (scale is None) != (shift is None):
+        raise RuntimeError('conv3x3_winograd: scale and shift go together')
+    if out is None:
+        out = torch.empty((N, cout, H, W), device=x.device, dtype=torch.float32)
+    elif not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (N, cout, H, W)):
+        raise RuntimeError('conv3x3_winograd: out must be a contiguous float32 HIP tensor (N,Cout,H,W)')
+    with torch.cuda.device(x.device):
+        _lib.call('pvsg_conv3x3_winograd', x.data_ptr(), u.data_ptr(),
+                  _chk(scale, 'scale').data_ptr() if scale is not None else None,
+                  _chk(shift, 'shift').data_ptr() if shift is not None else None,
+                  out.data_ptr(), N, Cin, cout, H, W, int(bool(relu)), _stream_ptr())
+    return out
+
+
 def decoder_kv_inputs(tokens, start, hw, level_embed, pos_enc):
     """tokens (F,S,256) encoder memory, level rows start..start+hw -> value input (F*hw,256) = tokens + level_embed and
     key input = value + pos_enc, pos_enc (F*hw,256) or (hw,256); one pass, both outputs."""

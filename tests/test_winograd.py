@@ -1,0 +1,70 @@
+"""3x3 convolution on the f32 matrix cores (csrc/winograd3x3.hip) against torch's direct convolution on the CPU in
+float64 -- the arithmetic the oracle's ResNet bottleneck / FPN output convolution perform
+([3P] mmdet ResNet Bottleneck.conv2, MSDeformAttnPixelDecoder.output_convs)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, scale, shift, relu):
+    y = F.conv2d(x.double().cpu(), w.double().cpu(), padding=1)
+    if scale is not None:
+        y = y * scale.double().cpu().view(1, -1, 1, 1) + shift.double().cpu().view(1, -1, 1, 1)
+    return F.relu(y) if relu else y
+
+
+# (N, Cin, Cout, H, W): full / ragged 16x16 blocks, odd heights, every channel count of the ResNet-50 and the FPN
+CASES = [(2, 64, 64, 32, 32), (1, 64, 64, 23, 40), (3, 128, 128, 46, 80), (1, 256, 256, 17, 18), (1, 512, 512, 23, 40),
+         (2, 8, 64, 5, 2), (1, 256, 256, 33, 50), (1, 16, 128, 1, 2)]
+
+
+@pytest.mark.parametrize('N,Cin,Cout,H,W', CASES)
+@pytest.mark.parametrize('affine,relu', [(True, True), (False, False), (True, False), (False, True)])
+def test_conv3x3_winograd_matches_direct_convolution(hip_lib, N, Cin, Cout, H, W, affine, relu):
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + Cin + H)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).cuda()
+    scale = (torch.rand(Cout, generator=g) + 0.5).cuda() if affine else None
+    shift = torch.randn(Cout, generator=g).cuda() if affine else None
+    u = ops.conv3x3_winograd_pack(w)
+    y = ops.conv3x3_winograd(x, u, Cout, scale, shift, relu=relu)
+    ref = _ref(x, w, scale, shift, relu)
+    # f32 Winograd F(2,3): the transforms add a few ulps of the operand magnitude on top of the K = 9 Cin chain
+    err = (y.double().cpu() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+    # same class as the library's own kernel for this layer
+    lib = F.conv2d(x, w, padding=1)
+    if affine:
+        lib = lib * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    lib = F.relu(lib) if relu else lib
+    err_lib = (lib.double().cpu() - ref).abs().max().item()
+    assert err < 4 * err_lib + 1e-6, (err, err_lib)
+
+
+def test_conv3x3_winograd_is_deterministic_and_writes_only_its_output(hip_lib):
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 23, 40, generator=g).cuda()
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).cuda()
+    u = ops.conv3x3_winograd_pack(w)
+    buf = torch.full((2 * 64 * 23 * 40 + 512,), 7.0, device='cuda')
+    out = buf[256:256 + 2 * 64 * 23 * 40].view(2, 64, 23, 40)
+    a = ops.conv3x3_winograd(x, u, 64, out=out).clone()
+    b = ops.conv3x3_winograd(x, u, 64)
+    assert torch.equal(a, b)
+    assert bool((buf[:256] == 7).all()) and bool((buf[-256:] == 7).all())
+
+
+def test_conv3x3_winograd_rejects_unsupported_shapes(hip_lib):
+    from openpvsg_amd import ops
+    x = torch.zeros(1, 8, 4, 5, device='cuda')                   # odd width
+    u = torch.zeros(16 * 8 * 64, device='cuda')
+    with pytest.raises(RuntimeError, match='unsupported'):
+        ops.conv3x3_winograd(x, u, 64)
+    with pytest.raises(RuntimeError, match='unsupported'):
+        ops.conv3x3_winograd_pack(torch.zeros(48, 8, 3, 3, device='cuda'))
+    with pytest.raises(RuntimeError, match='HIP device'):
+        ops.conv3x3_winograd(torch.zeros(1, 8, 4, 4), u, 64)
