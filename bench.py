@@ -203,6 +203,12 @@ class KernelTimer:
         if name == 'pvsg_conv1x1_affine':
             B, Cout, Cin, HW = a[6:10]
             return 4.0 * B * HW * (Cin + Cout * (2 if a[4] else 1)), 2.0 * B * HW * Cin * Cout
+        if name == 'pvsg_conv3x3_winograd':
+            # flops = the multiplications the F(2x2,3x3) form issues on the matrix cores (16 GEMMs over the 2x2 tiles):
+            # direct-convolution flops / 2.25 -- the kernel is priced against what it executes, not what it saves
+            N, Cin, Cout, H, W = a[5:10]
+            return (4.0 * N * H * W * (Cin + Cout) + 64.0 * Cin * Cout,
+                    32.0 * N * Cin * Cout * ((H + 1) // 2) * ((W + 1) // 2))
         if name == 'pvsg_fpn_merge_up2x':
             planes, h, w = a[5:8]
             return 4.0 * planes * h * w * 9, 0.0                     # lateral 4 + out 4 + top 1 (x h*w cells)
@@ -228,6 +234,15 @@ class KernelTimer:
             B, C, HW = a[4:7]
             return 8.0 * B * C * HW, 0.0
         return 0.0, 0.0
+
+    @classmethod
+    def step_flops(cls, name, a):
+        """Flops of the launch as the MODEL's arithmetic (what roofline_step sums): the direct-convolution count for the
+        Winograd kernel, so that the step total does not depend on which algorithm runs a convolution."""
+        if name == 'pvsg_conv3x3_winograd':
+            N, Cin, Cout, H, W = a[5:10]
+            return 18.0 * N * Cin * Cout * H * W
+        return cls.work(name, a)[1]
 
     def summary(self):
         agg = {}
@@ -565,7 +580,7 @@ def main():
                 step()
         torch.cuda.synchronize()
         timer.enabled = False
-        hw_flops_one = sum(KernelTimer.work(n, a)[1] for n, a, _, _ in timer.records[n0:])
+        hw_flops_one = sum(KernelTimer.step_flops(n, a) for n, a, _, _ in timer.records[n0:])
         del timer.records[n0:]
         lib_flops = float(fc.get_total_flops())
     except Exception:

@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .blocks import BaseModule
+from .blocks import BaseModule, conv3x3_fast
 from .registry import BACKBONES
 
 
@@ -70,7 +70,8 @@ class _Bottleneck(nn.Module):
         else:
             identity = _conv_bn(self.downsample[0], x, aff['ds'], None, False, None, gemm)
         y = _conv_bn(self.conv1, x, aff['bn1'], None, True, None, gemm)
-        y = ops.affine_act_nchw_(self.conv2(y), *aff['bn2'])
+        y2 = conv3x3_fast(self.conv2, y, aff['bn2'][0], aff['bn2'][1], relu=True)     # BN + ReLU in the epilogue
+        y = y2 if y2 is not None else ops.affine_act_nchw_(self.conv2(y), *aff['bn2'])
         return _conv_bn(self.conv3, y, aff['bn3'], identity, True, out, gemm)
 
 

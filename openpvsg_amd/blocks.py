@@ -67,6 +67,24 @@ class _ShapeCache(dict):
         super().__setitem__(k, v)
 
 
+def conv3x3_fast(conv, x, scale=None, shift=None, relu=False, out=None):
+    """3x3 / stride 1 / pad 1 convolution without bias on the matrix-core Winograd kernel (csrc/winograd3x3.hip), or None
+    when this convolution / input is outside what that kernel is built for (the caller then keeps the library call).
+    The transformed weights are cached on the module and rebuilt when the weight tensor changes."""
+    w = conv.weight
+    if not (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and
+            conv.groups == 1 and conv.bias is None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and
+            x.is_contiguous() and not torch.is_grad_enabled() and os.environ.get('PVSG_WINOGRAD', 'on') != 'off' and
+            ops.conv3x3_winograd_supported(w.shape[0], w.shape[1], x.shape[2], x.shape[3])):
+        return None
+    key = (w.data_ptr(), w._version, str(w.device))
+    cache = getattr(conv, '_pvsg_winograd', None)
+    if cache is None or cache[0] != key:
+        cache = (key, ops.conv3x3_winograd_pack(w.detach()))
+        conv._pvsg_winograd = cache
+    return ops.conv3x3_winograd(x, cache[1], w.shape[0], scale, shift, relu=relu, out=out)
+
+
 def _interleave_sin_cos(p):
     return torch.stack((p[..., 0::2].sin(), p[..., 1::2].cos()), dim=-1).flatten(-2)
 
@@ -645,7 +663,9 @@ class MSDeformAttnPixelDecoder(BaseModule):
                 # GN(lateral) + x2 bilinear(top) in one pass; GN + ReLU after the 3x3 conv in one in-place pass
                 raw = lm.conv(feats[i])
                 y = ops.fpn_merge_up2x(raw, *ops.group_norm_affine(raw, lm.gn), top.contiguous())
-                o = om.conv(y)
+                o = conv3x3_fast(om.conv, y)
+                if o is None:
+                    o = om.conv(y)
                 sc, sh = ops.group_norm_affine(o, om.gn)
                 ops.affine_act_nchw_(o.view(1, -1, *o.shape[-2:]), sc, sh, relu=True)
                 outs.append(o)
