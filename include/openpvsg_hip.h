@@ -286,7 +286,7 @@ int pvsg_conv1x1_affine(const float* weight, const float* x, const float* scale,
  *   y[n, co] = act( conv3x3(x[n], w[co]) * scale[co] + shift[co] )      scale == shift == NULL: no affine
  * `u_packed` = 16 * Cin * Cout floats written by pvsg_conv3x3_winograd_pack from the (Cout, Cin, 3, 3) weight (once per
  * weight; U = G g G^T in f64, stored in the kernel's operand order).  Requires Cin % 8 == 0, Cout % 64 == 0, even W,
- * Cin*H*W < 2^31; other shapes return PVSG_ERR_UNSUPPORTED (the caller keeps its library convolution for those). */
+ * Cin*H*W < 2^29, Cin*Cout < 2^25; other shapes return PVSG_ERR_UNSUPPORTED (the caller keeps its library convolution for those). */
 int pvsg_conv3x3_winograd_pack(const float* weight, float* u_packed, int Cin, int Cout, void* stream);
 int pvsg_conv3x3_winograd(const float* x, const float* u_packed, const float* scale, const float* shift, float* y,
                           int N, int Cin, int Cout, int H, int W, int relu, void* stream);

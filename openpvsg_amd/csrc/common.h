@@ -76,6 +76,7 @@ inline hipError_t ensure_dynamic_lds(const void* fn, int bytes, std::atomic<unsi
   return e;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

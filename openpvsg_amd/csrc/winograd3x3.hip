@@ -28,6 +28,8 @@
 // (1 MB at Cin = 256) while the input streams.
 #include "common.h"
 
+#include <type_traits>
+
 namespace pvsg {
 namespace {
 
@@ -58,9 +60,15 @@ void winograd_f2x3_kernel(const float* __restrict__ x, const float* __restrict__
   const size_t HW = (size_t)H * W;
   const float* xn = x + (size_t)n * Cin * HW;
 
+  // Every memory operand of the loop is a buffer load with a wave-uniform scalar offset: no per-load address
+  // arithmetic on the VALU (which shares the SIMD with the f32 MFMAs), and out-of-image halo elements are fetched at an
+  // offset beyond the descriptor's range, i.e. read as 0 by the bounds check -- no select either.
+  const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, (unsigned)(Cin * HW * 4), 0x00020000);
+  const auto usrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, (unsigned)((size_t)Cin * Cout * 64), 0x00020000);
+
   // staging plan of this thread: WINO_LD elements of the (8 x 18 x 18) halo block, the same for every stage
-  int goff[WINO_LD], loff[WINO_LD];
-  unsigned inb = 0;
+  unsigned goff[WINO_LD];
+  int loff[WINO_LD];
 #pragma unroll
   for (int i = 0; i < WINO_LD; ++i) {
     const int e = tid + 256 * i;
@@ -69,28 +77,31 @@ void winograd_f2x3_kernel(const float* __restrict__ x, const float* __restrict__
     const int iy = oy0 - 1 + r, ix = ox0 - 1 + c;
     const bool real = e < WINO_ELEMS, inside = real && iy >= 0 && iy < H && ix >= 0 && ix < W;
     loff[i] = real ? cl * WINO_PLANE + r * WINO_PITCH + c : WINO_ROWS;      // surplus threads: a pad column nobody reads
-    goff[i] = inside ? cl * (int)HW + iy * W + ix : 0;                      // outside the image: any valid address, zeroed below
-    inb |= (inside ? 1u : 0u) << i;
+    goff[i] = inside ? 4u * (unsigned)(cl * (int)HW + iy * W + ix) : 0x80000000u;
   }
   float hold[WINO_LD];
+  const unsigned stage_bytes = (unsigned)(WINO_KC * HW * 4);
   auto fetch = [&](int s) {
-    const float* xs = xn + (size_t)s * WINO_KC * HW;
+    const unsigned so = (unsigned)s * stage_bytes;
 #pragma unroll
-    for (int i = 0; i < WINO_LD; ++i) hold[i] = xs[goff[i]];
+    for (int i = 0; i < WINO_LD; ++i)
+      hold[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, goff[i], so, 0));
   };
   auto stash = [&](float* buf) {
 #pragma unroll
-    for (int i = 0; i < WINO_LD; ++i) buf[loff[i]] = ((inb >> i) & 1u) ? hold[i] : 0.f;
+    for (int i = 0; i < WINO_LD; ++i) buf[loff[i]] = hold[i];
   };
 
   // U operands: [cin pair][32-channel block][lane][16 xi], 64 B per lane and K-step
-  const size_t ustride = (size_t)Cout * 32;
-  const float* ua = U + ((size_t)(cg * 2 + cbw) * 64 + lane) * 16;
+  const unsigned ustride = (unsigned)Cout * 128;                                           // bytes per cin pair
+  const unsigned ubase = (unsigned)__builtin_amdgcn_readfirstlane((cg * 2 + cbw) * 4096);  // this wave's channel block
+  const unsigned ulane = lane * 64;
   f32x4 a[4][4];
   auto fetch_u = [&](int j, int pair) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(ua + (size_t)pair * ustride);
+    const unsigned so = ubase + (unsigned)pair * ustride;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a[j][q] = p[q];
+    for (int q = 0; q < 4; ++q)
+      a[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(usrc, ulane + 16 * q, so, 0));
   };
 
   f32x16 acc[16];
@@ -100,8 +111,15 @@ void winograd_f2x3_kernel(const float* __restrict__ x, const float* __restrict__
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   const int S = Cin / WINO_KC;
-  const int poff = k * WINO_PLANE + 2 * ty * WINO_PITCH + 2 * tx;
-  // this lane's 4x4 patch of one channel, read one K-step ahead of its use
+  const float* const lbase = lds + k * WINO_PLANE + 2 * ty * WINO_PITCH + 2 * tx;
+  // The f32 MFMAs and the VALU share the SIMD.  Measured on the FPN output convolution (32 x 256 x 184 x 320):
+  //   all non-MFMA instructions in front of each K-step's MFMA chain            10.8 ms
+  //   memory instructions (LDS, buffer loads) handed out one per MFMA            9.0 ms   <- this schedule
+  //   ... and the transform's adds as well, two per MFMA                        10.5 ms   (VALU between MFMAs costs a
+  //                                                                                        pipeline switch each time)
+  //   packed adds (v_pk_add_f32 with half selects) instead of scalar ones       no change
+  // So each K-step is one VALU block (the 32 adds of B^T d B for this K-step, on the patch read during the previous
+  // one), then the MFMA chain with one LDS / buffer instruction after each MFMA.
   float d[2][16];
   auto read_patch = [&](int slot, const float* plane) {
 #pragma unroll
@@ -119,28 +137,19 @@ void winograd_f2x3_kernel(const float* __restrict__ x, const float* __restrict__
 #pragma unroll
   for (int j = 0; j < 4; ++j) fetch_u(j, j);
   __syncthreads();
-  read_patch(0, lds + poff);
+  read_patch(0, lbase);
 
   // Three staging buffers: stage s+1 is written at the top of iteration s (fetched during iteration s-1), published by
   // the barrier in the middle of iteration s and first read by the last K-step of iteration s (the patch prefetch of
   // the next stage's first K-step); its buffer was last read in iteration s-2, which every wave has left by then.
-  int b_cur = 0;
-  for (int s = 0; s < S; ++s) {
-    const int b_nxt = b_cur == 2 ? 0 : b_cur + 1;
-    const float* cur = lds + b_cur * WINO_STAGE + poff;
-    const float* nxt = lds + b_nxt * WINO_STAGE + poff;
-    // past the last stage these re-stage / re-load the last one into buffers and registers nobody reads: no branches in
-    // the loop body, so the compiler knows how many loads are in flight at every wait
-    stash(lds + b_nxt * WINO_STAGE);
-    fetch(s + 2 < S ? s + 2 : S - 1);
+  // Past the last stage the body re-stages / re-loads the last one into buffers and registers nobody reads: no branches
+  // inside it, so the compiler knows how many loads are in flight at every wait.  The buffer index is a compile-time
+  // constant of each copy of the body (LDS addresses = immediate offsets).
+  auto stage = [&](int s, auto BC, auto BN) {
+    constexpr int b_cur = decltype(BC)::value, b_nxt = decltype(BN)::value;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (j == 2) __syncthreads();
-      if (j < 3)
-        read_patch((j + 1) & 1, cur + 2 * (j + 1) * WINO_PLANE);
-      else
-        read_patch(0, nxt);
-      __builtin_amdgcn_sched_barrier(0);            // keep the prefetch above this K-step's arithmetic
       const float* dd = d[j & 1];
       float t[4][4], v[16];
 #pragma unroll
@@ -157,13 +166,41 @@ void winograd_f2x3_kernel(const float* __restrict__ x, const float* __restrict__
         v[r * 4 + 2] = t[r][2] - t[r][1];
         v[r * 4 + 3] = t[r][1] - t[r][3];
       }
+      if (j == 0) {
+        stash(lds + b_nxt * WINO_STAGE);
+        fetch(s + 2 < S ? s + 2 : S - 1);
+      }
+      read_patch((j + 1) & 1, lbase + (j < 3 ? b_cur * WINO_STAGE + 2 * (j + 1) * WINO_PLANE : b_nxt * WINO_STAGE));
 #pragma unroll
       for (int xi = 0; xi < 16; ++xi)
         acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][xi >> 2][xi & 3], v[xi], acc[xi], 0, 0, 0);
       fetch_u(j, s + 1 < S ? 4 * (s + 1) + j : j);
+      __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);         // the transform
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // the next patch first
+      }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x210, 1, 0);        // then one buffer load / LDS write per MFMA
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
-    b_cur = b_nxt;
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  using B2 = std::integral_constant<int, 2>;
+  int s = 0;
+  for (; s + 3 <= S; s += 3) {
+    stage(s, B0{}, B1{});
+    stage(s + 1, B1{}, B2{});
+    stage(s + 2, B2{}, B0{});
+  }
+  if (s < S) {
+    stage(s, B0{}, B1{});
+    if (s + 1 < S) stage(s + 1, B1{}, B2{});
   }
 
   // A^T M A per (output channel, tile), then BN / ReLU, then two float2 rows per channel
@@ -234,9 +271,9 @@ extern "C" int pvsg_conv3x3_winograd(const float* x, const float* u_packed, cons
   PVSG_REQUIRE(x && u_packed && y, "conv3x3_winograd: null pointer argument");
   PVSG_REQUIRE((scale == nullptr) == (shift == nullptr), "conv3x3_winograd: scale and shift go together");
   PVSG_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_winograd: bad shape");
-  if (Cin % WINO_KC || Cout % 64 || (W & 1) || (long long)Cin * H * W >= (1LL << 31))
+  if (Cin % WINO_KC || Cout % 64 || (W & 1) || (long long)Cin * H * W >= (1LL << 29) || (long long)Cin * Cout >= (1LL << 25))
     return set_err(PVSG_ERR_UNSUPPORTED,
-                   "conv3x3_winograd: built for Cin %% 8 == 0, Cout %% 64 == 0, even W (got Cin=%d Cout=%d H=%d W=%d)", Cin, Cout,
+                   "conv3x3_winograd: built for Cin %% 8 == 0, Cout %% 64 == 0, even W, Cin*H*W < 2^29 (got Cin=%d Cout=%d H=%d W=%d)", Cin, Cout,
                    H, W);
   PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(u_packed) & 15u) | (reinterpret_cast<uintptr_t>(y) & 7u)),
                "conv3x3_winograd: u_packed must be 16-byte and y 8-byte aligned");

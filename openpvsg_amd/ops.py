@@ -516,7 +516,7 @@ def conv1x1_affine(x, weight, scale, shift, residual=None, relu=True, out=None):
 
 
 def conv3x3_winograd_supported(cout, cin, h, w):
-    return cin % 8 == 0 and cout % 64 == 0 and w % 2 == 0 and cin * h * w < 2 ** 31
+    return cin % 8 == 0 and cout % 64 == 0 and w % 2 == 0 and cin * h * w < 2 ** 29 and cin * cout < 2 ** 25
 
 
 def conv3x3_winograd_pack(weight):

@@ -1,6 +1,6 @@
 """3x3 stride-1 convolutions of the north-star step (ResNet-50 conv2 of every bottleneck, the FPN output convolution) at
 32 x 720p: csrc/winograd3x3.hip vs the library (MIOpen) convolution + the separate BN/ReLU pass.
-usage: python scripts/conv3x3_bench.py [frames]"""
+usage: python scripts/conv3x3_bench.py [frames] [layer-name filter] [own]      ("own": skip the library arm, e.g. under rocprofv3)"""
 import json
 import os
 import sys
@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openpvsg_amd import ops  # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+FILTER = sys.argv[2] if len(sys.argv) > 2 else ''
+OWN_ONLY = len(sys.argv) > 3 and sys.argv[3] == 'own'
 SHAPES = [('layer1.conv2', 64, 64, 184, 320, True), ('layer2.conv2', 128, 128, 92, 160, True),
           ('layer3.conv2', 256, 256, 46, 80, True), ('layer4.conv2', 512, 512, 23, 40, True),
           ('fpn.output_conv', 256, 256, 184, 320, False)]
@@ -33,6 +35,8 @@ def main():
     torch.backends.cudnn.deterministic = True
     rows = []
     for name, cin, cout, h, w, bn in SHAPES:
+        if FILTER not in name:
+            continue
         g = torch.Generator().manual_seed(1)
         x = torch.randn(T, cin, h, w, generator=g).cuda()
         wt = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).cuda()
@@ -47,9 +51,13 @@ def main():
         def own():
             return ops.conv3x3_winograd(x, u, cout, sc, sh, relu=bn, out=out)
 
-        ref, got = lib(), own()
-        err = (ref - got).abs().max().item()
-        t_lib, t_own = timed(lib), timed(own)
+        if OWN_ONLY:
+            err, t_lib, t_own = None, float('nan'), timed(own)
+        else:
+            ref, got = lib(), own()
+            err = (ref - got).abs().max().item()
+            del ref, got
+            t_lib, t_own = timed(lib), timed(own)
         flops = 2.0 * 9 * cin * cout * h * w * T
         rows.append(dict(layer=name, cin=cin, cout=cout, h=h, w=w, lib_ms=round(t_lib, 3), own_ms=round(t_own, 3),
                          own_direct_tflops=round(flops / t_own / 1e9, 1), own_mfma_tflops=round(flops / 2.25 / t_own / 1e9, 1),
