@@ -209,6 +209,10 @@ class KernelTimer:
             N, Cin, Cout, H, W = a[5:10]
             return (4.0 * N * H * W * (Cin + Cout) + 64.0 * Cin * Cout,
                     32.0 * N * Cin * Cout * ((H + 1) // 2) * ((W + 1) // 2))
+        if name == 'pvsg_conv3x3s2_affine':
+            N, Cin, Cout, H, W = a[5:10]
+            ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            return 4.0 * N * (Cin * H * W + Cout * ho * wo) + 36.0 * Cin * Cout, 18.0 * N * Cin * Cout * ho * wo
         if name == 'pvsg_fpn_merge_up2x':
             planes, h, w = a[5:8]
             return 4.0 * planes * h * w * 9, 0.0                     # lateral 4 + out 4 + top 1 (x h*w cells)

@@ -291,6 +291,16 @@ int pvsg_conv3x3_winograd_pack(const float* weight, float* u_packed, int Cin, in
 int pvsg_conv3x3_winograd(const float* x, const float* u_packed, const float* scale, const float* shift, float* y,
                           int N, int Cin, int Cout, int H, int W, int relu, void* stream);
 
+/* [3P] 3x3 / stride 2 / pad 1 convolution (NCHW f32) as a direct convolution on the f32 matrix cores with the frozen-BN
+ * affine (+ ReLU) in the epilogue, replacing the library call behind the stride-2 Bottleneck.conv2 -> bn2 -> relu of mmdet
+ * ResNet layers 2-4 (style='pytorch'):  y[n, co] = act( conv3x3_s2(x[n], w[co]) * scale[co] + shift[co] ),
+ * y (N, Cout, (H-1)/2+1, (W-1)/2+1).  `w_packed` = 24 * Cin * Cout floats written by pvsg_conv3x3s2_pack from the
+ * (Cout, Cin, 3, 3) weight (once per weight).  Requires Cin % 8 == 0, Cout % 128 == 0, Cin*H*W < 2^29, Cin*Cout < 2^25;
+ * other shapes return PVSG_ERR_UNSUPPORTED (the caller keeps its library convolution for those). */
+int pvsg_conv3x3s2_pack(const float* weight, float* w_packed, int Cin, int Cout, void* stream);
+int pvsg_conv3x3s2_affine(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
+                          int N, int Cin, int Cout, int H, int W, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,8 @@ SIGNATURES = {
     'pvsg_conv1x1_affine': [_c_f] * 6 + [_i, _i, _i, _ll, _i, _c_f],
     'pvsg_conv3x3_winograd_pack': [_c_f, _c_f, _i, _i, _c_f],
     'pvsg_conv3x3_winograd': [_c_f] * 5 + [_i] * 6 + [_c_f],
+    'pvsg_conv3x3s2_pack': [_c_f, _c_f, _i, _i, _c_f],
+    'pvsg_conv3x3s2_affine': [_c_f] * 5 + [_i] * 6 + [_c_f],
 }
 # entry points that return a value instead of a status code
 VALUE_RETURNING = ('pvsg_xattn_num_splits',)

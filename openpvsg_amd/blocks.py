@@ -68,21 +68,28 @@ class _ShapeCache(dict):
 
 
 def conv3x3_fast(conv, x, scale=None, shift=None, relu=False, out=None):
-    """3x3 / stride 1 / pad 1 convolution without bias on the matrix-core Winograd kernel (csrc/winograd3x3.hip), or None
-    when this convolution / input is outside what that kernel is built for (the caller then keeps the library call).
-    The transformed weights are cached on the module and rebuilt when the weight tensor changes."""
+    """3x3 / pad 1 convolution without bias on the matrix-core kernels -- stride 1: Winograd F(2x2,3x3)
+    (csrc/winograd3x3.hip); stride 2 (needs scale/shift): direct convolution (csrc/conv3x3s2.hip) -- or None when this
+    convolution / input is outside what they are built for (the caller then keeps the library call).  The packed
+    weights are cached on the module and rebuilt when the weight tensor changes."""
     w = conv.weight
-    if not (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and
+    if not (conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1) and
             conv.groups == 1 and conv.bias is None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and
-            x.is_contiguous() and not torch.is_grad_enabled() and os.environ.get('PVSG_WINOGRAD', 'on') != 'off' and
-            ops.conv3x3_winograd_supported(w.shape[0], w.shape[1], x.shape[2], x.shape[3])):
+            x.is_contiguous() and not torch.is_grad_enabled() and os.environ.get('PVSG_WINOGRAD', 'on') != 'off'):
+        return None
+    if conv.stride == (1, 1) and ops.conv3x3_winograd_supported(w.shape[0], w.shape[1], x.shape[2], x.shape[3]):
+        pack, run = ops.conv3x3_winograd_pack, ops.conv3x3_winograd
+    elif (conv.stride == (2, 2) and scale is not None and
+          ops.conv3x3s2_supported(w.shape[0], w.shape[1], x.shape[2], x.shape[3])):
+        pack, run = ops.conv3x3s2_pack, ops.conv3x3s2_affine          # direct convolution, csrc/conv3x3s2.hip
+    else:
         return None
     key = (w.data_ptr(), w._version, str(w.device))
-    cache = getattr(conv, '_pvsg_winograd', None)
+    cache = getattr(conv, '_pvsg_packed', None)
     if cache is None or cache[0] != key:
-        cache = (key, ops.conv3x3_winograd_pack(w.detach()))
-        conv._pvsg_winograd = cache
-    return ops.conv3x3_winograd(x, cache[1], w.shape[0], scale, shift, relu=relu, out=out)
+        cache = (key, pack(w.detach()))
+        conv._pvsg_packed = cache
+    return run(x, cache[1], w.shape[0], scale, shift, relu=relu, out=out)
 
 
 def _interleave_sin_cos(p):

@@ -553,6 +553,40 @@ def conv3x3_winograd(x, u_packed, cout, scale=None, shift=None, relu=False, out=
     return out
 
 
+def conv3x3s2_supported(cout, cin, h, w):
+    return cin % 8 == 0 and cout % 128 == 0 and cin * h * w < 2 ** 29 and cin * cout < 2 ** 25
+
+
+def conv3x3s2_pack(weight):
+    """(Cout,Cin,3,3) -> the 24*Cin*Cout weights in the operand order of csrc/conv3x3s2.hip (once per weight)."""
+    w = _chk(weight, 'weight')
+    Cout, Cin = w.shape[:2]
+    if tuple(w.shape[2:]) != (3, 3) or not conv3x3s2_supported(Cout, Cin, 2, 2):
+        raise RuntimeError('conv3x3s2_pack: unsupported weight shape %s' % (tuple(w.shape),))
+    wp = torch.empty(24 * Cin * Cout, device=w.device, dtype=torch.float32)
+    with torch.cuda.device(w.device):
+        _lib.call('pvsg_conv3x3s2_pack', w.data_ptr(), wp.data_ptr(), Cin, Cout, _stream_ptr())
+    return wp
+
+
+def conv3x3s2_affine(x, w_packed, cout, scale, shift, relu=True, out=None):
+    """act(conv3x3(x, w, stride 2, pad 1) * scale[c] + shift[c]) with w given as conv3x3s2_pack(w) (csrc/conv3x3s2.hip)."""
+    x = _chk(x, 'x')
+    N, Cin, H, W = x.shape
+    wp = _chk(w_packed, 'w_packed')
+    if wp.numel() != 24 * Cin * cout or not conv3x3s2_supported(cout, Cin, H, W):
+        raise RuntimeError('conv3x3s2_affine: unsupported shape Cout=%d Cin=%d H=%d W=%d' % (cout, Cin, H, W))
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((N, cout, Ho, Wo), device=x.device, dtype=torch.float32)
+    elif not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (N, cout, Ho, Wo)):
+        raise RuntimeError('conv3x3s2_affine: out must be a contiguous float32 HIP tensor (N,Cout,Ho,Wo)')
+    with torch.cuda.device(x.device):
+        _lib.call('pvsg_conv3x3s2_affine', x.data_ptr(), wp.data_ptr(), _chk(scale, 'scale').data_ptr(),
+                  _chk(shift, 'shift').data_ptr(), out.data_ptr(), N, Cin, cout, H, W, int(bool(relu)), _stream_ptr())
+    return out
+
+
 def decoder_kv_inputs(tokens, start, hw, level_embed, pos_enc):
     """tokens (F,S,256) encoder memory, level rows start..start+hw -> value input (F*hw,256) = tokens + level_embed and
     key input = value + pos_enc, pos_enc (F*hw,256) or (hw,256); one pass, both outputs."""

@@ -68,3 +68,57 @@ def test_conv3x3_winograd_rejects_unsupported_shapes(hip_lib):
         ops.conv3x3_winograd_pack(torch.zeros(48, 8, 3, 3, device='cuda'))
     with pytest.raises(RuntimeError, match='HIP device'):
         ops.conv3x3_winograd(torch.zeros(1, 8, 4, 4), u, 64)
+
+
+# ---- stride-2 direct convolution (csrc/conv3x3s2.hip): the first bottleneck of ResNet layers 2-4 --------------------
+S2_CASES = [(2, 128, 128, 32, 32), (1, 128, 128, 23, 41), (2, 256, 256, 46, 80), (1, 512, 512, 17, 19), (1, 8, 128, 5, 3),
+            (1, 16, 256, 1, 1), (1, 64, 128, 92, 160)]
+
+
+@pytest.mark.parametrize('N,Cin,Cout,H,W', S2_CASES)
+@pytest.mark.parametrize('relu', [True, False])
+def test_conv3x3s2_matches_direct_convolution(hip_lib, N, Cin, Cout, H, W, relu):
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + Cin + H)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).cuda()
+    scale, shift = (torch.rand(Cout, generator=g) + 0.5).cuda(), torch.randn(Cout, generator=g).cuda()
+    y = ops.conv3x3s2_affine(x, ops.conv3x3s2_pack(w), Cout, scale, shift, relu=relu)
+    ref = F.conv2d(x.double().cpu(), w.double().cpu(), stride=2, padding=1)
+    ref = ref * scale.double().cpu().view(1, -1, 1, 1) + shift.double().cpu().view(1, -1, 1, 1)
+    ref = F.relu(ref) if relu else ref
+    assert tuple(y.shape) == tuple(ref.shape)
+    err = (y.double().cpu() - ref).abs().max().item()
+    assert err < 1e-5 * max(1.0, ref.abs().max().item()), err              # plain f32 fma chain of length 9 Cin
+
+
+def test_conv3x3s2_is_deterministic_and_rejects_unsupported(hip_lib):
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 128, 23, 40, generator=g).cuda()
+    w = (torch.randn(128, 128, 3, 3, generator=g) / 34).cuda()
+    sc, sh = torch.ones(128).cuda(), torch.zeros(128).cuda()
+    wp = ops.conv3x3s2_pack(w)
+    assert torch.equal(ops.conv3x3s2_affine(x, wp, 128, sc, sh), ops.conv3x3s2_affine(x, wp, 128, sc, sh))
+    with pytest.raises(RuntimeError, match='unsupported'):
+        ops.conv3x3s2_pack(torch.zeros(64, 8, 3, 3, device='cuda'))
+    with pytest.raises(RuntimeError, match='HIP device'):
+        ops.conv3x3s2_affine(torch.zeros(1, 128, 4, 4), wp, 128, sc, sh)
+
+
+def test_conv3x3_fast_dispatch_follows_weight_updates(hip_lib):
+    import torch.nn as nn
+    from openpvsg_amd.blocks import conv3x3_fast
+    torch.manual_seed(0)
+    sc, sh = torch.ones(128).cuda(), torch.zeros(128).cuda()
+    x = torch.randn(1, 128, 12, 16).cuda()
+    with torch.no_grad():
+        for stride in (1, 2):
+            conv = nn.Conv2d(128, 128, 3, stride=stride, padding=1, bias=False).cuda()
+            a = conv3x3_fast(conv, x, sc, sh, relu=False)
+            assert torch.allclose(a, conv(x), atol=2e-5)
+            conv.weight.mul_(2.0)                                   # in-place update: the packed copy must follow
+            b = conv3x3_fast(conv, x, sc, sh, relu=False)
+            assert torch.allclose(b, conv(x), atol=4e-5) and not torch.allclose(a, b, atol=1e-3)
+        assert conv3x3_fast(nn.Conv2d(128, 128, 3, padding=1, bias=True).cuda(), x) is None      # bias: library path
+        assert conv3x3_fast(nn.Conv2d(128, 128, 3, stride=2, padding=1, bias=False).cuda(), x) is None   # stride 2 w/o affine
