@@ -37,6 +37,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TF = 157.3     # f32-input MFMA peak
+BF16_MFMA_PEAK_TF = 2516.6   # dense bf16 MFMA peak (16 x the f32 matrix rate)
 CLS_GAIN = 40.0              # random-init class logits are flat; peaky logits keep a few queries
 
 
@@ -209,6 +210,10 @@ class KernelTimer:
             N, Cin, Cout, H, W = a[5:10]
             return (4.0 * N * H * W * (Cin + Cout) + 64.0 * Cin * Cout,
                     32.0 * N * Cin * Cout * ((H + 1) // 2) * ((W + 1) // 2))
+        if name == 'pvsg_gemm_bf16x3':
+            # flops = the bf16 limb products the kernel issues (6 per f32 multiply-add), priced against the bf16 roof
+            M, N, K = a[4:7]
+            return 4.0 * M * (K + N) + 6.0 * N * K, 12.0 * M * N * K
         if name == 'pvsg_conv3x3s2_affine':
             N, Cin, Cout, H, W = a[5:10]
             ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -246,7 +251,17 @@ class KernelTimer:
         if name == 'pvsg_conv3x3_winograd':
             N, Cin, Cout, H, W = a[5:10]
             return 18.0 * N * Cin * Cout * H * W
+        if name == 'pvsg_gemm_bf16x3':
+            M, N, K = a[4:7]
+            return 2.0 * M * N * K
         return cls.work(name, a)[1]
+
+    @staticmethod
+    def mfma_peak(name):
+        """(peak TFLOP/s, what the flops of work() count) of the matrix pipe a kernel runs on."""
+        if name.startswith('pvsg_gemm_bf16x3'):
+            return BF16_MFMA_PEAK_TF, 'bf16 limb products issued (6 per f32 multiply-add), dense bf16 MFMA peak'
+        return F32_MFMA_PEAK_TF, 'f32 MFMA'
 
     def summary(self):
         agg = {}
@@ -490,6 +505,9 @@ def main():
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('PVSG_ONE_DEVICE') == '1' and world > 1:
+        from openpvsg_amd.parallel import isolate_shared_gpu
+        isolate_shared_gpu(rank, world)            # ranks sharing GPU 0 get disjoint CU ranges (see its docstring)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(args.backend, init_method='env://')
@@ -652,7 +670,8 @@ def main():
             d = agg[dom]
             per = d['ms'] / d['calls']
             # the roof that binds = the larger ideal time (bytes / HBM peak vs flops / f32 matrix peak) over its launches
-            mfma_bound = d['flops'] / (F32_MFMA_PEAK_TF * 1e12) > d['bytes'] / (HBM_PEAK_GBS * 1e9)
+            peak_tf, peak_note = KernelTimer.mfma_peak(dom)
+            mfma_bound = d['flops'] / (peak_tf * 1e12) > d['bytes'] / (HBM_PEAK_GBS * 1e9)
             # HBM-side bytes per launch from the PMC passes of scripts/pmc_traffic.py (FETCH_SIZE / WRITE_SIZE in
             # separate rocprofv3 runs of THIS bench at T=32, gfx950 read correction applied), keyed by C-ABI entry;
             # null when the file has no entry for this kernel / clip length
@@ -666,8 +685,8 @@ def main():
                      'the step are library GEMMs / convolutions -- roofline_step covers the whole step')
             if mfma_bound:
                 ach = d['flops'] / d['calls'] / per / 1e9
-                line['roofline'] = dict(kernel=dom, bound='mfma', achieved=ach, peak=F32_MFMA_PEAK_TF,
-                                        unit='TFLOP/s', frac=ach / F32_MFMA_PEAK_TF, traffic=traffic,
+                line['roofline'] = dict(kernel=dom, bound='mfma', achieved=ach, peak=peak_tf, flops_counted=peak_note,
+                                        unit='TFLOP/s', frac=ach / peak_tf, traffic=traffic,
                                         avg_launch_ms=per, launches_per_step=d['calls'] / args.steps,
                                         algorithmic_bytes_per_launch=d['bytes'] / d['calls'], scope=scope)
             else:

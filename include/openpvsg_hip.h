@@ -301,6 +301,17 @@ int pvsg_conv3x3s2_pack(const float* weight, float* w_packed, int Cin, int Cout,
 int pvsg_conv3x3s2_affine(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
                           int N, int Cin, int Cout, int H, int W, int relu, void* stream);
 
+/* Token-major linear layer out[M, N] = act(a[M, K] . w[N, K]^T + bias) (f32 in / out) on the bf16 matrix cores from an
+ * exact three-limb bf16 split of both operands (six limb products per multiply, f32 accumulation: f32-class accuracy,
+ * see csrc/gemm_bf16x3.hip), replacing the library f32 GEMM behind [3P] mmcv FFN / MultiScaleDeformableAttention /
+ * MultiheadAttention projections (torch.nn.functional.linear).  `w_packed`: pvsg_gemm_bf16x3_packed_elems(N, K) bf16
+ * elements written by pvsg_gemm_bf16x3_pack from the (N, K) f32 weight (once per weight).  bias NULL = none.
+ * Requires K % 16 == 0; other shapes return PVSG_ERR_UNSUPPORTED (the caller keeps its library GEMM). */
+long long pvsg_gemm_bf16x3_packed_elems(int N, int K);
+int pvsg_gemm_bf16x3_pack(const float* weight, void* w_packed, int N, int K, void* stream);
+int pvsg_gemm_bf16x3(const float* a, const void* w_packed, const float* bias, float* out, long long M, int N, int K,
+                     int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

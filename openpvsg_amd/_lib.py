@@ -68,10 +68,13 @@ SIGNATURES = {
     'pvsg_conv3x3_winograd_pack': [_c_f, _c_f, _i, _i, _c_f],
     'pvsg_conv3x3_winograd': [_c_f] * 5 + [_i] * 6 + [_c_f],
     'pvsg_conv3x3s2_pack': [_c_f, _c_f, _i, _i, _c_f],
+    'pvsg_gemm_bf16x3_packed_elems': [_i, _i],
+    'pvsg_gemm_bf16x3_pack': [_c_f, _c_f, _i, _i, _c_f],
+    'pvsg_gemm_bf16x3': [_c_f, _c_f, _c_f, _c_f, _ll, _i, _i, _i, _c_f],
     'pvsg_conv3x3s2_affine': [_c_f] * 5 + [_i] * 6 + [_c_f],
 }
 # entry points that return a value instead of a status code
-VALUE_RETURNING = ('pvsg_xattn_num_splits',)
+VALUE_RETURNING = ('pvsg_xattn_num_splits', 'pvsg_gemm_bf16x3_packed_elems')
 
 _lib = None
 
@@ -99,7 +102,7 @@ def load():
             f = getattr(lib, name)
         except AttributeError as e:
             raise BackendMissingError('symbol %s missing from %s' % (name, LIB_PATH)) from e
-        f.restype = _i
+        f.restype = _ll if name == 'pvsg_gemm_bf16x3_packed_elems' else _i
         f.argtypes = argtypes
     _lib = lib
     return lib

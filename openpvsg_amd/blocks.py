@@ -92,6 +92,27 @@ def conv3x3_fast(conv, x, scale=None, shift=None, relu=False, out=None):
     return run(x, cache[1], w.shape[0], scale, shift, relu=relu, out=out)
 
 
+def linear_fast(owner, tag, weights, x, bias=None, relu=False):
+    """act(F.linear(x, cat(weights), bias)) for a token-major f32 tensor.  On the HIP device this runs on the bf16 matrix
+    cores from an exact three-limb split of both operands (csrc/gemm_bf16x3.hip: f32-class accuracy, 1.3-1.45x the
+    library's f32 GEMM on the encoder's shapes); PVSG_GEMM=lib keeps the library GEMM.  The packed limbs of the weight(s)
+    are cached on `owner` under `tag` and rebuilt when a weight tensor changes (address or version)."""
+    ws = tuple(weights) if isinstance(weights, (list, tuple)) else (weights,)
+    n, k = sum(w.shape[0] for w in ws), ws[0].shape[1]
+    if not (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and
+            os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and ops.gemm_bf16x3_supported(n, k)):
+        y = F.linear(x, ws[0] if len(ws) == 1 else torch.cat(ws, 0), bias)
+        return F.relu(y, inplace=True) if relu else y
+    key = tuple((w.data_ptr(), w._version, str(w.device)) for w in ws)
+    cache = owner.__dict__.setdefault('_pvsg_gemm', {})
+    ent = cache.get(tag)
+    if ent is None or ent[0] != key:
+        w = ws[0] if len(ws) == 1 else torch.cat(ws, 0)
+        ent = cache[tag] = (key, ops.gemm_bf16x3_pack(w.detach().contiguous()))
+    y = ops.gemm_bf16x3(x.reshape(-1, k), ent[1], n, bias, relu=relu)
+    return y.view(*x.shape[:-1], n)
+
+
 def _interleave_sin_cos(p):
     return torch.stack((p[..., 0::2].sin(), p[..., 1::2].cos()), dim=-1).flatten(-2)
 
@@ -309,7 +330,8 @@ class MultiheadAttention(BaseModule):
         """(B,K,C) x2 -> projected keys / values (B,K,C): the two big GEMMs of the decoder."""
         C = self.embed_dims
         W, b = self.attn.in_proj_weight, self.attn.in_proj_bias
-        return F.linear(key, W[C:2 * C], b[C:2 * C]), F.linear(value, W[2 * C:], b[2 * C:])
+        return (linear_fast(self.attn, 'k', W[C:2 * C], key, b[C:2 * C]),
+                linear_fast(self.attn, 'v', W[2 * C:], value, b[2 * C:]))
 
     def project_q(self, q):
         C = self.embed_dims
@@ -589,10 +611,10 @@ class MSDeformAttnPixelDecoder(BaseModule):
         a = layer.attentions[0]
         w_oa = torch.cat([a.sampling_offsets.weight, a.attention_weights.weight], 0)
         b_oa = torch.cat([a.sampling_offsets.bias, a.attention_weights.bias], 0)
-        pos_oa = F.linear(pos, w_oa, b_oa)                                     # (S, 288)
-        w_cat = torch.cat([a.value_proj.weight, w_oa], 0)                      # (544, 256)
+        pos_oa = linear_fast(a, 'offsets_weights', (a.sampling_offsets.weight, a.attention_weights.weight), pos, b_oa)  # (S, 288)
         b_cat = torch.cat([a.value_proj.bias, torch.zeros_like(b_oa)], 0)
-        y = F.linear(x, w_cat, b_cat)                                          # (B, S, 544)
+        y = linear_fast(a, 'value_offsets_weights', (a.value_proj.weight, a.sampling_offsets.weight,
+                                                     a.attention_weights.weight), x, b_cat)      # (B, S, 544)
         if MSDeformAttnPixelDecoder.fuse_out_proj:
             # sampling + output_proj + identity + LayerNorm in one kernel (projection on the matrix cores under the
             # texture-bound gather); the packed weight is rebuilt when the parameter changes
@@ -603,13 +625,12 @@ class MSDeformAttnPixelDecoder(BaseModule):
             x = ops.msda_proj_ln(y, pos_oa, ref2d, ss, lsi, a._wo_packed, a.output_proj.bias, x, layer.norms[0])
         else:
             core = ops.msda_fused(y, pos_oa, ref2d, ss, lsi)
-            t = F.linear(core, a.output_proj.weight)
+            t = linear_fast(a, 'output_proj', a.output_proj.weight, core)
             x = ops.add_layernorm(t, x, a.output_proj.bias, layer.norms[0])
         ffn = layer.ffns[0]
         fc1, fc2 = ffn.layers[0][0], ffn.layers[1]
-        B, S, C = x.shape
-        h = torch._addmm_activation(fc1.bias, x.view(B * S, C), fc1.weight.t())   # bias + ReLU epilogue
-        t = F.linear(h, fc2.weight).view(B, S, C)
+        h = linear_fast(fc1, 'w', fc1.weight, x, fc1.bias, relu=True)              # bias + ReLU in the GEMM epilogue
+        t = linear_fast(fc2, 'w', fc2.weight, h)
         return ops.add_layernorm(t, x, fc2.bias, layer.norms[1])
 
     fuse_glue = True

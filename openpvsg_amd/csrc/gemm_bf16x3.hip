@@ -1,0 +1,239 @@
+// out[M, N] = act(A[M, K] . W[N, K]^T + bias) with f32 inputs and outputs, computed on the bf16 matrix cores from an
+// EXACT three-limb split of every operand.
+//
+// Replaces, on the north-star path, the library f32 GEMMs behind the token-major linear layers of the pixel decoder's
+// deformable-attention encoder and of the transformer decoder's key / value projections
+//   [3P] mmcv FFN.layers (Linear 256->1024 + ReLU, Linear 1024->256), MultiScaleDeformableAttention.{value_proj,
+//        sampling_offsets, attention_weights, output_proj}, MultiheadAttention in_proj (k, v)
+// which rocBLAS / hipBLASLt run on the f32 MFMA at 115-150 TFLOP/s (the f32 matrix rate is 1/16 of the bf16 rate).
+//
+// Arithmetic.  a = a_h + a_m + a_l with a_h = bf16(a), a_m = bf16(a - a_h), a_l = bf16(a - a_h - a_m): both residuals are
+// exact in f32 and |a - (a_h + a_m + a_l)| <= 2^-27 |a| (three 8-bit mantissas cover the 24 bits of an f32).  A product
+// a w is the sum of the nine limb products; the six with total order <= 2 (hh, hm, mh, hl, lh, mm) are kept, the other
+// three are below 2^-25 |a w|.  Each limb product is exact in f32 (8 x 8 bit mantissas) and accumulates in the f32
+// accumulator of v_mfma_f32_32x32x16_bf16, so the result is an f32-class dot product (same error class as the library's
+// f32 GEMM with a different summation order; tests/test_gemm_bf16x3.py measures both against f64).
+//
+// Kernel.  Workgroup = 4 waves = 128 x 128 outputs, wave = 64 x 64 (2 x 2 MFMA blocks, 64 accumulator registers),
+// K-step = 16: 6 limb pairs x 4 blocks = 24 MFMAs against 12 ds_read_b128 (the three limbs of two row blocks and two
+// column blocks).  A is split on the fly while it is staged (global f32 -> 3 x packed bf16 in LDS: 11 VALU instructions
+// per element pair, hidden beside the bf16 MFMAs); W is split once by pvsg_gemm_bf16x3_pack into the staging order.
+// LDS tiles are [limb][k-group of 8][row][8 bf16]: consecutive lanes read consecutive 16-byte groups.
+#include "common.h"
+
+#include <type_traits>
+
+namespace pvsg {
+namespace {
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GB_M = 128, GB_N = 128, GB_K = 16;
+constexpr int GB_LIMB = 2 * GB_M * 8;                 // bf16 elements of one limb of a 128 x 16 tile ([kg][row][8])
+constexpr int GB_TILE = 3 * GB_LIMB;                  // one operand, three limbs: 6144 bf16 = 12 KB
+constexpr int GB_STAGE = 2 * GB_TILE;                 // A and W: 24 KB
+
+// three-limb split of two floats -> packed bf16 pairs (hi, mid, lo)
+__device__ __forceinline__ void split2(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
+  const bf16x2 hh = __builtin_convertvector(f32x2{a0, a1}, bf16x2);
+  h = __builtin_bit_cast(unsigned, hh);
+  const float r0 = a0 - __builtin_bit_cast(float, h << 16), r1 = a1 - __builtin_bit_cast(float, h & 0xffff0000u);
+  const bf16x2 mm = __builtin_convertvector(f32x2{r0, r1}, bf16x2);
+  m = __builtin_bit_cast(unsigned, mm);
+  const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256, 2)
+void gemm_bf16x3_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
+                        float* __restrict__ out, int M, int N, int K, int Npad, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * GB_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tn = logical % tiles_n, tm = logical / tiles_n;      // column tiles of one row tile are neighbours: A from L2
+  const int m0 = tm * GB_M, n0 = tn * GB_N;
+
+  // staging: A -- thread = (row tid/2, k-group tid%2), 8 consecutive floats; W -- (k-group tid/128, column tid%128), 3 limbs
+  const int ar = tid >> 1, akg = tid & 1;
+  const bool a_in = m0 + ar < M;
+  const unsigned a_voff = a_in ? (unsigned)((ar * K + 8 * akg) * 4) : 0x80000000u;   // rows beyond M read as 0
+  const size_t a_base = (size_t)m0 * K * 4;                       // folded into the pointer below: keeps offsets 32-bit
+  const auto asrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A) + a_base), 0,
+                                                        (unsigned)((size_t)GB_M * K * 4), 0x00020000);
+  const int wkg = tid >> 7, wcol = tid & 127;
+  const size_t w_limb_stride = (size_t)2 * Npad * 8;              // elements per (k-tile, limb): [kg][Npad][8]
+  const __bf16* wsrc = Wp + ((size_t)wkg * Npad + n0 + wcol) * 8;
+
+  f32x4 a_regs[2][2];                                 // [fetch slot = K-step & 1][two float4]
+  u32x4 w_regs[2][3];
+  auto fetch = [&](int slot, int kt) {
+    const unsigned so = (unsigned)kt * (GB_K * 4);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      a_regs[slot][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc_t, a_voff + 16 * q, so, 0));
+    const __bf16* wk = wsrc + (size_t)kt * 3 * w_limb_stride;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) w_regs[slot][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
+  };
+  auto stash = [&](int slot, __bf16* st) {
+    unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      split2(a_regs[slot][q][0], a_regs[slot][q][1], hh[2 * q], mm[2 * q], ll[2 * q]);
+      split2(a_regs[slot][q][2], a_regs[slot][q][3], hh[2 * q + 1], mm[2 * q + 1], ll[2 * q + 1]);
+    }
+    const u32x4 h = {hh[0], hh[1], hh[2], hh[3]}, m = {mm[0], mm[1], mm[2], mm[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+    __bf16* pa = st + (akg * GB_M + ar) * 8;
+    *reinterpret_cast<u32x4*>(pa) = h;
+    *reinterpret_cast<u32x4*>(pa + GB_LIMB) = m;
+    *reinterpret_cast<u32x4*>(pa + 2 * GB_LIMB) = l;
+    __bf16* pw = st + GB_TILE + (wkg * GB_N + wcol) * 8;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(pw + i * GB_LIMB) = w_regs[slot][i];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int KT = K / GB_K;
+  const int kg = lane >> 5, li = lane & 31;
+  const int a_off = (kg * GB_M + wr * 64 + li) * 8, w_off = GB_TILE + (kg * GB_N + wc * 64 + li) * 8;
+  // Two LDS stages, one barrier per K-step: stage kt is read right after the barrier that publishes it while stage kt+1
+  // is being written; three workgroups per CU (48 KB, <= 168 registers) cover each other's barriers and load latencies.
+  // Global loads run two K-steps ahead of their staging (register ring of two slots).
+  // (A three-stage variant with the operands of K-step kt+1 prefetched into registers under the MFMAs of kt needs 72 KB
+  // and drops to two workgroups per CU: 2.34 vs 1.99 ms on the encoder's first FFN layer.)
+  fetch(0, 0);
+  stash(0, lds);
+  fetch(1, KT > 1 ? 1 : 0);
+  fetch(0, KT > 2 ? 2 : KT - 1);
+  auto kstep = [&](int kt, auto PAR) {
+    constexpr int par = decltype(PAR)::value;          // kt & 1
+    __syncthreads();                                   // stage kt visible; stage kt+1's buffer no longer read
+    const __bf16* cur = lds + par * GB_STAGE;
+    bf16x8 av[3][2], wv[3][2];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        av[l][b] = *reinterpret_cast<const bf16x8*>(cur + a_off + l * GB_LIMB + b * 32 * 8);
+        wv[l][b] = *reinterpret_cast<const bf16x8*>(cur + w_off + l * GB_LIMB + b * 32 * 8);
+      }
+    stash(par ^ 1, lds + (par ^ 1) * GB_STAGE);        // K-step kt+1; past the end: a copy of the last one, never read
+    fetch(par ^ 1, kt + 3 < KT ? kt + 3 : KT - 1);
+    // small terms first: (m,m) (h,l) (l,h) (h,m) (m,h) (h,h)
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PW[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[p]][rb], wv[PW[p]][cb], acc[rb][cb], 0, 0, 0);
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  int kt = 0;
+  for (; kt + 2 <= KT; kt += 2) {
+    kstep(kt, P0{});
+    kstep(kt + 1, P1{});
+  }
+  if (kt < KT) kstep(kt, P0{});
+
+  // bias / ReLU and store: register r of block (rb, cb) = row (r&3) + 8 (r>>2) + 4 kg, column li of the block
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int col = n0 + wc * 64 + cb * 32 + li;
+    if (col >= N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+    float* op = out + (size_t)(m0 + wr * 64 + 4 * kg) * N + col;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rrel = rb * 32 + (r & 3) + 8 * (r >> 2);
+        if (m0 + wr * 64 + 4 * kg + rrel < M) {
+          float o = acc[rb][cb][r] + bv;
+          if (RELU) o = fmaxf(o, 0.f);
+          op[(size_t)rrel * N] = o;
+        }
+      }
+  }
+}
+
+// W (N, K) f32 -> [k-tile K/16][limb 3][k-group 2][Npad][8] bf16, columns beyond N zero
+__global__ void gemm_bf16x3_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int N, int K, int Npad) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // one (column, k pair)
+  const long long total = (long long)Npad * (K / 2);
+  if (idx >= total) return;
+  const int kp = (int)(idx % (K / 2)), n = (int)(idx / (K / 2));
+  const int k = 2 * kp;
+  float a0 = 0.f, a1 = 0.f;
+  if (n < N) {
+    a0 = w[(size_t)n * K + k];
+    a1 = w[(size_t)n * K + k + 1];
+  }
+  unsigned h, m, l;
+  split2(a0, a1, h, m, l);
+  const int kt = k / GB_K, kg = (k % GB_K) / 8, e = k % 8;
+  const size_t limb_stride = (size_t)2 * Npad * 8;
+  unsigned* dst = reinterpret_cast<unsigned*>(wp + ((size_t)kt * 3 * limb_stride + ((size_t)kg * Npad + n) * 8 + e));
+  dst[0] = h;
+  dst[limb_stride / 2] = m;
+  dst[limb_stride] = l;
+}
+
+}  // namespace
+}  // namespace pvsg
+
+extern "C" long long pvsg_gemm_bf16x3_packed_elems(int N, int K) {
+  const long long npad = (N + 127) / 128 * 128;
+  return 3LL * npad * K;                                  // bf16 elements
+}
+
+extern "C" int pvsg_gemm_bf16x3_pack(const float* weight, void* w_packed, int N, int K, void* stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(weight && w_packed, "gemm_bf16x3_pack: null pointer argument");
+  PVSG_REQUIRE(N > 0 && K > 0, "gemm_bf16x3_pack: bad shape");
+  if (K % GB_K) return set_err(PVSG_ERR_UNSUPPORTED, "gemm_bf16x3: built for K %% 16 == 0 (got %d)", K);
+  const int Npad = (N + 127) / 128 * 128;
+  const long long total = (long long)Npad * (K / 2);
+  hipLaunchKernelGGL(gemm_bf16x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), weight, static_cast<__bf16*>(w_packed), N, K, Npad);
+  PVSG_LAUNCH_CHECK("gemm_bf16x3_pack");
+  return PVSG_OK;
+}
+
+extern "C" int pvsg_gemm_bf16x3(const float* a, const void* w_packed, const float* bias, float* out, long long M, int N, int K,
+                                int relu, void* stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(a && w_packed && out, "gemm_bf16x3: null pointer argument");
+  PVSG_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_bf16x3: bad shape");
+  if (K % GB_K || M >= (1LL << 31) || (long long)GB_M * K * 4 >= (1LL << 31))
+    return set_err(PVSG_ERR_UNSUPPORTED, "gemm_bf16x3: built for K %% 16 == 0, M < 2^31 (got M=%lld N=%d K=%d)", M, N, K);
+  PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w_packed)) & 15u),
+               "gemm_bf16x3: a and w_packed must be 16-byte aligned");
+  const int Npad = (N + 127) / 128 * 128;
+  const int tiles_n = Npad / GB_N;
+  const long long tiles_m = (M + GB_M - 1) / GB_M;
+  const long long blocks = tiles_m * tiles_n;
+  PVSG_REQUIRE(blocks < (1LL << 31), "gemm_bf16x3: too many blocks");
+  const dim3 grid((unsigned)blocks), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const __bf16* wp = static_cast<const __bf16*>(w_packed);
+  if (relu)
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<true>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n);
+  else
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n);
+  PVSG_LAUNCH_CHECK("gemm_bf16x3");
+  return PVSG_OK;
+}

@@ -587,6 +587,45 @@ def conv3x3s2_affine(x, w_packed, cout, scale, shift, relu=True, out=None):
     return out
 
 
+def gemm_bf16x3_supported(n, k):
+    return k % 16 == 0 and k <= 4096
+
+
+def gemm_bf16x3_pack(weight):
+    """(N,K) f32 linear weight -> its three bf16 limbs in the staging order of csrc/gemm_bf16x3.hip (once per weight)."""
+    w = _chk(weight, 'weight')
+    if w.dim() != 2 or not gemm_bf16x3_supported(w.shape[0], w.shape[1]):
+        raise RuntimeError('gemm_bf16x3_pack: unsupported weight shape %s' % (tuple(w.shape),))
+    N, K = w.shape
+    n = _lib.load().pvsg_gemm_bf16x3_packed_elems(N, K)
+    wp = torch.empty(n, device=w.device, dtype=torch.bfloat16)
+    with torch.cuda.device(w.device):
+        _lib.call('pvsg_gemm_bf16x3_pack', w.data_ptr(), wp.data_ptr(), N, K, _stream_ptr())
+    return wp
+
+
+def gemm_bf16x3(a, w_packed, n, bias=None, relu=False, out=None):
+    """act(a (M,K) @ w (n,K)^T + bias) in f32-class arithmetic on the bf16 matrix cores (exact three-limb split,
+    csrc/gemm_bf16x3.hip); w given as gemm_bf16x3_pack(w)."""
+    a = _chk(a, 'a')
+    if a.dim() != 2 or not gemm_bf16x3_supported(n, a.shape[1]):
+        raise RuntimeError('gemm_bf16x3: unsupported shape %s x %d' % (tuple(a.shape), n))
+    M, K = a.shape
+    wp = _chk(w_packed, 'w_packed', torch.bfloat16)
+    if wp.numel() != _lib.load().pvsg_gemm_bf16x3_packed_elems(n, K):
+        raise RuntimeError('gemm_bf16x3: w_packed does not match N=%d K=%d' % (n, K))
+    if out is None:
+        out = torch.empty((M, n), device=a.device, dtype=torch.float32)
+    elif not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (M, n)):
+        raise RuntimeError('gemm_bf16x3: out must be a contiguous float32 HIP tensor (M,N)')
+    if M == 0:
+        return out
+    with torch.cuda.device(a.device):
+        _lib.call('pvsg_gemm_bf16x3', a.data_ptr(), wp.data_ptr(), _chk(bias, 'bias').data_ptr() if bias is not None else None,
+                  out.data_ptr(), M, n, K, int(bool(relu)), _stream_ptr())
+    return out
+
+
 def decoder_kv_inputs(tokens, start, hw, level_embed, pos_enc):
     """tokens (F,S,256) encoder memory, level rows start..start+hw -> value input (F*hw,256) = tokens + level_embed and
     key input = value + pos_enc, pos_enc (F*hw,256) or (hw,256); one pass, both outputs."""

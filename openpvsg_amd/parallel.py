@@ -14,12 +14,29 @@ two exchanges exist, both tiny and latency-bound:
      (segment id per query per frame, + per-frame queries/logits in per-frame mode).
 Messages are <= a few MB: one direct all-gather over the 7 xGMI links, no ring tuning needed.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def is_dist(group=None):
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def isolate_shared_gpu(slot, slots, device_index=0, cus=256):
+    """Several PROCESSES on one MI355X (the gloo logic tests, `bench.py` with PVSG_ONE_DEVICE=1): give each its own
+    range of compute units (HSA_CU_MASK), to be called before the process touches the HIP runtime.
+
+    Why it is needed, not just tidy: waves of csrc/gemm_bf16x3.hip (v_mfma_f32_32x32x16_bf16 at high occupancy) that are
+    CO-RESIDENT on a CU with waves of ANOTHER process were observed to corrupt that process's results -- e.g. its
+    deformable-attention gather returns wrong values in lanes 48-63 of a wave (heads 6-7) in 1-20 % of launches, on every
+    box tried; the same kernel built on the f32 MFMA does not, and neither process is affected once their CU sets are
+    disjoint (scripts/coresidency_probe.py).  Inside one process kernels run back to back on one stream, so this never
+    arises in the supported deployment (one process per GPU)."""
+    if slots > 1 and 'HSA_CU_MASK' not in os.environ:
+        per = cus // slots
+        os.environ['HSA_CU_MASK'] = '%d:%d-%d' % (device_index, slot * per, (slot + 1) * per - 1)
 
 
 def shard_frames(num_frames, rank, world):

@@ -1,0 +1,70 @@
+"""Token-major linear layers on the bf16 matrix cores with an exact three-limb operand split (csrc/gemm_bf16x3.hip):
+f32-class accuracy is the claim, so the error against float64 is compared with the library's own f32 GEMM on the same
+operands ([3P] torch.nn.functional.linear as used by mmcv FFN / MultiScaleDeformableAttention)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (M, N, K): encoder FFN / projections, ragged M and N, K = 16
+CASES = [(1024, 1024, 256), (640, 256, 1024), (384, 544, 256), (1000, 256, 256), (77, 96, 16), (129, 130, 48), (1, 1, 16),
+         (300, 2048, 256)]
+
+
+@pytest.mark.parametrize('M,N,K', CASES)
+@pytest.mark.parametrize('bias,relu', [(True, True), (True, False), (False, False)])
+def test_gemm_bf16x3_is_f32_class(hip_lib, M, N, K, bias, relu):
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).cuda() * 3.0
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda() if bias else None
+    y = ops.gemm_bf16x3(a, ops.gemm_bf16x3_pack(w), N, b, relu=relu)
+    ref = a.double().cpu() @ w.double().cpu().t()
+    if bias:
+        ref = ref + b.double().cpu()
+    ref = F.relu(ref) if relu else ref
+    lib = F.linear(a, w, b)
+    lib = F.relu(lib) if relu else lib
+    # scale of the accumulated magnitudes: sum_k |a||w|
+    mag = (a.abs().double().cpu() @ w.abs().double().cpu().t()).max().item() + 1.0
+    err = (y.double().cpu() - ref).abs().max().item()
+    err_lib = (lib.double().cpu() - ref).abs().max().item()
+    assert err < 4e-7 * mag, (err, mag)                  # a few f32 ulps of the accumulated magnitude
+    assert err < 3 * err_lib + 1e-7 * mag, (err, err_lib)
+
+
+def test_split_is_exact_for_extreme_operands(hip_lib):
+    """Values whose 24 mantissa bits are all set, tiny and huge magnitudes: limb products must reproduce a * w."""
+    from openpvsg_amd import ops
+    K = 16
+    a = torch.zeros(128, K)
+    w = torch.zeros(128, K)
+    vals = torch.tensor([1.9999999, -1.0000001, 3.1415927, 1e-20, -7.3e18, 0.33333334, 255.99998, 1.1754944e-38])
+    a[:, 0] = vals.repeat(16)
+    w[:, 0] = vals.flip(0).repeat(16)
+    y = ops.gemm_bf16x3(a.cuda(), ops.gemm_bf16x3_pack(w.cuda()), 128).cpu().double()
+    ref = a.double() @ w.double().t()
+    rel = ((y - ref).abs() / ref.abs().clamp_min(1e-300))[ref.abs() > 1e-30]
+    assert rel.max().item() < 2.0 ** -22, rel.max().item()
+
+
+def test_gemm_bf16x3_deterministic_and_guards(hip_lib):
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(300, 256, generator=g).cuda()
+    w = torch.randn(200, 256, generator=g).cuda()
+    wp = ops.gemm_bf16x3_pack(w)
+    buf = torch.full((300 * 200 + 512,), 5.0, device='cuda')
+    out = buf[256:256 + 300 * 200].view(300, 200)
+    y1 = ops.gemm_bf16x3(a, wp, 200, out=out).clone()
+    y2 = ops.gemm_bf16x3(a, wp, 200)
+    assert torch.equal(y1, y2)
+    assert bool((buf[:256] == 5).all()) and bool((buf[-256:] == 5).all())
+    with pytest.raises(RuntimeError, match='unsupported'):
+        ops.gemm_bf16x3_pack(torch.zeros(8, 20, device='cuda'))
+    with pytest.raises(RuntimeError, match='does not match'):
+        ops.gemm_bf16x3(a, wp, 100)
+    with pytest.raises(RuntimeError, match='HIP device'):
+        ops.gemm_bf16x3(torch.zeros(4, 256), wp, 200)

@@ -43,10 +43,14 @@ def _build(seed=6):
 
 def _worker(rank, world, port, tmp):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
     from openpvsg_amd import parallel
+    parallel.isolate_shared_gpu(rank, world)      # two processes on one GPU: disjoint CU ranges (see its docstring)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
     from oracle.detweights import det_input
     torch.cuda.set_device(0)
+    # spawned workers do not inherit conftest's session fixture: without this MIOpen may pick split-K kernels whose
+    # atomics make the two ranks' backbones differ in the last bits (and a thresholded decoder amplifies that)
+    torch.backends.cudnn.deterministic = True
     pipe = _build()
     T = 4
     clip = det_input('clip', (T, 3, 64, 96), 6)
