@@ -214,6 +214,10 @@ class KernelTimer:
             # flops = the bf16 limb products the kernel issues (6 per f32 multiply-add), priced against the bf16 roof
             M, N, K = a[4:7]
             return 4.0 * M * (K + N) + 6.0 * N * K, 12.0 * M * N * K
+        if name == 'pvsg_conv1x1_bf16x3':
+            B, Cin, Cout, H, W, st = a[6:12]
+            hw = ((H - 1) // st + 1) * ((W - 1) // st + 1)
+            return 4.0 * B * hw * (Cin + Cout * (2 if a[4] else 1)) + 6.0 * Cin * Cout, 12.0 * B * Cin * Cout * hw
         if name == 'pvsg_conv3x3s2_affine':
             N, Cin, Cout, H, W = a[5:10]
             ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -254,12 +258,14 @@ class KernelTimer:
         if name == 'pvsg_gemm_bf16x3':
             M, N, K = a[4:7]
             return 2.0 * M * N * K
+        if name == 'pvsg_conv1x1_bf16x3':
+            return cls.work(name, a)[1] / 6.0
         return cls.work(name, a)[1]
 
     @staticmethod
     def mfma_peak(name):
         """(peak TFLOP/s, what the flops of work() count) of the matrix pipe a kernel runs on."""
-        if name.startswith('pvsg_gemm_bf16x3'):
+        if name.startswith('pvsg_gemm_bf16x3') or name.startswith('pvsg_conv1x1_bf16x3'):
             return BF16_MFMA_PEAK_TF, 'bf16 limb products issued (6 per f32 multiply-add), dense bf16 MFMA peak'
         return F32_MFMA_PEAK_TF, 'f32 MFMA'
 

@@ -312,6 +312,16 @@ int pvsg_gemm_bf16x3_pack(const float* weight, void* w_packed, int N, int K, voi
 int pvsg_gemm_bf16x3(const float* a, const void* w_packed, const float* bias, float* out, long long M, int N, int K,
                      int relu, void* stream);
 
+/* 1x1 convolution in NCHW (stride 1 or 2) on the same exact three-limb bf16 arithmetic, with the frozen-BN affine, the
+ * bottleneck identity and ReLU in the epilogue:
+ *   y[b, co, p] = act( conv1x1(x[b], w)[co, p] * scale[co] + shift[co] (+ residual[b, co, p]) )
+ * `w_packed` = pvsg_gemm_bf16x3_pack of the (Cout, Cin) weight; scale / shift / residual may be NULL (1 / 0 / none).
+ * Replaces the library GEMM / MIOpen call + separate BN pass behind [3P] mmdet ResNet Bottleneck.conv1 / conv3 /
+ * downsample and the pixel decoder's 1x1 convolutions.  Requires Cin % 16 == 0, Cin*H*W < 2^29. */
+int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const float* scale, const float* shift,
+                        const float* residual, float* y, int B, int Cin, int Cout, int H, int W, int stride, int relu,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .blocks import BaseModule, conv3x3_fast
+from .blocks import BaseModule, conv1x1_fast, conv3x3_fast
 from .registry import BACKBONES
 
 
@@ -30,6 +30,10 @@ def _conv_bn(conv, x, aff, residual, relu, out, gemm):
     """conv -> frozen BN (+ identity) (+ ReLU).  Stride-1 1x1 convolutions with <= 256 input channels are HBM-bound
     GEMMs: they run with the BN / identity / ReLU in the epilogue of the matrix-core kernel (csrc/conv1x1.hip, e.g.
     layer1 conv3 at 32 x 720p: 1.65 -> 0.97 ms); the others run on the library and take one streaming pass."""
+    if conv.kernel_size == (1, 1) and conv.bias is None and (out is None or out.is_contiguous()):
+        y = conv1x1_fast(conv, x, aff[0], aff[1], residual, relu, out)        # split-bf16 kernel where it is the fastest
+        if y is not None:
+            return y
     if (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.bias is None and x.is_contiguous() and
             ops.conv1x1_affine_supported(conv.out_channels, conv.in_channels, x.shape[2] * x.shape[3])):
         return ops.conv1x1_affine(x, conv.weight, aff[0], aff[1], residual=residual, relu=relu, out=out)

@@ -92,6 +92,31 @@ def conv3x3_fast(conv, x, scale=None, shift=None, relu=False, out=None):
     return run(x, cache[1], w.shape[0], scale, shift, relu=relu, out=out)
 
 
+def conv1x1_fast(conv, x, scale=None, shift=None, residual=None, relu=False, out=None, always=False):
+    """1x1 convolution (stride 1 or 2, NCHW) with BN affine / bias (`shift`), identity and ReLU in the epilogue on the
+    split-bf16 matrix-core kernel (csrc/gemm_bf16x3.hip: conv1x1_bf16x3), or None where another path is at least as fast
+    (measured at 32 x 720p, scripts/conv1x1_bf16x3_bench.py: the HBM-bound layers with <= 128 input channels and the
+    256 -> 64 / 256 -> 1024 layers stay on csrc/conv1x1.hip) or the shape is unsupported.  A convolution bias is
+    folded into `shift`."""
+    w = conv.weight
+    cout, cin = w.shape[:2]
+    if not (conv.kernel_size == (1, 1) and conv.stride in ((1, 1), (2, 2)) and conv.padding == (0, 0) and conv.groups == 1 and
+            x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and not torch.is_grad_enabled() and
+            os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and ops.conv1x1_bf16x3_supported(cout, cin, x.shape[2], x.shape[3])):
+        return None
+    stride = conv.stride[0]
+    if not always and stride == 1 and (cin < 256 or (cin == 256 and not 128 <= cout <= 512)):
+        return None
+    if conv.bias is not None:
+        shift = conv.bias if shift is None else shift + conv.bias * (scale if scale is not None else 1.0)
+    key = (w.data_ptr(), w._version, str(w.device))
+    cache = getattr(conv, '_pvsg_packed', None)
+    if cache is None or cache[0] != key:
+        cache = (key, ops.gemm_bf16x3_pack(w.detach().reshape(cout, cin).contiguous()))
+        conv._pvsg_packed = cache
+    return ops.conv1x1_bf16x3(x, cache[1], cout, scale, shift, residual, relu=relu, stride=stride, out=out)
+
+
 def linear_fast(owner, tag, weights, x, bias=None, relu=False):
     """act(F.linear(x, cat(weights), bias)) for a token-major f32 tensor.  On the HIP device this runs on the bf16 matrix
     cores from an exact three-limb split of both operands (csrc/gemm_bf16x3.hip: f32-class accuracy, 1.3-1.45x the
@@ -647,7 +672,9 @@ class MSDeformAttnPixelDecoder(BaseModule):
             start = 0
             for i, (h, w) in enumerate(shapes):
                 m = self.input_convs[i]
-                raw = m.conv(feats[self.num_input_levels - 1 - i])
+                raw = conv1x1_fast(m.conv, feats[self.num_input_levels - 1 - i], always=True)
+                if raw is None:
+                    raw = m.conv(feats[self.num_input_levels - 1 - i])
                 sc, sh = ops.group_norm_affine(raw, m.gn) if m.gn is not None else (None, None)
                 ops.nchw_to_tokens(raw, x, start, sc, sh)
                 start += h * w
@@ -689,7 +716,9 @@ class MSDeformAttnPixelDecoder(BaseModule):
             if (glue and lm.gn is not None and not lm.act and om.gn is not None and om.act and
                     (hl, wl) == (2 * top.shape[-2], 2 * top.shape[-1]) and top.shape[-1] % 2 == 0):
                 # GN(lateral) + x2 bilinear(top) in one pass; GN + ReLU after the 3x3 conv in one in-place pass
-                raw = lm.conv(feats[i])
+                raw = conv1x1_fast(lm.conv, feats[i], always=True)
+                if raw is None:
+                    raw = lm.conv(feats[i])
                 y = ops.fpn_merge_up2x(raw, *ops.group_norm_affine(raw, lm.gn), top.contiguous())
                 o = conv3x3_fast(om.conv, y)
                 if o is None:
@@ -701,4 +730,5 @@ class MSDeformAttnPixelDecoder(BaseModule):
             lat = lm(feats[i])
             y = lat + F.interpolate(top, size=lat.shape[-2:], mode='bilinear', align_corners=False)
             outs.append(om(y))
-        return self.mask_feature(outs[-1]), outs[:self.num_outs]
+        mf = conv1x1_fast(self.mask_feature, outs[-1], always=True) if glue and isinstance(self.mask_feature, nn.Conv2d) else None
+        return (mf if mf is not None else self.mask_feature(outs[-1])), outs[:self.num_outs]

@@ -626,6 +626,36 @@ def gemm_bf16x3(a, w_packed, n, bias=None, relu=False, out=None):
     return out
 
 
+def conv1x1_bf16x3_supported(cout, cin, h, w):
+    return cin % 16 == 0 and cin <= 4096 and cin * h * w < 2 ** 29
+
+
+def conv1x1_bf16x3(x, w_packed, cout, scale=None, shift=None, residual=None, relu=False, stride=1, out=None):
+    """act(conv1x1(x, w, stride) * scale[c] + shift[c] (+ residual)) in NCHW, f32-class arithmetic on the bf16 matrix
+    cores (csrc/gemm_bf16x3.hip); w given as gemm_bf16x3_pack(w.view(Cout, Cin))."""
+    x = _chk(x, 'x')
+    B, Cin, H, W = x.shape
+    wp = _chk(w_packed, 'w_packed', torch.bfloat16)
+    if stride not in (1, 2) or not conv1x1_bf16x3_supported(cout, Cin, H, W) or \
+            wp.numel() != _lib.load().pvsg_gemm_bf16x3_packed_elems(cout, Cin):
+        raise RuntimeError('conv1x1_bf16x3: unsupported shape Cout=%d Cin=%d H=%d W=%d stride=%d' % (cout, Cin, H, W, stride))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out is None:
+        out = torch.empty((B, cout, Ho, Wo), device=x.device, dtype=torch.float32)
+    elif not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (B, cout, Ho, Wo)):
+        raise RuntimeError('conv1x1_bf16x3: out must be a contiguous float32 HIP tensor (B,Cout,Ho,Wo)')
+    r = _chk(residual, 'residual') if residual is not None else None
+    if r is not None and r.shape != out.shape:
+        raise RuntimeError('conv1x1_bf16x3: residual shape mismatch')
+    with torch.cuda.device(x.device):
+        _lib.call('pvsg_conv1x1_bf16x3', x.data_ptr(), wp.data_ptr(),
+                  _chk(scale, 'scale').data_ptr() if scale is not None else None,
+                  _chk(shift, 'shift').data_ptr() if shift is not None else None,
+                  r.data_ptr() if r is not None else None, out.data_ptr(), B, Cin, cout, H, W, stride, int(bool(relu)),
+                  _stream_ptr())
+    return out
+
+
 def decoder_kv_inputs(tokens, start, hw, level_embed, pos_enc):
     """tokens (F,S,256) encoder memory, level rows start..start+hw -> value input (F*hw,256) = tokens + level_embed and
     key input = value + pos_enc, pos_enc (F*hw,256) or (hw,256); one pass, both outputs."""

@@ -68,3 +68,37 @@ def test_gemm_bf16x3_deterministic_and_guards(hip_lib):
         ops.gemm_bf16x3(a, wp, 100)
     with pytest.raises(RuntimeError, match='HIP device'):
         ops.gemm_bf16x3(torch.zeros(4, 256), wp, 200)
+
+
+# ---- NCHW 1x1 convolution on the same arithmetic (backbone bottleneck convs, pixel decoder 1x1 convs) ---------------
+C1_CASES = [(2, 256, 64, 16, 24, 1), (1, 512, 128, 23, 40, 1), (2, 256, 512, 23, 41, 2), (1, 1024, 2048, 7, 9, 2),
+            (1, 2048, 256, 5, 8, 1), (3, 64, 256, 9, 13, 1), (1, 16, 8, 3, 3, 1)]
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,stride', C1_CASES)
+@pytest.mark.parametrize('affine,res,relu', [(True, True, True), (True, False, False), (False, False, False), (True, False, True)])
+def test_conv1x1_bf16x3_is_f32_class(hip_lib, B, Cin, Cout, H, W, stride, affine, res, relu):
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(B + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).cuda()
+    sc = (torch.rand(Cout, generator=g) + 0.5).cuda() if affine else None
+    sh = torch.randn(Cout, generator=g).cuda() if affine else None
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = torch.randn(B, Cout, Ho, Wo, generator=g).cuda() if res else None
+    y = ops.conv1x1_bf16x3(x, ops.gemm_bf16x3_pack(w.view(Cout, Cin)), Cout, sc, sh, r, relu=relu, stride=stride)
+
+    def ref_of(t):
+        o = F.conv2d(x.to(t).cpu() if t == torch.float64 else x, (w.to(t).cpu() if t == torch.float64 else w), stride=stride)
+        if affine:
+            o = o * sc.to(o).view(1, -1, 1, 1) + sh.to(o).view(1, -1, 1, 1)
+        if res:
+            o = o + r.to(o)
+        return F.relu(o) if relu else o
+    ref, lib = ref_of(torch.float64), ref_of(torch.float32)
+    assert tuple(y.shape) == tuple(ref.shape)
+    mag = F.conv2d(x.abs().double().cpu(), w.abs().double().cpu(), stride=stride).max().item() * (2.0 if affine else 1.0) + 4.0
+    err = (y.double().cpu() - ref).abs().max().item()
+    err_lib = (lib.double().cpu() - ref).abs().max().item()
+    assert err < 4e-7 * mag, (err, mag)
+    assert err < 3 * err_lib + 1e-7 * mag, (err, err_lib)
