@@ -218,6 +218,10 @@ class KernelTimer:
             B, Cin, Cout, H, W, st = a[6:12]
             hw = ((H - 1) // st + 1) * ((W - 1) // st + 1)
             return 4.0 * B * hw * (Cin + Cout * (2 if a[4] else 1)) + 6.0 * Cin * Cout, 12.0 * B * Cin * Cout * hw
+        if name == 'pvsg_stem7x7_bn_relu_pool':
+            N, H, W = a[5:8]
+            hc, wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            return 4.0 * N * (3 * H * W + 64 * ((hc - 1) // 2 + 1) * ((wc - 1) // 2 + 1)), 2.0 * 147 * 64 * N * hc * wc
         if name == 'pvsg_conv3x3s2_affine':
             N, Cin, Cout, H, W = a[5:10]
             ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1

@@ -322,6 +322,13 @@ int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const float* scale
                         const float* residual, float* y, int B, int Cin, int Cout, int H, int W, int stride, int relu,
                         void* stream);
 
+/* [3P] mmdet ResNet stem in one launch: conv1 (7x7 / 2, pad 3, 3 -> 64, no bias) -> frozen BN (scale, shift) -> ReLU ->
+ * MaxPool2d(3, 2, 1):  x (N, 3, H, W) -> out (N, 64, Hp, Wp), Hc = (H-1)/2+1, Hp = (Hc-1)/2+1 (same for W).
+ * `w_packed` = 21*64*8 floats written by pvsg_stem7x7_pack from the (64, 3, 7, 7) weight (once per weight). */
+int pvsg_stem7x7_pack(const float* weight, float* w_packed, void* stream);
+int pvsg_stem7x7_bn_relu_pool(const float* x, const float* w_packed, const float* scale, const float* shift, float* out,
+                              int N, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

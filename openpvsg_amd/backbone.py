@@ -151,9 +151,25 @@ class ResNet(BaseModule):
             shapes.append((N, planes * 4, h, w))
         return shapes
 
+    def _stem(self, x, aff):
+        """conv1 -> BN -> ReLU -> max-pool: one launch on the matrix cores (csrc/stem7x7.hip) for the standard 7x7 / 2 stem
+        on 3-channel input, else the library convolution + the BN / ReLU / pool pass."""
+        c = self.conv1
+        w = c.weight
+        if (tuple(w.shape) == (64, 3, 7, 7) and c.stride == (2, 2) and c.padding == (3, 3) and c.bias is None and
+                x.is_contiguous() and x.dtype == torch.float32 and os.environ.get('PVSG_WINOGRAD', 'on') != 'off' and
+                3 * x.shape[2] * x.shape[3] < 2 ** 29):
+            key = (w.data_ptr(), w._version, str(w.device))
+            cache = getattr(c, '_pvsg_packed', None)
+            if cache is None or cache[0] != key:
+                cache = (key, ops.stem7x7_pack(w.detach()))
+                c._pvsg_packed = cache
+            return ops.stem7x7_bn_relu_pool(x, cache[1], *aff['stem'])
+        return ops.stem_bn_relu_pool(c(x), *aff['stem'])            # BN + ReLU + 3x3/2 max-pool in one pass
+
     def _forward_fused(self, x, aff, outs, gemm=True):
         """x: a batch slice; outs[li-1]: the matching slice of the stage-output tensors (written in place)."""
-        x = ops.stem_bn_relu_pool(self.conv1(x), *aff['stem'])      # BN + ReLU + 3x3/2 max-pool in one pass
+        x = self._stem(x, aff)
         for li in range(1, 5):
             blocks = getattr(self, 'layer%d' % li)
             for bi, blk in enumerate(blocks):

@@ -656,6 +656,32 @@ def conv1x1_bf16x3(x, w_packed, cout, scale=None, shift=None, residual=None, rel
     return out
 
 
+def stem7x7_pack(weight):
+    """(64,3,7,7) stem weight -> the operand order of csrc/stem7x7.hip (once per weight)."""
+    w = _chk(weight, 'weight')
+    if tuple(w.shape) != (64, 3, 7, 7):
+        raise RuntimeError('stem7x7_pack: unsupported weight shape %s' % (tuple(w.shape),))
+    wp = torch.empty(21 * 64 * 8, device=w.device, dtype=torch.float32)
+    with torch.cuda.device(w.device):
+        _lib.call('pvsg_stem7x7_pack', w.data_ptr(), wp.data_ptr(), _stream_ptr())
+    return wp
+
+
+def stem7x7_bn_relu_pool(x, w_packed, scale, shift):
+    """maxpool3x3/2(relu(conv7x7/2(x) * scale[c] + shift[c])) in one launch (csrc/stem7x7.hip).  x (N,3,H,W)."""
+    x = _chk(x, 'x')
+    N, C, H, W = x.shape
+    wp = _chk(w_packed, 'w_packed')
+    if C != 3 or wp.numel() != 21 * 64 * 8 or 3 * H * W >= 2 ** 29:
+        raise RuntimeError('stem7x7_bn_relu_pool: unsupported input %s' % (tuple(x.shape),))
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, 64, (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.call('pvsg_stem7x7_bn_relu_pool', x.data_ptr(), wp.data_ptr(), _chk(scale, 'scale').data_ptr(),
+                  _chk(shift, 'shift').data_ptr(), out.data_ptr(), N, H, W, _stream_ptr())
+    return out
+
+
 def decoder_kv_inputs(tokens, start, hw, level_embed, pos_enc):
     """tokens (F,S,256) encoder memory, level rows start..start+hw -> value input (F*hw,256) = tokens + level_embed and
     key input = value + pos_enc, pos_enc (F*hw,256) or (hw,256); one pass, both outputs."""

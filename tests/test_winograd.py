@@ -122,3 +122,20 @@ def test_conv3x3_fast_dispatch_follows_weight_updates(hip_lib):
             assert torch.allclose(b, conv(x), atol=4e-5) and not torch.allclose(a, b, atol=1e-3)
         assert conv3x3_fast(nn.Conv2d(128, 128, 3, padding=1, bias=True).cuda(), x) is None      # bias: library path
         assert conv3x3_fast(nn.Conv2d(128, 128, 3, stride=2, padding=1, bias=False).cuda(), x) is None   # stride 2 w/o affine
+
+
+# ---- ResNet stem in one launch (csrc/stem7x7.hip): conv 7x7/2 -> BN -> ReLU -> max-pool 3x3/2 -------------------------
+@pytest.mark.parametrize('N,H,W', [(2, 64, 96), (1, 37, 53), (1, 736, 1280), (3, 7, 9), (1, 1, 1), (1, 130, 66)])
+def test_stem7x7_bn_relu_pool_matches_the_module_chain(hip_lib, N, H, W):
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(N + H + W)
+    x = torch.randn(N, 3, H, W, generator=g).cuda()
+    w = (torch.randn(64, 3, 7, 7, generator=g) / 12.0).cuda()
+    sc, sh = (torch.rand(64, generator=g) - 0.3).cuda(), torch.randn(64, generator=g).cuda()      # some negative scales
+    y = ops.stem7x7_bn_relu_pool(x, ops.stem7x7_pack(w), sc, sh)
+    ref = F.conv2d(x.double().cpu(), w.double().cpu(), stride=2, padding=3)
+    ref = F.max_pool2d(F.relu(ref * sc.double().cpu().view(1, -1, 1, 1) + sh.double().cpu().view(1, -1, 1, 1)), 3, 2, 1)
+    assert tuple(y.shape) == tuple(ref.shape)
+    err = (y.double().cpu() - ref).abs().max().item()
+    assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
+    assert torch.equal(y, ops.stem7x7_bn_relu_pool(x, ops.stem7x7_pack(w), sc, sh))
