@@ -215,7 +215,7 @@ class KernelTimer:
             M, N, K = a[4:7]
             return 4.0 * M * (K + N) + 6.0 * N * K, 12.0 * M * N * K
         if name == 'pvsg_conv1x1_bf16x3':
-            B, Cin, Cout, H, W, st = a[6:12]
+            B, Cin, Cout, H, W, st = a[8:14]
             hw = ((H - 1) // st + 1) * ((W - 1) // st + 1)
             return 4.0 * B * hw * (Cin + Cout * (2 if a[4] else 1)) + 6.0 * Cin * Cout, 12.0 * B * Cin * Cout * hw
         if name == 'pvsg_stem7x7_bn_relu_pool':
@@ -630,6 +630,11 @@ def main():
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
+            'dtype_note': ('every tensor, accumulation and result f32; the 3x3 convolutions run on the f32 MFMA, the large '
+                           'GEMMs / 1x1 convolutions issue an EXACT three-limb bf16 split of their f32 operands on the bf16 MFMA '
+                           '(6 limb products per multiply, f32 accumulate: error vs f64 at or below the library f32 GEMM, '
+                           'tests/test_gemm_bf16x3.py)' if os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' else
+                           'every tensor, accumulation and result f32 (PVSG_GEMM=lib: library f32 GEMMs)'),
             'config': {'workload': 'Mask2Former-VPS R50 clip-level forward, %d frames %dx%d (padded %dx%d), '
                                    '100 queries, 9 decoder layers over T*h*w keys, panoptic fusion per frame, '
                                    'tube assembly, relation head (TemporalTransformer, top-100 pairs)'

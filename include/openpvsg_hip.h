@@ -316,11 +316,15 @@ int pvsg_gemm_bf16x3(const float* a, const void* w_packed, const float* bias, fl
  * bottleneck identity and ReLU in the epilogue:
  *   y[b, co, p] = act( conv1x1(x[b], w)[co, p] * scale[co] + shift[co] (+ residual[b, co, p]) )
  * `w_packed` = pvsg_gemm_bf16x3_pack of the (Cout, Cin) weight; scale / shift / residual may be NULL (1 / 0 / none).
+ * in_scale / in_shift (B, Cin) or NULL: the input is first normalised per (image, channel) and rectified,
+ * x' = relu(x * in_scale + in_shift) -- a GroupNorm + ReLU with known statistics folded into the operand staging
+ * (mmdet ConvModule(norm GN, act ReLU) in front of the pixel decoder's mask_feature convolution); only with relu = 0 and
+ * residual = NULL.
  * Replaces the library GEMM / MIOpen call + separate BN pass behind [3P] mmdet ResNet Bottleneck.conv1 / conv3 /
  * downsample and the pixel decoder's 1x1 convolutions.  Requires Cin % 16 == 0, Cin*H*W < 2^29. */
 int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const float* scale, const float* shift,
-                        const float* residual, float* y, int B, int Cin, int Cout, int H, int W, int stride, int relu,
-                        void* stream);
+                        const float* residual, const float* in_scale, const float* in_shift, float* y, int B, int Cin,
+                        int Cout, int H, int W, int stride, int relu, void* stream);
 
 /* [3P] mmdet ResNet stem in one launch: conv1 (7x7 / 2, pad 3, 3 -> 64, no bias) -> frozen BN (scale, shift) -> ReLU ->
  * MaxPool2d(3, 2, 1):  x (N, 3, H, W) -> out (N, 64, Hp, Wp), Hc = (H-1)/2+1, Hp = (Hc-1)/2+1 (same for W).

@@ -92,7 +92,7 @@ def conv3x3_fast(conv, x, scale=None, shift=None, relu=False, out=None):
     return run(x, cache[1], w.shape[0], scale, shift, relu=relu, out=out)
 
 
-def conv1x1_fast(conv, x, scale=None, shift=None, residual=None, relu=False, out=None, always=False):
+def conv1x1_fast(conv, x, scale=None, shift=None, residual=None, relu=False, out=None, always=False, in_norm=None):
     """1x1 convolution (stride 1 or 2, NCHW) with BN affine / bias (`shift`), identity and ReLU in the epilogue on the
     split-bf16 matrix-core kernel (csrc/gemm_bf16x3.hip: conv1x1_bf16x3), or None where another path is at least as fast
     (measured at 32 x 720p, scripts/conv1x1_bf16x3_bench.py: the HBM-bound layers with <= 128 input channels and the
@@ -114,7 +114,9 @@ def conv1x1_fast(conv, x, scale=None, shift=None, residual=None, relu=False, out
     if cache is None or cache[0] != key:
         cache = (key, ops.gemm_bf16x3_pack(w.detach().reshape(cout, cin).contiguous()))
         conv._pvsg_packed = cache
-    return ops.conv1x1_bf16x3(x, cache[1], cout, scale, shift, residual, relu=relu, stride=stride, out=out)
+    return ops.conv1x1_bf16x3(x, cache[1], cout, scale, shift, residual, relu=relu, stride=stride, out=out,
+                              in_scale=in_norm[0] if in_norm is not None else None,
+                              in_shift=in_norm[1] if in_norm is not None else None)
 
 
 def linear_fast(owner, tag, weights, x, bias=None, relu=False):
@@ -724,6 +726,12 @@ class MSDeformAttnPixelDecoder(BaseModule):
                 if o is None:
                     o = om.conv(y)
                 sc, sh = ops.group_norm_affine(o, om.gn)
+                if i == 0 and isinstance(self.mask_feature, nn.Conv2d):
+                    # last FPN level: its only consumer is the mask-feature 1x1 convolution, which applies the GroupNorm
+                    # + ReLU while it stages its input -- the 1.9 GB normalise pass never runs
+                    mf = conv1x1_fast(self.mask_feature, o, always=True, in_norm=(sc, sh))
+                    if mf is not None:
+                        return mf, outs[:self.num_outs]
                 ops.affine_act_nchw_(o.view(1, -1, *o.shape[-2:]), sc, sh, relu=True)
                 outs.append(o)
                 continue

@@ -180,10 +180,13 @@ void gemm_bf16x3_kernel(const float* __restrict__ A, const __bf16* __restrict__ 
 // Replaces [3P] mmdet ResNet Bottleneck.conv1 / conv3 / downsample[0] (+ frozen BN, identity, ReLU) with > 128 input
 // channels and the pixel decoder's 1x1 input / lateral / mask-feature convolutions (library GEMM or MIOpen + separate
 // BN / bias pass before).
-template <bool RELU, bool RESIDUAL>
+// IN_NORM: the input is normalised on the way in, x' = relu(x * in_scale[b, ci] + in_shift[b, ci]) (a GroupNorm + ReLU
+// whose statistics are already known), so that pass never touches HBM.
+template <bool RELU, bool RESIDUAL, bool IN_NORM>
 __global__ __launch_bounds__(256, 2)
 void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ scale,
-                           const float* __restrict__ shift, const float* __restrict__ residual, float* __restrict__ y,
+                           const float* __restrict__ shift, const float* __restrict__ residual,
+                           const float* __restrict__ in_scale, const float* __restrict__ in_shift, float* __restrict__ y,
                            int Cin, int Cout, int Cpad, int HWin, int Win, int HWo, int Wo, int stride, int tiles_c,
                            int tiles_p) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * GB_STAGE];
@@ -217,8 +220,13 @@ void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict
 #pragma unroll
     for (int l = 0; l < 3; ++l) w_regs[slot][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
   };
-  auto stash = [&](int slot, __bf16* st) {
+  auto stash = [&](int slot, __bf16* st, int kt) {
     unsigned hh[4], mm[4], ll[4];
+    if (IN_NORM) {                                     // channel kt*16 + 8*skg + j of this image: wave-uniform scalars
+      const int ci = img * Cin + kt * GB_K + 8 * skg;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x_regs[slot][j] = fmaxf(fmaf(x_regs[slot][j], in_scale[ci + j], in_shift[ci + j]), 0.f);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) split2(x_regs[slot][2 * q], x_regs[slot][2 * q + 1], hh[q], mm[q], ll[q]);
     const u32x4 h = {hh[0], hh[1], hh[2], hh[3]}, m = {mm[0], mm[1], mm[2], mm[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
@@ -243,7 +251,7 @@ void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict
   const int kg = lane >> 5, li = lane & 31;
   const int a_off = (kg * GB_M + wr * 64 + li) * 8, w_off = GB_TILE + (kg * GB_N + wc * 64 + li) * 8;
   fetch(0, 0);
-  stash(0, lds);
+  stash(0, lds, 0);
   fetch(1, KT > 1 ? 1 : 0);
   fetch(0, KT > 2 ? 2 : KT - 1);
   auto kstep = [&](int kt, auto PAR) {
@@ -258,7 +266,7 @@ void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict
         av[l][b] = *reinterpret_cast<const bf16x8*>(cur + a_off + l * GB_LIMB + b * 32 * 8);
         wv[l][b] = *reinterpret_cast<const bf16x8*>(cur + w_off + l * GB_LIMB + b * 32 * 8);
       }
-    stash(par ^ 1, lds + (par ^ 1) * GB_STAGE);
+    stash(par ^ 1, lds + (par ^ 1) * GB_STAGE, kt + 1 < KT ? kt + 1 : KT - 1);
     fetch(par ^ 1, kt + 3 < KT ? kt + 3 : KT - 1);
     constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PW[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
@@ -371,11 +379,12 @@ extern "C" int pvsg_gemm_bf16x3(const float* a, const void* w_packed, const floa
 }
 
 extern "C" int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const float* scale, const float* shift,
-                                   const float* residual, float* y, int B, int Cin, int Cout, int H, int W, int stride,
-                                   int relu, void* stream) {
+                                   const float* residual, const float* in_scale, const float* in_shift, float* y, int B,
+                                   int Cin, int Cout, int H, int W, int stride, int relu, void* stream) {
   using namespace pvsg;
   PVSG_REQUIRE(x && w_packed && y, "conv1x1_bf16x3: null pointer argument");
   PVSG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "conv1x1_bf16x3: bad shape");
+  PVSG_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv1x1_bf16x3: in_scale and in_shift go together");
   if (Cin % GB_K || (long long)Cin * H * W >= (1LL << 29))
     return set_err(PVSG_ERR_UNSUPPORTED, "conv1x1_bf16x3: built for Cin %% 16 == 0, Cin*H*W < 2^29 (got Cin=%d H=%d W=%d)", Cin, H, W);
   PVSG_REQUIRE(!(reinterpret_cast<uintptr_t>(w_packed) & 15u), "conv1x1_bf16x3: w_packed must be 16-byte aligned");
@@ -388,9 +397,14 @@ extern "C" int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const f
   hipStream_t st = static_cast<hipStream_t>(stream);
   const __bf16* wp = static_cast<const __bf16*>(w_packed);
 #define PVSG_C1_LAUNCH(R, S)                                                                                            \
-  hipLaunchKernelGGL((conv1x1_bf16x3_kernel<R, S>), grid, block, 0, st, x, wp, scale, shift, residual, y, Cin, Cout, Cpad, \
-                     H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p)
-  if (relu) {
+  hipLaunchKernelGGL((conv1x1_bf16x3_kernel<R, S, false>), grid, block, 0, st, x, wp, scale, shift, residual, in_scale,   \
+                     in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p)
+  if (in_scale) {          // normalised input: the pixel decoder's mask-feature convolution (no ReLU / identity behind it)
+    if (relu || residual)
+      return set_err(PVSG_ERR_UNSUPPORTED, "conv1x1_bf16x3: in_scale / in_shift come without relu / residual");
+    hipLaunchKernelGGL((conv1x1_bf16x3_kernel<false, false, true>), grid, block, 0, st, x, wp, scale, shift, residual, in_scale,
+                       in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p);
+  } else if (relu) {
     if (residual) PVSG_C1_LAUNCH(true, true); else PVSG_C1_LAUNCH(true, false);
   } else {
     if (residual) PVSG_C1_LAUNCH(false, true); else PVSG_C1_LAUNCH(false, false);

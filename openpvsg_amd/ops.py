@@ -630,9 +630,11 @@ def conv1x1_bf16x3_supported(cout, cin, h, w):
     return cin % 16 == 0 and cin <= 4096 and cin * h * w < 2 ** 29
 
 
-def conv1x1_bf16x3(x, w_packed, cout, scale=None, shift=None, residual=None, relu=False, stride=1, out=None):
+def conv1x1_bf16x3(x, w_packed, cout, scale=None, shift=None, residual=None, relu=False, stride=1, out=None,
+                   in_scale=None, in_shift=None):
     """act(conv1x1(x, w, stride) * scale[c] + shift[c] (+ residual)) in NCHW, f32-class arithmetic on the bf16 matrix
-    cores (csrc/gemm_bf16x3.hip); w given as gemm_bf16x3_pack(w.view(Cout, Cin))."""
+    cores (csrc/gemm_bf16x3.hip); w given as gemm_bf16x3_pack(w.view(Cout, Cin)).  in_scale / in_shift (B*Cin,): the input
+    is first normalised and rectified, relu(x * in_scale[b, ci] + in_shift[b, ci]) (GroupNorm + ReLU with known statistics)."""
     x = _chk(x, 'x')
     B, Cin, H, W = x.shape
     wp = _chk(w_packed, 'w_packed', torch.bfloat16)
@@ -647,12 +649,16 @@ def conv1x1_bf16x3(x, w_packed, cout, scale=None, shift=None, residual=None, rel
     r = _chk(residual, 'residual') if residual is not None else None
     if r is not None and r.shape != out.shape:
         raise RuntimeError('conv1x1_bf16x3: residual shape mismatch')
+    if (in_scale is None) != (in_shift is None) or (in_scale is not None and (in_scale.numel() != B * Cin or in_shift.numel() != B * Cin)):
+        raise RuntimeError('conv1x1_bf16x3: in_scale / in_shift must both be (B*Cin,)')
     with torch.cuda.device(x.device):
         _lib.call('pvsg_conv1x1_bf16x3', x.data_ptr(), wp.data_ptr(),
                   _chk(scale, 'scale').data_ptr() if scale is not None else None,
                   _chk(shift, 'shift').data_ptr() if shift is not None else None,
-                  r.data_ptr() if r is not None else None, out.data_ptr(), B, Cin, cout, H, W, stride, int(bool(relu)),
-                  _stream_ptr())
+                  r.data_ptr() if r is not None else None,
+                  _chk(in_scale, 'in_scale').data_ptr() if in_scale is not None else None,
+                  _chk(in_shift, 'in_shift').data_ptr() if in_shift is not None else None,
+                  out.data_ptr(), B, Cin, cout, H, W, stride, int(bool(relu)), _stream_ptr())
     return out
 
 

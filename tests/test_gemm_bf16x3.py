@@ -102,3 +102,23 @@ def test_conv1x1_bf16x3_is_f32_class(hip_lib, B, Cin, Cout, H, W, stride, affine
     err_lib = (lib.double().cpu() - ref).abs().max().item()
     assert err < 4e-7 * mag, (err, mag)
     assert err < 3 * err_lib + 1e-7 * mag, (err, err_lib)
+
+
+def test_conv1x1_bf16x3_normalised_input(hip_lib):
+    """GroupNorm + ReLU folded into the operand staging (pixel decoder: output_conv's GN/ReLU in front of mask_feature)."""
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, Cin, Cout, H, W = 2, 256, 256, 23, 41
+    x = torch.randn(B, Cin, H, W, generator=g).cuda() * 2
+    w = (torch.randn(Cout, Cin, generator=g) / 16).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    isc, ish = (torch.rand(B * Cin, generator=g) + 0.5).cuda(), torch.randn(B * Cin, generator=g).cuda()
+    y = ops.conv1x1_bf16x3(x, ops.gemm_bf16x3_pack(w), Cout, None, b, in_scale=isc, in_shift=ish)
+    xn = F.relu(x.double().cpu() * isc.double().cpu().view(B, Cin, 1, 1) + ish.double().cpu().view(B, Cin, 1, 1))
+    ref = F.conv2d(xn, w.double().cpu().view(Cout, Cin, 1, 1), b.double().cpu())
+    err = (y.double().cpu() - ref).abs().max().item()
+    assert err < 2e-5, err
+    with pytest.raises(RuntimeError, match='in_scale'):
+        ops.conv1x1_bf16x3(x, ops.gemm_bf16x3_pack(w), Cout, None, b, in_scale=isc)
+    with pytest.raises(RuntimeError, match='unsupported|UNSUPPORTED|relu'):
+        ops.conv1x1_bf16x3(x, ops.gemm_bf16x3_pack(w), Cout, None, b, relu=True, in_scale=isc, in_shift=ish)
