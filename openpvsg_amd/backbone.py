@@ -137,7 +137,9 @@ class ResNet(BaseModule):
     # cannot be timed one by one (bench.py's per-kernel roofline would read the shared-GPU durations), and only this
     # MIOpen + streaming-kernel region is safe -- torch GEMMs (rocBLAS / hipBLASLt) issued from two side streams
     # stall on this stack (scripts/stream_probe4.py).
-    num_streams = int(os.environ.get('PVSG_BACKBONE_STREAMS', '1'))
+    # With the split-bf16 1x1 kernels in the backbone the option is ignored: their waves must not share a CU with other
+    # kernels' waves (co-residency finding), which is exactly what two streams would arrange.
+    num_streams = int(os.environ.get('PVSG_BACKBONE_STREAMS', '1')) if os.environ.get('PVSG_GEMM', 'bf16x3') == 'lib' else 1
     min_stream_batch = 8
 
     def _stage_shapes(self, x):
@@ -183,7 +185,7 @@ class ResNet(BaseModule):
             aff = self._affines()
             full = [x.new_empty(s) for s in self._stage_shapes(x)]
             # only where it pays (>= 8 frames): small batches keep the single-stream path
-            n = self.num_streams if (x.shape[0] >= self.min_stream_batch and
+            n = self.num_streams if (x.shape[0] >= self.min_stream_batch and os.environ.get('PVSG_GEMM', 'bf16x3') == 'lib' and
                                      not torch.cuda.is_current_stream_capturing()) else 1
             if n <= 1:
                 self._forward_fused(x, aff, full)

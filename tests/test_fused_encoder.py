@@ -117,10 +117,12 @@ def test_backbone_fused_bn_act_equals_plain(hip_lib):
         np.testing.assert_allclose(v.cpu().numpy(), r.numpy(), rtol=1e-3, atol=1e-4 * sc)
 
 
-def test_backbone_two_streams_equal_one_and_odd_sizes(hip_lib):
+def test_backbone_two_streams_equal_one_and_odd_sizes(hip_lib, monkeypatch):
     """Batch halves on two HIP streams (>= 8 frames) write the same stage outputs as the single-stream path;
-    odd image sizes go through the fused stem (BN + ReLU + max-pool) and the stage-shape arithmetic."""
+    odd image sizes go through the fused stem (BN + ReLU + max-pool) and the stage-shape arithmetic.  The two-stream
+    option exists only with the library GEMMs (PVSG_GEMM=lib): the split-bf16 kernels must not co-run with others."""
     from openpvsg_amd.backbone import ResNet
+    monkeypatch.setenv('PVSG_GEMM', 'lib')
     m = ResNet(depth=50).eval()
     m.load_state_dict(det_state_dict(m, 9))
     m = m.to(DEV)
