@@ -122,3 +122,28 @@ def test_conv1x1_bf16x3_normalised_input(hip_lib):
         ops.conv1x1_bf16x3(x, ops.gemm_bf16x3_pack(w), Cout, None, b, in_scale=isc)
     with pytest.raises(RuntimeError, match='unsupported|UNSUPPORTED|relu'):
         ops.conv1x1_bf16x3(x, ops.gemm_bf16x3_pack(w), Cout, None, b, relu=True, in_scale=isc, in_shift=ish)
+
+
+# ---- BASELINE sizes: the encoder's token count of 4 frames at 720p (77 280 rows), all four layer shapes -------------------
+@pytest.mark.parametrize('N,K,relu', [(1024, 256, True), (256, 1024, False), (544, 256, False), (256, 256, False)])
+def test_gemm_bf16x3_at_encoder_sizes(hip_lib, N, K, relu):
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(N + K)
+    M = 77280
+    a = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    wp = ops.gemm_bf16x3_pack(w)
+    y = ops.gemm_bf16x3(a, wp, N, b, relu=relu)
+    lib = F.linear(a, w, b)
+    lib = F.relu(lib) if relu else lib
+    assert float((y - lib).abs().max()) < 2e-5 * max(1.0, float(lib.abs().max()))
+    rows = torch.randint(0, M, (256,), generator=g)
+    ref = a[rows.cuda()].double().cpu() @ w.double().cpu().t() + b.double().cpu()
+    ref = F.relu(ref) if relu else ref
+    e_own, e_lib = (y[rows.cuda()].double().cpu() - ref).abs().max().item(), (lib[rows.cuda()].double().cpu() - ref).abs().max().item()
+    assert e_own < 3 * e_lib + 1e-6, (e_own, e_lib)
+    if not relu:      # linearity on the whole matrix (bias cancels): f(2 a1 - a2) - (2 f(a1) - f(a2)) = 0 up to rounding
+        a2 = torch.randn(M, K, generator=g).cuda()
+        lhs, rhs = ops.gemm_bf16x3(2 * a - a2, wp, N), 2 * ops.gemm_bf16x3(a, wp, N) - ops.gemm_bf16x3(a2, wp, N)
+        assert float((lhs - rhs).abs().max()) < 3e-5 * max(1.0, float(rhs.abs().max()))

@@ -139,3 +139,28 @@ def test_stem7x7_bn_relu_pool_matches_the_module_chain(hip_lib, N, H, W):
     err = (y.double().cpu() - ref).abs().max().item()
     assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
     assert torch.equal(y, ops.stem7x7_bn_relu_pool(x, ops.stem7x7_pack(w), sc, sh))
+
+
+# ---- BASELINE sizes (720p, stride-4 / 8 maps): against the library convolution on the GPU + a size-independent property ----
+@pytest.mark.parametrize('name,Cin,Cout,H,W,stride', [('fpn', 256, 256, 184, 320, 1), ('layer1', 64, 64, 184, 320, 1),
+                                                       ('layer2.0', 128, 128, 184, 320, 2), ('layer4', 512, 512, 23, 40, 1)])
+def test_conv3x3_kernels_at_720p_sizes(hip_lib, name, Cin, Cout, H, W, stride):
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(Cin + H)
+    N = 2
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).cuda()
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).cuda(), torch.randn(Cout, generator=g).cuda()
+
+    def own(t):
+        if stride == 2:
+            return ops.conv3x3s2_affine(t, ops.conv3x3s2_pack(w), Cout, sc, torch.zeros_like(sh), relu=False)
+        return ops.conv3x3_winograd(t, ops.conv3x3_winograd_pack(w), Cout, sc, torch.zeros_like(sh), relu=False)
+    y = own(x)
+    ref = F.conv2d(x, w, stride=stride, padding=1) * sc.view(1, -1, 1, 1)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert float((y - ref).abs().max()) < 3e-5 * max(1.0, float(ref.abs().max()))
+    # linearity in the input (zero shift): f(2 x1 - x2) = 2 f(x1) - f(x2) up to rounding, on the whole map
+    x2 = torch.randn(N, Cin, H, W, generator=g).cuda()
+    lhs, rhs = own(2 * x - x2), 2 * y - own(x2)
+    assert float((lhs - rhs).abs().max()) < 5e-5 * max(1.0, float(rhs.abs().max()))
