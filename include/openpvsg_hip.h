@@ -333,6 +333,13 @@ int pvsg_stem7x7_pack(const float* weight, float* w_packed, void* stream);
 int pvsg_stem7x7_bn_relu_pool(const float* x, const float* w_packed, const float* scale, const float* shift, float* out,
                               int N, int H, int W, void* stream);
 
+/* [3P] torch.nn.GroupNorm (mmdet ConvModule norm_cfg=GN) as per-(image, channel) scale / shift:
+ * GroupNorm(x)[b, c] == x[b, c] * scale[b*C + c] + shift[b*C + c]  (biased variance over the group's channels x pixels),
+ * for consumers that apply it on the fly.  x (B, C, HW) f32; weight / bias (C) or NULL; workspace: B*G*128 doubles;
+ * two launches with a fixed reduction order.  Requires (C/G)*HW % 4 == 0. */
+int pvsg_group_norm_affine(const float* x, const float* weight, const float* bias, double* workspace, float* scale,
+                           float* shift, int B, int C, int G, long long HW, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -178,6 +178,73 @@ __global__ __launch_bounds__(256) void decoder_kv_inputs_kernel(const float* __r
   }
 }
 
+
+// GroupNorm statistics -> per-(image, channel) scale / shift, so that GroupNorm(x) == x * scale + shift can ride in a
+// consumer (fpn_merge_up2x, nchw_to_tokens, the mask-feature convolution's operand staging).  [3P] torch.nn.GroupNorm as
+// used by mmdet ConvModule(norm_cfg=GN): biased variance over the group's channels x pixels.  Two launches, fixed
+// reduction order (bitwise reproducible): partial (sum, sum of squares) of 64 chunks per (image, group) -- f32 per
+// thread over <= a few hundred elements, f64 from there on -- then one thread per (image, group).
+constexpr int GN_CHUNKS = 64;
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part, long long n_per_group) {
+  const long long bg = blockIdx.x;
+  const int chunk = blockIdx.y;
+  const float* p = x + bg * n_per_group;
+  const long long n4 = n_per_group >> 2;
+  const long long per = (n4 + GN_CHUNKS - 1) / GN_CHUNKS;
+  const long long lo = chunk * per, hi = (lo + per < n4) ? lo + per : n4;
+  double s = 0.0, q = 0.0;
+  float fs = 0.f, fq = 0.f;
+  int cnt = 0;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const float4 v = ld4_stream(p + 4 * i);
+    fs += (v.x + v.y) + (v.z + v.w);
+    fq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    if (++cnt == 64) { s += fs; q += fq; fs = fq = 0.f; cnt = 0; }
+  }
+  s += fs; q += fq;
+  if (chunk == GN_CHUNKS - 1)                                    // the < 4 trailing elements
+    for (long long i = 4 * n4 + threadIdx.x; i < n_per_group; i += 256) { const double v = p[i]; s += v; q += v * v; }
+  __shared__ double red[2][256];
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + st];
+      red[1][threadIdx.x] += red[1][threadIdx.x + st];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[(bg * GN_CHUNKS + chunk) * 2] = red[0][0];
+    part[(bg * GN_CHUNKS + chunk) * 2 + 1] = red[1][0];
+  }
+}
+
+__global__ void gn_finish_kernel(const double* __restrict__ part, const float* __restrict__ weight, const float* __restrict__ bias,
+                                 float* __restrict__ scale, float* __restrict__ shift, int B, int C, int G, long long n_per_group,
+                                 float eps) {
+  const int bg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bg >= B * G) return;
+  double s = 0.0, q = 0.0;
+  for (int c = 0; c < GN_CHUNKS; ++c) {
+    s += part[((long long)bg * GN_CHUNKS + c) * 2];
+    q += part[((long long)bg * GN_CHUNKS + c) * 2 + 1];
+  }
+  const double mean = s / (double)n_per_group;
+  double var = q / (double)n_per_group - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const int b = bg / G, g = bg - b * G, cpg = C / G;
+  for (int i = 0; i < cpg; ++i) {
+    const int ch = g * cpg + i;
+    const float sc = rstd * (weight ? weight[ch] : 1.f);
+    scale[b * C + ch] = sc;
+    shift[b * C + ch] = (bias ? bias[ch] : 0.f) - (float)mean * sc;
+  }
+}
+
 }  // namespace pvsg
 
 extern "C" int pvsg_fpn_merge_up2x(const float* lateral, const float* scale, const float* shift, const float* top,
@@ -255,5 +322,20 @@ extern "C" int pvsg_decoder_kv_inputs(const float* tokens, const float* level_em
   hipLaunchKernelGGL(decoder_kv_inputs_kernel, dim3((unsigned)nb), dim3(256), 0, stream, tokens, level_embed, pos_enc,
                      v_out, k_out, rows, hw, frame_stride, pe_rows);
   PVSG_LAUNCH_CHECK("decoder_kv_inputs");
+  return PVSG_OK;
+}
+
+extern "C" int pvsg_group_norm_affine(const float* x, const float* weight, const float* bias, double* workspace, float* scale,
+                                      float* shift, int B, int C, int G, long long HW, float eps, hipStream_t stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(x && workspace && scale && shift, "group_norm_affine: null pointer argument");
+  PVSG_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && HW > 0, "group_norm_affine: bad shape");
+  const long long npg = (long long)(C / G) * HW;
+  PVSG_REQUIRE(!(reinterpret_cast<uintptr_t>(x) & 15u) && !(npg & 3), "group_norm_affine: 16-byte aligned groups required");
+  hipLaunchKernelGGL(gn_partial_kernel, dim3((unsigned)(B * G), GN_CHUNKS), dim3(256), 0, stream, x, workspace, npg);
+  PVSG_LAUNCH_CHECK("group_norm_affine");
+  hipLaunchKernelGGL(gn_finish_kernel, dim3((unsigned)((B * G + 63) / 64)), dim3(64), 0, stream, workspace, weight, bias, scale, shift,
+                     B, C, G, npg, eps);
+  PVSG_LAUNCH_CHECK("group_norm_affine");
   return PVSG_OK;
 }

@@ -428,6 +428,17 @@ def group_norm_affine(x, gn):
     """GroupNorm(x) == x * scale[b,c] + shift[b,c]: the statistics pass only (one read of x).  x (B,C,H,W)."""
     B, C = x.shape[:2]
     G = gn.num_groups
+    hw = x[0, 0].numel()
+    if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and ((C // G) * hw) % 4 == 0 and not torch.is_grad_enabled():
+        # own two-launch reduction (csrc/fpn_fuse.hip): replaces var_mean + six small element-wise kernels
+        ws = torch.empty(B * G * 128, device=x.device, dtype=torch.float64)
+        scale = torch.empty(B * C, device=x.device, dtype=torch.float32)
+        shift = torch.empty(B * C, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.call('pvsg_group_norm_affine', x.data_ptr(), gn.weight.data_ptr() if gn.weight is not None else None,
+                      gn.bias.data_ptr() if gn.bias is not None else None, ws.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                      B, C, G, hw, float(gn.eps), _stream_ptr())
+        return scale, shift
     var, mean = torch.var_mean(x.reshape(B, G, -1), dim=2, correction=0)
     rstd = torch.rsqrt(var + gn.eps)
     scale = (rstd[:, :, None] * gn.weight.view(1, G, C // G)).reshape(B * C)

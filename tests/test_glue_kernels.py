@@ -116,3 +116,26 @@ def test_decoder_kv_inputs(hip_lib, F_, S, start, hw, video):
     v_ref = tok + le[None]
     k_ref = v_ref + (pe if video else pe.repeat(F_, 1))
     assert torch.equal(v, v_ref) and torch.equal(k, k_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,C,G,H,W', [(2, 256, 32, 23, 40), (3, 256, 32, 46, 80), (1, 64, 8, 5, 4), (2, 256, 32, 184, 320)])
+def test_group_norm_affine_equals_torch_group_norm(hip_lib, B, C, G, H, W):
+    """ops.group_norm_affine (own two-launch reduction) x * scale + shift == torch.nn.GroupNorm(x) (float64 reference)."""
+    import torch.nn as nn
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(B + H)
+    x = (torch.randn(B, C, H, W, generator=g) * 3 + 5).cuda()            # mean >> 0: E[x^2] - E[x]^2 must hold up
+    gn = nn.GroupNorm(G, C).cuda()
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        gn.bias.copy_(torch.randn(C, generator=g))
+        sc, sh = ops.group_norm_affine(x, gn)
+        y = x * sc.view(B, C, 1, 1) + sh.view(B, C, 1, 1)
+        ref = nn.functional.group_norm(x.double().cpu(), G, gn.weight.double().cpu(), gn.bias.double().cpu(), gn.eps)
+        lib = gn(x)
+    err, err_lib = (y.double().cpu() - ref).abs().max().item(), (lib.double().cpu() - ref).abs().max().item()
+    assert err < 1e-5 and err < 4 * err_lib + 2e-6, (err, err_lib)
+    with torch.no_grad():
+        sc2, sh2 = ops.group_norm_affine(x, gn)
+    assert torch.equal(sc, sc2) and torch.equal(sh, sh2)
