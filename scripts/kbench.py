@@ -145,7 +145,7 @@ def crowd_video(T, H, W, n_obj, seed=0):
     return frames, outputs
 
 
-def bench_track(frames, n_obj=16, cpu_frames=3):
+def bench_track(frames, n_obj=16):
     """IPS tube association (8f row 4): whole-video time on the GPU backend vs the oracle on the host cores."""
     import time
     import numpy as np
@@ -178,19 +178,8 @@ def bench_track(frames, n_obj=16, cpu_frames=3):
                           fps=frames / wall, ms_per_frame=1e3 * wall / frames, cnn_ms_per_frame=cnn_ms,
                           extract_emb_ms=emb_ms, reconsdot_ms=dist_ms, cells=cells,
                           reconsdot_GFLOP=2e-9 * cells * cells * 1024)))
-    if cpu_frames:
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        from oracle import unitrack as U
-        import bench
-        torch.set_num_threads(bench.host_cores())
-        net = U.AppearanceResNet50()
-        net.load_state_dict({k.replace('model.', '', 1): v.cpu() for k, v in model.state_dict().items()})
-        t0 = time.perf_counter()
-        ref, _ = U.eval_seq(net, vid[:cpu_frames], outs[:cpu_frames], 126)
-        cw = time.perf_counter() - t0
-        same = [list(r[3]) for r in ref] == [list(r[3]) for r in res[:cpu_frames]]
-        print(json.dumps(dict(kernel='ips_tube_association_cpu_oracle', frames=cpu_frames, cores=torch.get_num_threads(),
-                              fps=cpu_frames / cw, ms_per_frame=1e3 * cw / cpu_frames, same_track_ids=same)))
+    # the CPU side of this comparison (oracle/unitrack.py on the host cores, same track ids) lives in tests/test_unitrack.py:
+    # scripts never import oracle/
 
 
 if __name__ == '__main__':
