@@ -65,8 +65,12 @@ def build_hip_lib(force=False, verbose=True):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(cc, jobs))
+    # objects of sources that no longer exist: drop them and relink, or their symbols live on in the library
+    orphans = [os.path.join(OBJDIR, f) for f in os.listdir(OBJDIR) if f.endswith('.o') and os.path.join(OBJDIR, f) not in objs]
+    for o in orphans:
+        os.remove(o)
     out = lib_path()
-    if force or jobs or _stale(out, objs):
+    if force or jobs or orphans or _stale(out, objs):
         cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC'] + objs + ['-o', out]
         if verbose:
             print('[build]', ' '.join(cmd), flush=True)
