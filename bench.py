@@ -518,9 +518,13 @@ def main():
     if os.environ.get('PVSG_ONE_DEVICE') == '1' and world > 1:
         from openpvsg_amd.parallel import isolate_shared_gpu
         isolate_shared_gpu(rank, world)            # ranks sharing GPU 0 get disjoint CU ranges (see its docstring)
-    if world > 1:
+    # PVSG_FORCE_COLLECTIVES=1 at N = 1: the process group is created anyway and every exchange of the frame-sharded layout
+    # runs over RCCL with a single rank (openpvsg_amd/parallel.py) -- the only way a one-GPU box executes that code path
+    force = os.environ.get('PVSG_FORCE_COLLECTIVES', '0') == '1'
+    if world > 1 or force:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(args.backend, init_method='env://')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group(args.backend, init_method='env://', rank=rank, world_size=world)
     if os.environ.get('PVSG_ONE_DEVICE') == '1':   # logic test: every rank on GPU 0 (gloo backend)
         local = 0
     elif torch.cuda.device_count() <= local:
@@ -606,7 +610,7 @@ def main():
         n0 = len(timer.records)
         timer.enabled = bool(timer.records)
         with FlopCounterMode(display=False) as fc:
-            if world > 1:      # same local compute without the exchanges: no collective runs under the dispatch mode
+            if world > 1 or force:   # same local compute without the exchanges: no collective runs under the dispatch mode
                 pipe(clip_local, (Hp, Wp), (args.height, args.width), total_frames=T, group=group, shard='none')
             else:
                 step()
@@ -630,6 +634,9 @@ def main():
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
+            'collectives': {'backend': dist.get_backend() if dist.is_initialized() else None,
+                            'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
+                            'exchanges_run': bool(parallel.is_dist()), 'forced_at_world_1': bool(force and world == 1)},
             'dtype_note': ('every tensor, accumulation and result f32; the 3x3 convolutions run on the f32 MFMA, the large '
                            'GEMMs / 1x1 convolutions issue an EXACT three-limb bf16 split of their f32 operands on the bf16 MFMA '
                            '(6 limb products per multiply, f32 accumulate: error vs f64 at or below the library f32 GEMM, '
@@ -753,7 +760,7 @@ def main():
                 line['cpu_baseline'] = dict(value=None, unit='frames/s', cores=host_cores(), kind='port',
                                             sample='failed: %r' % (e,))
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

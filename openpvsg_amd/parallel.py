@@ -20,8 +20,16 @@ import torch
 import torch.distributed as dist
 
 
+# PVSG_FORCE_COLLECTIVES=1: run the exchanges even in a world of ONE rank (all_gather_into_tensor of a single shard, the
+# merge kernels on one record).  That is how a one-GPU box exercises the RCCL code path of the N > 1 layout end to end
+# (tests/test_parallel_gpu.py::test_rccl_world_size_1_*); results are those of the purely local run.
+FORCE_COLLECTIVES = os.environ.get('PVSG_FORCE_COLLECTIVES', '0') == '1'
+
+
 def is_dist(group=None):
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or FORCE_COLLECTIVES
 
 
 def isolate_shared_gpu(slot, slots, device_index=0, cus=256):

@@ -74,3 +74,89 @@ void oracle_pair_score(const float* sub, const float* obj, const float* W1, cons
     }
   free(st);
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * COCO compressed run-length strings -- [3P] pycocotools 2.0.x `mask.encode` / `mask.decode` (cocoapi
+ * common/maskApi.c: rleEncode, rleToString, rleFrString), used by models/mask2former_vps/utils.py:8,48 and
+ * models/unitrack/utils/io.py:31.  pycocotools is not installed here ("parity unpinned" against the package itself);
+ * this is a scalar restatement of the PUBLISHED algorithm, independent of the vectorised numpy codec the product
+ * ships (openpvsg_amd/tubes.py), and tests/golden/rle_known_answers.json holds hand-derived strings for it.
+ *   runs:    column-major scan of the (h, w) mask, counts alternate 0-run, 1-run, ... starting with zeros
+ *            (a mask that starts with a one gets a leading 0 count)
+ *   string:  count i >= 3 is stored as the difference to count i-2; each value in 5-bit groups, least significant
+ *            first, bit 0x20 = "more groups follow", a value ends when the rest is 0 with bit 0x10 clear or -1 with
+ *            bit 0x10 set (sign extension); every group + 48 is one ASCII character
+ * oracle_rle_encode: mask row-major (h, w) uint8 -> string (returns its length, or -1 if `cap` is too small)
+ * oracle_rle_decode: string -> row-major mask (returns the number of counts, -1 on overrun)
+ */
+static long rle_counts(const uint8_t* mask, int h, int w, uint32_t* cnts) {
+  long k = 0;
+  uint32_t c = 0;
+  uint8_t p = 0;
+  for (long j = 0; j < (long)h * w; ++j) {
+    const uint8_t v = mask[(j % h) * (long)w + (j / h)] != 0;     /* element j of the column-major order */
+    if (v != p) {
+      cnts[k++] = c;
+      c = 0;
+      p = v;
+    }
+    ++c;
+  }
+  cnts[k++] = c;
+  return k;
+}
+
+long oracle_rle_encode(const uint8_t* mask, int h, int w, char* s, long cap) {
+  uint32_t* cnts = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)h * w + 1));
+  const long m = rle_counts(mask, h, w, cnts);
+  long p = 0;
+  for (long i = 0; i < m; ++i) {
+    long x = (long)cnts[i];
+    if (i > 2) x -= (long)cnts[i - 2];
+    int more = 1;
+    while (more) {
+      char c = (char)(x & 0x1f);
+      x >>= 5;
+      more = (c & 0x10) ? x != -1 : x != 0;
+      if (more) c |= 0x20;
+      c += 48;
+      if (p + 1 >= cap) {
+        free(cnts);
+        return -1;
+      }
+      s[p++] = c;
+    }
+  }
+  s[p] = 0;
+  free(cnts);
+  return p;
+}
+
+long oracle_rle_decode(const char* s, int h, int w, uint8_t* mask) {
+  long m = 0, p = 0, pos = 0;
+  long prev1 = 0, prev2 = 0;                                    /* counts m-1 and m-2 */
+  uint8_t v = 0;
+  for (long j = 0; j < (long)h * w; ++j) mask[j] = 0;
+  while (s[p]) {
+    long x = 0;
+    int k = 0, more = 1;
+    while (more) {
+      const char c = (char)(s[p] - 48);
+      x |= (long)(c & 0x1f) << (5 * k);
+      more = c & 0x20;
+      ++p;
+      ++k;
+      if (!more && (c & 0x10)) x |= -1L << (5 * k);
+    }
+    if (m > 2) x += prev2;
+    if (pos + x > (long)h * w) return -1;
+    if (v)
+      for (long j = pos; j < pos + x; ++j) mask[(j % h) * (long)w + (j / h)] = 1;
+    pos += x;
+    v ^= 1;
+    prev2 = prev1;
+    prev1 = x;
+    ++m;
+  }
+  return m;
+}

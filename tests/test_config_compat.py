@@ -97,6 +97,29 @@ def test_registry_builds_reference_model_sections_and_state_dict_keys():
         assert m.panoptic_head.cls_embed.weight.shape == (127, 256)
 
 
+def test_state_dict_equals_the_published_mmdet_checkpoint_layout(golden_dir):
+    """Every name and shape of the mmdet 2.25 Mask2Former R50 checkpoint (configs/mask2former/...single_video_test.py:7-9,
+    tools/test.py:233 load_checkpoint) against model.state_dict(): the table is generated by oracle/make_ckpt_keys.py from
+    the published module layout, independently of this repository's classes; load_state_dict(strict=True) of such a
+    checkpoint therefore succeeds for both detectors."""
+    import json
+    import torch
+    from openpvsg_amd import backbone, blocks, detectors, fusion, heads  # noqa: F401
+    from openpvsg_amd.model_zoo import mask2former_r50_model_cfg
+    from openpvsg_amd.registry import build_detector
+    table = json.load(open(os.path.join(golden_dir, 'mmdet225_mask2former_r50_keys.json')))['keys']
+    assert len(table) == 610
+    for video in (False, True):
+        m = build_detector(mask2former_r50_model_cfg(video))
+        sd = {k: list(v.shape) for k, v in m.state_dict().items()}
+        assert sorted(sd) == sorted(table)
+        assert [k for k in sd if sd[k] != table[k]] == []
+        ckpt = {k: torch.zeros(shape, dtype=torch.long if k.endswith('num_batches_tracked') else torch.float32)
+                for k, shape in table.items()}
+        res = m.load_state_dict(ckpt, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+
+
 def test_product_refuses_cpu_forward():
     """No CPU fallback: a CPU tensor through the product model raises instead of computing."""
     import torch

@@ -118,6 +118,74 @@ def test_bench_gpus_2_runs_two_ranks_on_the_frame_sharded_clip(hip_lib):
     assert abs(two['checksum']['tube_feat_sum'] - one['checksum']['tube_feat_sum']) < 1e-2 * max(1.0, abs(one['checksum']['tube_feat_sum']))
 
 
+def _rccl_solo_worker(rank, tmp):
+    """One rank, backend nccl (= RCCL), collectives forced: ClipShard.combine and the segment-record gather really call
+    all_gather_into_tensor; the result must equal the purely local run of the same process."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), PVSG_FORCE_COLLECTIVES='1')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    from openpvsg_amd import parallel
+    from oracle.detweights import det_input
+    assert parallel.FORCE_COLLECTIVES and parallel.is_dist()
+    calls = []
+    real = dist.all_gather_into_tensor
+
+    def counted(out, t, group=None, **kw):
+        calls.append(tuple(t.shape))
+        return real(out, t, group=group, **kw)
+    dist.all_gather_into_tensor = counted
+    torch.backends.cudnn.deterministic = True
+    pipe = _build()
+    T = 4
+    clip = det_input('clip', (T, 3, 64, 96), 6).cuda()
+    # the helper itself: one rank's tensor comes back unchanged, through RCCL
+    x = torch.arange(24, dtype=torch.float32, device='cuda').reshape(2, 3, 4)
+    assert torch.equal(parallel.all_gather_cat(x, 0), x) and torch.equal(parallel.all_gather_cat(x, 1), x)
+    assert torch.equal(parallel.or_flags(torch.tensor([[1, 2, 4, 8]], dtype=torch.int32, device='cuda')).cpu(),
+                       torch.tensor([[1, 2, 4, 8]], dtype=torch.int32))
+    n_helper = len(calls)
+    out = pipe(clip, (64, 96), total_frames=T, group=None, shard='frames')      # 9 layer exchanges + the segment records
+    n_frames_mode = len(calls) - n_helper
+    seg = pipe(clip, (64, 96), group=None, shard='segments')
+    solo = pipe(clip, (64, 96), shard='none')
+    torch.cuda.synchronize()
+    assert n_frames_mode == 10, calls
+    rec = [c for c in calls[n_helper:n_helper + 9]]
+    assert all(c == (1, 1, 8 * 100 * 34 + 4) for c in rec), rec             # the 108.8 KB record per decoder layer
+    assert out['tube_ids'].tolist() == solo['tube_ids'].tolist() == seg['tube_ids'].tolist()
+    assert torch.allclose(out['query'], solo['query'], rtol=1e-4, atol=1e-4)
+    assert torch.allclose(out['tube_feats'], solo['tube_feats'], rtol=1e-4, atol=1e-4)
+    assert float((out['pan_results'] != solo['pan_results']).float().mean()) < 2e-3
+    if solo['relation'] is not None:
+        assert torch.allclose(out['relation']['pred_matrix'], solo['relation']['pred_matrix'], rtol=1e-3, atol=1e-4)
+    open(os.path.join(tmp, 'ok'), 'w').write('%d %s' % (len(calls), dist.get_backend()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_world_size_1_runs_every_exchange_of_the_frame_sharded_clip(hip_lib, tmp_path):
+    """tools/test.py:186-190,248-254 (init_dist + nccl): the one-GPU box cannot host two RCCL ranks, but it can host one --
+    with PVSG_FORCE_COLLECTIVES the N > 1 layout's exchanges all execute on the `nccl` backend."""
+    mp.spawn(_rccl_solo_worker, args=(str(tmp_path),), nprocs=1, join=True)
+    n, backend = open(os.path.join(str(tmp_path), 'ok')).read().split()
+    assert backend == 'nccl' and int(n) >= 13
+
+
+def test_bench_line_reports_rccl_ranks(hip_lib):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PVSG_FORCE_COLLECTIVES='1', PVSG_GEMM_TABLE='off', MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--frames', '4', '--height', '64', '--width', '96',
+                        '--steps', '1', '--warmup', '1', '--cpu-baseline', 'off', '--sub-benchmarks', 'off', '--keep', '6'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['collectives'] == dict(backend='nccl', rccl_ranks=1, exchanges_run=True, forced_at_world_1=True)
+    assert line['n_gpus'] == 1
+
+
 def test_relation_graph_replay_equals_eager_and_follows_weight_updates(hip_lib):
     """PVSGPipeline replays the relation head as a hipGraph from the second sighting of a (tubes, frames) shape: same
     results as eager, results are copies (valid after the next call), and a weight update invalidates the graph."""

@@ -36,6 +36,58 @@ def test_rle_round_trip_and_known_vectors():
     assert tubes.rle_encode(m)['counts'] == '1232'
 
 
+def test_rle_known_answer_vectors_and_c_restatement(golden_dir):
+    """the string codec against committed, hand-derived vectors of the published format and
+    against an independent scalar restatement (oracle/c/ref_kernels.c) on random masks."""
+    import ctypes
+    import json
+    from oracle import cbuild
+    lib = cbuild.load()
+    lib.oracle_rle_encode.restype = ctypes.c_long
+    lib.oracle_rle_decode.restype = ctypes.c_long
+
+    def c_encode(m):
+        m = np.ascontiguousarray(m, dtype=np.uint8)
+        buf = ctypes.create_string_buffer(6 * m.size + 16)
+        n = lib.oracle_rle_encode(m.ctypes.data_as(ctypes.c_void_p), m.shape[0], m.shape[1], buf, len(buf))
+        assert n >= 0
+        return buf.value.decode('ascii')
+
+    def c_decode(s, h, w):
+        out = np.full((h, w), 7, np.uint8)
+        assert lib.oracle_rle_decode(s.encode('ascii'), h, w, out.ctypes.data_as(ctypes.c_void_p)) >= 0
+        return out
+    cases = json.load(open(os.path.join(golden_dir, 'rle_known_answers.json')))['cases']
+    assert len(cases) >= 12
+    for c in cases:
+        h, w = c['size']
+        assert sum(c['counts']) == h * w
+        assert tubes.rle_counts_to_string(c['counts']) == c['string'], c
+        flat = np.concatenate([np.full(n, i & 1, np.uint8) for i, n in enumerate(c['counts'])])
+        m = flat.reshape((h, w), order='F')
+        if 'mask' in c:
+            assert (m == np.array(c['mask'])).all()
+        assert tubes.rle_encode(m)['counts'] == c['string'] and c_encode(m) == c['string']
+        assert (tubes.rle_decode({'size': [h, w], 'counts': c['string']}) == m).all()
+        assert (c_decode(c['string'], h, w) == m).all()
+    rs = np.random.RandomState(3)
+    for shape in ((1, 1), (2, 7), (33, 5), (64, 96), (181, 240)):
+        for p in (0.0, 0.01, 0.3, 0.5, 0.99, 1.0):
+            m = (rs.rand(*shape) < p).astype(np.uint8)
+            s = tubes.rle_encode(m)['counts']
+            assert s == c_encode(m)
+            assert (c_decode(s, *shape) == m).all()
+    # long runs (> 2^15: four groups) and a large negative delta
+    m = np.zeros((400, 300), np.uint8)
+    m[:, 150:] = 1
+    m[5, 0] = 1
+    assert tubes.rle_encode(m)['counts'] == c_encode(m)
+    # rle_from_runs (the device run-length pass of the IPS association) writes the same strings
+    flat = m.T.reshape(-1)
+    ch = np.flatnonzero(np.diff(np.concatenate(([0], flat, [0]))))
+    assert tubes.rle_from_runs(ch[0::2], ch[1::2] - ch[0::2], 400, 300)['counts'] == c_encode(m)
+
+
 def _outputs(T=5):
     rs = np.random.RandomState(1)
     outs = []

@@ -75,6 +75,76 @@ def test_third_party_restatements_on_known_answers():
     assert abs(float(U.box_iou(t, torch.tensor([[5., 0., 15., 10.]]))[0, 0]) - 50 / 150) < 1e-7
 
 
+def _partial_matchings(n, m):
+    """every partial matching of n rows to m columns as a tuple x (x[i] = column or -1)"""
+    def rec(i, used):
+        if i == n:
+            yield ()
+            return
+        for rest in rec(i + 1, used):
+            yield (-1,) + rest
+        for j in range(m):
+            if j not in used:
+                for rest in rec(i + 1, used | {j}):
+                    yield (j,) + rest
+    return rec(0, frozenset())
+
+
+def test_lapjv_extend_cost_semantics_brute_force_and_properties():
+    """[3P] lap 0.4.0 `lapjv(cost, extend_cost=True, cost_limit=t)` (models/unitrack/core/association/matching.py:33):
+    the published embedding -- cost in the top-left of an (n+m)^2 matrix, t/2 on both off-diagonal blocks, 0 bottom-right
+    -- means: minimise  sum(matched costs) + (t/2) * (#unmatched rows + #unmatched columns)  over all PARTIAL matchings.
+    Checked against exhaustive enumeration (small rectangles, random thresholds, ties broken by objective only) and, on
+    larger problems, against scipy's optimum of the same objective plus the local optimality conditions."""
+    from scipy.optimize import linear_sum_assignment
+    from openpvsg_amd import unitrack as P
+    rs = np.random.RandomState(11)
+
+    def objective(c, x, t):
+        x = np.asarray(x)
+        mt = x >= 0
+        return float(c[np.flatnonzero(mt), x[mt]].sum()) + 0.5 * t * ((~mt).sum() + c.shape[1] - mt.sum())
+    for trial in range(60):
+        n, m = rs.randint(1, 5), rs.randint(1, 5)
+        c = rs.rand(n, m)
+        if trial % 4 == 0:
+            c[rs.rand(n, m) < 0.3] = np.inf                      # class gate of the reconstruction distance
+        t = float(rs.choice([0.2, 0.5, 0.7, 0.9, 1.5]))
+        cf = np.where(np.isfinite(c), c, 1e9)
+        best = min(objective(cf, x, t) for x in _partial_matchings(n, m))
+        for name, (x, y) in (('oracle', U.lapjv_extend(c, t)), ('product', P.lapjv(c, True, t)[1:])):
+            assert abs(objective(cf, x, t) - best) < 1e-9, (name, c, t, x)
+            assert all((j < 0) or y[j] == i for i, j in enumerate(x)) and sum(j >= 0 for j in x) == sum(i >= 0 for i in y)
+            assert all(np.isfinite(c[i, j]) and c[i, j] <= t + 1e-12 for i, j in enumerate(x) if j >= 0)
+    for trial in range(20):
+        n, m = rs.randint(5, 40), rs.randint(5, 40)
+        c = rs.rand(n, m)
+        t = float(rs.choice([0.1, 0.3, 0.6, 0.9]))
+        ext = np.full((n + m, n + m), t / 2.0)
+        ext[n:, m:] = 0.0
+        ext[:n, :m] = c
+        r, cc = linear_sum_assignment(ext)
+        opt = ext[r, cc].sum()
+        xo, yo = U.lapjv_extend(c, t)
+        cost, xp, yp = P.lapjv(c, True, t)
+        for x, y in ((xo, yo), (xp, yp)):
+            assert abs(objective(c, x, t) - opt) < 1e-9
+            free_r, free_c = np.flatnonzero(np.asarray(x) < 0), np.flatnonzero(np.asarray(y) < 0)
+            if len(free_r) and len(free_c):                      # no free pair would be cheaper than leaving both alone
+                assert c[np.ix_(free_r, free_c)].min() >= t - 1e-12
+        assert abs(cost - sum(c[i, j] for i, j in enumerate(xp) if j >= 0)) < 1e-12
+        # matches / unmatched lists of matching.py:29-41
+        mt, ua, ub = P.linear_assignment(c, t)
+        mo, uao, ubo = U.linear_assignment(c, t)
+        assert sorted(map(tuple, np.asarray(mt).tolist())) == sorted(map(tuple, np.asarray(mo).tolist()))
+        assert list(ua) == list(uao) and list(ub) == list(ubo)
+    # cost_limit = inf with extend_cost: lap fills the extension with max(cost) + 1 -> a maximum matching of least cost
+    c = rs.rand(4, 7)
+    _, x, y = P.lapjv(c, True, np.inf)
+    r, cc = linear_sum_assignment(c)
+    assert (np.asarray(x) >= 0).all() and abs(c[np.arange(4), x].sum() - c[r, cc].sum()) < 1e-12
+
+
 @pytest.mark.parametrize('fixture,cfg', [('unitrack_sequence.npz', {}),
                                          ('unitrack_sequence_motion.npz', dict(motion_lambda=0.95, motion_gated=True))])
 def test_tracking_sequence_matches_reference(fixture, cfg):
