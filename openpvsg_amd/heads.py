@@ -50,14 +50,24 @@ class DecoderRows:
         if head.decoder_embed_dims != 256 or head.num_heads != 8 or head.num_queries > 128 or head.num_classes + 1 > 128:
             return False
         me = head.mask_embed
-        if not (len(me) == 5 and all(isinstance(me[i], nn.Linear) for i in (0, 2, 4)) and me[4].out_features == 256):
+        if not (len(me) == 5 and all(isinstance(me[i], nn.Linear) for i in (0, 2, 4)) and me[4].out_features == 256 and
+                all(isinstance(me[i], nn.ReLU) for i in (1, 3))):
+            return False
+
+        def plain_ln(n):                     # the kernels hard-code LayerNorm(256) with eps 1e-5 and an affine pair
+            return isinstance(n, nn.LayerNorm) and n.eps == 1e-5 and n.elementwise_affine and tuple(n.normalized_shape) == (256,)
+        if not plain_ln(dec.post_norm):
             return False
         for layer in dec.layers:
             if layer.operation_order != FAST_ORDER or len(layer.ffns) != 1:
                 return False
+            if len(layer.norms) != 3 or not all(plain_ln(n) for n in layer.norms):
+                return False
             ffn = layer.ffns[0]
             if not (isinstance(ffn, FFN) and ffn.add_identity and len(ffn.layers) == 3 and
-                    isinstance(ffn.layers[1], nn.Linear) and ffn.layers[1].in_features % 512 == 0):
+                    isinstance(ffn.layers[1], nn.Linear) and ffn.layers[1].in_features % 512 == 0 and
+                    isinstance(ffn.layers[0], nn.Sequential) and isinstance(ffn.layers[0][0], nn.Linear) and
+                    isinstance(ffn.layers[0][1], nn.ReLU)):
                 return False
             if not all(isinstance(a, MultiheadAttention) and a.attn.in_proj_weight is not None for a in layer.attentions):
                 return False
@@ -229,8 +239,8 @@ class _Mask2FormerHeadBase(BaseModule):
         """DecoderRows for the current weights, or None when the generic module path has to run."""
         if getattr(self, '_rows_ok', None) is None:
             self._rows_ok = DecoderRows.supported(self)
-        if not self._rows_ok or not self.query_feat.weight.is_cuda:
-            return None
+        if not self._rows_ok or not self.query_feat.weight.is_cuda or torch.is_grad_enabled():
+            return None                      # forward-only kernels: under autograd the module path runs, like the other fast paths
         st = getattr(self, '_rows_state', None)
         if st is None or st.sig != DecoderRows.signature(self):
             with torch.no_grad():
@@ -277,6 +287,9 @@ class _Mask2FormerHeadBase(BaseModule):
             v_in.append(v)
             k_in.append(v + pe[None])
         self._level_sizes = sizes
+        if tokens is not None:
+            self.pixel_decoder.last_tokens = None      # consumed: do not keep the encoder's token tensor alive between calls
+        del tokens
         # integer-factor levels: bits straight from down-sampled features
         lows = None
         fast = (not exact_masks and L == 3 and H4 % 8 == 0 and W4 % 8 == 0 and

@@ -701,11 +701,14 @@ def stem7x7_bn_relu_pool(x, w_packed, scale, shift):
 
 def decoder_kv_inputs(tokens, start, hw, level_embed, pos_enc):
     """tokens (F,S,256) encoder memory, level rows start..start+hw -> value input (F*hw,256) = tokens + level_embed and
-    key input = value + pos_enc, pos_enc (F*hw,256) or (hw,256); one pass, both outputs."""
+    key input = value + pos_enc; pos_enc (p,256) is tiled over the F*hw key rows (row r uses pos_enc[r % p]): p = hw for
+    images, T*hw for a clip of T frames -- also when `tokens` holds B clips of T frames (F = B*T); one pass, both outputs."""
     x, le, pe = _chk(tokens, 'tokens'), _chk(level_embed, 'level_embed'), _chk(pos_enc, 'pos_enc')
     Fr, S, C = x.shape
-    if pe.shape[0] not in (Fr * hw, hw) or pe.shape[1] != C or start + hw > S:
-        raise RuntimeError('decoder_kv_inputs: inconsistent shapes')
+    p = pe.shape[0]
+    if p == 0 or p % hw or (Fr * hw) % p or pe.shape[1] != C or start + hw > S:
+        raise RuntimeError('decoder_kv_inputs: inconsistent shapes (tokens %s, hw %d, pos_enc %s)'
+                           % (tuple(x.shape), hw, tuple(pe.shape)))
     v = torch.empty((Fr * hw, C), device=x.device, dtype=torch.float32)
     k = torch.empty_like(v)
     with torch.cuda.device(x.device):

@@ -133,12 +133,15 @@ class PVSGPipeline(torch.nn.Module):
         # in place or by swapping modules, gets a new graph
         sig = tuple((p.data_ptr(), p._version) for m in (self.subject_encoder, self.object_encoder, self.pair_model, self.relation_model)
                     for p in m.parameters())
-        key = (tuple(feats.shape), str(feats.device), hash(sig))
+        key = (tuple(feats.shape), str(feats.device), sig)
         ent = self._rel_graphs.get(key)
         if ent is None:
+            if len(self._rel_seen) >= 64:                    # bounded like the graphs: forget the oldest sightings
+                self._rel_seen.pop(next(iter(self._rel_seen)))
             self._rel_seen[key] = self._rel_seen.get(key, 0) + 1
             if self._rel_seen[key] < 2:
                 return run(feats)                      # first sighting of this shape: eager (also warms the libraries)
+            self._rel_seen.pop(key, None)
             try:
                 static_in = feats.clone()
                 side = torch.cuda.Stream(device=feats.device)

@@ -35,6 +35,7 @@ __device__ __forceinline__ unsigned xcd_contiguous_block(unsigned bid, unsigned 
   return base + slot;
 }
 
+static int g_cus = 256;
 constexpr int GB_M = 128, GB_N = 128, GB_K = 16;
 constexpr int GB_LIMB = 2 * GB_M * 8;
 constexpr int GB_TILE = 3 * GB_LIMB;
@@ -53,6 +54,9 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& h, unsigned
 // ---------------------------------------------------------------------------------------------------------------
 // The shipped kernel with ablation switches.  ABL: 0 = as shipped, 1 = no VALU split (raw bits staged),
 // 2 = no staging writes (loads kept alive), 3 = no global loads either, 4 = MFMAs only (no LDS reads, no barrier)
+__device__ unsigned long long g_phase[8];      // [0] prologue, [1] loop, [2] epilogue cycles (wave 0 of every block), [3] blocks
+
+// ABL 5 = 4 without the epilogue stores; ABL 10 = shipped + phase timing (s_memtime)
 template <int ABL>
 __global__ __launch_bounds__(256, 2)
 void gemm_abl_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
@@ -60,6 +64,7 @@ void gemm_abl_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp,
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * GB_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
+  const unsigned long long tp0 = __builtin_readcyclecounter();
   const unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int tn = logical % tiles_n, tm = logical / tiles_n;
   const int m0 = tm * GB_M, n0 = tn * GB_N;
@@ -76,7 +81,7 @@ void gemm_abl_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp,
   f32x4 a_regs[2][2];
   u32x4 w_regs[2][3];
   auto fetch = [&](int slot, int kt) {
-    if (ABL >= 3) return;
+    if (ABL >= 3 && ABL < 10) return;
     const unsigned so = (unsigned)kt * (GB_K * 4);
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -86,7 +91,7 @@ void gemm_abl_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp,
     for (int l = 0; l < 3; ++l) w_regs[slot][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
   };
   auto stash = [&](int slot, __bf16* st) {
-    if (ABL >= 3) return;
+    if (ABL >= 3 && ABL < 10) return;
     if (ABL == 2) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) asm volatile("" ::"v"(a_regs[slot][q]));
@@ -135,7 +140,7 @@ void gemm_abl_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp,
   fetch(1, KT > 1 ? 1 : 0);
   fetch(0, KT > 2 ? 2 : KT - 1);
   bf16x8 av[3][2], wv[3][2];
-  if (ABL == 4) {   // operands: whatever the (never written) LDS holds once -- random-ish bits from A instead
+  if (ABL == 4 || ABL == 5) {   // operands: whatever the (never written) LDS holds once -- random-ish bits from A instead
 #pragma unroll
     for (int l = 0; l < 3; ++l)
 #pragma unroll
@@ -146,7 +151,7 @@ void gemm_abl_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp,
   }
   auto kstep = [&](int kt, auto PAR) {
     constexpr int par = decltype(PAR)::value;
-    if (ABL != 4) {
+    if (ABL != 4 && ABL != 5) {
       __syncthreads();
       const __bf16* cur = lds + par * GB_STAGE;
 #pragma unroll
@@ -170,13 +175,79 @@ void gemm_abl_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp,
   };
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
+  const unsigned long long tp1 = __builtin_readcyclecounter();
   int kt = 0;
   for (; kt + 2 <= KT; kt += 2) {
     kstep(kt, P0{});
     kstep(kt + 1, P1{});
   }
   if (kt < KT) kstep(kt, P0{});
+  unsigned long long tp2 = 0;
+  if (ABL == 10) {
+    asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][1]));
+    tp2 = __builtin_readcyclecounter();
+  }
 
+  unsigned long long tpe[2] = {0, 0};
+  if (ABL == 11 || ABL == 12 || ABL == 13) {
+    // full tiles: no per-element guards, bias fetched and waited for ONCE -> 64 stores issue back to back
+    // (the guarded form makes the compiler put an s_waitcnt vmcnt(0) in front of every store: each waits for its predecessor)
+    const bool full = (m0 + GB_M <= M) && (n0 + GB_N <= N);
+    if (full) {
+      float bv[2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) bv[cb] = bias ? bias[n0 + wc * 64 + cb * 32 + li] : 0.f;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long te0 = __builtin_readcyclecounter();
+      if (ABL == 11 || ABL == 13) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          float* op = out + (size_t)(m0 + wr * 64 + 4 * kg) * N + n0 + wc * 64 + cb * 32 + li;
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) op[(size_t)(rb * 32 + (r & 3) + 8 * (r >> 2)) * N] = acc[rb][cb][r] + bv[cb];
+        }
+        if (ABL == 13) {
+          asm volatile("" ::: "memory");
+          const unsigned long long te1 = __builtin_readcyclecounter();
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const unsigned long long te2 = __builtin_readcyclecounter();
+          if (tid == 0) {
+            atomicAdd(&g_phase[0], tp1 - tp0);
+            atomicAdd(&g_phase[1], te0 - tp1);
+            atomicAdd(&g_phase[2], te2 - te0);
+            atomicAdd(&g_phase[3], 1ull);
+            atomicAdd(&g_phase[4], te1 - te0);
+            atomicAdd(&g_phase[5], 0ull);
+            atomicAdd(&g_phase[6], te2 - te1);
+          }
+        }
+      } else {
+        // transposed through LDS: 16-byte stores, 256 contiguous bytes per row
+        __syncthreads();
+        float* reg = reinterpret_cast<float*>(lds) + wave * (32 * 64);
+        const int rr = lane >> 4, c4 = (lane & 15) * 4;
+        const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + n0 + wc * 64 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) reg[((r & 3) + 8 * (r >> 2) + 4 * kg) * 64 + cb * 32 + li] = acc[rb][cb][r];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int row = 4 * i + rr;
+            f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * 64 + c4);
+            v += b4;
+            *reinterpret_cast<f32x4*>(out + (size_t)(m0 + wr * 64 + rb * 32 + row) * N + n0 + wc * 64 + c4) = v;
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int col = n0 + wc * 64 + cb * 32 + li;
@@ -188,8 +259,27 @@ void gemm_abl_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp,
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rrel = rb * 32 + (r & 3) + 8 * (r >> 2);
-        if (m0 + wr * 64 + 4 * kg + rrel < M) op[(size_t)rrel * N] = acc[rb][cb][r] + bv;
+        if (ABL == 5) {
+          if (acc[rb][cb][r] == 123.456f) op[(size_t)rrel * N] = acc[rb][cb][r] + bv;
+        } else if (m0 + wr * 64 + 4 * kg + rrel < M) op[(size_t)rrel * N] = acc[rb][cb][r] + bv;
       }
+    if (ABL == 10) {
+      asm volatile("" ::: "memory");
+      tpe[cb] = __builtin_readcyclecounter();
+    }
+  }
+  if (ABL == 10) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tp3 = __builtin_readcyclecounter();
+    if (tid == 0) {
+      atomicAdd(&g_phase[0], tp1 - tp0);
+      atomicAdd(&g_phase[1], tp2 - tp1);
+      atomicAdd(&g_phase[2], tp3 - tp2);
+      atomicAdd(&g_phase[3], 1ull);
+      atomicAdd(&g_phase[4], tpe[0] - tp2);
+      atomicAdd(&g_phase[5], tpe[1] - tpe[0]);
+      atomicAdd(&g_phase[6], tp3 - tpe[1]);
+    }
   }
 }
 
@@ -307,6 +397,391 @@ void gemm_ps_kernel(const __bf16* __restrict__ Ap, const __bf16* __restrict__ Wp
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no DMA may land after the workgroup's LDS is released
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Epilogue study.  Same main loop as the shipped kernel (f32 A split while staged), different accumulator -> memory paths:
+//   EPI 1: operand roles swapped (accumulator rows = output columns n, lanes = token rows m): a lane owns 4 consecutive n
+//          -> 16 dwordx4 stores per wave (32 rows x 32 B per instruction)
+//   EPI 2: as shipped (rows = tokens), accumulators transposed through the (now free) LDS stages, 16 dwordx4 stores per wave,
+//          256 contiguous bytes per row and instruction
+// STAG > 0: the first generation of workgroups (the 3 x 256 that are resident at launch) starts staggered: residency slot
+// s = blockIdx / 256 waits s * STAG microseconds, so that the three workgroups of a CU are not in the same phase (loop /
+// store burst) at the same time; later workgroups start when a predecessor ends and inherit the offset.
+template <int EPI, int STAG = 0>
+__global__ __launch_bounds__(256, 2)
+void gemm_epi_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
+                     float* __restrict__ out, int M, int N, int K, int Npad, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * GB_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (STAG > 0 && blockIdx.x < 768u) {
+    const unsigned slot = blockIdx.x >> 8;
+    const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)slot * STAG * 100ull;
+    while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(32);
+  }
+  const int wr = wave >> 1, wc = wave & 1;
+  const unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tn = logical % tiles_n, tm = logical / tiles_n;
+  const int m0 = tm * GB_M, n0 = tn * GB_N;
+  const int ar = tid >> 1, akg = tid & 1;
+  const bool a_in = m0 + ar < M;
+  const unsigned a_voff = a_in ? (unsigned)((ar * K + 8 * akg) * 4) : 0x80000000u;
+  const size_t a_base = (size_t)m0 * K * 4;
+  const auto asrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A) + a_base), 0,
+                                                        (unsigned)((size_t)GB_M * K * 4), 0x00020000);
+  const int wkg = tid >> 7, wcol = tid & 127;
+  const size_t w_limb_stride = (size_t)2 * Npad * 8;
+  const __bf16* wsrc = Wp + ((size_t)wkg * Npad + n0 + wcol) * 8;
+  f32x4 a_regs[2][2];
+  u32x4 w_regs[2][3];
+  auto fetch = [&](int slot, int kt) {
+    const unsigned so = (unsigned)kt * (GB_K * 4);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      a_regs[slot][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc_t, a_voff + 16 * q, so, 0));
+    const __bf16* wk = wsrc + (size_t)kt * 3 * w_limb_stride;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) w_regs[slot][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
+  };
+  auto stash = [&](int slot, __bf16* st) {
+    unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      split2(a_regs[slot][q][0], a_regs[slot][q][1], hh[2 * q], mm[2 * q], ll[2 * q]);
+      split2(a_regs[slot][q][2], a_regs[slot][q][3], hh[2 * q + 1], mm[2 * q + 1], ll[2 * q + 1]);
+    }
+    const u32x4 h = {hh[0], hh[1], hh[2], hh[3]}, m = {mm[0], mm[1], mm[2], mm[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+    __bf16* pa = st + (akg * GB_M + ar) * 8;
+    *reinterpret_cast<u32x4*>(pa) = h;
+    *reinterpret_cast<u32x4*>(pa + GB_LIMB) = m;
+    *reinterpret_cast<u32x4*>(pa + 2 * GB_LIMB) = l;
+    __bf16* pw = st + GB_TILE + (wkg * GB_N + wcol) * 8;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(pw + i * GB_LIMB) = w_regs[slot][i];
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int KT = K / GB_K;
+  const int kg = lane >> 5, li = lane & 31;
+  // EPI 1: wave (wr, wc) = (n half, m half); otherwise (m half, n half)
+  const int a_off = (kg * GB_M + (EPI == 1 ? wc : wr) * 64 + li) * 8;
+  const int w_off = GB_TILE + (kg * GB_N + (EPI == 1 ? wr : wc) * 64 + li) * 8;
+  fetch(0, 0);
+  stash(0, lds);
+  fetch(1, KT > 1 ? 1 : 0);
+  fetch(0, KT > 2 ? 2 : KT - 1);
+  auto kstep = [&](int kt, auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    __syncthreads();
+    const __bf16* cur = lds + par * GB_STAGE;
+    bf16x8 av[3][2], wv[3][2];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        av[l][b] = *reinterpret_cast<const bf16x8*>(cur + a_off + l * GB_LIMB + b * 32 * 8);
+        wv[l][b] = *reinterpret_cast<const bf16x8*>(cur + w_off + l * GB_LIMB + b * 32 * 8);
+      }
+    stash(par ^ 1, lds + (par ^ 1) * GB_STAGE);
+    fetch(par ^ 1, kt + 3 < KT ? kt + 3 : KT - 1);
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PW[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          if (EPI == 1)
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[PW[p]][rb], av[PA[p]][cb], acc[rb][cb], 0, 0, 0);
+          else
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[p]][rb], wv[PW[p]][cb], acc[rb][cb], 0, 0, 0);
+        }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  int kt = 0;
+  for (; kt + 2 <= KT; kt += 2) {
+    kstep(kt, P0{});
+    kstep(kt + 1, P1{});
+  }
+  if (kt < KT) kstep(kt, P0{});
+
+  if (EPI == 1) {
+    // register r of block (rb, cb): n = n0 + wr*64 + 32 rb + (r&3) + 8 (r>>2) + 4 kg,  m = m0 + wc*64 + 32 cb + li
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int m = m0 + wc * 64 + cb * 32 + li;
+      if (m >= M) continue;
+      float* orow = out + (size_t)m * N;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + wr * 64 + rb * 32 + 8 * j + 4 * kg;
+          if (n < N) {
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + n);
+            f32x4 v = {acc[rb][cb][4 * j] + b4[0], acc[rb][cb][4 * j + 1] + b4[1], acc[rb][cb][4 * j + 2] + b4[2],
+                       acc[rb][cb][4 * j + 3] + b4[3]};
+            *reinterpret_cast<f32x4*>(orow + n) = v;
+          }
+        }
+    }
+  } else {
+    // transposition through LDS: wave-private 8 KB region, one 32-row half at a time: [32 rows][64 floats]
+    __syncthreads();                                     // every wave is past its last fragment reads
+    float* reg = reinterpret_cast<float*>(lds) + wave * (32 * 64);
+    const int rr = lane >> 4, c4 = (lane & 15) * 4;
+    const int ncol = n0 + wc * 64 + c4;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias && ncol < N) b4 = *reinterpret_cast<const f32x4*>(bias + ncol);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) reg[((r & 3) + 8 * (r >> 2) + 4 * kg) * 64 + cb * 32 + li] = acc[rb][cb][r];
+      // (same wave wrote and reads: no barrier, the compiler's lgkmcnt orders it)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + rr;
+        f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * 64 + c4);
+        const int m = m0 + wr * 64 + rb * 32 + row;
+        if (m < M && ncol < N) {
+          v += b4;
+          *reinterpret_cast<f32x4*>(out + (size_t)m * N + ncol) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, int STAG = 0>
+void launch_epi(const float* A, const __bf16* Ap, const __bf16* Wp, const float* bias, float* out, int M, int N, int K) {
+  const int Npad = (N + 127) / 128 * 128, tiles_n = Npad / 128;
+  const long long blocks = (long long)((M + 127) / 128) * tiles_n;
+  hipLaunchKernelGGL((gemm_epi_kernel<EPI, STAG>), dim3((unsigned)blocks), dim3(256), 0, 0, A, Wp, bias, out, M, N, K, Npad, tiles_n);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// v2: persistent workgroups, ONE continuous stream of K-steps over the workgroup's tiles (the loads of the next tile's first
+// K-steps are requested under the last K-steps of the current one: no per-tile prologue), operand roles swapped (accumulator
+// rows = output columns: a lane owns 4 consecutive n -> 16-byte stores), and the finished tile's 16 stores issued ONE PER
+// K-STEP inside the next tile's K loop (inline asm: invisible to the compiler's vmcnt bookkeeping, so its counted waits for the
+// operand loads stay counted).  Bias enters through the accumulator's initial value (staged in LDS once per workgroup).
+// Needs K % 32 == 0 and K >= 256 (16 K-steps carry the 16 stores).
+template <bool RELU>
+__global__ __launch_bounds__(256, 2)
+void gemm_v2_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
+                    float* __restrict__ out, int M, int N, int K, int Npad, int tiles_n, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];           // 2 stages + Npad floats of bias
+  float* bias_lds = reinterpret_cast<float*>(lds + 2 * GB_STAGE);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;                               // (n half, m half)
+  const int KT = K / GB_K;
+  const int kg = lane >> 5, li = lane & 31;
+  for (int i = tid; i < Npad; i += 256) bias_lds[i] = (bias && i < N) ? bias[i] : 0.f;
+
+  // this workgroup's tiles: XCD x = blockIdx % 8 owns a contiguous chunk of the tile list, its workgroups take every per-th tile
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int cbase = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, ccnt = q + (xcd < r ? 1 : 0);
+  const int n_my = ccnt > j ? (ccnt - j + per - 1) / per : 0;
+  if (n_my == 0) return;
+
+  // staging roles as in the shipped kernel: A -- thread = (row tid/2, k-group tid%2); W -- (k-group tid/128, column tid%128)
+  const int ar = tid >> 1, akg = tid & 1;
+  const auto asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (unsigned)((size_t)M * K * 4), 0x00020000);
+  const int wkg = tid >> 7, wcol = tid & 127;
+  const size_t w_limb_stride = (size_t)2 * Npad * 8;
+
+  // fetch cursor (runs 3 K-steps ahead of the compute cursor)
+  int f_tile = cbase + j, f_kt = 0, f_left = n_my;                       // f_left: tiles not yet completely fetched
+  unsigned f_avoff = 0, f_asoff = 0;
+  const __bf16* f_w = Wp;
+  auto fetch_tile_setup = [&]() {
+    const int tm = f_tile / tiles_n, tn = f_tile - tm * tiles_n;
+    const int m0 = tm * GB_M;
+    f_avoff = (m0 + ar < M) ? (unsigned)((ar * K + 8 * akg) * 4) : 0x80000000u;
+    f_asoff = (unsigned)((size_t)m0 * K * 4);
+    f_w = Wp + ((size_t)wkg * Npad + tn * GB_N + wcol) * 8;
+  };
+  fetch_tile_setup();
+  f32x4 a_regs[2][2];
+  u32x4 w_regs[2][3];
+  auto fetch = [&](int slot) {                            // next K-step of the stream (past the end: repeats the last one)
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq)
+      a_regs[slot][qq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc, f_avoff + 16 * qq,
+                                                                                           f_asoff + (unsigned)f_kt * 64u, 0));
+    const __bf16* wk = f_w + (size_t)f_kt * 3 * w_limb_stride;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) w_regs[slot][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
+    if (f_left > 0) {
+      if (++f_kt == KT) {
+        if (--f_left > 0) {
+          f_kt = 0;
+          f_tile += per;
+          fetch_tile_setup();
+        } else {
+          f_kt = KT - 1;
+        }
+      }
+    }
+  };
+  auto stash = [&](int slot, __bf16* st) {
+    unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      split2(a_regs[slot][qq][0], a_regs[slot][qq][1], hh[2 * qq], mm[2 * qq], ll[2 * qq]);
+      split2(a_regs[slot][qq][2], a_regs[slot][qq][3], hh[2 * qq + 1], mm[2 * qq + 1], ll[2 * qq + 1]);
+    }
+    const u32x4 h = {hh[0], hh[1], hh[2], hh[3]}, m = {mm[0], mm[1], mm[2], mm[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+    __bf16* pa = st + (akg * GB_M + ar) * 8;
+    *reinterpret_cast<u32x4*>(pa) = h;
+    *reinterpret_cast<u32x4*>(pa + GB_LIMB) = m;
+    *reinterpret_cast<u32x4*>(pa + 2 * GB_LIMB) = l;
+    __bf16* pw = st + GB_TILE + (wkg * GB_N + wcol) * 8;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(pw + i * GB_LIMB) = w_regs[slot][i];
+  };
+
+  const int a_off = (kg * GB_M + wc * 64 + li) * 8, w_off = GB_TILE + (kg * GB_N + wr * 64 + li) * 8;
+  f32x16 acc[2][2], prev[2][2];
+  float* pptr[2] = {nullptr, nullptr};                    // this lane's store bases of the parked tile (cb = 0, 1)
+  bool pok[2] = {false, false};
+  unsigned pnmask = 0;                                    // bit (rb*4 + j): column group inside N
+
+  fetch(0);
+  __syncthreads();                                        // bias staged
+  stash(0, lds);
+  fetch(1);
+  fetch(0);
+
+  // one K-step; S = index of the parked tile's store that rides on it (-1: none)
+  auto kstep = [&](auto PAR, auto SIDX) {
+    constexpr int par = decltype(PAR)::value, S = decltype(SIDX)::value;
+    __syncthreads();
+    const __bf16* cur = lds + par * GB_STAGE;
+    bf16x8 av[3][2], wv[3][2];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        av[l][b] = *reinterpret_cast<const bf16x8*>(cur + a_off + l * GB_LIMB + b * 32 * 8);
+        wv[l][b] = *reinterpret_cast<const bf16x8*>(cur + w_off + l * GB_LIMB + b * 32 * 8);
+      }
+    stash(par ^ 1, lds + (par ^ 1) * GB_STAGE);
+    fetch(par ^ 1);
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PW[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[PW[p]][rb], av[PA[p]][cb], acc[rb][cb], 0, 0, 0);
+    if constexpr (S >= 0) {
+      constexpr int cb = S >> 3, rb = (S >> 2) & 1, jj = S & 3;
+      if (pok[cb] && ((pnmask >> (rb * 4 + jj)) & 1u)) {
+        f32x4 v = {prev[rb][cb][4 * jj], prev[rb][cb][4 * jj + 1], prev[rb][cb][4 * jj + 2], prev[rb][cb][4 * jj + 3]};
+        if (RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        float* const pp = pptr[cb];
+        asm volatile("global_store_dwordx4 %0, %1, off offset:%2" ::"v"(pp), "v"(v), "n"((rb * 32 + 8 * jj) * 4));
+      }
+    }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  auto park = [&](int tile) {                             // finished accumulators -> prev, store addresses of that tile
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jx = 0; jx < 2; ++jx) prev[i][jx] = acc[i][jx];
+    const int nb = tn * GB_N + wr * 64 + 4 * kg;
+    pnmask = 0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+      if (nb + (g >> 2) * 32 + 8 * (g & 3) < N) pnmask |= 1u << g;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int m = tm * GB_M + wc * 64 + cb * 32 + li;
+      pok[cb] = m < M;
+      pptr[cb] = out + (size_t)m * N + nb;
+    }
+  };
+  auto init_acc = [&](int tile) {                         // accumulators start at the bias of their output column
+    const int tn = tile % tiles_n;
+    const float* bl = bias_lds + tn * GB_N + wr * 64 + 4 * kg;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + rb * 32 + 8 * jj);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[rb][0][4 * jj + e] = acc[rb][1][4 * jj + e] = b4[e];
+      }
+  };
+  auto flush = [&]() {                                    // all 16 stores of the parked tile at once
+#pragma unroll
+    for (int S = 0; S < 16; ++S) {
+      const int cb = S >> 3, rb = (S >> 2) & 1, jj = S & 3;
+      if (pok[cb] && ((pnmask >> (rb * 4 + jj)) & 1u)) {
+        f32x4 v = {prev[rb][cb][4 * jj], prev[rb][cb][4 * jj + 1], prev[rb][cb][4 * jj + 2], prev[rb][cb][4 * jj + 3]};
+        if (RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(pptr[cb] + rb * 32 + 8 * jj) = v;
+      }
+    }
+  };
+
+  int tile = cbase + j;
+  for (int it = 0; it < n_my; ++it, tile += per) {
+    init_acc(tile);
+    // first 16 K-steps carry the parked tile's stores (none parked during the first tile: pok = false)
+    kstep(P0{}, std::integral_constant<int, 0>{});   kstep(P1{}, std::integral_constant<int, 1>{});
+    kstep(P0{}, std::integral_constant<int, 2>{});   kstep(P1{}, std::integral_constant<int, 3>{});
+    kstep(P0{}, std::integral_constant<int, 4>{});   kstep(P1{}, std::integral_constant<int, 5>{});
+    kstep(P0{}, std::integral_constant<int, 6>{});   kstep(P1{}, std::integral_constant<int, 7>{});
+    kstep(P0{}, std::integral_constant<int, 8>{});   kstep(P1{}, std::integral_constant<int, 9>{});
+    kstep(P0{}, std::integral_constant<int, 10>{});  kstep(P1{}, std::integral_constant<int, 11>{});
+    kstep(P0{}, std::integral_constant<int, 12>{});  kstep(P1{}, std::integral_constant<int, 13>{});
+    kstep(P0{}, std::integral_constant<int, 14>{});  kstep(P1{}, std::integral_constant<int, 15>{});
+#pragma unroll 1
+    for (int kt = 16; kt < KT; kt += 2) {
+      kstep(P0{}, std::integral_constant<int, -1>{});
+      kstep(P1{}, std::integral_constant<int, -1>{});
+    }
+    park(tile);
+  }
+  flush();
+}
+
+template <bool RELU>
+void launch_v2(const float* A, const __bf16* Ap, const __bf16* Wp, const float* bias, float* out, int M, int N, int K) {
+  const int Npad = (N + 127) / 128 * 128, tiles_n = Npad / 128;
+  const int ntiles = ((M + 127) / 128) * tiles_n;
+  const int lds_bytes = 2 * GB_STAGE * 2 + Npad * 4;
+  static bool once = false;
+  if (!once) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v2_kernel<RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    once = true;
+  }
+  const unsigned grid = (unsigned)std::min(ntiles, g_cus * 2) & ~7u;
+  hipLaunchKernelGGL((gemm_v2_kernel<RELU>), dim3(grid), dim3(256), lds_bytes, 0, A, Wp, bias, out, M, N, K, Npad, tiles_n, ntiles);
+}
+
 // f32 (M, K) -> limb tiles (RN split, as split2)
 __global__ void split_tiles_kernel(const float* __restrict__ a, __bf16* __restrict__ ap, int M, int K) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one (row, k pair)
@@ -385,7 +860,6 @@ struct Variant {
   void (*launch)(const float*, const __bf16*, const __bf16*, const float*, float*, int, int, int);
 };
 
-static int g_cus = 256;
 
 template <int ABL>
 void launch_abl(const float* A, const __bf16* Ap, const __bf16* Wp, const float* bias, float* out, int M, int N, int K) {
@@ -422,10 +896,10 @@ int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 5;
   std::vector<Variant> vars = {
       {"shipped", launch_abl<0>},      {"abl1_nosplit", launch_abl<1>}, {"abl2_nostash", launch_abl<2>},
-      {"abl3_noload", launch_abl<3>},  {"abl4_mfma_only", launch_abl<4>},
-      {"ps_ns2_w3", launch_ps<2, false, 3>}, {"ps_ns2_w4", launch_ps<2, false, 4>}, {"ps_ns3_w2", launch_ps<3, false, 2>},
-      {"ps_ns2_w3_persist", launch_ps<2, true, 3>}, {"ps_ns3_w2_persist", launch_ps<3, true, 2>},
-      {"ps_ns4_w1_persist", launch_ps<4, true, 1>},
+      {"abl3_noload", launch_abl<3>},  {"abl4_mfma_only", launch_abl<4>}, {"abl5_mfma_nostore", launch_abl<5>},
+      {"abl10_shipped_timed", launch_abl<10>}, {"abl11_fullpath_dword", launch_abl<11>}, {"abl12_fullpath_ldsT", launch_abl<12>}, {"epi1_swapped_x4", launch_epi<1>}, {"epi2_ldsT_x4", launch_epi<2>},
+      {"v2_persist_defer", launch_v2<false>},
+      {"ps_ns2_w3", launch_ps<2, false, 3>},
   };
   for (const auto& s : shapes) {
     const int M = s.M, N = s.N, K = s.K;
@@ -457,7 +931,8 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     for (size_t v = 0; v < vars.size(); ++v) {               // correctness of the non-ablated variants vs shipped
-      if (vars[v].name.rfind("abl", 0) == 0) continue;
+      if (vars[v].name.rfind("abl", 0) == 0 && vars[v].name != "abl10_shipped_timed" && vars[v].name.rfind("abl1", 0) != 0) continue;
+      if (vars[v].name == "abl1_nosplit") continue;
       CK(hipMemset(out, 0xff, (size_t)M * N * 4));
       vars[v].launch(A, Ap, Wp, bias, out, M, N, K);
       CK(hipMemset(nbad, 0, 8));
@@ -480,6 +955,28 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         times[v].push_back(ms / 5);
       }
+    {
+      unsigned long long z[8] = {0}, h[8];
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)));
+      launch_abl<10>(A, Ap, Wp, bias, out, M, N, K);
+      CK(hipDeviceSynchronize());
+      launch_abl<13>(A, Ap, Wp, bias, out, M, N, K);      // warm
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)));
+      launch_abl<13>(A, Ap, Wp, bias, out, M, N, K);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)));
+      printf("phase %-6s unguarded dword epilogue: prologue %.0f  loop %.0f  epilogue %.0f  (64 stores issued in %.0f, drain %.0f) cycles, %llu full tiles\n",
+             s.name, (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[4] / h[3], (double)h[6] / h[3], h[3]);
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)));
+      launch_abl<10>(A, Ap, Wp, bias, out, M, N, K);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)));
+      printf("phase %-6s shipped: per tile (wave 0) prologue %.0f  loop %.0f  epilogue(+drain) %.0f cycles  (%llu tiles; MFMA-only loop = %d cycles)\n",
+             s.name, (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], h[3], (K / 16) * 24 * 32);
+      printf("phase %-6s   epilogue split: first 32 stores issued after %.0f, next 32 after another %.0f, drain (vmcnt 0) %.0f cycles\n",
+             s.name, (double)h[4] / h[3], (double)h[5] / h[3], (double)h[6] / h[3]);
+    }
     for (size_t v = 0; v < vars.size(); ++v) {
       std::sort(times[v].begin(), times[v].end());
       const float med = times[v][times[v].size() / 2], mn = times[v][0];

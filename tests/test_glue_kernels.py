@@ -116,6 +116,14 @@ def test_decoder_kv_inputs(hip_lib, F_, S, start, hw, video):
     v_ref = tok + le[None]
     k_ref = v_ref + (pe if video else pe.repeat(F_, 1))
     assert torch.equal(v, v_ref) and torch.equal(k, k_ref)
+    if video and F_ % 2 == 0:
+        # B = 2 clips of T = F/2 frames in one token tensor (clip inference with bs > 1): the (T*hw, C) encoding is
+        # shared by both clips -- the kernel tiles it (this shape used to raise)
+        pe2 = pe[:F_ // 2 * hw].contiguous()
+        v2, k2 = ops.decoder_kv_inputs(x, start, hw, le, pe2)
+        assert torch.equal(v2, v_ref) and torch.equal(k2, v_ref + pe2.repeat(2, 1))
+    with pytest.raises(RuntimeError, match='inconsistent shapes'):
+        ops.decoder_kv_inputs(x, start, hw, le, torch.zeros(hw + 1, 256, device=DEV))
 
 
 @pytest.mark.gpu

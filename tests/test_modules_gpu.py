@@ -61,6 +61,23 @@ def test_head_forward_vs_reference_golden(hip_lib, golden_dir, name, video, T):
     np.testing.assert_allclose(qf.cpu().numpy(), g['final_query'], rtol=1e-3, atol=1e-3)
 
 
+def test_video_head_two_clips_per_batch_equals_one_clip_at_a_time(hip_lib):
+    """Clip inference with bs > 1 (B = 2 clips of T = 2 frames in one call): the (T*h*w, C) positional encoding is shared
+    by the clips.  ADVICE r2: the one-pass key / value input kernel used to reject this shape."""
+    seed, B, T = 4, 2, 2
+    h = build_head(True, seed)
+    f = [x.to(DEV) for x in feats(B * T, seed)]
+    with torch.no_grad():
+        cls, masks, q = h.clip_logits(f, B, T)
+        assert cls.shape[0] == B and masks.shape[:2] == (B, T) and q.shape[1] == B
+        for b in range(B):
+            fb = [x[b * T:(b + 1) * T].contiguous() for x in f]
+            cls1, masks1, q1 = h.clip_logits(fb, 1, T)
+            np.testing.assert_allclose(cls[b].cpu().numpy(), cls1[0].cpu().numpy(), rtol=2e-3, atol=2e-3)
+            np.testing.assert_allclose(q[:, b].cpu().numpy(), q1[:, 0].cpu().numpy(), rtol=2e-3, atol=2e-3)
+            np.testing.assert_allclose(masks[b].cpu().numpy(), masks1[0].cpu().numpy(), rtol=2e-3, atol=2e-3)
+
+
 def test_forward_head_mask_bits_match_reference(hip_lib, golden_dir):
     g = np.load(os.path.join(golden_dir, 'head_ips_s1.npz'))
     h = build_head(False, int(g['seed']))
