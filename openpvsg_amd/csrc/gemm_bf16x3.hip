@@ -149,7 +149,29 @@ void gemm_bf16x3_kernel(const float* __restrict__ A, const __bf16* __restrict__ 
   }
   if (kt < KT) kstep(kt, P0{});
 
-  // bias / ReLU and store: register r of block (rb, cb) = row (r&3) + 8 (r>>2) + 4 kg, column li of the block
+  // bias / ReLU and store: register r of block (rb, cb) = row (r&3) + 8 (r>>2) + 4 kg, column li of the block.
+  // Full tiles (all but the last row / column tile) take a path without per-element guards: with the guards the compiler
+  // puts an `s_waitcnt vmcnt(0)` in front of every store (the bias load is live across the branches), so each of the 64
+  // stores of a lane waits for its predecessor's acknowledgement -- 600-900 cycles per store, more than the K loop of a
+  // K = 256 tile (profiles/r03_lab_gemm_epilogues.txt).  Here the bias is waited for once and the stores go back to back.
+  if (m0 + GB_M <= M && n0 + GB_N <= N) {
+    float bv[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) bv[cb] = bias ? bias[n0 + wc * 64 + cb * 32 + li] : 0.f;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      float* op = out + (size_t)(m0 + wr * 64 + 4 * kg) * N + n0 + wc * 64 + cb * 32 + li;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float o = acc[rb][cb][r] + bv[cb];
+          if (RELU) o = fmaxf(o, 0.f);
+          op[(size_t)(rb * 32 + (r & 3) + 8 * (r >> 2)) * N] = o;
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int col = n0 + wc * 64 + cb * 32 + li;
@@ -288,6 +310,41 @@ void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict
 
   // BN affine (+ identity) (+ ReLU): register r of block (rb, cb) = channel (r&3) + 8 (r>>2) + 4 kg of the block, pixel li
   const size_t obase = (size_t)img * Cout * HWo;
+  // Full tiles: no per-element guards.  In the guarded form every element is its own load(scale, shift, identity) -> wait ->
+  // store chain with `s_waitcnt vmcnt(0)` in between (64 dependent memory round trips per lane); here the 4 + 4 float4 of
+  // scale / shift and the 32 identity values of a 32-channel block are requested together, then the 32 stores go back to back.
+  if (c0 + GB_M <= Cout && p0 + GB_N <= HWo) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int chb = c0 + wr * 64 + rb * 32 + 4 * kg;               // channels chb + (r&3) + 8 (r>>2)
+      f32x4 sc4[4], sh4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sc4[j] = scale ? *reinterpret_cast<const f32x4*>(scale + chb + 8 * j) : f32x4{1.f, 1.f, 1.f, 1.f};
+        sh4[j] = shift ? *reinterpret_cast<const f32x4*>(shift + chb + 8 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      float res[2][16];
+      if (RESIDUAL) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            res[cb][r] = residual[obase + (size_t)(chb + (r & 3) + 8 * (r >> 2)) * HWo + p0 + wc * 64 + cb * 32 + li];
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        float* yp = y + obase + (size_t)chb * HWo + p0 + wc * 64 + cb * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = fmaf(acc[rb][cb][r], sc4[r >> 2][r & 3], sh4[r >> 2][r & 3]);
+          if (RESIDUAL) v += res[cb][r];
+          if (RELU) v = fmaxf(v, 0.f);
+          yp[(size_t)((r & 3) + 8 * (r >> 2)) * HWo] = v;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int p = p0 + wc * 64 + cb * 32 + li;
@@ -387,7 +444,8 @@ extern "C" int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const f
   PVSG_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv1x1_bf16x3: in_scale and in_shift go together");
   if (Cin % GB_K || (long long)Cin * H * W >= (1LL << 29))
     return set_err(PVSG_ERR_UNSUPPORTED, "conv1x1_bf16x3: built for Cin %% 16 == 0, Cin*H*W < 2^29 (got Cin=%d H=%d W=%d)", Cin, H, W);
-  PVSG_REQUIRE(!(reinterpret_cast<uintptr_t>(w_packed) & 15u), "conv1x1_bf16x3: w_packed must be 16-byte aligned");
+  PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15u),
+               "conv1x1_bf16x3: w_packed, scale and shift must be 16-byte aligned");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const int Cpad = (Cout + 127) / 128 * 128;
   const int tiles_c = Cpad / GB_M, tiles_p = (Ho * Wo + GB_N - 1) / GB_N;
