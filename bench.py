@@ -738,6 +738,21 @@ def main():
                 if bound == 'hbm':
                     a_ = dd['bytes'] / dd['calls'] / per_ms / 1e6
                     named.append(dict(kernel=k, bound='hbm', achieved=a_, peak=HBM_PEAK_GBS, unit='GB/s', frac=a_ / HBM_PEAK_GBS))
+                    # the deformable-attention gather is bound by the texture path (TA busy 80-87 %, profiles/r03_msda_pmc.txt),
+                    # not by HBM: second entry = measured 64-byte L1 accesses per query x queries of THIS launch / time,
+                    # against 256 CUs x 64 B/clk x 2.4 GHz
+                    tex = os.path.join(ROOT, 'profiles', 'msda_texture_path.json')
+                    kern = {'pvsg_msda_fused_forward': 'msda_fused_m8d32', 'pvsg_ms_deform_attn_forward': 'msda_fwd_m8d32'}.get(k)
+                    if kern and os.path.exists(tex):
+                        ent = json.load(open(tex)).get(kern)
+                        args0 = next(a for n, a, _, _ in timer.records if n == k)
+                        queries = args0[9] * args0[13] if k == 'pvsg_msda_fused_forward' else args0[6] * args0[10]
+                        if ent:
+                            tb = ent['l1_accesses_per_query'] * queries * 64.0 / per_ms / 1e9          # TB/s through the L1
+                            peak = 256 * 64 * 2.4e9 / 1e12
+                            named.append(dict(kernel=k, bound='ta_l1', achieved=tb, peak=peak, unit='TB/s (vector-L1 / texture path)',
+                                              frac=tb / peak, l1_accesses_per_query=ent['l1_accesses_per_query'],
+                                              ta_busy_frac_under_pmc=ent['ta_busy_frac'], source='profiles/msda_texture_path.json'))
                 elif bound == 'mfma':
                     a_ = dd['flops'] / dd['calls'] / per_ms / 1e9
                     named.append(dict(kernel=k, bound='mfma', achieved=a_, peak=F32_MFMA_PEAK_TF, unit='TFLOP/s',

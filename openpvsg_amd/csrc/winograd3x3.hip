@@ -208,6 +208,17 @@ void winograd_f2x3_kernel(const float* __restrict__ x, const float* __restrict__
   if (ox >= W || oy >= H) return;
   const bool row1 = oy + 1 < H;
   float* yn = y + ((size_t)n * Cout + cg * 64 + cbw * 32 + 4 * k) * HW + (size_t)oy * W + ox;
+  // BN scale / shift of the lane's 16 channels requested together, ahead of the store loop: fetched per element inside the
+  // loop the compiler puts an s_waitcnt vmcnt(0) in front of every store and each store then also waits for its predecessor
+  f32x4 sc4[4], sh4[4];
+  if (AFFINE) {
+    const int chb = cg * 64 + cbw * 32 + 4 * k;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sc4[j] = *reinterpret_cast<const f32x4*>(scale + chb + 8 * j);
+      sh4[j] = *reinterpret_cast<const f32x4*>(shift + chb + 8 * j);
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int co = (r & 3) + 8 * (r >> 2);                    // + 4 k + block base: accumulator row of register r
@@ -220,8 +231,7 @@ void winograd_f2x3_kernel(const float* __restrict__ x, const float* __restrict__
     float o00 = s0[0] + s0[1] + s0[2], o01 = s0[1] - s0[2] - s0[3];
     float o10 = s1[0] + s1[1] + s1[2], o11 = s1[1] - s1[2] - s1[3];
     if (AFFINE) {
-      const int ch = cg * 64 + cbw * 32 + 4 * k + co;
-      const float sc = scale[ch], sh = shift[ch];
+      const float sc = sc4[r >> 2][r & 3], sh = sh4[r >> 2][r & 3];
       o00 = fmaf(o00, sc, sh); o01 = fmaf(o01, sc, sh); o10 = fmaf(o10, sc, sh); o11 = fmaf(o11, sc, sh);
     }
     if (RELU) {
@@ -275,6 +285,8 @@ extern "C" int pvsg_conv3x3_winograd(const float* x, const float* u_packed, cons
     return set_err(PVSG_ERR_UNSUPPORTED,
                    "conv3x3_winograd: built for Cin %% 8 == 0, Cout %% 64 == 0, even W, Cin*H*W < 2^29 (got Cin=%d Cout=%d H=%d W=%d)", Cin, Cout,
                    H, W);
+  PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15u),
+               "conv3x3_winograd: scale and shift must be 16-byte aligned");
   PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(u_packed) & 15u) | (reinterpret_cast<uintptr_t>(y) & 7u)),
                "conv3x3_winograd: u_packed must be 16-byte and y 8-byte aligned");
   const int TY = (H + 15) / 16, TX = (W + 15) / 16;
