@@ -180,6 +180,12 @@ class KernelTimer:
         if name == 'pvsg_mask_logits_forward':
             B, T, Q, C, N = a[3:8]
             return 4.0 * B * T * N * (C + Q), 2.0 * B * T * Q * C * N
+        if name == 'pvsg_mask_logits_bf16x3':       # flops = bf16 limb products issued (6 per f32 multiply-add)
+            B, T, Q, C, N = a[4:9]
+            return 4.0 * B * T * N * (C + Q), 12.0 * B * T * Q * C * N
+        if name == 'pvsg_attn_mask_bits_bf16x3':
+            B, T, Q, C, N = a[5:10]
+            return 4.0 * B * T * N * C + 16.0 * B * T * N, 12.0 * B * T * Q * C * N
         if name == 'pvsg_attn_mask_bits_forward':
             B, T, Q, C, N = a[4:9]
             return 4.0 * B * T * N * C + 16.0 * B * T * N, 2.0 * B * T * Q * C * N
@@ -268,14 +274,14 @@ class KernelTimer:
         if name == 'pvsg_gemm_bf16x3':
             M, N, K = a[4:7]
             return 2.0 * M * N * K
-        if name == 'pvsg_conv1x1_bf16x3':
+        if name in ('pvsg_conv1x1_bf16x3', 'pvsg_mask_logits_bf16x3', 'pvsg_attn_mask_bits_bf16x3'):
             return cls.work(name, a)[1] / 6.0
         return cls.work(name, a)[1]
 
     @staticmethod
     def mfma_peak(name):
         """(peak TFLOP/s, what the flops of work() count) of the matrix pipe a kernel runs on."""
-        if name.startswith('pvsg_gemm_bf16x3') or name.startswith('pvsg_conv1x1_bf16x3'):
+        if name.startswith(('pvsg_gemm_bf16x3', 'pvsg_conv1x1_bf16x3', 'pvsg_mask_logits_bf16x3', 'pvsg_attn_mask_bits_bf16x3')):
             return BF16_MFMA_PEAK_TF, 'bf16 limb products issued (6 per f32 multiply-add), dense bf16 MFMA peak'
         return F32_MFMA_PEAK_TF, 'f32 MFMA'
 
@@ -727,7 +733,8 @@ def main():
             # the four kernels the north-star names, each against its own roof (same HIP-event data)
             named = []
             for key, bound in (('pvsg_msda_fused_forward', 'hbm'), ('pvsg_ms_deform_attn_forward', 'hbm'),
-                               ('pvsg_mask_logits_forward', 'mfma'), ('pvsg_attn_mask_bits_forward', 'mfma'),
+                               ('pvsg_mask_logits_forward', 'mfma'), ('pvsg_mask_logits_bf16x3', 'mfma'),
+                               ('pvsg_attn_mask_bits_forward', 'mfma'), ('pvsg_attn_mask_bits_bf16x3', 'mfma'),
                                ('pvsg_masked_xattn_partial', 'mfma'), ('pvsg_pair_score_forward', 'latency')):
                 ks = [k for k in agg if k.startswith(key)]
                 if not ks:
@@ -755,8 +762,12 @@ def main():
                                               ta_busy_frac_under_pmc=ent['ta_busy_frac'], source='profiles/msda_texture_path.json'))
                 elif bound == 'mfma':
                     a_ = dd['flops'] / dd['calls'] / per_ms / 1e9
-                    named.append(dict(kernel=k, bound='mfma', achieved=a_, peak=F32_MFMA_PEAK_TF, unit='TFLOP/s',
-                                      frac=a_ / F32_MFMA_PEAK_TF))
+                    pk, what = KernelTimer.mfma_peak(k.split('[')[0])
+                    ent = dict(kernel=k, bound='mfma', achieved=a_, peak=pk, unit='TFLOP/s', frac=a_ / pk, flops_counted=what)
+                    if pk != F32_MFMA_PEAK_TF:      # split-bf16 kernels: also the model's f32 arithmetic against the f32 matrix roof
+                        ent['f32_equivalent_TFLOPs'] = a_ / 6.0
+                        ent['f32_equivalent_frac_of_f32_mfma_peak'] = a_ / 6.0 / F32_MFMA_PEAK_TF
+                    named.append(ent)
                 else:
                     named.append(dict(kernel=k, bound='launch-latency', avg_launch_us=per_ms * 1e3))
             line['roofline_named_kernels'] = named

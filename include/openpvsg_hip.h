@@ -63,6 +63,14 @@ int pvsg_ms_deform_attn_forward(const float* value, const int64_t* spatial_shape
 int pvsg_mask_logits_forward(const float* mask_embed, const float* mask_feature, float* out, int B,
                              int T, int Q, int C, int N, void* stream);
 
+/* Same contraction (mask2former_head.py:382, mask2former_video_head.py:344) on the bf16 matrix cores from the exact
+ * three-limb split (csrc/gemm_bf16x3.hip: the mask embeddings are packed on the fly as the weight of a 1x1 convolution over
+ * the (T, C, N) feature planes).  f32-class result (same error class as the library's f32 contraction).
+ *   w_scratch  B * pvsg_gemm_bf16x3_packed_elems(Q, C) bf16 elements of device scratch, 16-byte aligned
+ * Supported: C % 16 == 0, Q % 4 == 0, C*N and Q*N < 2^29 (else PVSG_ERR_UNSUPPORTED). */
+int pvsg_mask_logits_bf16x3(const float* mask_embed, const float* mask_feature, void* w_scratch, float* out, int B, int T,
+                            int Q, int C, long long N, void* stream);
+
 /* ---- a3: attention-mask bits straight from low-resolution features --------------------------
  * Replaces F.interpolate(mask_pred, level size) -> flatten -> repeat(num_heads) -> sigmoid() < 0.5
  * (mask2former_head.py:383-393, video_head.py:346-357) and the all-masked-row test that feeds the
@@ -73,6 +81,13 @@ int pvsg_mask_logits_forward(const float* mask_embed, const float* mask_feature,
  *   flags          (B, 4) uint32:        bit q = 1 <=> query q has at least one unblocked key */
 int pvsg_attn_mask_bits_forward(const float* mask_embed, const float* feature_lowres, uint32_t* bits,
                                 uint32_t* flags, int B, int T, int Q, int C, int N, void* stream);
+
+/* Same bits and flag words (mask2former_head.py:383-393,453-454; video_head.py:346-357) from the split-bf16 kernel
+ * (csrc/gemm_bf16x3.hip: logits on the bf16 matrix cores from the exact three-limb split, thresholded in registers).
+ *   w_scratch  B * pvsg_gemm_bf16x3_packed_elems(Q, C) bf16 elements of device scratch, 16-byte aligned
+ * Supported: C % 16 == 0, Q <= 128, C*N < 2^29 (else PVSG_ERR_UNSUPPORTED). */
+int pvsg_attn_mask_bits_bf16x3(const float* mask_embed, const float* feature_lowres, void* w_scratch, uint32_t* bits,
+                               uint32_t* flags, int B, int T, int Q, int C, long long N, void* stream);
 
 /* Same bits/flags from already resized logits (general sizes; exact for any interpolate factor).
  *   logits_lowres (B, T, Q, HW) */

@@ -38,6 +38,8 @@ class DecoderHead(ctypes.Structure):
 SIGNATURES = {
     'pvsg_ms_deform_attn_forward': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _i, _i, _i, _c_f],
     'pvsg_mask_logits_forward': [_c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _c_f],
+    'pvsg_mask_logits_bf16x3': [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _ll, _c_f],
+    'pvsg_attn_mask_bits_bf16x3': [_c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _ll, _c_f],
     'pvsg_attn_mask_bits_forward': [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _c_f],
     'pvsg_attn_mask_pack': [_c_f, _c_f, _c_f, _i, _i, _i, _i, _c_f],
     'pvsg_center_downsample': [_c_f, _c_f, _c_f, _c_f, _ll, _i, _i, _c_f],

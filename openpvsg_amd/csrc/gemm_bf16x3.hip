@@ -150,45 +150,30 @@ void gemm_bf16x3_kernel(const float* __restrict__ A, const __bf16* __restrict__ 
   if (kt < KT) kstep(kt, P0{});
 
   // bias / ReLU and store: register r of block (rb, cb) = row (r&3) + 8 (r>>2) + 4 kg, column li of the block.
-  // Full tiles (all but the last row / column tile) take a path without per-element guards: with the guards the compiler
-  // puts an `s_waitcnt vmcnt(0)` in front of every store (the bias load is live across the branches), so each of the 64
-  // stores of a lane waits for its predecessor's acknowledgement -- 600-900 cycles per store, more than the K loop of a
-  // K = 256 tile (profiles/r03_lab_gemm_epilogues.txt).  Here the bias is waited for once and the stores go back to back.
-  if (m0 + GB_M <= M && n0 + GB_N <= N) {
-    float bv[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) bv[cb] = bias ? bias[n0 + wc * 64 + cb * 32 + li] : 0.f;
+  // No branch and no memory wait between the 64 stores of a lane: the tile's rows go through a buffer descriptor that ends
+  // at row min(m0 + 128, M) (stores beyond it are dropped by the bounds check), lanes of columns >= N get an offset outside
+  // every descriptor, and the bias is read once (clamped index) before the first store.  With per-element `if (row < M)`
+  // guards the compiler put an `s_waitcnt vmcnt(0)` in front of every store -- each waited for its predecessor's
+  // acknowledgement, 600-900 cycles per store, more than the K loop of a K = 256 tile (profiles/r03_lab_gemm_epilogues.txt).
+  {
+    const int rows = M - m0 < GB_M ? M - m0 : GB_M;
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)m0 * N, 0, (unsigned)((size_t)rows * N * 4), 0x00020000);
+    const unsigned rowpitch = (unsigned)N * 4u;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-      float* op = out + (size_t)(m0 + wr * 64 + 4 * kg) * N + n0 + wc * 64 + cb * 32 + li;
+      const int col = n0 + wc * 64 + cb * 32 + li;
+      const float bv = bias ? bias[col < N ? col : N - 1] : 0.f;
+      const unsigned vbase = col < N ? (unsigned)(wr * 64 + 4 * kg) * rowpitch + (unsigned)col * 4u : 0x80000000u;
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float o = acc[rb][cb][r] + bv[cb];
-          if (RELU) o = fmaxf(o, 0.f);
-          op[(size_t)(rb * 32 + (r & 3) + 8 * (r >> 2)) * N] = o;
-        }
-    }
-    return;
-  }
-#pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
-    const int col = n0 + wc * 64 + cb * 32 + li;
-    if (col >= N) continue;
-    const float bv = bias ? bias[col] : 0.f;
-    float* op = out + (size_t)(m0 + wr * 64 + 4 * kg) * N + col;
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rrel = rb * 32 + (r & 3) + 8 * (r >> 2);
-        if (m0 + wr * 64 + 4 * kg + rrel < M) {
           float o = acc[rb][cb][r] + bv;
           if (RELU) o = fmaxf(o, 0.f);
-          op[(size_t)rrel * N] = o;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), orsrc,
+                                                vbase + (unsigned)(rb * 32 + (r & 3) + 8 * (r >> 2)) * rowpitch, 0, 0);
         }
-      }
+    }
   }
 }
 
@@ -204,13 +189,17 @@ void gemm_bf16x3_kernel(const float* __restrict__ A, const __bf16* __restrict__ 
 // BN / bias pass before).
 // IN_NORM: the input is normalised on the way in, x' = relu(x * in_scale[b, ci] + in_shift[b, ci]) (a GroupNorm + ReLU
 // whose statistics are already known), so that pass never touches HBM.
-template <bool RELU, bool RESIDUAL, bool IN_NORM>
+// BITS (attention-mask mode; rows = queries, one channel tile, no affine): the epilogue thresholds the logits in registers
+// (masked <=> sigmoid(x) < 0.5 <=> x < 0) and writes one 128-bit record per key -- bit q = query q masked -- plus the
+// "query has an unmasked key" flag words, exactly the format of csrc/mask_gemm.hip (`y` then points at the uint32 records of
+// this batch element, image = frame t, key = t * HWo + pixel; `flags` at its 4 flag words).
+template <bool RELU, bool RESIDUAL, bool IN_NORM, bool BITS = false>
 __global__ __launch_bounds__(256, 2)
 void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ scale,
                            const float* __restrict__ shift, const float* __restrict__ residual,
                            const float* __restrict__ in_scale, const float* __restrict__ in_shift, float* __restrict__ y,
                            int Cin, int Cout, int Cpad, int HWin, int Win, int HWo, int Wo, int stride, int tiles_c,
-                           int tiles_p) {
+                           int tiles_p, unsigned* __restrict__ flags = nullptr) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * GB_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -308,20 +297,72 @@ void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict
   }
   if (kt < KT) kstep(kt, P0{});
 
-  // BN affine (+ identity) (+ ReLU): register r of block (rb, cb) = channel (r&3) + 8 (r>>2) + 4 kg of the block, pixel li
-  const size_t obase = (size_t)img * Cout * HWo;
-  // Full tiles: no per-element guards.  In the guarded form every element is its own load(scale, shift, identity) -> wait ->
-  // store chain with `s_waitcnt vmcnt(0)` in between (64 dependent memory round trips per lane); here the 4 + 4 float4 of
-  // scale / shift and the 32 identity values of a 32-channel block are requested together, then the 32 stores go back to back.
-  if (c0 + GB_M <= Cout && p0 + GB_N <= HWo) {
+  if constexpr (BITS) {
+    // register r of block (rb, cb): query 64 wr + 32 rb + 4 kg + (r&3) + 8 (r>>2) = bit (4 kg + (r&3) + 8 (r>>2)) of word 2 wr + rb;
+    // key = pixel 64 wc + 32 cb + li.  The two k-group halves of a wave hold complementary bits of the same words.
+    unsigned w[2][2];                                    // [cb][rb]
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        unsigned v = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (acc[rb][cb][r] < 0.f) v |= 1u << (4 * kg + (r & 3) + 8 * (r >> 2));
+        v |= (unsigned)__shfl_xor((int)v, 32);
+        w[cb][rb] = v;
+      }
+    // lane (li, kg) stores the key of column block cb = kg: words 2 wr, 2 wr + 1 of its 16-byte record
+    const int p = p0 + wc * 64 + kg * 32 + li;
+    const unsigned w0 = kg ? w[1][0] : w[0][0], w1 = kg ? w[1][1] : w[0][1];
+    unsigned a0 = 0u, a1 = 0u;
+    if (p < HWo) {
+      unsigned* rec = reinterpret_cast<unsigned*>(y) + ((size_t)img * HWo + p) * 4 + 2 * wr;
+      *reinterpret_cast<uint2*>(rec) = make_uint2(w0, w1);
+      a0 = ~w0;
+      a1 = ~w1;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      a0 |= (unsigned)__shfl_xor((int)a0, off);
+      a1 |= (unsigned)__shfl_xor((int)a1, off);
+    }
+    if (lane == 0) {
+      if (a0) atomicOr(flags + 2 * wr, a0);
+      if (a1) atomicOr(flags + 2 * wr + 1, a1);
+    }
+    return;
+  }
+  // BN affine (+ identity) (+ ReLU): register r of block (rb, cb) = channel (r&3) + 8 (r>>2) + 4 kg of the block, pixel li.
+  // Branch-free: scale / shift / identity are read through buffer descriptors (channels >= Cout read 0), the stores go
+  // through a descriptor of this image's output (channels >= Cout are dropped by the bounds check) and lanes of pixels
+  // beyond the map carry an offset outside every descriptor.  The guarded form was one load(scale, shift, identity) ->
+  // `s_waitcnt vmcnt(0)` -> store chain per element: 64 dependent memory round trips per lane.  Needs Cout % 4 == 0 for the
+  // float4 reads of scale / shift (checked by the entry point).
+  {
+    const auto srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scale), 0, scale ? (unsigned)Cout * 4u : 0u, 0x00020000);
+    const auto hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(shift), 0, shift ? (unsigned)Cout * 4u : 0u, 0x00020000);
+    const size_t obase = (size_t)img * Cout * HWo;
+    const unsigned img_bytes = (unsigned)((size_t)Cout * HWo * 4);
+    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(y + obase, 0, img_bytes, 0x00020000);
+    const auto rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual) + (RESIDUAL ? obase : 0), 0,
+                                                       RESIDUAL ? img_bytes : 0u, 0x00020000);
+    const unsigned chpitch = (unsigned)HWo * 4u;
+    unsigned pvoff[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int p = p0 + wc * 64 + cb * 32 + li;
+      pvoff[cb] = p < HWo ? (unsigned)p * 4u : 0x80000000u;
+    }
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
       const int chb = c0 + wr * 64 + rb * 32 + 4 * kg;               // channels chb + (r&3) + 8 (r>>2)
       f32x4 sc4[4], sh4[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        sc4[j] = scale ? *reinterpret_cast<const f32x4*>(scale + chb + 8 * j) : f32x4{1.f, 1.f, 1.f, 1.f};
-        sh4[j] = shift ? *reinterpret_cast<const f32x4*>(shift + chb + 8 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        sc4[j] = scale ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)(chb + 8 * j) * 4u, 0, 0))
+                       : f32x4{1.f, 1.f, 1.f, 1.f};
+        sh4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, (unsigned)(chb + 8 * j) * 4u, 0, 0));
       }
       float res[2][16];
       if (RESIDUAL) {
@@ -329,40 +370,19 @@ void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            res[cb][r] = residual[obase + (size_t)(chb + (r & 3) + 8 * (r >> 2)) * HWo + p0 + wc * 64 + cb * 32 + li];
+            res[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                rrs, pvoff[cb] + (unsigned)(chb + (r & 3) + 8 * (r >> 2)) * chpitch, 0, 0));
       }
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        float* yp = y + obase + (size_t)chb * HWo + p0 + wc * 64 + cb * 32 + li;
+      for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = fmaf(acc[rb][cb][r], sc4[r >> 2][r & 3], sh4[r >> 2][r & 3]);
           if (RESIDUAL) v += res[cb][r];
           if (RELU) v = fmaxf(v, 0.f);
-          yp[(size_t)((r & 3) + 8 * (r >> 2)) * HWo] = v;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
+                                                pvoff[cb] + (unsigned)(chb + (r & 3) + 8 * (r >> 2)) * chpitch, 0, 0);
         }
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
-    const int p = p0 + wc * 64 + cb * 32 + li;
-    if (p >= HWo) continue;
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-      const int ch0 = c0 + wr * 64 + rb * 32 + 4 * kg;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ch = ch0 + (r & 3) + 8 * (r >> 2);
-        if (ch < Cout) {
-          const size_t o = obase + (size_t)ch * HWo + p;
-          float v = fmaf(acc[rb][cb][r], scale ? scale[ch] : 1.f, shift ? shift[ch] : 0.f);
-          if (RESIDUAL) v += residual[o];
-          if (RELU) v = fmaxf(v, 0.f);
-          y[o] = v;
-        }
-      }
     }
   }
 }
@@ -415,8 +435,8 @@ extern "C" int pvsg_gemm_bf16x3(const float* a, const void* w_packed, const floa
   using namespace pvsg;
   PVSG_REQUIRE(a && w_packed && out, "gemm_bf16x3: null pointer argument");
   PVSG_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_bf16x3: bad shape");
-  if (K % GB_K || M >= (1LL << 31) || (long long)GB_M * K * 4 >= (1LL << 31))
-    return set_err(PVSG_ERR_UNSUPPORTED, "gemm_bf16x3: built for K %% 16 == 0, M < 2^31 (got M=%lld N=%d K=%d)", M, N, K);
+  if (K % GB_K || M >= (1LL << 31) || (long long)GB_M * K * 4 >= (1LL << 31) || (long long)GB_M * N * 4 >= (1LL << 31))
+    return set_err(PVSG_ERR_UNSUPPORTED, "gemm_bf16x3: built for K %% 16 == 0, M < 2^31, 128 rows < 2 GiB (got M=%lld N=%d K=%d)", M, N, K);
   PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w_packed)) & 15u),
                "gemm_bf16x3: a and w_packed must be 16-byte aligned");
   const int Npad = (N + 127) / 128 * 128;
@@ -442,8 +462,9 @@ extern "C" int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const f
   PVSG_REQUIRE(x && w_packed && y, "conv1x1_bf16x3: null pointer argument");
   PVSG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "conv1x1_bf16x3: bad shape");
   PVSG_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv1x1_bf16x3: in_scale and in_shift go together");
-  if (Cin % GB_K || (long long)Cin * H * W >= (1LL << 29))
-    return set_err(PVSG_ERR_UNSUPPORTED, "conv1x1_bf16x3: built for Cin %% 16 == 0, Cin*H*W < 2^29 (got Cin=%d H=%d W=%d)", Cin, H, W);
+  if (Cin % GB_K || Cout % 4 || (long long)Cin * H * W >= (1LL << 29) || (long long)Cout * H * W >= (1LL << 29))
+    return set_err(PVSG_ERR_UNSUPPORTED, "conv1x1_bf16x3: built for Cin %% 16 == 0, Cout %% 4 == 0, C*H*W < 2^29 (got Cin=%d Cout=%d H=%d W=%d)",
+                   Cin, Cout, H, W);
   PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15u),
                "conv1x1_bf16x3: w_packed, scale and shift must be 16-byte aligned");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
@@ -469,5 +490,59 @@ extern "C" int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const f
   }
 #undef PVSG_C1_LAUNCH
   PVSG_LAUNCH_CHECK("conv1x1_bf16x3");
+  return PVSG_OK;
+}
+
+// einsum('bqc,b[t]chw->b[t]qhw') (mask2former_head.py:382, mask2former_video_head.py:344) on the split-bf16 kernel: per batch
+// element a 1x1 "convolution" of the (T, C, N) mask features with the Q mask embeddings as the weight (packed on the fly:
+// Q x C is 100 x 256), output (T, Q, N).  Same f32-class arithmetic as above; the f32-MFMA form stays as
+// pvsg_mask_logits_forward (csrc/mask_gemm.hip).  w_scratch: B * pvsg_gemm_bf16x3_packed_elems(Q, C) bf16 elements.
+extern "C" int pvsg_mask_logits_bf16x3(const float* mask_embed, const float* mask_feature, void* w_scratch, float* out, int B,
+                                       int T, int Q, int C, long long N, void* stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(mask_embed && mask_feature && w_scratch && out, "mask_logits_bf16x3: null pointer argument");
+  PVSG_REQUIRE(B > 0 && T > 0 && Q > 0 && C > 0 && N > 0, "mask_logits_bf16x3: bad shape");
+  if (C % GB_K || Q % 4 || N >= (1LL << 31) || (long long)C * N >= (1LL << 29) || (long long)Q * N >= (1LL << 29))
+    return set_err(PVSG_ERR_UNSUPPORTED, "mask_logits_bf16x3: built for C %% 16 == 0, Q %% 4 == 0, C*N and Q*N < 2^29 (got Q=%d C=%d N=%lld)",
+                   Q, C, N);
+  const long long welems = pvsg_gemm_bf16x3_packed_elems(Q, C);
+  for (int b = 0; b < B; ++b) {
+    __bf16* wp = static_cast<__bf16*>(w_scratch) + (size_t)b * welems;
+    int rc = pvsg_gemm_bf16x3_pack(mask_embed + (size_t)b * Q * C, wp, Q, C, stream);
+    if (rc != PVSG_OK) return rc;
+    rc = pvsg_conv1x1_bf16x3(mask_feature + (size_t)b * T * C * N, wp, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             out + (size_t)b * T * Q * N, T, C, Q, 1, (int)N, 1, 0, stream);
+    if (rc != PVSG_OK) return rc;
+  }
+  return PVSG_OK;
+}
+
+// Attention-mask bits of a decoder level straight from the down-sampled mask features (mask2former_head.py:383-393,
+// video_head.py:346-357; the all-masked-row test of mask2former_head.py:453-454 becomes the flag words) on the split-bf16
+// kernel: same record format as pvsg_attn_mask_bits_forward (csrc/mask_gemm.hip), which stays as the f32-MFMA form.
+extern "C" int pvsg_attn_mask_bits_bf16x3(const float* mask_embed, const float* feature_lowres, void* w_scratch, uint32_t* bits,
+                                          uint32_t* flags, int B, int T, int Q, int C, long long N, void* stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(mask_embed && feature_lowres && w_scratch && bits && flags, "attn_mask_bits_bf16x3: null pointer argument");
+  PVSG_REQUIRE(B > 0 && T > 0 && Q > 0 && C > 0 && N > 0, "attn_mask_bits_bf16x3: bad shape");
+  if (C % GB_K || Q > GB_M || (long long)C * N >= (1LL << 29) || (reinterpret_cast<uintptr_t>(bits) & 15u))
+    return set_err(PVSG_ERR_UNSUPPORTED, "attn_mask_bits_bf16x3: built for C %% 16 == 0, Q <= 128, C*N < 2^29, 16B-aligned bits (got Q=%d C=%d N=%lld)",
+                   Q, C, N);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * 4 * sizeof(uint32_t), st);
+  if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "attn_mask_bits_bf16x3: memset: %s", hipGetErrorString(e));
+  const long long welems = pvsg_gemm_bf16x3_packed_elems(Q, C);
+  const int tiles_p = (int)((N + GB_N - 1) / GB_N);
+  for (int b = 0; b < B; ++b) {
+    __bf16* wp = static_cast<__bf16*>(w_scratch) + (size_t)b * welems;
+    const int rc = pvsg_gemm_bf16x3_pack(mask_embed + (size_t)b * Q * C, wp, Q, C, stream);
+    if (rc != PVSG_OK) return rc;
+    hipLaunchKernelGGL((conv1x1_bf16x3_kernel<false, false, false, true>), dim3((unsigned)(T * tiles_p)), dim3(256), 0, st,
+                       feature_lowres + (size_t)b * T * C * N, wp, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       reinterpret_cast<float*>(bits + (size_t)b * T * N * 4), C, Q, GB_M, (int)N, (int)N, (int)N, (int)N, 1, 1,
+                       tiles_p, flags + (size_t)b * 4);
+    PVSG_LAUNCH_CHECK("attn_mask_bits_bf16x3");
+  }
   return PVSG_OK;
 }

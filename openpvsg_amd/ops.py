@@ -6,6 +6,7 @@ torch's), and calls the C ABI with raw device pointers on torch's CURRENT HIP st
 Nothing here computes on the CPU; a CPU tensor is an error.
 """
 import ctypes
+import os
 
 import torch
 
@@ -72,9 +73,16 @@ def mask_logits(mask_embed, mask_feature):
     if f.shape[0] != B or f.shape[-3] != C:
         raise RuntimeError('mask_logits: inconsistent shapes %s vs %s' % (tuple(e.shape), tuple(f.shape)))
     out = torch.empty((B, T, Q, h, w), device=e.device, dtype=torch.float32)
+    N = h * w
     with torch.cuda.device(e.device):
-        _lib.call('pvsg_mask_logits_forward', e.data_ptr(), f.data_ptr(), out.data_ptr(), B, T, Q, C,
-                  h * w, _stream_ptr())
+        if (os.environ.get('PVSG_MASK_GEMM', 'bf16x3') != 'f32' and C % 16 == 0 and Q % 4 == 0 and C * N < 2 ** 29 and
+                Q * N < 2 ** 29):
+            # exact three-limb bf16 split on the bf16 matrix cores (f32-class result; csrc/gemm_bf16x3.hip)
+            scratch = torch.empty((B * _lib.load().pvsg_gemm_bf16x3_packed_elems(Q, C),), device=e.device, dtype=torch.bfloat16)
+            _lib.call('pvsg_mask_logits_bf16x3', e.data_ptr(), f.data_ptr(), scratch.data_ptr(), out.data_ptr(), B, T, Q, C,
+                      N, _stream_ptr())
+        else:
+            _lib.call('pvsg_mask_logits_forward', e.data_ptr(), f.data_ptr(), out.data_ptr(), B, T, Q, C, N, _stream_ptr())
     return out if video else out[:, 0]
 
 
@@ -124,8 +132,13 @@ def attn_mask_from_lowres_feature(mask_embed, feature_lowres):
     bits = torch.empty((B, T * N, 4), device=e.device, dtype=torch.int32)
     flags = torch.empty((B, 4), device=e.device, dtype=torch.int32)
     with torch.cuda.device(e.device):
-        _lib.call('pvsg_attn_mask_bits_forward', e.data_ptr(), f.data_ptr(), bits.data_ptr(),
-                  flags.data_ptr(), B, T, Q, C, N, _stream_ptr())
+        if os.environ.get('PVSG_MASK_GEMM', 'bf16x3') != 'f32' and C % 16 == 0 and Q <= 128 and C * N < 2 ** 29:
+            scratch = torch.empty((B * _lib.load().pvsg_gemm_bf16x3_packed_elems(Q, C),), device=e.device, dtype=torch.bfloat16)
+            _lib.call('pvsg_attn_mask_bits_bf16x3', e.data_ptr(), f.data_ptr(), scratch.data_ptr(), bits.data_ptr(),
+                      flags.data_ptr(), B, T, Q, C, N, _stream_ptr())
+        else:
+            _lib.call('pvsg_attn_mask_bits_forward', e.data_ptr(), f.data_ptr(), bits.data_ptr(),
+                      flags.data_ptr(), B, T, Q, C, N, _stream_ptr())
     return AttnMask(bits, flags, Q)
 
 

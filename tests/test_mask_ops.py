@@ -29,14 +29,22 @@ def oracle_forward_head_mask(emb, feat, target, heads=8):
                                          (1, 2, 100, 256, (184, 320)), (2, None, 37, 64, (8, 12)),
                                          (1, None, 112, 256, (5, 4)), (3, 1, 1, 16, (2, 2)),
                                          (2, 2, 100, 256, (5, 3)), (1, None, 100, 256, (15, 21))])
-def test_mask_logits(hip_lib, B, T, Q, C, hw):
+@pytest.mark.parametrize('path', ['bf16x3', 'f32'])
+def test_mask_logits(hip_lib, monkeypatch, path, B, T, Q, C, hw):
+    """both forms of the contraction: the split-bf16 kernel (default where Q % 4 == 0: pvsg_mask_logits_bf16x3) and the f32
+    matrix-core kernel (pvsg_mask_logits_forward), against torch.einsum in float64"""
     from openpvsg_amd import ops
+    monkeypatch.setenv('PVSG_MASK_GEMM', path)
     emb = det_input('emb', (B, Q, C), 1)
     feat = det_input('feat', (B, C) + hw if T is None else (B, T, C) + hw, 2)
-    ref = torch.einsum('bqc,bchw->bqhw', emb, feat) if T is None else torch.einsum('bqc,btchw->btqhw', emb, feat)
+    eq = 'bqc,bchw->bqhw' if T is None else 'bqc,btchw->btqhw'
+    ref = torch.einsum(eq, emb.double(), feat.double())
+    lib = torch.einsum(eq, emb, feat)
     out = ops.mask_logits(emb.to(DEV), feat.to(DEV)).cpu()
     scale = float(ref.abs().max())
-    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(out.numpy(), ref.float().numpy(), rtol=1e-4, atol=1e-5 * scale)
+    err, err_lib = float((out.double() - ref).abs().max()), float((lib.double() - ref).abs().max())
+    assert err <= 3 * err_lib + 1e-6 * scale, (err, err_lib)           # f32-class: no worse than a plain f32 contraction
 
 
 def test_mask_logits_identity_asymmetric(hip_lib):
@@ -81,11 +89,14 @@ def test_attn_mask_pack_is_exact(hip_lib, B, T):
     assert bool(raw[0, 7].all())
 
 
-@pytest.mark.parametrize('B,T,hw', [(1, None, (16, 24)), (2, 3, (16, 24)), (1, 2, (64, 96))])
-def test_attn_mask_from_lowres_feature(hip_lib, B, T, hw):
+@pytest.mark.parametrize('path', ['bf16x3', 'f32'])
+@pytest.mark.parametrize('B,T,hw', [(1, None, (16, 24)), (2, 3, (16, 24)), (1, 2, (64, 96)), (1, 3, (184, 320))])
+def test_attn_mask_from_lowres_feature(hip_lib, monkeypatch, path, B, T, hw):
     """bits via (down-sampled features) x (mask embed) == threshold of the resized full-res logits,
-    up to logits within fp32 rounding of 0 (reported as a flip rate)."""
+    up to logits within fp32 rounding of 0 (reported as a flip rate); both the split-bf16 kernel
+    (pvsg_attn_mask_bits_bf16x3, default) and the f32 matrix-core kernel (pvsg_attn_mask_bits_forward)."""
     from openpvsg_amd import ops
+    monkeypatch.setenv('PVSG_MASK_GEMM', path)
     Q, C = 100, 256
     emb = det_input('emb', (B, Q, C), 5, scale=0.2)
     feat = det_input('feat', (B, C) + hw if T is None else (B, T, C) + hw, 6)
