@@ -245,8 +245,11 @@ int pvsg_affine_act_nchw(float* x, const float* scale, const float* shift, const
  * Replaces match_from_embds (models/mask2former_vps/mask2former_min_vis.py:244-258: cosine cost, C.cpu(),
  * scipy linear_sum_assignment per frame) + the chaining loop models/mask2former_vps/mask2former.py:146-158.
  *   embds (V, T, Q, C) per-frame query embeddings of V videos;  perm (V, T, Q) int32:
- *   perm[v,0] = identity, perm[v,t][j] = query of frame t placed on slot j (chained through t-1). */
-int pvsg_minvis_chain(const float* embds, int* perm, int V, int T, int Q, int C, void* stream);
+ *   perm[v,0] = identity, perm[v,t][j] = query of frame t placed on slot j (chained through t-1).
+ *   workspace: pvsg_minvis_chain_workspace_bytes(V, T, Q) bytes of device scratch (the T-1 cosine tables of every video,
+ *   computed by the whole GPU ahead of the sequential assignment chain). */
+long long pvsg_minvis_chain_workspace_bytes(int V, int T, int Q);
+int pvsg_minvis_chain(const float* embds, int* perm, float* workspace, int V, int T, int Q, int C, void* stream);
 
 /* ---- 8f row 4: IPS tube association (UniTrack flavour) -- per-object appearance embeddings ----------
  * Replaces MaskAssociationTracker.extract_emb, models/unitrack/mask.py:21-47 (mask * feature map,

@@ -59,7 +59,8 @@ SIGNATURES = {
     'pvsg_msda_proj_ln_forward': [_c_f, _ll, _c_f, _ll] + [_c_f] * 10 + [_i] * 7 + [_f, _c_f],
     'pvsg_add_layernorm': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _ll, _i, _f, _c_f],
     'pvsg_affine_act_nchw': [_c_f, _c_f, _c_f, _c_f, _c_f, _ll, _i, _ll, _i, _c_f],
-    'pvsg_minvis_chain': [_c_f, _c_f, _i, _i, _i, _i, _c_f],
+    'pvsg_minvis_chain_workspace_bytes': [_i, _i, _i],
+    'pvsg_minvis_chain': [_c_f, _c_f, _c_f, _i, _i, _i, _i, _c_f],
     'pvsg_mask_embed_forward': [_c_f] * 7 + [_i] * 5 + [_c_f],
     'pvsg_fpn_merge_up2x': [_c_f] * 5 + [_ll, _i, _i, _c_f],
     'pvsg_stem_bn_relu_pool': [_c_f] * 4 + [_ll, _i, _i, _i, _c_f],
@@ -80,7 +81,7 @@ SIGNATURES = {
     'pvsg_conv3x3s2_affine': [_c_f] * 5 + [_i] * 6 + [_c_f],
 }
 # entry points that return a value instead of a status code
-VALUE_RETURNING = ('pvsg_xattn_num_splits', 'pvsg_gemm_bf16x3_packed_elems')
+VALUE_RETURNING = ('pvsg_xattn_num_splits', 'pvsg_gemm_bf16x3_packed_elems', 'pvsg_minvis_chain_workspace_bytes')
 
 _lib = None
 
@@ -108,7 +109,7 @@ def load():
             f = getattr(lib, name)
         except AttributeError as e:
             raise BackendMissingError('symbol %s missing from %s' % (name, LIB_PATH)) from e
-        f.restype = _ll if name == 'pvsg_gemm_bf16x3_packed_elems' else _i
+        f.restype = _ll if name in ('pvsg_gemm_bf16x3_packed_elems', 'pvsg_minvis_chain_workspace_bytes') else _i
         f.argtypes = argtypes
     _lib = lib
     return lib

@@ -18,7 +18,8 @@ def multi_apply(func, *args, **kwargs):
 
 
 def encode_mask_results(mask_results):
-    """[3P] RLE-encode instance masks (needs pycocotools, which the backend does not depend on)."""
-    import pycocotools.mask as mask_util
-    cls_segms = mask_results[0] if isinstance(mask_results, tuple) else mask_results
-    return [[mask_util.encode(np.array(m[:, :, np.newaxis], order='F', dtype='uint8'))[0] for m in c] for c in cls_segms]
+    """[3P] mmdet.core.encode_mask_results: per-class lists of binary masks -> lists of COCO RLE dicts.  The backend's own
+    codec (openpvsg_amd/tubes.py; device-side run boundaries for masks that are still on the GPU) -- pycocotools is not a
+    dependency."""
+    from openpvsg_amd.detectors import encode_mask_results as _enc
+    return _enc(mask_results)

@@ -327,9 +327,13 @@ void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict
       a0 |= (unsigned)__shfl_xor((int)a0, off);
       a1 |= (unsigned)__shfl_xor((int)a1, off);
     }
+    // the flag words saturate after the first few workgroups (bits only ever get set): look before the atomic, or thousands
+    // of workgroups serialise on four L2 atomics
     if (lane == 0) {
-      if (a0) atomicOr(flags + 2 * wr, a0);
-      if (a1) atomicOr(flags + 2 * wr + 1, a1);
+      const unsigned c0w = __hip_atomic_load(flags + 2 * wr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned c1w = __hip_atomic_load(flags + 2 * wr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a0 & ~c0w) atomicOr(flags + 2 * wr, a0);
+      if (a1 & ~c1w) atomicOr(flags + 2 * wr + 1, a1);
     }
     return;
   }

@@ -12,6 +12,7 @@ target; `inference_mode='per_frame'` is the shipped flow (one frame per head cal
 matching across frames, which the shipped class borrows from the MinVIS class -- SURVEY.md fact 5).
 """
 import copy
+import os
 
 import numpy as np
 import torch
@@ -26,7 +27,9 @@ def encode_mask_results(mask_results):
     """[3P] mmdet.core.encode_mask_results: per-class lists of binary masks -> lists of COCO RLE dicts
     (only reached with num_stuff_classes == 0, the video-instance flavour; tubes.rle_encode is the codec)."""
     from .tubes import rle_encode
-    return [[rle_encode(np.asarray(m, dtype=np.uint8)) for m in per_cls] for per_cls in mask_results]
+    cls_segms = mask_results[0] if isinstance(mask_results, tuple) else mask_results
+    return [[m.rle() if hasattr(m, 'rle') else rle_encode(np.asarray(m, dtype=np.uint8)) for m in per_cls]
+            for per_cls in cls_segms]
 
 
 def bbox2result(bboxes, labels, num_classes):
@@ -54,6 +57,15 @@ class _Base(BaseModule):
         self.num_classes = self.panoptic_head.num_classes
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
         self.fused_postprocess = True
+        # EXPERIMENTAL, off by default: replay backbone + pixel decoder + decoder of small calls as one hipGraph
+        # (PVSG_DETECTOR_GRAPH=on).  Measured 80 -> 96 frames/s for one 720p image per call, but the replay is NOT correct
+        # yet: on a second, different input the decoder's outputs differ from the eager ones unless every intermediate
+        # tensor of the captured region is kept alive (scripts/lab/graph_bisect.py: backbone and pixel decoder replay
+        # exactly, the first decoder layer does not) -- a buffer-lifetime issue under the graph's private pool that is
+        # still open.  The host cost per launch was cut instead (ops._stream_ptr, DecoderRows signature).
+        self.use_graph = os.environ.get('PVSG_DETECTOR_GRAPH', 'off') == 'on'
+        self.graph_max_frames = 4
+        self._graphs, self._graph_seen = {}, {}
 
     @property
     def with_neck(self):
@@ -62,6 +74,54 @@ class _Base(BaseModule):
     def extract_feat(self, img):
         x = self.backbone(img)
         return self.neck(x) if self.with_neck else x
+
+    def _weights_signature(self):
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def _graphed(self, tag, fn, x):
+        """fn(x) -> tuple of tensors (no host sync inside).  Eager on the first sighting of (tag, shape), then two warm-up
+        runs + capture on a side stream, then replays; the graph bakes in parameter addresses, so a weight change (address
+        or in-place version) triggers a new capture.  Falls back to eager when capture is not possible.  The outputs are
+        the graph's static buffers: valid until the next call with the same key (callers consume them within the call)."""
+        # large batches are GPU-bound (launches run ahead of the device): the replay only pays where the host is the limit
+        if (not self.use_graph or not x.is_cuda or x.shape[0] > self.graph_max_frames or torch.is_grad_enabled() or
+                torch.cuda.is_current_stream_capturing()):
+            return fn(x)
+        key = (tag, tuple(x.shape), str(x.device))
+        sig = self._weights_signature()
+        ent = self._graphs.get(key)
+        if ent is not None and ent is not False and ent[3] != sig:
+            ent = None
+        if ent is None:
+            seen = self._graph_seen.get(key, 0) + 1
+            self._graph_seen[key] = seen
+            if seen < 2:
+                return fn(x)
+            try:
+                static_in = x.clone()
+                side = torch.cuda.Stream(device=x.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        fn(static_in)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    static_out = fn(static_in)
+                ent = (graph, static_in, static_out, sig)
+            except Exception as e:      # an op that cannot be captured: stay eager for this key, say so once
+                import warnings
+                warnings.warn('hipGraph capture of the detector forward failed (%r); running eagerly' % (e,))
+                ent = False
+            if len(self._graphs) >= 4:
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[key] = ent
+        if ent is False:
+            return fn(x)
+        graph, static_in, static_out, _ = ent
+        static_in.copy_(x)
+        graph.replay()
+        return static_out
 
     def forward(self, img=None, img_metas=None, return_loss=True, **kwargs):
         if return_loss:
@@ -76,11 +136,20 @@ class _Base(BaseModule):
     def _ins_to_host(labels, bboxes, binm, num_things):
         """(labels (n,), boxes (n,5|6), masks (n,H,W) bool) -> (bbox2result lists, per-class lists of numpy masks)
         (mask2former.py:172-181, mask2former_vps/mask2former.py:201-206)."""
-        bbox_results = bbox2result(bboxes, labels, num_things)
-        masks_np = binm.detach().cpu().numpy()
+        both = torch.cat([bboxes.detach().float(), labels.detach()[:, None].float()], dim=1).cpu().numpy()   # one sync
+        return _Base._ins_from_host(both[:, :-1], both[:, -1].astype(np.int64), binm, num_things)
+
+    @staticmethod
+    def _ins_from_host(b, lab, binm, num_things):
+        """host boxes (n,5|6) / labels (n,) + device masks (n,H,W) -> the reference's (bbox2result lists, per-class mask lists);
+        the masks stay on the device behind ndarray-like handles (tubes.DeviceMask): copied / run-length coded on demand"""
+        from .tubes import DeviceMask, DeviceMaskStack
+        bbox_results = ([b[lab == i, :] for i in range(num_things)] if b.shape[0] else
+                        [np.zeros((0, b.shape[1]), dtype=np.float32) for _ in range(num_things)])
+        stack = DeviceMaskStack(binm.detach())
         mask_results = [[] for _ in range(num_things)]
-        for j, lab in enumerate(labels.tolist()):
-            mask_results[lab].append(masks_np[j])
+        for j, l in enumerate(lab.tolist()):
+            mask_results[l].append(DeviceMask(stack, j))
         return bbox_results, mask_results
 
     @classmethod
@@ -142,12 +211,20 @@ class _Base(BaseModule):
         if cfg.get('instance_on', False):
             ins = fusion.instance_fused(cls, masks4, meta['batch_input_shape'], meta['img_shape'], ori,
                                         top=10 if video else None)
-            for t in range(T):
-                if video:
-                    labels, boxes, binm, order = ins[t]
-                    out[t]['ins_results'] = self._video_ins_to_host(labels, boxes, binm, self.num_things_classes, order)
-                else:
-                    out[t]['ins_results'] = self._ins_to_host(*ins[t], self.num_things_classes)
+            if video and T > 0 and ins[0][1].shape[0] > 0:
+                # all frames' (id, box, score, label) rows in ONE device->host transfer (was one sync per frame)
+                rows = torch.stack([torch.cat([ins[t][3].to(ins[t][1].dtype)[:, None] + 1, ins[t][1].float(),
+                                               ins[t][0][:, None].float()], dim=1) for t in range(T)]).cpu().numpy()
+                for t in range(T):
+                    out[t]['ins_results'] = self._ins_from_host(rows[t][:, :-1], rows[t][:, -1].astype(np.int64), ins[t][2],
+                                                                self.num_things_classes)
+            else:
+                for t in range(T):
+                    if video:
+                        labels, boxes, binm, order = ins[t]
+                        out[t]['ins_results'] = self._video_ins_to_host(labels, boxes, binm, self.num_things_classes, order)
+                    else:
+                        out[t]['ins_results'] = self._ins_to_host(*ins[t], self.num_things_classes)
         return out
 
 
@@ -162,13 +239,16 @@ class Mask2FormerCustom(_Base):
         return self.simple_test(imgs, img_metas, **kwargs)
 
     def simple_test(self, imgs, img_metas, rescale=False, **kwargs):
-        feats = self.extract_feat(imgs)
         if self.fused_postprocess and len(img_metas) == 1 and self._fused_ok(img_metas, rescale):
             # one image per call (the reference's own limit)
-            cls_list, mask_list, q = self.panoptic_head._decode(feats, 1, 1, all_masks=False)
-            res = self._fused_frames(cls_list[-1][0], mask_list[-1], q[:, 0], img_metas[0], rescale, video=False)
+            def logits(x):
+                cls_list, mask_list, q = self.panoptic_head._decode(self.extract_feat(x), 1, 1, all_masks=False)
+                return cls_list[-1], mask_list[-1], q
+            cls, masks4, q = self._graphed('image', logits, imgs)
+            res = self._fused_frames(cls[0], masks4, q[:, 0], img_metas[0], rescale, video=False)
             if res is not None:
                 return [r['ins_results'] for r in res] if self.num_stuff_classes == 0 else res
+        feats = self.extract_feat(imgs)
         cls, masks, qf = self.panoptic_head.simple_test_with_query(feats, img_metas, **kwargs)
         results = self.panoptic_fusion_head.simple_test_with_query(cls, masks, qf, img_metas, rescale=rescale,
                                                                    **kwargs)
@@ -212,7 +292,7 @@ class Mask2FormerVideoCustom(_Base):
     def simple_test(self, img, img_metas, ref_img, ref_img_metas, rescale=False, **kwargs):
         kwargs['rescale'] = rescale
         bs, T = ref_img.shape[:2]
-        feats = self.extract_feat(ref_img.reshape((bs * T,) + tuple(ref_img.shape[2:])))
+        frames = ref_img.reshape((bs * T,) + tuple(ref_img.shape[2:]))
         flat_metas = [m for per_video in ref_img_metas for m in per_video]
         fused = self.fused_postprocess and bs == 1 and self._fused_ok(flat_metas, rescale)
         head = self.panoptic_head
@@ -220,25 +300,31 @@ class Mask2FormerVideoCustom(_Base):
         if self.inference_mode == 'clip':
             if fused:
                 # all frames of the clip share the class logits -> one fused post-processing launch set
-                cls, masks4, q = head.clip_logits(feats, 1, T)
-                logits, embds, masks4 = cls, q.permute(1, 0, 2), masks4[0]
+                def clip_fn(x):
+                    cls, m4, q = head.clip_logits(self.extract_feat(x), 1, T)
+                    return cls, q.permute(1, 0, 2), m4[0]
+                logits, embds, masks4 = self._graphed('clip', clip_fn, frames)
             else:
+                feats = self.extract_feat(frames)
                 cls, masks, q = head.simple_test_with_query(feats, ref_img_metas, **kwargs)
                 logits, embds = cls, q.permute(1, 0, 2)                    # (bs,Q,C+1), (bs,Q,C)
         else:
             if bs != 1:
                 raise NotImplementedError('per-frame VPS inference runs one video per call (as shipped)')
+
             # Shipped flow: one head call per frame (mask2former.py:136-143) + MinVIS chaining (:146-165).
             # Frames are independent inside the head, so they run as ONE batch of T; the matching chain
             # over the T frames is one on-device launch (ops.minvis_chain) instead of T-1 host LAPs.
-            cls_list, mask_list, qq = head._decode(feats, T, 1, all_masks=False)
-            cls_t, masks4 = cls_list[-1], mask_list[-1][:, 0]                 # (T,Q,C+1), (T,Q,h,w)
-            embds_t = qq.permute(1, 0, 2).contiguous()                        # (T,Q,C)
-            perm = ops.minvis_chain(embds_t)                                  # (T,Q)
-            ar = torch.arange(T, device=perm.device)[:, None]
-            logits = cls_t[ar, perm].mean(0, keepdim=True)                    # (1,Q,C+1)
-            embds = embds_t[ar, perm].mean(0, keepdim=True)                   # (1,Q,C)
-            masks4 = masks4[ar, perm]                                         # (T,Q,h,w) on frame-0 slots
+            def per_frame_fn(x):
+                cls_list, mask_list, qq = head._decode(self.extract_feat(x), T, 1, all_masks=False)
+                cls_t, m4 = cls_list[-1], mask_list[-1][:, 0]                     # (T,Q,C+1), (T,Q,h,w)
+                embds_t = qq.permute(1, 0, 2).contiguous()                        # (T,Q,C)
+                perm = ops.minvis_chain(embds_t)                                  # (T,Q)
+                ar = torch.arange(T, device=perm.device)[:, None]
+                return (cls_t[ar, perm].mean(0, keepdim=True),                   # (1,Q,C+1)
+                        embds_t[ar, perm].mean(0, keepdim=True),                 # (1,Q,C)
+                        m4[ar, perm])                                            # (T,Q,h,w) on frame-0 slots
+            logits, embds, masks4 = self._graphed('per_frame', per_frame_fn, frames)
         if fused and masks4 is not None:
             out = self._fused_frames(logits[0], masks4, embds[0], flat_metas[0], rescale, video=True)
             if out is not None:

@@ -13,7 +13,35 @@ import torch
 from . import _lib
 
 
+try:                                      # the raw handle of the current stream without building a torch.cuda.Stream object:
+    _raw_stream = torch._C._cuda_getCurrentRawStream      # ~0.2 us instead of ~8 us per launch (3 000 launches per clip)
+    _cur_dev = torch._C._cuda_getDevice
+except AttributeError:                    # pragma: no cover  (a torch build without the private accessor)
+    _raw_stream = _cur_dev = None
+
+
+class _Here:
+    """no-op context: the tensor's device already is the current one (the deployment: one process per GPU)"""
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_HERE = _Here()
+
+
+def _on(device):
+    """`torch.cuda.device(device)` only when it would change anything (its enter / exit cost 0.5 us x 2 per launch)"""
+    if _cur_dev is not None and device.index == _cur_dev():
+        return _HERE
+    return torch.cuda.device(device)
+
+
 def _stream_ptr():
+    if _raw_stream is not None:
+        return _raw_stream(_cur_dev())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -51,7 +79,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     out = torch.empty((B, Lq, M * D), device=value.device, dtype=torch.float32)
     if out.numel() == 0:
         return out
-    with torch.cuda.device(value.device):
+    with _on(value.device):
         _lib.call('pvsg_ms_deform_attn_forward', value.data_ptr(), ss.data_ptr(), lsi.data_ptr(),
                   loc.data_ptr(), w.data_ptr(), out.data_ptr(), B, S, M, D, Lq, L, P,
                   int(im2col_step), _stream_ptr())
@@ -74,7 +102,7 @@ def mask_logits(mask_embed, mask_feature):
         raise RuntimeError('mask_logits: inconsistent shapes %s vs %s' % (tuple(e.shape), tuple(f.shape)))
     out = torch.empty((B, T, Q, h, w), device=e.device, dtype=torch.float32)
     N = h * w
-    with torch.cuda.device(e.device):
+    with _on(e.device):
         if (os.environ.get('PVSG_MASK_GEMM', 'bf16x3') != 'f32' and C % 16 == 0 and Q % 4 == 0 and C * N < 2 ** 29 and
                 Q * N < 2 ** 29):
             # exact three-limb bf16 split on the bf16 matrix cores (f32-class result; csrc/gemm_bf16x3.hip)
@@ -95,7 +123,7 @@ def center_downsample(feature):
     for s in lead:
         planes *= s
     outs = [torch.empty(lead + (H // s, W // s), device=f.device, dtype=torch.float32) for s in (2, 4, 8)]
-    with torch.cuda.device(f.device):
+    with _on(f.device):
         _lib.call('pvsg_center_downsample', f.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(),
                   outs[2].data_ptr(), planes, H, W, _stream_ptr())
     return outs
@@ -131,7 +159,7 @@ def attn_mask_from_lowres_feature(mask_embed, feature_lowres):
     N = f.shape[-1] * f.shape[-2]
     bits = torch.empty((B, T * N, 4), device=e.device, dtype=torch.int32)
     flags = torch.empty((B, 4), device=e.device, dtype=torch.int32)
-    with torch.cuda.device(e.device):
+    with _on(e.device):
         if os.environ.get('PVSG_MASK_GEMM', 'bf16x3') != 'f32' and C % 16 == 0 and Q <= 128 and C * N < 2 ** 29:
             scratch = torch.empty((B * _lib.load().pvsg_gemm_bf16x3_packed_elems(Q, C),), device=e.device, dtype=torch.bfloat16)
             _lib.call('pvsg_attn_mask_bits_bf16x3', e.data_ptr(), f.data_ptr(), scratch.data_ptr(), bits.data_ptr(),
@@ -150,7 +178,7 @@ def attn_mask_pack(logits_lowres):
     B, T, Q, h, w = x.shape
     bits = torch.empty((B, T * h * w, 4), device=x.device, dtype=torch.int32)
     flags = torch.empty((B, 4), device=x.device, dtype=torch.int32)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.call('pvsg_attn_mask_pack', x.data_ptr(), bits.data_ptr(), flags.data_ptr(), B, T, Q, h * w,
                   _stream_ptr())
     return AttnMask(bits, flags, Q)
@@ -176,7 +204,7 @@ def masked_xattn_partial(q_proj, k_proj, v_proj, mask=None, num_heads=8, num_spl
     part_ml = torch.empty((B, NS, num_heads, Q, 2), device=q.device, dtype=torch.float32)
     if mask is not None and (mask.bits.shape[1] != K or mask.bits.shape[0] != B):
         raise RuntimeError('masked_xattn: mask covers %d keys, K=%d' % (mask.bits.shape[1], K))
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         _lib.call('pvsg_masked_xattn_partial', q.data_ptr(), k.data_ptr(), v.data_ptr(),
                   mask.bits.data_ptr() if mask is not None else None,
                   mask.flags.data_ptr() if mask is not None else None,
@@ -189,7 +217,7 @@ def xattn_combine(part_o, part_ml):
     po, pml = _chk(part_o, 'part_o'), _chk(part_ml, 'part_ml')
     B, NS, M, Q, D = po.shape
     out = torch.empty((B, Q, M * D), device=po.device, dtype=torch.float32)
-    with torch.cuda.device(po.device):
+    with _on(po.device):
         _lib.call('pvsg_xattn_combine', po.data_ptr(), pml.data_ptr(), out.data_ptr(), B, Q, M, D, NS,
                   _stream_ptr())
     return out
@@ -202,7 +230,7 @@ def xattn_merge_local(part_o, part_ml, mask=None):
     po, pml = _chk(part_o, 'part_o'), _chk(part_ml, 'part_ml')
     B, NS, M, Q, D = po.shape
     packed = torch.empty((B, M * Q * (D + 2) + 4), device=po.device, dtype=torch.float32)
-    with torch.cuda.device(po.device):
+    with _on(po.device):
         _lib.call('pvsg_xattn_merge_local', po.data_ptr(), pml.data_ptr(),
                   mask.flags.data_ptr() if mask is not None else None, packed.data_ptr(), B, Q, M, D, NS, _stream_ptr())
     return packed
@@ -215,7 +243,7 @@ def xattn_combine_packed(packed, num_queries, num_heads=8, head_dim=32):
     if rec != num_heads * num_queries * (head_dim + 2) + 4:
         raise RuntimeError('xattn_combine_packed: record length %d does not match Q=%d' % (rec, num_queries))
     out = torch.empty((B, num_queries, num_heads * head_dim), device=p.device, dtype=torch.float32)
-    with torch.cuda.device(p.device):
+    with _on(p.device):
         _lib.call('pvsg_xattn_combine_packed', p.data_ptr(), out.data_ptr(), R, B, num_queries, num_heads, head_dim,
                   _stream_ptr())
     return out
@@ -230,7 +258,7 @@ def pair_prepare_weights(W1):
     W1 = _chk(W1, 'W1')
     Hd, C2 = W1.shape
     out = torch.empty((2, C2 // 2, Hd), device=W1.device, dtype=torch.float32)
-    with torch.cuda.device(W1.device):
+    with _on(W1.device):
         _lib.call('pvsg_pair_prepare_weights', W1.data_ptr(), out.data_ptr(), C2 // 2, Hd, _stream_ptr())
     return out
 
@@ -255,7 +283,7 @@ def pair_score(sub_feats, obj_feats, W1, b1, w2, b2, return_tokens=False, W1T=No
         W1T = pair_prepare_weights(W1)
     work = torch.empty((2, N, Hd), device=s.device, dtype=torch.float32)
     tok = torch.empty((2, N, C), device=s.device, dtype=torch.float32) if return_tokens else None
-    with torch.cuda.device(s.device):
+    with _on(s.device):
         _lib.call('pvsg_pair_score_forward', s.data_ptr(), o.data_ptr(), W1T.data_ptr(), b1.data_ptr(),
                   w2.data_ptr(), b2.data_ptr(), work.data_ptr(), tok.data_ptr() if tok is not None else None,
                   out.data_ptr(), N, T, C, Hd, _stream_ptr())
@@ -289,7 +317,7 @@ def panoptic_fuse(mask_logits, kept_idx, kept_score, kept_class, out_hw, crop_hw
         ptrs = (ki.data_ptr(), ks.data_ptr(), kc.data_ptr())
     else:
         ptrs = (None, None, None)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.call('pvsg_panoptic_fuse', x.data_ptr(), ptrs[0], ptrs[1], ptrs[2], pan.data_ptr(),
                   seg.data_ptr() if K else None, owner.data_ptr(), counters.data_ptr(), T, Q, K, h, w, H, W,
                   ih, iw, oh, ow, int(num_things), int(num_classes), float(iou_thr), int(bool(filter_low_score)),
@@ -322,7 +350,7 @@ def instance_masks(mask_logits, sel_idx, out_hw, crop_hw, ori_hw=None, want_mask
     sbox = torch.zeros((T, n, 5), device=dev, dtype=torch.int32)
     if n:
         si = _chk(sel_idx.to(torch.int32), 'sel_idx', torch.int32)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call('pvsg_instance_masks', x.data_ptr(), si.data_ptr(),
                       masks.data_ptr() if masks is not None else None, ssum.data_ptr(), sbox.data_ptr(),
                       T, Q, n, int(per_frame), h, w, H, W, ih, iw, oh, ow, _stream_ptr())
@@ -341,7 +369,7 @@ def msda_fused(y, pos_oa, ref_points, spatial_shapes, level_start_index, num_hea
     ss = _chk(spatial_shapes, 'spatial_shapes', torch.int64)
     lsi = _chk(level_start_index, 'level_start_index', torch.int64)
     out = torch.empty((B, S, C), device=y.device, dtype=torch.float32)
-    with torch.cuda.device(y.device):
+    with _on(y.device):
         _lib.call('pvsg_msda_fused_forward', y.data_ptr(), W, y.data_ptr() + 4 * C, W,
                   pos.data_ptr() if pos is not None else None, ref.data_ptr(), ss.data_ptr(), lsi.data_ptr(),
                   out.data_ptr(), B, S, num_heads, C // num_heads, S, num_levels, num_points, _stream_ptr())
@@ -361,7 +389,7 @@ def msda_proj_ln(y, pos_oa, ref_points, spatial_shapes, level_start_index, wo_pa
     lsi = _chk(level_start_index, 'level_start_index', torch.int64)
     idt = _chk(identity, 'identity')
     out = torch.empty((B, S, C), device=y.device, dtype=torch.float32)
-    with torch.cuda.device(y.device):
+    with _on(y.device):
         _lib.call('pvsg_msda_proj_ln_forward', y.data_ptr(), W, y.data_ptr() + 4 * C, W,
                   pos.data_ptr() if pos is not None else None, ref.data_ptr(), ss.data_ptr(), lsi.data_ptr(),
                   wo_packed.data_ptr(), wo_bias.data_ptr() if wo_bias is not None else None, idt.data_ptr(),
@@ -376,7 +404,7 @@ def add_layernorm(a, b, bias, norm):
     b = _chk(b, 'b') if b is not None else None
     out = torch.empty_like(a)
     rows = a.numel() // a.shape[-1]
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         _lib.call('pvsg_add_layernorm', a.data_ptr(), b.data_ptr() if b is not None else None,
                   bias.data_ptr() if bias is not None else None, norm.weight.data_ptr(), norm.bias.data_ptr(),
                   out.data_ptr(), rows, a.shape[-1], float(norm.eps), _stream_ptr())
@@ -394,7 +422,7 @@ def affine_act_nchw_(x, scale, shift, residual=None, relu=True, out=None):
         raise RuntimeError('affine_act_nchw_: residual shape mismatch')
     if out is not None and not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and out.shape == x.shape):
         raise RuntimeError('affine_act_nchw_: out must be a contiguous float32 HIP tensor of the same shape')
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.call('pvsg_affine_act_nchw', x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                   r.data_ptr() if r is not None else None, out.data_ptr() if out is not None else None,
                   N * C, C, H * W, int(bool(relu)), _stream_ptr())
@@ -411,8 +439,9 @@ def minvis_chain(embds):
         e = e[None]
     V, T, Q, C = e.shape
     perm = torch.empty((V, T, Q), device=e.device, dtype=torch.int32)
-    with torch.cuda.device(e.device):
-        _lib.call('pvsg_minvis_chain', e.data_ptr(), perm.data_ptr(), V, T, Q, C, _stream_ptr())
+    ws = torch.empty(((_lib.load().pvsg_minvis_chain_workspace_bytes(V, T, Q) + 3) // 4,), device=e.device, dtype=torch.float32)
+    with _on(e.device):
+        _lib.call('pvsg_minvis_chain', e.data_ptr(), perm.data_ptr(), ws.data_ptr(), V, T, Q, C, _stream_ptr())
     perm = perm.to(torch.long)
     return perm[0] if squeeze else perm
 
@@ -430,7 +459,7 @@ def mask_embed(feat_hwd, pan_low, entries, obj_id, obj_inv_scale, normalised=Tru
             raise RuntimeError('mask_embed: %s must be a contiguous %s tensor on the GPU (no CPU path)' % (name, dt))
     out = torch.empty((k, d), device=f.device, dtype=torch.float32)
     out_n = torch.empty_like(out) if normalised else None
-    with torch.cuda.device(f.device):
+    with _on(f.device):
         _lib.call('pvsg_mask_embed_forward', f.data_ptr(), pan_low.data_ptr(), entries.data_ptr(), obj_id.data_ptr(),
                   obj_inv_scale.data_ptr(), out.data_ptr(), out_n.data_ptr() if normalised else None, h, w, d, k,
                   int(obj_id.shape[0]), _stream_ptr())
@@ -447,7 +476,7 @@ def group_norm_affine(x, gn):
         ws = torch.empty(B * G * 128, device=x.device, dtype=torch.float64)
         scale = torch.empty(B * C, device=x.device, dtype=torch.float32)
         shift = torch.empty(B * C, device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.call('pvsg_group_norm_affine', x.data_ptr(), gn.weight.data_ptr() if gn.weight is not None else None,
                       gn.bias.data_ptr() if gn.bias is not None else None, ws.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                       B, C, G, hw, float(gn.eps), _stream_ptr())
@@ -468,7 +497,7 @@ def fpn_merge_up2x(lateral, scale, shift, top):
     if (H, W) != (2 * h, 2 * w) or tp.shape[:2] != (B, C):
         raise RuntimeError('fpn_merge_up2x: lateral %s is not the x2 of top %s' % (tuple(lat.shape), tuple(tp.shape)))
     out = torch.empty_like(lat)
-    with torch.cuda.device(lat.device):
+    with _on(lat.device):
         _lib.call('pvsg_fpn_merge_up2x', lat.data_ptr(), scale.data_ptr() if scale is not None else None,
                   shift.data_ptr() if shift is not None else None, tp.data_ptr(), out.data_ptr(), B * C, h, w, _stream_ptr())
     return out
@@ -479,7 +508,7 @@ def stem_bn_relu_pool(x, scale, shift):
     x = _chk(x, 'x')
     N, C, H, W = x.shape
     out = torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=x.device, dtype=torch.float32)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.call('pvsg_stem_bn_relu_pool', x.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(), N * C, C, H, W,
                   _stream_ptr())
     return out
@@ -493,7 +522,7 @@ def nchw_to_tokens(src, dst, start, scale=None, shift=None):
     if not (dst.is_cuda and dst.is_contiguous() and dst.dtype == torch.float32 and dst.shape[0] == B and dst.shape[2] == C
             and start + H * W <= dst.shape[1]):
         raise RuntimeError('nchw_to_tokens: dst %s does not take %s at %d' % (tuple(dst.shape), tuple(s.shape), start))
-    with torch.cuda.device(s.device):
+    with _on(s.device):
         _lib.call('pvsg_nchw_to_tokens', s.data_ptr(), scale.data_ptr() if scale is not None else None,
                   shift.data_ptr() if shift is not None else None, dst.data_ptr() + 4 * start * C, B, C, H * W,
                   dst.shape[1] * C, _stream_ptr())
@@ -507,7 +536,7 @@ def tokens_to_nchw(tokens, start, h, w):
     if start + h * w > S:
         raise RuntimeError('tokens_to_nchw: %d tokens do not hold [%d, %d)' % (S, start, start + h * w))
     out = torch.empty((B, C, h, w), device=t.device, dtype=torch.float32)
-    with torch.cuda.device(t.device):
+    with _on(t.device):
         _lib.call('pvsg_tokens_to_nchw', t.data_ptr() + 4 * start * C, out.data_ptr(), B, C, h * w, S * C, _stream_ptr())
     return out
 
@@ -532,7 +561,7 @@ def conv1x1_affine(x, weight, scale, shift, residual=None, relu=True, out=None):
         raise RuntimeError('conv1x1_affine: out must be a contiguous float32 HIP tensor (B,Cout,H,W)')
     if r is not None and r.shape != out.shape:
         raise RuntimeError('conv1x1_affine: residual shape mismatch')
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.call('pvsg_conv1x1_affine', w.data_ptr(), x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                   r.data_ptr() if r is not None else None, out.data_ptr(), B, Cout, Cin, H * W, int(bool(relu)),
                   _stream_ptr())
@@ -550,7 +579,7 @@ def conv3x3_winograd_pack(weight):
     if tuple(w.shape[2:]) != (3, 3) or not conv3x3_winograd_supported(Cout, Cin, 2, 2):
         raise RuntimeError('conv3x3_winograd_pack: unsupported weight shape %s' % (tuple(w.shape),))
     u = torch.empty(16 * Cin * Cout, device=w.device, dtype=torch.float32)
-    with torch.cuda.device(w.device):
+    with _on(w.device):
         _lib.call('pvsg_conv3x3_winograd_pack', w.data_ptr(), u.data_ptr(), Cin, Cout, _stream_ptr())
     return u
 
@@ -569,7 +598,7 @@ def conv3x3_winograd(x, u_packed, cout, scale=None, shift=None, relu=False, out=
         out = torch.empty((N, cout, H, W), device=x.device, dtype=torch.float32)
     elif not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (N, cout, H, W)):
         raise RuntimeError('conv3x3_winograd: out must be a contiguous float32 HIP tensor (N,Cout,H,W)')
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.call('pvsg_conv3x3_winograd', x.data_ptr(), u.data_ptr(),
                   _chk(scale, 'scale').data_ptr() if scale is not None else None,
                   _chk(shift, 'shift').data_ptr() if shift is not None else None,
@@ -588,7 +617,7 @@ def conv3x3s2_pack(weight):
     if tuple(w.shape[2:]) != (3, 3) or not conv3x3s2_supported(Cout, Cin, 2, 2):
         raise RuntimeError('conv3x3s2_pack: unsupported weight shape %s' % (tuple(w.shape),))
     wp = torch.empty(24 * Cin * Cout, device=w.device, dtype=torch.float32)
-    with torch.cuda.device(w.device):
+    with _on(w.device):
         _lib.call('pvsg_conv3x3s2_pack', w.data_ptr(), wp.data_ptr(), Cin, Cout, _stream_ptr())
     return wp
 
@@ -605,7 +634,7 @@ def conv3x3s2_affine(x, w_packed, cout, scale, shift, relu=True, out=None):
         out = torch.empty((N, cout, Ho, Wo), device=x.device, dtype=torch.float32)
     elif not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (N, cout, Ho, Wo)):
         raise RuntimeError('conv3x3s2_affine: out must be a contiguous float32 HIP tensor (N,Cout,Ho,Wo)')
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.call('pvsg_conv3x3s2_affine', x.data_ptr(), wp.data_ptr(), _chk(scale, 'scale').data_ptr(),
                   _chk(shift, 'shift').data_ptr(), out.data_ptr(), N, Cin, cout, H, W, int(bool(relu)), _stream_ptr())
     return out
@@ -623,7 +652,7 @@ def gemm_bf16x3_pack(weight):
     N, K = w.shape
     n = _lib.load().pvsg_gemm_bf16x3_packed_elems(N, K)
     wp = torch.empty(n, device=w.device, dtype=torch.bfloat16)
-    with torch.cuda.device(w.device):
+    with _on(w.device):
         _lib.call('pvsg_gemm_bf16x3_pack', w.data_ptr(), wp.data_ptr(), N, K, _stream_ptr())
     return wp
 
@@ -644,7 +673,7 @@ def gemm_bf16x3(a, w_packed, n, bias=None, relu=False, out=None):
         raise RuntimeError('gemm_bf16x3: out must be a contiguous float32 HIP tensor (M,N)')
     if M == 0:
         return out
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         _lib.call('pvsg_gemm_bf16x3', a.data_ptr(), wp.data_ptr(), _chk(bias, 'bias').data_ptr() if bias is not None else None,
                   out.data_ptr(), M, n, K, int(bool(relu)), _stream_ptr())
     return out
@@ -675,7 +704,7 @@ def conv1x1_bf16x3(x, w_packed, cout, scale=None, shift=None, residual=None, rel
         raise RuntimeError('conv1x1_bf16x3: residual shape mismatch')
     if (in_scale is None) != (in_shift is None) or (in_scale is not None and (in_scale.numel() != B * Cin or in_shift.numel() != B * Cin)):
         raise RuntimeError('conv1x1_bf16x3: in_scale / in_shift must both be (B*Cin,)')
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.call('pvsg_conv1x1_bf16x3', x.data_ptr(), wp.data_ptr(),
                   _chk(scale, 'scale').data_ptr() if scale is not None else None,
                   _chk(shift, 'shift').data_ptr() if shift is not None else None,
@@ -692,7 +721,7 @@ def stem7x7_pack(weight):
     if tuple(w.shape) != (64, 3, 7, 7):
         raise RuntimeError('stem7x7_pack: unsupported weight shape %s' % (tuple(w.shape),))
     wp = torch.empty(21 * 64 * 8, device=w.device, dtype=torch.float32)
-    with torch.cuda.device(w.device):
+    with _on(w.device):
         _lib.call('pvsg_stem7x7_pack', w.data_ptr(), wp.data_ptr(), _stream_ptr())
     return wp
 
@@ -706,7 +735,7 @@ def stem7x7_bn_relu_pool(x, w_packed, scale, shift):
         raise RuntimeError('stem7x7_bn_relu_pool: unsupported input %s' % (tuple(x.shape),))
     Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     out = torch.empty((N, 64, (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1), device=x.device, dtype=torch.float32)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.call('pvsg_stem7x7_bn_relu_pool', x.data_ptr(), wp.data_ptr(), _chk(scale, 'scale').data_ptr(),
                   _chk(shift, 'shift').data_ptr(), out.data_ptr(), N, H, W, _stream_ptr())
     return out
@@ -724,7 +753,7 @@ def decoder_kv_inputs(tokens, start, hw, level_embed, pos_enc):
                            % (tuple(x.shape), hw, tuple(pe.shape)))
     v = torch.empty((Fr * hw, C), device=x.device, dtype=torch.float32)
     k = torch.empty_like(v)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.call('pvsg_decoder_kv_inputs', x.data_ptr() + 4 * start * C, le.data_ptr(), pe.data_ptr(), v.data_ptr(),
                   k.data_ptr(), Fr, hw, C, S * C, pe.shape[0], _stream_ptr())
     return v, k
@@ -736,7 +765,7 @@ def pack_rows_weight(W):
     W = _chk(W.detach(), 'W')
     N, K = W.shape
     out = torch.empty((((N + 15) // 16) * 16 * K,), device=W.device, dtype=torch.float32)
-    with torch.cuda.device(W.device):
+    with _on(W.device):
         _lib.call('pvsg_pack_rows_weight', W.data_ptr(), out.data_ptr(), N, K, _stream_ptr())
     return out
 
@@ -747,7 +776,7 @@ def decoder_rows_pre(layer_struct, attn_core, query, query_pos):
     B, Q, C = q.shape
     x1 = torch.empty_like(q)
     qkv = torch.empty((B, Q, 3 * C), device=q.device, dtype=torch.float32)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         _lib.call('pvsg_decoder_rows_pre', ctypes.byref(layer_struct), core.data_ptr(), q.data_ptr(), pos.data_ptr(),
                   x1.data_ptr(), qkv.data_ptr(), B, Q, _stream_ptr())
     return x1, qkv
@@ -764,7 +793,7 @@ def decoder_rows_post(layer_struct, head_struct, next_q, x1, qkv, query_pos, num
     cls = torch.empty((B, Q, num_cls_out), device=dev, dtype=torch.float32)
     emb = torch.empty_like(x1)
     nq = torch.empty_like(x1) if next_q is not None else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.call('pvsg_decoder_rows_post', ctypes.byref(layer_struct) if layer_struct is not None else None,
                   ctypes.byref(head_struct), next_q[0].data_ptr() if next_q is not None else None,
                   next_q[1].data_ptr() if next_q is not None else None, x1.data_ptr(),

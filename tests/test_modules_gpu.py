@@ -252,6 +252,34 @@ def test_ips_detector_vs_oracle(hip_lib):
             assert ma.shape[1:] == (45, 70) and (ma != mb).mean() < 2e-3
 
 
+@pytest.mark.parametrize('video', [False, True])
+def test_detector_instance_masks_are_lazy_device_handles(hip_lib, video):
+    """The detectors hand out instance masks as on-device handles (tubes.DeviceMask) in the reference's list-of-lists
+    format: numpy conversion on demand equals the mask, the device-side run-length code equals the host codec's, and
+    [3P] mmdet's encode step (`encode_mask_results`, applied by compat single_gpu_test) needs no mask copy."""
+    from openpvsg_amd import tubes
+    from openpvsg_amd.detectors import encode_mask_results
+    m = build_detector(video, 3, {'cls_embed.weight': 40.0})
+    assert not m.use_graph                      # hipGraph replay of the detector forward is experimental / opt-in
+    T = 2 if video else 1
+    meta = dict(img_shape=(60, 90, 3), ori_shape=(45, 70, 3))
+    if video:
+        clip = det_input('clip', (1, T, 3, 64, 96), 12).to(DEV)
+        out = m.forward(img=None, img_metas=None, return_loss=False, rescale=True, ref_img=clip,
+                        ref_img_metas=[[dict(meta) for _ in range(T)]])[0]
+    else:
+        out = m.forward([det_input('img', (1, 3, 64, 96), 12).to(DEV)], [[dict(meta)]], return_loss=False, rescale=True)
+    some = [x for r in out for c in r['ins_results'][1] for x in c]
+    assert some and all(isinstance(x, tubes.DeviceMask) for x in some)
+    for x in some[:6]:
+        a = np.asarray(x)
+        assert a.shape == (45, 70) and a.dtype == bool
+        assert x.stack.rles(boundaries=True)[x.j] == tubes.rle_encode(a) == x.rle()
+    enc = encode_mask_results(out[0]['ins_results'][1])
+    assert sum(len(c) for c in enc) == sum(len(c) for c in out[0]['ins_results'][1])
+    assert all(isinstance(r['counts'], str) and r['size'] == [45, 70] for c in enc for r in c)
+
+
 def test_vps_detector_instance_on_and_rescale_vs_reference_golden(hip_lib, golden_dir):
     """Unmodified shipped test_cfg (instance_on=True, per-frame mode) with ori_shape != img_shape against the
     REFERENCE detector's own output: fused two-resize panoptic map + `ins_results` in the reference's format

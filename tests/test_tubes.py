@@ -88,6 +88,32 @@ def test_rle_known_answer_vectors_and_c_restatement(golden_dir):
     assert tubes.rle_from_runs(ch[0::2], ch[1::2] - ch[0::2], 400, 300)['counts'] == c_encode(m)
 
 
+def test_device_mask_stack_boundary_rle_equals_host_codec():
+    """tubes.DeviceMaskStack: run boundaries found with tensor ops (the device path of the detectors' lazy instance masks)
+    give the strings of rle_encode; DeviceMask behaves like the (H, W) bool ndarray of the reference's result format."""
+    import pickle
+    rs = np.random.RandomState(4)
+    m = np.zeros((7, 45, 70), bool)
+    m[0, 5:20, 10:30] = 1
+    m[1, :, :3] = 1                       # starts with a one: leading zero-length run
+    m[2] = rs.rand(45, 70) < 0.5          # noise
+    m[4, 44, 69] = 1                      # single last pixel
+    m[5] = 1                              # all ones; m[3], m[6] all zeros
+    st = tubes.DeviceMaskStack(torch.from_numpy(m))
+    via_bounds = st.rles(boundaries=True)
+    assert [r['counts'] for r in via_bounds] == [tubes.rle_encode(m[j])['counts'] for j in range(7)]
+    assert all(r['size'] == [45, 70] for r in via_bounds)
+    assert st.rles(boundaries=False) == via_bounds
+    a, b = tubes.DeviceMask(st, 0), tubes.DeviceMask(st, 2)
+    assert a.shape == (45, 70) and a.dtype == bool and a.ndim == 2
+    assert (np.stack([a, b]) == m[[0, 2]]).all() and (np.asarray(a, dtype=np.uint8) == m[0]).all()
+    assert (pickle.loads(pickle.dumps(b)) == m[2]).all()
+    from openpvsg_amd.detectors import encode_mask_results
+    enc = encode_mask_results([[a], [], [b, m[1]]])
+    assert enc[0][0] == via_bounds[0] and enc[1] == [] and enc[2][0] == via_bounds[2] and enc[2][1] == tubes.rle_encode(m[1])
+    assert tubes.DeviceMaskStack(torch.zeros(0, 4, 4, dtype=torch.bool)).rles() == []
+
+
 def _outputs(T=5):
     rs = np.random.RandomState(1)
     outs = []
