@@ -19,12 +19,10 @@ import pickle
 import numpy as np
 
 
-def rle_counts_to_string(counts):
-    """COCO compressed-RLE string of run lengths (zeros first): delta against counts[i-2] from the 4th on,
-    5 bits per character + continuation bit, offset 48.  Vectorised over the counts (<= 13 chunks of 5 bits)."""
-    x = np.asarray(counts, dtype=np.int64).copy()
-    if x.size > 3:
-        x[3:] -= np.asarray(counts, dtype=np.int64)[1:-2]
+def _rle_chunks(x):
+    """delta-coded run lengths (int64) -> (characters as uint8 in emission order, characters per value): 5 bits per
+    character, least significant first, bit 0x20 = more follow, offset 48.  Vectorised (<= 13 chunks per value)."""
+    x = x.copy()
     cols, alive = [], np.ones(x.shape, bool)
     while alive.any():
         bits = x & 0x1f
@@ -33,9 +31,40 @@ def rle_counts_to_string(counts):
         cols.append(np.where(alive, bits | np.where(more, 0x20, 0), -1))
         alive = alive & more
     if not cols:
-        return ''
+        return np.zeros(0, np.uint8), np.zeros(0, np.int64)
     m = np.stack(cols, 1)
-    return (m[m >= 0] + 48).astype(np.uint8).tobytes().decode('ascii')
+    return (m[m >= 0] + 48).astype(np.uint8), (m >= 0).sum(1)
+
+
+def rle_counts_to_string(counts):
+    """COCO compressed-RLE string of run lengths (zeros first): delta against counts[i-2] from the 4th on,
+    5 bits per character + continuation bit, offset 48."""
+    c = np.asarray(counts, dtype=np.int64)
+    x = c.copy()
+    if x.size > 3:
+        x[3:] -= c[1:-2]
+    return _rle_chunks(x)[0].tobytes().decode('ascii')
+
+
+def rle_counts_to_strings(counts, seg_lengths):
+    """The same for MANY masks at once: `counts` = the run lengths of all masks back to back, seg_lengths[j] of them belong
+    to mask j.  One vectorised pass instead of one per mask (100 instance masks per image)."""
+    c = np.asarray(counts, dtype=np.int64)
+    seg = np.asarray(seg_lengths, dtype=np.int64)
+    starts = np.concatenate(([0], np.cumsum(seg)[:-1]))
+    x = c.copy()
+    if c.size > 2:
+        x[2:] -= c[:-2]
+    pos = np.arange(c.size) - np.repeat(starts, seg)          # index inside the own mask
+    head = pos < 3                                            # the first three counts of a mask are stored as they are
+    x[head] = c[head]
+    chars, per_value = _rle_chunks(x)
+    per_mask = np.add.reduceat(per_value, starts[seg > 0]) if (seg > 0).any() else np.zeros(0, np.int64)
+    lens = np.zeros(seg.size, np.int64)
+    lens[seg > 0] = per_mask
+    raw = chars.tobytes().decode('ascii')
+    ends = np.cumsum(lens)
+    return [raw[e - n:e] for e, n in zip(ends.tolist(), lens.tolist())]
 
 
 def rle_encode(mask):
@@ -129,15 +158,25 @@ class DeviceMaskStack:
                 idx = change.nonzero()                                       # (m, 2), sorted by mask, then position
                 host = torch.cat([idx.reshape(-1), flat[:, 0].to(idx.dtype)]).cpu().numpy()
                 idx, first = host[:2 * m].reshape(m, 2), host[2 * m:]
-                lo = np.searchsorted(idx[:, 0], np.arange(n), side='left')
-                hi = np.searchsorted(idx[:, 0], np.arange(n), side='right')
-                out = []
-                for j in range(n):
-                    bounds = np.concatenate(([0], idx[lo[j]:hi[j], 1] + 1, [H * W]))
-                    counts = np.diff(bounds)
-                    if first[j]:
-                        counts = np.concatenate(([0], counts))
-                    out.append({'size': [H, W], 'counts': rle_counts_to_string(counts)})
+                # all masks in one vectorised pass: boundaries [0, p+1 ..., HW] per mask -> run lengths -> strings
+                per = np.bincount(idx[:, 0], minlength=n)                         # change points per mask
+                lead = (first != 0).astype(np.int64)                              # masks starting with a one: leading 0-run
+                seg = per + 1 + lead
+                total = int(seg.sum())
+                starts = np.concatenate(([0], np.cumsum(seg)[:-1]))
+                bounds = np.empty(total + n, np.int64)                            # per mask: [0 (, 0)] + (p + 1 ...) + [HW]
+                bstart = starts + np.arange(n)                                    # one more boundary than counts per mask
+                # positions of the change points inside `bounds`
+                off = np.repeat(bstart + 1 + lead, per) + (np.arange(idx.shape[0]) - np.repeat(np.concatenate(([0], np.cumsum(per)[:-1])), per))
+                bounds[off] = idx[:, 1] + 1
+                bounds[bstart] = 0
+                bounds[bstart[lead == 1] + 1] = 0
+                bounds[bstart + seg] = H * W
+                counts = np.diff(bounds)
+                keep = np.ones(total + n - 1, bool)
+                keep[(bstart + seg)[:-1]] = False                                 # the differences across two masks
+                strings = rle_counts_to_strings(counts[keep], seg)
+                out = [{'size': [H, W], 'counts': st} for st in strings]
                 self._rles = out
                 return out
         arr = self.numpy()

@@ -1,6 +1,9 @@
 """End-to-end IPS flavour on one GPU (what tools/prepare_query_tube_ips.py + tools/rel_test.py do for one video):
 per-frame Mask2Former (R50) -> fused panoptic post-process -> UniTrack-style tube association -> relation head.
-32 synthetic 720p frames, random-init weights.  Prints stage times and frames/s."""
+32 synthetic 720p frames, random-init weights; as in bench.py controlled class logits / mask-logit
+offsets are ADDED to the decoder's outputs so that ~32 blob-shaped segments per frame reach fusion and association (random
+weights alone give noise-like maps whose run-length codes are as large as the maps; `--raw` keeps them).
+Prints stage times and frames/s."""
 import os, sys, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,7 +16,9 @@ from openpvsg_amd.model_zoo import mask2former_r50_model_cfg
 from openpvsg_amd.registry import build_detector
 from openpvsg_amd.tubes import process_feats
 
-T = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+RAW = '--raw' in sys.argv
+_argv = [a for a in sys.argv[1:] if not a.startswith('--')]
+T = int(_argv[0]) if _argv else 32
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 cfg = mask2former_r50_model_cfg(video=False)
@@ -34,6 +39,9 @@ app = U.AppearanceModel(tcfg).to(dev)
 clip, (Hp, Wp) = bench.make_clip(T, 720, 1280)
 clip = clip.to(dev)
 head, fusion = det.panoptic_head, det.panoptic_fusion_head
+syn_cls, syn_off = bench.synthetic_head_outputs(T, Hp // 4, Wp // 4, n_keep=32)
+syn_off[:, syn_off.abs().amax(dim=(0, 2, 3)) == 0] = -40.0          # queries without an object: empty masks
+syn_cls, syn_off = syn_cls.to(dev), syn_off.to(dev)
 
 
 def step():
@@ -45,7 +53,11 @@ def step():
         outputs = []
         for t in range(T):
             m = mask_list[-1][t]
-            pan, seg, keep = fusion.panoptic_fused(cls_list[-1][t], m if m.dim() == 4 else m[None], (Hp, Wp), (720, 1280))
+            m = m if m.dim() == 4 else m[None]
+            cls_t = cls_list[-1][t]
+            if not RAW:
+                m, cls_t = m + syn_off[t][None], syn_cls[0]
+            pan, seg, keep = fusion.panoptic_fused(cls_t, m, (Hp, Wp), (720, 1280))
             kf = q[:, t][keep]
             qd = {}
             for i, sid in enumerate(seg[0].tolist()):

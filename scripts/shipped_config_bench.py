@@ -37,6 +37,9 @@ for video in (True, False):
     meta = dict(img_shape=(720, 1280, 3), ori_shape=(720, 1280, 3))
     if not RAW:
         syn_cls, syn_off = bench.synthetic_head_outputs(T, Hp // 4, Wp // 4, n_keep=32)
+        # queries without an object: empty masks (-40 everywhere), as a trained decoder produces them -- left at the random
+        # decoder's noise they would each contribute a noise mask to the top-100 instance list
+        syn_off[:, syn_off.abs().amax(dim=(0, 2, 3)) == 0] = -40.0
         syn_cls, syn_off = syn_cls.to(dev), syn_off.to(dev)
         head = det.panoptic_head
         orig = head._decode
