@@ -75,6 +75,29 @@ def test_third_party_restatements_on_known_answers():
     assert abs(float(U.box_iou(t, torch.tensor([[5., 0., 15., 10.]]))[0, 0]) - 50 / 150) < 1e-7
 
 
+def test_panoptic_obs_run_length_codes_of_all_ids_in_one_pass():
+    """openpvsg_amd.unitrack.PanopticObs.rle: the MOTS codes of every id of a frame from one vectorised pass over the
+    column-major runs == the codec applied to each id's mask (blobs, single pixels at both ends, an id without pixels,
+    a noise map)."""
+    from openpvsg_amd import tubes
+    from openpvsg_amd import unitrack as P
+    pan = np.full((37, 53), 126, np.int32)
+    pan[3:10, 5:20] = 1005
+    pan[20:37, 40:53] = 7
+    pan[0, 0] = 9
+    pan[36, 52] = 11
+    pan[15:18, :] = 2003
+    obs = P.PanopticObs(pan, [1005, 7, 9, 11, 2003, 555], 'cpu')
+    for oid in (1005, 7, 9, 11, 2003, 126):
+        assert obs.rle(oid) == tubes.rle_encode(pan == oid), oid
+    assert obs.rle(555) == tubes.rle_encode(np.zeros_like(pan))
+    assert obs[0].rle() == tubes.rle_encode(pan == 1005) and obs[0].sum() == int((pan == 1005).sum())
+    noise = np.random.RandomState(0).randint(0, 5, (41, 29)).astype(np.int32)
+    o2 = P.PanopticObs(noise, list(range(5)), 'cpu')
+    for oid in range(5):
+        assert o2.rle(oid) == tubes.rle_encode(noise == oid)
+
+
 def _partial_matchings(n, m):
     """every partial matching of n rows to m columns as a tuple x (x[i] = column or -1)"""
     def rec(i, used):
