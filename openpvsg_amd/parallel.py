@@ -32,7 +32,26 @@ def is_dist(group=None):
     return dist.get_world_size(group) > 1 or FORCE_COLLECTIVES
 
 
-def isolate_shared_gpu(slot, slots, device_index=0, cus=256):
+KFD_NODES = '/sys/class/kfd/kfd/topology/nodes'
+
+
+def device_cu_count(device_index=0, default=256):
+    """Compute units of GPU `device_index` WITHOUT touching the HIP runtime (HSA_CU_MASK must be set before it starts):
+    from the KFD topology in sysfs (`simd_count / simd_per_cu` of the device_index-th node that has SIMDs)."""
+    base = KFD_NODES
+    try:
+        gpus = []
+        for node in sorted(os.listdir(base), key=int):
+            props = dict(line.split() for line in open(os.path.join(base, node, 'properties')) if len(line.split()) == 2)
+            simd = int(props.get('simd_count', 0))
+            if simd > 0:
+                gpus.append(simd // max(1, int(props.get('simd_per_cu', 4))))
+        return gpus[device_index] if device_index < len(gpus) else default
+    except Exception:
+        return default
+
+
+def isolate_shared_gpu(slot, slots, device_index=0, cus=None):
     """Several PROCESSES on one MI355X (the gloo logic tests, `bench.py` with PVSG_ONE_DEVICE=1): give each its own
     range of compute units (HSA_CU_MASK), to be called before the process touches the HIP runtime.
 
@@ -40,9 +59,11 @@ def isolate_shared_gpu(slot, slots, device_index=0, cus=256):
     CO-RESIDENT on a CU with waves of ANOTHER process were observed to corrupt that process's results -- e.g. its
     deformable-attention gather returns wrong values in lanes 48-63 of a wave (heads 6-7) in 1-20 % of launches, on every
     box tried; the same kernel built on the f32 MFMA does not, and neither process is affected once their CU sets are
-    disjoint (scripts/coresidency_probe.py).  Inside one process kernels run back to back on one stream, so this never
-    arises in the supported deployment (one process per GPU)."""
+    disjoint (scripts/coresidency_probe.py; stand-alone reproducer scripts/coresidency_repro.hip: the gather next to a
+    register-only v_mfma_f32_16x16x32_bf16 loop, also from a second stream of the SAME process).  The backend runs its
+    kernels back to back on one stream, so this never arises in the supported deployment (one process per GPU, one stream)."""
     if slots > 1 and 'HSA_CU_MASK' not in os.environ:
+        cus = cus or device_cu_count(device_index)
         per = cus // slots
         os.environ['HSA_CU_MASK'] = '%d:%d-%d' % (device_index, slot * per, (slot + 1) * per - 1)
 

@@ -149,3 +149,24 @@ def test_bench_gpus_flag_self_spawns_one_rank_per_gpu(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert 'WORLD_SIZE=2' in str(e.value.code)
+
+
+def test_cu_mask_is_derived_from_the_kfd_topology(tmp_path, monkeypatch):
+    """parallel.isolate_shared_gpu partitions the CUs the device really has (no hard-coded 256): the count comes
+    from the KFD topology in sysfs, read without starting the HIP runtime."""
+    import os
+    from openpvsg_amd import parallel
+    for node, simd in (('0', 0), ('1', 1216), ('2', 1024)):                 # node 0 = the CPU, two GPUs with 304 / 256 CUs
+        d = tmp_path / node
+        d.mkdir()
+        (d / 'properties').write_text('cpu_cores_count 64\nsimd_count %d\nsimd_per_cu 4\n' % simd)
+    monkeypatch.setattr(parallel, 'KFD_NODES', str(tmp_path))
+    assert parallel.device_cu_count(0) == 304 and parallel.device_cu_count(1) == 256 and parallel.device_cu_count(5) == 256
+    monkeypatch.delenv('HSA_CU_MASK', raising=False)
+    parallel.isolate_shared_gpu(1, 2, device_index=0)
+    assert os.environ['HSA_CU_MASK'] == '0:152-303'
+    monkeypatch.delenv('HSA_CU_MASK', raising=False)
+    monkeypatch.setattr(parallel, 'KFD_NODES', str(tmp_path / 'missing'))
+    parallel.isolate_shared_gpu(0, 4)
+    assert os.environ['HSA_CU_MASK'] == '0:0-63'
+    monkeypatch.delenv('HSA_CU_MASK', raising=False)
