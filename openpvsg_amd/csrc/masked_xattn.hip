@@ -44,6 +44,29 @@ namespace pvsg {
 
 constexpr int XQT = 7;  // 7 x 16 = 112 query rows
 
+typedef float xf32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 xbf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
+
+// exact three-limb bf16 split of two floats (hi + mid + lo == a, every limb a bf16), packed as pairs; same scheme as
+// gemm_bf16x3.hip: the six limb products with a combined weight >= 2^-16 carry the f32 product to f32-class error
+__device__ __forceinline__ void xsplit2(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(xf32x2{a0, a1}, xbf16x2));
+  const float r0 = a0 - __builtin_bit_cast(float, h << 16), r1 = a1 - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(xf32x2{r0, r1}, xbf16x2));
+  const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(xf32x2{s0, s1}, xbf16x2));
+}
+__device__ __forceinline__ void xsplit2v(float a0, float a1, xu32x4& h, xu32x4& m, xu32x4& l, int i) {
+  unsigned x, y, z;
+  xsplit2(a0, a1, x, y, z);
+  h[i] = x; m[i] = y; l[i] = z;
+}
+__device__ __forceinline__ f32x4 xmfma_bf16(xu32x4 a, xu32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xbf16x8, a), __builtin_bit_cast(xbf16x8, b), c, 0, 0, 0);
+}
+
 // Reductions over the 4 lane groups (lane>>4) that hold the 16 key rows of one S^T tile.  gfx950's
 // v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows between two registers in the VALU
 // (no LDS crossbar trip like ds_bpermute): with both operands = v the results are (r0,r0,r2,r2) and
@@ -76,7 +99,7 @@ __device__ __forceinline__ float group_sum4(float v) {
 constexpr int TK = 32;                                   // keys per LDS tile
 constexpr int XLDS_TILE_FLOATS = TK * 256 * 2 + TK * 4;  // K rows + V rows + mask words (as floats)
 
-template <bool LEAN>
+template <bool LEAN, bool BX>
 __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
     const float* __restrict__ qp, const float* __restrict__ kp, const float* __restrict__ vp,
     const uint32_t* __restrict__ bits, const uint32_t* __restrict__ flags, float* __restrict__ part_o,
@@ -116,6 +139,15 @@ __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
       }
       if (use_mask && ((fw[qt >> 1] >> ((qt & 1) * 16 + j)) & 1u)) honor |= 1u << qt;
     }
+  }
+  // BX: Q as three bf16 limbs, the B operand of v_mfma_f32_16x16x32_bf16 (lane (query j, k-group g) holds dims 8g..8g+7
+  // of its head -- the same eight values the f32 path keeps)
+  xu32x4 qh[XQT], qm[XQT], ql[XQT];
+  if constexpr (BX) {
+#pragma unroll
+    for (int qt = 0; qt < XQT; ++qt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xsplit2v(qf[qt][2 * i], qf[qt][2 * i + 1], qh[qt], qm[qt], ql[qt], i);
   }
   float mrun[XQT], lrun[XQT];
   f32x4 o[XQT][2];
@@ -176,11 +208,30 @@ __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
       f32x4 st[XQT];
 #pragma unroll
       for (int qt = 0; qt < XQT; ++qt) st[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (BX) {
+        // all 32 head dims are ONE k-step of the bf16 MFMA: 6 limb products per 16x16 block, small terms first
+        xu32x4 kh, km, kl;
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 4; ++i) xsplit2v(kf[2 * i], kf[2 * i + 1], kh, km, kl, i);
 #pragma unroll
-        for (int qt = 0; qt < XQT; ++qt)
-          st[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[i], qf[qt][i], st[qt], 0, 0, 0);
+        for (int qt = 0; qt < XQT; ++qt) st[qt] = xmfma_bf16(km, qm[qt], st[qt]);
+#pragma unroll
+        for (int qt = 0; qt < XQT; ++qt) st[qt] = xmfma_bf16(kh, ql[qt], st[qt]);
+#pragma unroll
+        for (int qt = 0; qt < XQT; ++qt) st[qt] = xmfma_bf16(kl, qh[qt], st[qt]);
+#pragma unroll
+        for (int qt = 0; qt < XQT; ++qt) st[qt] = xmfma_bf16(kh, qm[qt], st[qt]);
+#pragma unroll
+        for (int qt = 0; qt < XQT; ++qt) st[qt] = xmfma_bf16(km, qh[qt], st[qt]);
+#pragma unroll
+        for (int qt = 0; qt < XQT; ++qt) st[qt] = xmfma_bf16(kh, qh[qt], st[qt]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int qt = 0; qt < XQT; ++qt)
+            st[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[i], qf[qt][i], st[qt], 0, 0, 0);
+      }
       bool kvalid[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) kvalid[r] = kt + sub * 16 + g * 4 + r < k1;
@@ -266,15 +317,50 @@ __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
         }
       }
       // ---- O^T += V^T . P^T (V fragments from LDS right before use) ---------------------------------------------
+      if constexpr (BX) {
+        // the 16 keys of the sub-tile fill k-slots 8g..8g+3 of the 32-deep bf16 MFMA (slots 8g+4..8g+7 are zero on both
+        // operands): the S^T accumulator registers are again the B operand without leaving their lane
+        float2 vf[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = sub * 16 + g * 4 + r;
-        const int ch = (h * 8 + (j >> 1)) ^ (row & 15);
-        const float2 vf = *reinterpret_cast<const float2*>(tb + TK * 256 + row * 256 + ch * 4 + (j & 1) * 2);
+        for (int r = 0; r < 4; ++r) {
+          const int row = sub * 16 + g * 4 + r;
+          const int ch = (h * 8 + (j >> 1)) ^ (row & 15);
+          vf[r] = *reinterpret_cast<const float2*>(tb + TK * 256 + row * 256 + ch * 4 + (j & 1) * 2);
+        }
+        xu32x4 vh[2], vm[2], vl[2];
+        vh[0] = vm[0] = vl[0] = vh[1] = vm[1] = vl[1] = xu32x4{0u, 0u, 0u, 0u};
+        xsplit2v(vf[0].x, vf[1].x, vh[0], vm[0], vl[0], 0);
+        xsplit2v(vf[2].x, vf[3].x, vh[0], vm[0], vl[0], 1);
+        xsplit2v(vf[0].y, vf[1].y, vh[1], vm[1], vl[1], 0);
+        xsplit2v(vf[2].y, vf[3].y, vh[1], vm[1], vl[1], 1);
 #pragma unroll
         for (int qt = 0; qt < XQT; ++qt) {
-          o[qt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, st[qt][r], o[qt][0], 0, 0, 0);
-          o[qt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, st[qt][r], o[qt][1], 0, 0, 0);
+          xu32x4 ph = {0u, 0u, 0u, 0u}, pm = ph, pl = ph;
+          xsplit2v(st[qt][0], st[qt][1], ph, pm, pl, 0);
+          xsplit2v(st[qt][2], st[qt][3], ph, pm, pl, 1);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            f32x4 acc = o[qt][dt];
+            acc = xmfma_bf16(vm[dt], pm, acc);
+            acc = xmfma_bf16(vh[dt], pl, acc);
+            acc = xmfma_bf16(vl[dt], ph, acc);
+            acc = xmfma_bf16(vh[dt], pm, acc);
+            acc = xmfma_bf16(vm[dt], ph, acc);
+            acc = xmfma_bf16(vh[dt], ph, acc);
+            o[qt][dt] = acc;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = sub * 16 + g * 4 + r;
+          const int ch = (h * 8 + (j >> 1)) ^ (row & 15);
+          const float2 vf = *reinterpret_cast<const float2*>(tb + TK * 256 + row * 256 + ch * 4 + (j & 1) * 2);
+#pragma unroll
+          for (int qt = 0; qt < XQT; ++qt) {
+            o[qt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, st[qt][r], o[qt][0], 0, 0, 0);
+            o[qt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, st[qt][r], o[qt][1], 0, 0, 0);
+          }
         }
       }
     }
@@ -432,21 +518,22 @@ extern "C" int pvsg_masked_xattn_partial(const float* q_proj, const float* k_pro
   // ranges past the end are legal: they publish (m=-inf, l=0, o=0) and the merge skips them
   chunk = (chunk + TK - 1) / TK * TK;
   const size_t lds = (size_t)2 * XLDS_TILE_FLOATS * sizeof(float);
+  // PVSG_XATTN=f32 selects the f32-MFMA kernels (default: exact three-limb bf16 split on the bf16 matrix path);
+  // PVSG_XATTN_LEAN=0 the textbook online soft-max
+  static const bool lean = []() { const char* e = getenv("PVSG_XATTN_LEAN"); return !(e && e[0] == '0'); }();
+  static const bool bx = []() { const char* e = getenv("PVSG_XATTN"); return !(e && e[0] == 'f'); }();
+  using kern_t = void (*)(const float*, const float*, const float*, const uint32_t*, const uint32_t*, float*, float*, int,
+                          long long, int, long long);
+  static const kern_t kern = bx ? (lean ? &xattn_partial_lds_kernel<true, true> : &xattn_partial_lds_kernel<false, true>)
+                                : (lean ? &xattn_partial_lds_kernel<true, false> : &xattn_partial_lds_kernel<false, false>);
   static std::atomic<unsigned long long> attr_done;
   {
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&xattn_partial_lds_kernel<true>), (int)lds, attr_done);
-    static std::atomic<unsigned long long> attr_done2;
-    if (e == hipSuccess) e = ensure_dynamic_lds(reinterpret_cast<const void*>(&xattn_partial_lds_kernel<false>), (int)lds, attr_done2);
+    const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, attr_done);
     if (e != hipSuccess)
       return set_err(PVSG_ERR_HIP, "masked_xattn_partial: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
   }
-  static const bool lean = []() { const char* e = getenv("PVSG_XATTN_LEAN"); return !(e && e[0] == '0'); }();
-  if (lean)
-    hipLaunchKernelGGL(xattn_partial_lds_kernel<true>, dim3(B * NS), dim3(512), lds, stream, q_proj, k_proj, v_proj,
-                       mask_bits, mask_flags, part_o, part_ml, Q, K, NS, chunk);
-  else
-    hipLaunchKernelGGL(xattn_partial_lds_kernel<false>, dim3(B * NS), dim3(512), lds, stream, q_proj, k_proj, v_proj,
-                       mask_bits, mask_flags, part_o, part_ml, Q, K, NS, chunk);
+  hipLaunchKernelGGL(kern, dim3(B * NS), dim3(512), lds, stream, q_proj, k_proj, v_proj, mask_bits, mask_flags, part_o,
+                     part_ml, Q, K, NS, chunk);
   PVSG_LAUNCH_CHECK("masked_xattn_partial");
   return PVSG_OK;
 }
