@@ -44,29 +44,6 @@ namespace pvsg {
 
 constexpr int XQT = 7;  // 7 x 16 = 112 query rows
 
-typedef float xf32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 xbf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
-
-// exact three-limb bf16 split of two floats (hi + mid + lo == a, every limb a bf16), packed as pairs; same scheme as
-// gemm_bf16x3.hip: the six limb products with a combined weight >= 2^-16 carry the f32 product to f32-class error
-__device__ __forceinline__ void xsplit2(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
-  h = __builtin_bit_cast(unsigned, __builtin_convertvector(xf32x2{a0, a1}, xbf16x2));
-  const float r0 = a0 - __builtin_bit_cast(float, h << 16), r1 = a1 - __builtin_bit_cast(float, h & 0xffff0000u);
-  m = __builtin_bit_cast(unsigned, __builtin_convertvector(xf32x2{r0, r1}, xbf16x2));
-  const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
-  l = __builtin_bit_cast(unsigned, __builtin_convertvector(xf32x2{s0, s1}, xbf16x2));
-}
-__device__ __forceinline__ void xsplit2v(float a0, float a1, xu32x4& h, xu32x4& m, xu32x4& l, int i) {
-  unsigned x, y, z;
-  xsplit2(a0, a1, x, y, z);
-  h[i] = x; m[i] = y; l[i] = z;
-}
-__device__ __forceinline__ f32x4 xmfma_bf16(xu32x4 a, xu32x4 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xbf16x8, a), __builtin_bit_cast(xbf16x8, b), c, 0, 0, 0);
-}
-
 // Reductions over the 4 lane groups (lane>>4) that hold the 16 key rows of one S^T tile.  gfx950's
 // v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows between two registers in the VALU
 // (no LDS crossbar trip like ds_bpermute): with both operands = v the results are (r0,r0,r2,r2) and
@@ -99,7 +76,7 @@ __device__ __forceinline__ float group_sum4(float v) {
 constexpr int TK = 32;                                   // keys per LDS tile
 constexpr int XLDS_TILE_FLOATS = TK * 256 * 2 + TK * 4;  // K rows + V rows + mask words (as floats)
 
-template <bool LEAN, bool BX>
+template <bool LEAN>
 __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
     const float* __restrict__ qp, const float* __restrict__ kp, const float* __restrict__ vp,
     const uint32_t* __restrict__ bits, const uint32_t* __restrict__ flags, float* __restrict__ part_o,
@@ -139,15 +116,6 @@ __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
       }
       if (use_mask && ((fw[qt >> 1] >> ((qt & 1) * 16 + j)) & 1u)) honor |= 1u << qt;
     }
-  }
-  // BX: Q as three bf16 limbs, the B operand of v_mfma_f32_16x16x32_bf16 (lane (query j, k-group g) holds dims 8g..8g+7
-  // of its head -- the same eight values the f32 path keeps)
-  xu32x4 qh[XQT], qm[XQT], ql[XQT];
-  if constexpr (BX) {
-#pragma unroll
-    for (int qt = 0; qt < XQT; ++qt)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xsplit2v(qf[qt][2 * i], qf[qt][2 * i + 1], qh[qt], qm[qt], ql[qt], i);
   }
   float mrun[XQT], lrun[XQT];
   f32x4 o[XQT][2];
@@ -208,30 +176,11 @@ __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
       f32x4 st[XQT];
 #pragma unroll
       for (int qt = 0; qt < XQT; ++qt) st[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (BX) {
-        // all 32 head dims are ONE k-step of the bf16 MFMA: 6 limb products per 16x16 block, small terms first
-        xu32x4 kh, km, kl;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xsplit2v(kf[2 * i], kf[2 * i + 1], kh, km, kl, i);
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int qt = 0; qt < XQT; ++qt) st[qt] = xmfma_bf16(km, qm[qt], st[qt]);
-#pragma unroll
-        for (int qt = 0; qt < XQT; ++qt) st[qt] = xmfma_bf16(kh, ql[qt], st[qt]);
-#pragma unroll
-        for (int qt = 0; qt < XQT; ++qt) st[qt] = xmfma_bf16(kl, qh[qt], st[qt]);
-#pragma unroll
-        for (int qt = 0; qt < XQT; ++qt) st[qt] = xmfma_bf16(kh, qm[qt], st[qt]);
-#pragma unroll
-        for (int qt = 0; qt < XQT; ++qt) st[qt] = xmfma_bf16(km, qh[qt], st[qt]);
-#pragma unroll
-        for (int qt = 0; qt < XQT; ++qt) st[qt] = xmfma_bf16(kh, qh[qt], st[qt]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int qt = 0; qt < XQT; ++qt)
-            st[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[i], qf[qt][i], st[qt], 0, 0, 0);
-      }
+        for (int qt = 0; qt < XQT; ++qt)
+          st[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[i], qf[qt][i], st[qt], 0, 0, 0);
       bool kvalid[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) kvalid[r] = kt + sub * 16 + g * 4 + r < k1;
@@ -317,50 +266,15 @@ __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
         }
       }
       // ---- O^T += V^T . P^T (V fragments from LDS right before use) ---------------------------------------------
-      if constexpr (BX) {
-        // the 16 keys of the sub-tile fill k-slots 8g..8g+3 of the 32-deep bf16 MFMA (slots 8g+4..8g+7 are zero on both
-        // operands): the S^T accumulator registers are again the B operand without leaving their lane
-        float2 vf[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = sub * 16 + g * 4 + r;
-          const int ch = (h * 8 + (j >> 1)) ^ (row & 15);
-          vf[r] = *reinterpret_cast<const float2*>(tb + TK * 256 + row * 256 + ch * 4 + (j & 1) * 2);
-        }
-        xu32x4 vh[2], vm[2], vl[2];
-        vh[0] = vm[0] = vl[0] = vh[1] = vm[1] = vl[1] = xu32x4{0u, 0u, 0u, 0u};
-        xsplit2v(vf[0].x, vf[1].x, vh[0], vm[0], vl[0], 0);
-        xsplit2v(vf[2].x, vf[3].x, vh[0], vm[0], vl[0], 1);
-        xsplit2v(vf[0].y, vf[1].y, vh[1], vm[1], vl[1], 0);
-        xsplit2v(vf[2].y, vf[3].y, vh[1], vm[1], vl[1], 1);
+      for (int r = 0; r < 4; ++r) {
+        const int row = sub * 16 + g * 4 + r;
+        const int ch = (h * 8 + (j >> 1)) ^ (row & 15);
+        const float2 vf = *reinterpret_cast<const float2*>(tb + TK * 256 + row * 256 + ch * 4 + (j & 1) * 2);
 #pragma unroll
         for (int qt = 0; qt < XQT; ++qt) {
-          xu32x4 ph = {0u, 0u, 0u, 0u}, pm = ph, pl = ph;
-          xsplit2v(st[qt][0], st[qt][1], ph, pm, pl, 0);
-          xsplit2v(st[qt][2], st[qt][3], ph, pm, pl, 1);
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            f32x4 acc = o[qt][dt];
-            acc = xmfma_bf16(vm[dt], pm, acc);
-            acc = xmfma_bf16(vh[dt], pl, acc);
-            acc = xmfma_bf16(vl[dt], ph, acc);
-            acc = xmfma_bf16(vh[dt], pm, acc);
-            acc = xmfma_bf16(vm[dt], ph, acc);
-            acc = xmfma_bf16(vh[dt], ph, acc);
-            o[qt][dt] = acc;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = sub * 16 + g * 4 + r;
-          const int ch = (h * 8 + (j >> 1)) ^ (row & 15);
-          const float2 vf = *reinterpret_cast<const float2*>(tb + TK * 256 + row * 256 + ch * 4 + (j & 1) * 2);
-#pragma unroll
-          for (int qt = 0; qt < XQT; ++qt) {
-            o[qt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, st[qt][r], o[qt][0], 0, 0, 0);
-            o[qt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, st[qt][r], o[qt][1], 0, 0, 0);
-          }
+          o[qt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, st[qt][r], o[qt][0], 0, 0, 0);
+          o[qt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, st[qt][r], o[qt][1], 0, 0, 0);
         }
       }
     }
@@ -379,6 +293,303 @@ __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
       float mo = mrun[qt], lo = lrun[qt];
       if (LEAN) { lo = group_sum4(lo); mo *= 0.6931471805599453f; }        // log2 domain -> natural, -inf stays -inf
       if (g == 0) *reinterpret_cast<float2*>(part_ml + (slot * Q + q) * 2) = make_float2(mo, lo);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same attention on the bf16 matrix pipe, exact: every f32 operand is split into three bf16 limbs (hi + mid + lo == x,
+// the scheme of gemm_bf16x3.hip) and a product is the six limb products of weight >= 2^-16 accumulated in f32 --
+// f32-class error (tests/test_xattn.py runs both kernels against the same f64 statement at the same tolerance).
+// ------------------------------------------------------------------------------------------------
+typedef float xf32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 xbf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned xu32x2 __attribute__((ext_vector_type(2)));
+typedef short xs16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void xsplit2(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(xf32x2{a0, a1}, xbf16x2));
+  const float r0 = a0 - __builtin_bit_cast(float, h << 16), r1 = a1 - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(xf32x2{r0, r1}, xbf16x2));
+  const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(xf32x2{s0, s1}, xbf16x2));
+}
+__device__ __forceinline__ void xsplit2v(float a0, float a1, xu32x4& h, xu32x4& m, xu32x4& l, int i) {
+  unsigned x, y, z;
+  xsplit2(a0, a1, x, y, z);
+  h[i] = x; m[i] = y; l[i] = z;
+}
+__device__ __forceinline__ void xsplit2w(float a0, float a1, xu32x2& h, xu32x2& m, xu32x2& l, int i) {
+  unsigned x, y, z;
+  xsplit2(a0, a1, x, y, z);
+  h[i] = x; m[i] = y; l[i] = z;
+}
+// 32-deep: lane (row/col j, k-group g) holds k = 8g..8g+7 -- the eight head dims a lane of the f32 kernel keeps
+__device__ __forceinline__ f32x4 xmfma_bf16(xu32x4 a, xu32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xbf16x8, a), __builtin_bit_cast(xbf16x8, b), c, 0, 0, 0);
+}
+// 16-deep (two VGPRs per operand): lane (row/col j, k-group g) holds k = 4g..4g+3 -- the four keys a lane group owns
+__device__ __forceinline__ f32x4 xmfma_bf16_k16(xu32x2 a, xu32x2 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(xs16x4, a), __builtin_bit_cast(xs16x4, b), c, 0, 0, 0);
+}
+
+constexpr int TKB = 16;                                   // keys per LDS tile = one S^T tile
+constexpr int XBX_RING = 3;                               // tiles in the ring: one consumed, two in flight
+constexpr int xbx_tile_floats(int hw) { return TKB * hw * 32 * 2 + TKB * 4; }     // K rows + V rows of hw heads + mask words
+constexpr int xbx_lds_floats(int hw) { return XBX_RING * xbx_tile_floats(hw) + hw * XQT * 64 * 4; }   // + low limbs of Q
+
+// Workgroup = (batch, key range) [HW = 8 heads, whole 1 KiB rows] or (batch, key range, half of the heads) [HW = 4, 512 B
+// runs of every row]; wave = head.  Registers are the scarce resource: per lane, Q as three limbs is 84 VGPRs, O^T 56,
+// S^T 28, the running maximum / sum 14 -- so the LOW limb of Q lives in LDS (read a query tile ahead, 4 VGPRs), and the K/V
+// tiles are 16 keys in a ring of three to make room for it.  Nothing may spill inside the key loop: a scratch reload waits
+// on vmcnt, which also counts the LDS-DMA loads in flight, and the staging pipeline would drain on every tile
+// (measured: the 24-spill first version ran at the speed of the f32 kernel).
+// The bf16 MFMA has its own pipe (the f32 MFMA of the kernel above runs at the vector rate on the VALU), but a wave issues
+// in order: measured, the matrix and vector phases of the straightforward schedule add up.  So the loop is software
+// pipelined over the query tiles, each stage pairing matrix instructions of tile s with vector work of tile s-1:
+//   stage A(s):  S^T[s] = K . Q^T[s], 6 limb products (one dependent chain)      |  mask + row maximum of tile s-1
+//   stage B(s):  P[s] = 2^(S - m), partial sums, 3-limb split                    |  O^T[s-1] += V^T . P^T[s-1] (12 MFMAs)
+// sched_barrier fences keep the pairing, and an empty asm pins each vector result where it is computed (plain arithmetic
+// is otherwise free to sink past a fence).  P.V contracts over the tile's 16 keys with v_mfma_f32_16x16x16_bf16, whose k
+// index 4g+i is the key row 4g+i of the S^T accumulator: P never leaves its lane.
+template <int HW>
+__global__ __launch_bounds__(HW * 64, HW == 8 ? 1 : 2) void xattn_partial_bf16x3_kernel(
+    const float* __restrict__ qp, const float* __restrict__ kp, const float* __restrict__ vp,
+    const uint32_t* __restrict__ bits, const uint32_t* __restrict__ flags, float* __restrict__ part_o,
+    float* __restrict__ part_ml, int Q, long long K, int NS, long long chunk) {
+  constexpr int HD = 256, D = 32, M = 8;
+  constexpr int TILE = xbx_tile_floats(HW), RS = HW * 32;            // RS: floats per staged row
+  extern __shared__ __attribute__((aligned(16))) float xl[];          // [XBX_RING][TILE] then ql[HW][XQT][64] (16 B each)
+  const int half = HW == 8 ? 0 : (int)(blockIdx.x & 1u), bs = HW == 8 ? (int)blockIdx.x : (int)(blockIdx.x >> 1);
+  const int b = bs / NS, s = bs - b * NS;
+  const int hl = threadIdx.x >> 6, lane = threadIdx.x & 63;           // hl: head within the workgroup
+  const int h = half * HW + hl;
+  const int j = lane & 15, g = lane >> 4;
+  const long long k0 = (long long)s * chunk;
+  const long long k1 = (k0 + chunk < K) ? k0 + chunk : K;
+  const bool use_mask = bits != nullptr;
+  xu32x4* qlow = reinterpret_cast<xu32x4*>(xl + XBX_RING * TILE) + hl * XQT * 64 + lane;   // [qt * 64]
+
+  xu32x4 qh[XQT], qm[XQT];
+  uint32_t honor = 0u;
+  {
+    uint32_t fw[4] = {0u, 0u, 0u, 0u};
+    if (use_mask) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) fw[k] = flags[b * 4 + k];
+    }
+#pragma unroll
+    for (int qt = 0; qt < XQT; ++qt) {
+      const int q = qt * 16 + j;
+      float qf[8];
+      if (q < Q) {
+        const float* p = qp + ((long long)b * Q + q) * HD + h * D + g * 8;
+        const float4 a = ld4(p), c = ld4(p + 4);
+        qf[0] = a.x; qf[1] = a.y; qf[2] = a.z; qf[3] = a.w; qf[4] = c.x; qf[5] = c.y; qf[6] = c.z; qf[7] = c.w;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qf[i] *= 1.4426950408889634f;     // logits in the log2 domain
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qf[i] = 0.f;
+      }
+      xu32x4 lo;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xsplit2v(qf[2 * i], qf[2 * i + 1], qh[qt], qm[qt], lo, i);
+      qlow[qt * 64] = lo;                                              // written and read by this lane only
+      if (use_mask && ((fw[qt >> 1] >> ((qt & 1) * 16 + j)) & 1u)) honor |= 1u << qt;
+    }
+  }
+  float mrun[XQT], lrun[XQT];
+  f32x4 o[XQT][2];
+#pragma unroll
+  for (int qt = 0; qt < XQT; ++qt) {
+    mrun[qt] = -INFINITY; lrun[qt] = 0.f;
+    o[qt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float* kb = kp + (long long)b * K * HD + half * RS;
+  const float* vb = vp + (long long)b * K * HD + half * RS;
+  const uint32_t* mb = use_mask ? bits + (long long)b * K * 4 : nullptr;
+  const long long klast = k1 - 1;
+
+  // HW = 8: wave w brings rows 2w, 2w+1 of K and of V (+ 8 mask dwords) of a tile; HW = 4: the half rows 4w..4w+3, two per
+  // instruction (lanes 0-31 / 32-63), + 16 mask dwords.  Rows are stored with their 16-byte chunks XOR-swizzled by the row
+  // index (applied on the source address; the LDS side of the DMA is lane-linear), see the f32 kernel.
+  auto issue = [&](long long kt, int slot) {
+    float* base = xl + slot * TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = HW == 8 ? hl * 2 + i : 2 * (hl * 2 + i) + (lane >> 5);
+      const int ln = HW == 8 ? lane : (lane & 31);
+      const int r0 = HW == 8 ? r : 2 * (hl * 2 + i);
+      long long key = kt + r;
+      key = key < klast ? key : klast;
+      const int src_chunk = ln ^ r;
+      __builtin_amdgcn_global_load_lds(kb + key * HD + src_chunk * 4,
+                                       (__attribute__((address_space(3))) void*)(base + r0 * RS), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(vb + key * HD + src_chunk * 4,
+                                       (__attribute__((address_space(3))) void*)(base + TKB * RS + r0 * RS), 16, 0, 0);
+    }
+    constexpr int MW = TKB * 4 / HW;                                   // mask dwords per wave
+    if (use_mask && lane < MW) {
+      long long word = kt + (hl * MW + lane) / 4;
+      word = word < klast ? word : klast;
+      __builtin_amdgcn_global_load_lds(mb + word * 4 + (lane & 3),
+                                       (__attribute__((address_space(3))) void*)(base + TKB * RS * 2 + hl * MW), 4, 0, 0);
+    }
+  };
+
+#define XFENCE __builtin_amdgcn_sched_barrier(0)
+#define XPIN(x) asm volatile("" : "+v"(x))
+  const int ntile = (int)((k1 - k0 + TKB - 1) / TKB);
+  if (ntile > 0) issue(k0, 0);
+  if (ntile > 1) issue(k0 + TKB, 1);
+  xu32x4 qlr = qlow[0];                                                // low limb of query tile 0
+  int slot = 0;
+  for (int t = 0; t < ntile; ++t) {
+    const long long kt = k0 + (long long)t * TKB;
+    if (t + 1 < ntile) {
+      if (use_mask) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // tile t landed, tile t+1 may be in flight
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();            // every wave's rows of tile t are in LDS, and everyone is done with tile t-1,
+    if (t + 2 < ntile) issue(kt + 2 * TKB, slot == 0 ? 2 : slot - 1);     // whose slot tile t+2 now overwrites
+    const float* tb = xl + slot * TILE;
+    const uint32_t* tm = reinterpret_cast<const uint32_t*>(tb + TKB * RS * 2);
+    slot = slot == 2 ? 0 : slot + 1;
+
+    // K fragment = two swizzled 16-byte chunks of row j
+    const float4 ka = *reinterpret_cast<const float4*>(tb + j * RS + (((hl * 8 + g * 2) ^ j) << 2));
+    const float4 kc = *reinterpret_cast<const float4*>(tb + j * RS + (((hl * 8 + g * 2 + 1) ^ j) << 2));
+    xu32x4 kh, km, kl;
+    xsplit2v(ka.x, ka.y, kh, km, kl, 0); xsplit2v(ka.z, ka.w, kh, km, kl, 1);
+    xsplit2v(kc.x, kc.y, kh, km, kl, 2); xsplit2v(kc.z, kc.w, kh, km, kl, 3);
+    uint32_t inv[4];                          // all ones for key rows past the end of the range
+#pragma unroll
+    for (int r = 0; r < 4; ++r) inv[r] = kt + g * 4 + r < k1 ? 0u : 0xffffffffu;
+    f32x4 st[XQT];
+    uint32_t need = 0u;
+    uint32_t mw[4];                          // mask words of the key rows 4g..4g+3 for a PAIR of query tiles (16 bits each)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mw[r] = tm[(g * 4 + r) * 4];
+    XFENCE;
+#pragma unroll
+    for (int s2 = 0; s2 <= XQT; ++s2) {
+      // chunk = one MFMA of S^T[s2] + one piece of the mask / maximum of tile s2-1
+      const int qc = s2 < XQT ? s2 : XQT - 1, qv = s2 > 0 ? s2 - 1 : 0;
+      const uint32_t hm = ((honor >> qv) & 1u) << ((qv & 1) * 16 + j);   // this lane's bit of the pair's word, 0 if not honoured
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (s2 < XQT) acc = xmfma_bf16(kh, qlr, acc);                   // the three small terms first
+      XFENCE;
+      if (s2 < XQT) acc = xmfma_bf16(km, qm[qc], acc);
+      qlr = qlow[(s2 + 1 < XQT ? s2 + 1 : 0) * 64];                   // next tile's low limb (tile 0 again for the next keys)
+      XFENCE;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (s2 < XQT) acc = c == 0 ? xmfma_bf16(kl, qh[qc], acc) : c == 1 ? xmfma_bf16(kh, qm[qc], acc)
+                          : c == 2 ? xmfma_bf16(km, qh[qc], acc) : xmfma_bf16(kh, qh[qc], acc);
+        if (s2 > 0) {
+          float v = ((mw[c] & hm) | inv[c]) ? -INFINITY : st[qv][c];   // v_and_or, v_cmp, v_cndmask: no scalar detour
+          XPIN(v);
+          st[qv][c] = v;
+        }
+        XFENCE;
+      }
+      if (s2 < XQT) st[qc] = acc;
+      if (s2 > 0) {
+        float tl = fmaxf(fmaxf(st[qv][0], st[qv][1]), fmaxf(st[qv][2], st[qv][3]));
+        XPIN(tl);
+        need |= (uint32_t)(tl > mrun[qv] + 10.f);
+        if ((qv & 1) && qv + 1 < XQT) {                               // last use of this pair's words: fetch the next pair's
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mw[r] = tm[(g * 4 + r) * 4 + ((qv + 1) >> 1)];
+        }
+      }
+      XFENCE;
+    }
+    // lean online soft-max (see the f32 kernel): the reference maximum may go stale by 10 (log2 domain) before a wave vote
+    // takes the rare path that renews it and rescales O and l
+    if (__ballot(need != 0u) != 0ull) {
+#pragma unroll
+      for (int qt = 0; qt < XQT; ++qt) {
+        const float tl = fmaxf(fmaxf(st[qt][0], st[qt][1]), fmaxf(st[qt][2], st[qt][3]));
+        const float mnew = fmaxf(mrun[qt], group_max4(tl));
+        const float alpha = (mnew == -INFINITY) ? 1.f : exp2f(mrun[qt] - mnew);
+        lrun[qt] *= alpha;
+        o[qt][0] *= alpha;
+        o[qt][1] *= alpha;
+        mrun[qt] = mnew;
+      }
+    }
+    float2 vf[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = g * 4 + r;
+      const int ch = (hl * 8 + (j >> 1)) ^ row;
+      vf[r] = *reinterpret_cast<const float2*>(tb + TKB * RS + row * RS + ch * 4 + (j & 1) * 2);
+    }
+    xu32x2 vh[2], vm[2], vl[2];
+    xsplit2w(vf[0].x, vf[1].x, vh[0], vm[0], vl[0], 0);
+    xsplit2w(vf[2].x, vf[3].x, vh[0], vm[0], vl[0], 1);
+    xsplit2w(vf[0].y, vf[1].y, vh[1], vm[1], vl[1], 0);
+    xsplit2w(vf[2].y, vf[3].y, vh[1], vm[1], vl[1], 1);
+    xu32x2 ph[2], pm[2], pl[2];
+    XFENCE;
+#pragma unroll
+    for (int s2 = 0; s2 <= XQT; ++s2) {
+      // chunk = the two MFMAs (one per 16-row half of O^T) of one limb product of tile s2-1 + a piece of P[s2]
+      const int qc = s2 < XQT ? s2 : XQT - 1, bc = s2 & 1, qv = s2 > 0 ? s2 - 1 : 0, bv = qv & 1;
+      f32x4 a0 = o[qv][0], a1 = o[qv][1];
+      xf32x2 p01, p23;
+      if (s2 > 0) { a0 = xmfma_bf16_k16(vm[0], pm[bv], a0); a1 = xmfma_bf16_k16(vm[1], pm[bv], a1); }
+      const float mref = (mrun[qc] == -INFINITY) ? 0.f : mrun[qc];        // nothing unblocked yet: every p = 2^-inf = 0
+      if (s2 < XQT) {
+        p01[0] = __builtin_amdgcn_exp2f(st[qc][0] - mref);                // raw v_exp_f32: arguments <= 10, and a result
+        p01[1] = __builtin_amdgcn_exp2f(st[qc][1] - mref);                // below 2^-126 may flush to zero
+        XPIN(p01);
+      }
+      XFENCE;
+      if (s2 > 0) { a0 = xmfma_bf16_k16(vh[0], pl[bv], a0); a1 = xmfma_bf16_k16(vh[1], pl[bv], a1); }
+      if (s2 < XQT) {
+        p23[0] = __builtin_amdgcn_exp2f(st[qc][2] - mref);
+        p23[1] = __builtin_amdgcn_exp2f(st[qc][3] - mref);
+        XPIN(p23);
+        const xf32x2 ps = p01 + p23;
+        lrun[qc] += ps[0] + ps[1];                                         // per-lane partial: groups merged at the end
+        XPIN(lrun[qc]);
+      }
+      XFENCE;
+      // P limbs of tile s2 go to buffer bc, the MFMAs read buffer bv = the other one
+      if (s2 > 0) { a0 = xmfma_bf16_k16(vl[0], ph[bv], a0); a1 = xmfma_bf16_k16(vl[1], ph[bv], a1); }
+      if (s2 < XQT) { xsplit2w(p01[0], p01[1], ph[bc], pm[bc], pl[bc], 0); XPIN(pl[bc]); }
+      XFENCE;
+      if (s2 > 0) { a0 = xmfma_bf16_k16(vh[0], pm[bv], a0); a1 = xmfma_bf16_k16(vh[1], pm[bv], a1); }
+      if (s2 < XQT) { xsplit2w(p23[0], p23[1], ph[bc], pm[bc], pl[bc], 1); XPIN(pl[bc]); }
+      XFENCE;
+      if (s2 > 0) {
+        a0 = xmfma_bf16_k16(vm[0], ph[bv], a0); a1 = xmfma_bf16_k16(vm[1], ph[bv], a1);
+        a0 = xmfma_bf16_k16(vh[0], ph[bv], a0); a1 = xmfma_bf16_k16(vh[1], ph[bv], a1);
+        o[qv][0] = a0; o[qv][1] = a1;
+      }
+      XFENCE;
+    }
+  }
+#undef XFENCE
+#undef XPIN
+
+  const long long slot_o = ((long long)b * NS + s) * M + h;
+#pragma unroll
+  for (int qt = 0; qt < XQT; ++qt) {
+    const int q = qt * 16 + j;
+    if (q < Q) {
+      float* op = part_o + (slot_o * Q + q) * D + g * 8;
+      st4(op, make_float4(o[qt][0][0], o[qt][1][0], o[qt][0][1], o[qt][1][1]));
+      st4(op + 4, make_float4(o[qt][0][2], o[qt][1][2], o[qt][0][3], o[qt][1][3]));
+      const float mo = mrun[qt] * 0.6931471805599453f, lo = group_sum4(lrun[qt]);   // log2 domain -> natural, -inf stays -inf
+      if (g == 0) *reinterpret_cast<float2*>(part_ml + (slot_o * Q + q) * 2) = make_float2(mo, lo);
     }
   }
 }
@@ -518,22 +729,42 @@ extern "C" int pvsg_masked_xattn_partial(const float* q_proj, const float* k_pro
   // ranges past the end are legal: they publish (m=-inf, l=0, o=0) and the merge skips them
   chunk = (chunk + TK - 1) / TK * TK;
   const size_t lds = (size_t)2 * XLDS_TILE_FLOATS * sizeof(float);
-  // PVSG_XATTN=f32 selects the f32-MFMA kernels (default: exact three-limb bf16 split on the bf16 matrix path);
-  // PVSG_XATTN_LEAN=0 the textbook online soft-max
-  static const bool lean = []() { const char* e = getenv("PVSG_XATTN_LEAN"); return !(e && e[0] == '0'); }();
-  static const bool bx = []() { const char* e = getenv("PVSG_XATTN"); return !(e && e[0] == 'f'); }();
-  using kern_t = void (*)(const float*, const float*, const float*, const uint32_t*, const uint32_t*, float*, float*, int,
-                          long long, int, long long);
-  static const kern_t kern = bx ? (lean ? &xattn_partial_lds_kernel<true, true> : &xattn_partial_lds_kernel<false, true>)
-                                : (lean ? &xattn_partial_lds_kernel<true, false> : &xattn_partial_lds_kernel<false, false>);
   static std::atomic<unsigned long long> attr_done;
   {
-    const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, attr_done);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&xattn_partial_lds_kernel<true>), (int)lds, attr_done);
+    static std::atomic<unsigned long long> attr_done2;
+    if (e == hipSuccess) e = ensure_dynamic_lds(reinterpret_cast<const void*>(&xattn_partial_lds_kernel<false>), (int)lds, attr_done2);
     if (e != hipSuccess)
       return set_err(PVSG_ERR_HIP, "masked_xattn_partial: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(kern, dim3(B * NS), dim3(512), lds, stream, q_proj, k_proj, v_proj, mask_bits, mask_flags, part_o,
-                     part_ml, Q, K, NS, chunk);
+  // default: the bf16-split kernel (f32-exact on the bf16 matrix pipe).  PVSG_XATTN=f32 selects the f32-MFMA kernel,
+  // PVSG_XATTN_LEAN=0 its textbook online soft-max, PVSG_XATTN_HW=4 half-head workgroups for the split kernel
+  static const bool lean = []() { const char* e = getenv("PVSG_XATTN_LEAN"); return !(e && e[0] == '0'); }();
+  static const bool bx = []() { const char* e = getenv("PVSG_XATTN"); return !(e && e[0] == 'f'); }() && lean;
+  static const bool hw4 = []() { const char* e = getenv("PVSG_XATTN_HW"); return e && e[0] == '4'; }();
+  if (bx) {
+    const long long cb = (chunk + TKB - 1) / TKB * TKB;
+    const int hw = hw4 ? 4 : 8;
+    const size_t ldsb = (size_t)xbx_lds_floats(hw) * sizeof(float);
+    const void* kern = hw4 ? reinterpret_cast<const void*>(&xattn_partial_bf16x3_kernel<4>)
+                           : reinterpret_cast<const void*>(&xattn_partial_bf16x3_kernel<8>);
+    static std::atomic<unsigned long long> attr_done3;
+    const hipError_t e = ensure_dynamic_lds(kern, (int)ldsb, attr_done3);
+    if (e != hipSuccess)
+      return set_err(PVSG_ERR_HIP, "masked_xattn_partial: cannot reserve %zu bytes of LDS: %s", ldsb, hipGetErrorString(e));
+    if (hw4)
+      hipLaunchKernelGGL(xattn_partial_bf16x3_kernel<4>, dim3(B * NS * 2), dim3(256), ldsb, stream, q_proj, k_proj, v_proj,
+                         mask_bits, mask_flags, part_o, part_ml, Q, K, NS, cb);
+    else
+      hipLaunchKernelGGL(xattn_partial_bf16x3_kernel<8>, dim3(B * NS), dim3(512), ldsb, stream, q_proj, k_proj, v_proj,
+                         mask_bits, mask_flags, part_o, part_ml, Q, K, NS, cb);
+  } else if (lean) {
+    hipLaunchKernelGGL(xattn_partial_lds_kernel<true>, dim3(B * NS), dim3(512), lds, stream, q_proj, k_proj, v_proj,
+                       mask_bits, mask_flags, part_o, part_ml, Q, K, NS, chunk);
+  } else {
+    hipLaunchKernelGGL(xattn_partial_lds_kernel<false>, dim3(B * NS), dim3(512), lds, stream, q_proj, k_proj, v_proj,
+                       mask_bits, mask_flags, part_o, part_ml, Q, K, NS, chunk);
+  }
   PVSG_LAUNCH_CHECK("masked_xattn_partial");
   return PVSG_OK;
 }

@@ -91,7 +91,10 @@ def bench_xattn(frames):
     from openpvsg_amd import ops
     dev = torch.device('cuda:0')
     Q = 100
-    for hw in ((23, 40), (46, 80), (92, 160)):
+    levels = ((23, 40), (46, 80), (92, 160))
+    if os.environ.get('KBENCH_XATTN_LEVEL'):                 # one level only (counter runs: one dispatch shape)
+        levels = (levels[int(os.environ['KBENCH_XATTN_LEVEL'])],)
+    for hw in levels:
         K = frames * hw[0] * hw[1]
         q = torch.randn(1, Q, 256, device=dev) * 0.2
         k = torch.randn(1, K, 256, device=dev)
