@@ -38,6 +38,8 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TF = 157.3     # f32-input MFMA peak
 BF16_MFMA_PEAK_TF = 2516.6   # dense bf16 MFMA peak (16 x the f32 matrix rate)
+# the library's switch for the masked cross-attention kernel (csrc/masked_xattn.hip): anything starting with 'f' = f32 MFMA
+XATTN_F32 = os.environ.get('PVSG_XATTN', '')[:1] == 'f' or os.environ.get('PVSG_XATTN_LEAN', '')[:1] == '0'
 CLS_GAIN = 40.0              # random-init class logits are flat; peaky logits keep a few queries
 
 
@@ -191,7 +193,8 @@ class KernelTimer:
             return 4.0 * B * T * N * C + 16.0 * B * T * N, 2.0 * B * T * Q * C * N
         if name == 'pvsg_masked_xattn_partial':
             B, Q, K, M, D, NS = a[7:13]
-            return B * K * (2.0 * M * D * 4 + (16 if a[3] else 0)) + 4.0 * B * NS * M * Q * (D + 2), 4.0 * B * Q * M * D * K
+            limb = 1.0 if XATTN_F32 else 6.0        # default kernel: six bf16 limb products per f32 multiply-add
+            return B * K * (2.0 * M * D * 4 + (16 if a[3] else 0)) + 4.0 * B * NS * M * Q * (D + 2), limb * 4.0 * B * Q * M * D * K
         if name == 'pvsg_affine_act_nchw':
             planes, C, HW = a[5:8]
             return 4.0 * planes * HW * (3 if a[3] else 2), 0.0
@@ -281,7 +284,8 @@ class KernelTimer:
     @staticmethod
     def mfma_peak(name):
         """(peak TFLOP/s, what the flops of work() count) of the matrix pipe a kernel runs on."""
-        if name.startswith(('pvsg_gemm_bf16x3', 'pvsg_conv1x1_bf16x3', 'pvsg_mask_logits_bf16x3', 'pvsg_attn_mask_bits_bf16x3')):
+        if name.startswith(('pvsg_gemm_bf16x3', 'pvsg_conv1x1_bf16x3', 'pvsg_mask_logits_bf16x3', 'pvsg_attn_mask_bits_bf16x3')) \
+                or (name.startswith('pvsg_masked_xattn_partial') and not XATTN_F32):
             return BF16_MFMA_PEAK_TF, 'bf16 limb products issued (6 per f32 multiply-add), dense bf16 MFMA peak'
         return F32_MFMA_PEAK_TF, 'f32 MFMA'
 

@@ -1,5 +1,8 @@
-// Masked cross-attention of the Mask2Former transformer decoder, streaming (flash-style), exact
-// f32 on the gfx950 matrix cores.
+// Masked cross-attention of the Mask2Former transformer decoder, streaming (flash-style), f32-exact on the gfx950 matrix
+// cores.  Two kernels behind one entry point: `xattn_partial_bf16x3_kernel` (default since round 3: every f32 operand as
+// three bf16 limbs on the bf16 matrix pipe, 0.516 ms = 93 TF/s of model arithmetic at 471 040 keys) and
+// `xattn_partial_lds_kernel` (f32 MFMA, 0.705 ms = 68 TF/s; PVSG_XATTN=f32).  Both are described at their definitions;
+// the common design is below.
 //
 // Replaces: [3P] mmcv MultiheadAttention -> nn.MultiheadAttention(attn_mask=bool (B*8,Q,K)) as called
 //   by the decoder loop, models/mask2former/mask2former_head.py:457-468 and
@@ -352,7 +355,20 @@ constexpr int xbx_lds_floats(int hw) { return XBX_RING * xbx_tile_floats(hw) + h
 //   stage A(s):  S^T[s] = K . Q^T[s], 6 limb products (one dependent chain)      |  mask + row maximum of tile s-1
 //   stage B(s):  P[s] = 2^(S - m), partial sums, 3-limb split                    |  O^T[s-1] += V^T . P^T[s-1] (12 MFMAs)
 // sched_barrier fences keep the pairing, and an empty asm pins each vector result where it is computed (plain arithmetic
-// is otherwise free to sink past a fence).  P.V contracts over the tile's 16 keys with v_mfma_f32_16x16x16_bf16, whose k
+// is otherwise free to sink past a fence).
+// Measured on the way (471 040 keys; scripts/lab/issue_lab.hip, valu_lab.hip, pmc_xattn.sh, profiles/r03_xattn_*):
+//   straightforward schedule (all MFMAs of a phase, then its vector work), 24 spilled VGPRs      0.705 ms (= the f32 kernel)
+//   + stages paired as above, P.V on the 16-deep MFMA (2 VGPRs per operand)                       0.590 ms
+//   + low Q limb in LDS, 16-key ring: no spill in the loop (expected to be the big one: it was not)  0.592 ms
+//   + mask select without the scalar detour (v_and_or / v_cmp / v_cndmask), vote flag as integer  0.564 ms
+//   + v_max3 by asm (no re-quieting), row-validity words only in the last tile                    0.537 ms
+//   + half-head workgroups (HW = 4)                                                               0.516 ms
+// One barrier per tile placed between the stages with the LDS reads of the next tile behind it: 0.575 ms (slower: one
+// tile in flight instead of two).  Counters at 0.59 ms: matrix pipe 38 % busy, a wave issues 39 % of its cycles
+// (VALU 28 %, scalar 9.5 %), waits to issue 21 %, waits on a dependency 40 %; the lab puts an MFMA at ~6.5 issue cycles
+// next to 4.2 per VALU instruction and shows a dependent MFMA chain hiding NO vector work of the same wave, two
+// independent chains most of it.  What is left is instruction count (about 460 VALU + 126 MFMA per wave and 16 keys,
+// 154 of the VALU in the three-limb split of P): every instruction removed showed up in the time.  P.V contracts over the tile's 16 keys with v_mfma_f32_16x16x16_bf16, whose k
 // index 4g+i is the key row 4g+i of the S^T accumulator: P never leaves its lane.
 template <int HW>
 __global__ __launch_bounds__(HW * 64, HW == 8 ? 1 : 2) void xattn_partial_bf16x3_kernel(
@@ -401,11 +417,14 @@ __global__ __launch_bounds__(HW * 64, HW == 8 ? 1 : 2) void xattn_partial_bf16x3
       if (use_mask && ((fw[qt >> 1] >> ((qt & 1) * 16 + j)) & 1u)) honor |= 1u << qt;
     }
   }
+  // running reference maximum (log2 domain); "nothing unblocked yet" is the finite XNONE instead of -inf, so that
+  // 2^(s - m) needs no special case: s = -inf gives 0, and a finite s against XNONE trips the renewal vote first
+  constexpr float XNONE = -1.0e30f;
   float mrun[XQT], lrun[XQT];
   f32x4 o[XQT][2];
 #pragma unroll
   for (int qt = 0; qt < XQT; ++qt) {
-    mrun[qt] = -INFINITY; lrun[qt] = 0.f;
+    mrun[qt] = XNONE; lrun[qt] = 0.f;
     o[qt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float* kb = kp + (long long)b * K * HD + half * RS;
@@ -446,6 +465,7 @@ __global__ __launch_bounds__(HW * 64, HW == 8 ? 1 : 2) void xattn_partial_bf16x3
   if (ntile > 0) issue(k0, 0);
   if (ntile > 1) issue(k0 + TKB, 1);
   xu32x4 qlr = qlow[0];                                                // low limb of query tile 0
+  uint32_t inv[4] = {0u, 0u, 0u, 0u};     // all ones for key rows past the end of the range (last tile only)
   int slot = 0;
   for (int t = 0; t < ntile; ++t) {
     const long long kt = k0 + (long long)t * TKB;
@@ -467,9 +487,10 @@ __global__ __launch_bounds__(HW * 64, HW == 8 ? 1 : 2) void xattn_partial_bf16x3
     xu32x4 kh, km, kl;
     xsplit2v(ka.x, ka.y, kh, km, kl, 0); xsplit2v(ka.z, ka.w, kh, km, kl, 1);
     xsplit2v(kc.x, kc.y, kh, km, kl, 2); xsplit2v(kc.z, kc.w, kh, km, kl, 3);
-    uint32_t inv[4];                          // all ones for key rows past the end of the range
+    if (t == ntile - 1) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) inv[r] = kt + g * 4 + r < k1 ? 0u : 0xffffffffu;
+      for (int r = 0; r < 4; ++r) inv[r] = kt + g * 4 + r < k1 ? 0u : 0xffffffffu;
+    }
     f32x4 st[XQT];
     uint32_t need = 0u;
     uint32_t mw[4];                          // mask words of the key rows 4g..4g+3 for a PAIR of query tiles (16 bits each)
@@ -500,8 +521,10 @@ __global__ __launch_bounds__(HW * 64, HW == 8 ? 1 : 2) void xattn_partial_bf16x3
       }
       if (s2 < XQT) st[qc] = acc;
       if (s2 > 0) {
-        float tl = fmaxf(fmaxf(st[qv][0], st[qv][1]), fmaxf(st[qv][2], st[qv][3]));
-        XPIN(tl);
+        // (asm: the values are already canonical, fmaxf would re-quiet every input; it also pins the result here)
+        float tl;
+        asm volatile("v_max_f32 %0, %1, %2\n\tv_max3_f32 %0, %3, %4, %0"
+                     : "=&v"(tl) : "v"(st[qv][2]), "v"(st[qv][3]), "v"(st[qv][0]), "v"(st[qv][1]));
         need |= (uint32_t)(tl > mrun[qv] + 10.f);
         if ((qv & 1) && qv + 1 < XQT) {                               // last use of this pair's words: fetch the next pair's
 #pragma unroll
@@ -517,7 +540,7 @@ __global__ __launch_bounds__(HW * 64, HW == 8 ? 1 : 2) void xattn_partial_bf16x3
       for (int qt = 0; qt < XQT; ++qt) {
         const float tl = fmaxf(fmaxf(st[qt][0], st[qt][1]), fmaxf(st[qt][2], st[qt][3]));
         const float mnew = fmaxf(mrun[qt], group_max4(tl));
-        const float alpha = (mnew == -INFINITY) ? 1.f : exp2f(mrun[qt] - mnew);
+        const float alpha = exp2f(mrun[qt] - mnew);                     // XNONE -> finite: 0 (O and l are still 0); equal: 1
         lrun[qt] *= alpha;
         o[qt][0] *= alpha;
         o[qt][1] *= alpha;
@@ -545,21 +568,22 @@ __global__ __launch_bounds__(HW * 64, HW == 8 ? 1 : 2) void xattn_partial_bf16x3
       f32x4 a0 = o[qv][0], a1 = o[qv][1];
       xf32x2 p01, p23;
       if (s2 > 0) { a0 = xmfma_bf16_k16(vm[0], pm[bv], a0); a1 = xmfma_bf16_k16(vm[1], pm[bv], a1); }
-      const float mref = (mrun[qc] == -INFINITY) ? 0.f : mrun[qc];        // nothing unblocked yet: every p = 2^-inf = 0
+      const xf32x2 mref = {mrun[qc], mrun[qc]};
       if (s2 < XQT) {
-        p01[0] = __builtin_amdgcn_exp2f(st[qc][0] - mref);                // raw v_exp_f32: arguments <= 10, and a result
-        p01[1] = __builtin_amdgcn_exp2f(st[qc][1] - mref);                // below 2^-126 may flush to zero
+        const xf32x2 d01 = xf32x2{st[qc][0], st[qc][1]} - mref;           // one v_pk_add_f32
+        p01[0] = __builtin_amdgcn_exp2f(d01[0]);                          // raw v_exp_f32: arguments <= 10, and a result
+        p01[1] = __builtin_amdgcn_exp2f(d01[1]);                          // below 2^-126 may flush to zero
         XPIN(p01);
       }
       XFENCE;
       if (s2 > 0) { a0 = xmfma_bf16_k16(vh[0], pl[bv], a0); a1 = xmfma_bf16_k16(vh[1], pl[bv], a1); }
       if (s2 < XQT) {
-        p23[0] = __builtin_amdgcn_exp2f(st[qc][2] - mref);
-        p23[1] = __builtin_amdgcn_exp2f(st[qc][3] - mref);
+        const xf32x2 d23 = xf32x2{st[qc][2], st[qc][3]} - mref;
+        p23[0] = __builtin_amdgcn_exp2f(d23[0]);
+        p23[1] = __builtin_amdgcn_exp2f(d23[1]);
         XPIN(p23);
         const xf32x2 ps = p01 + p23;
         lrun[qc] += ps[0] + ps[1];                                         // per-lane partial: groups merged at the end
-        XPIN(lrun[qc]);
       }
       XFENCE;
       // P limbs of tile s2 go to buffer bc, the MFMAs read buffer bv = the other one
@@ -588,7 +612,8 @@ __global__ __launch_bounds__(HW * 64, HW == 8 ? 1 : 2) void xattn_partial_bf16x3
       float* op = part_o + (slot_o * Q + q) * D + g * 8;
       st4(op, make_float4(o[qt][0][0], o[qt][1][0], o[qt][0][1], o[qt][1][1]));
       st4(op + 4, make_float4(o[qt][0][2], o[qt][1][2], o[qt][0][3], o[qt][1][3]));
-      const float mo = mrun[qt] * 0.6931471805599453f, lo = group_sum4(lrun[qt]);   // log2 domain -> natural, -inf stays -inf
+      // log2 domain -> natural; a range with nothing unblocked publishes m = -inf (the merge skips it)
+      const float mo = mrun[qt] == XNONE ? -INFINITY : mrun[qt] * 0.6931471805599453f, lo = group_sum4(lrun[qt]);
       if (g == 0) *reinterpret_cast<float2*>(part_ml + (slot_o * Q + q) * 2) = make_float2(mo, lo);
     }
   }
@@ -737,19 +762,21 @@ extern "C" int pvsg_masked_xattn_partial(const float* q_proj, const float* k_pro
     if (e != hipSuccess)
       return set_err(PVSG_ERR_HIP, "masked_xattn_partial: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
   }
-  // default: the bf16-split kernel (f32-exact on the bf16 matrix pipe).  PVSG_XATTN=f32 selects the f32-MFMA kernel,
-  // PVSG_XATTN_LEAN=0 its textbook online soft-max, PVSG_XATTN_HW=4 half-head workgroups for the split kernel
-  static const bool lean = []() { const char* e = getenv("PVSG_XATTN_LEAN"); return !(e && e[0] == '0'); }();
-  static const bool bx = []() { const char* e = getenv("PVSG_XATTN"); return !(e && e[0] == 'f'); }() && lean;
-  static const bool hw4 = []() { const char* e = getenv("PVSG_XATTN_HW"); return e && e[0] == '4'; }();
+  // default: the bf16-split kernel (f32-exact on the bf16 matrix pipe), half-head workgroups.  PVSG_XATTN=f32 selects the
+  // f32-MFMA kernel, PVSG_XATTN_LEAN=0 its textbook online soft-max, PVSG_XATTN_HW=8 whole-row workgroups for the split
+  // kernel.  Read per call (a getenv is nanoseconds against a launch) so that one process can test them all.
+  const auto env_is = [](const char* name, char c) { const char* e = getenv(name); return e && e[0] == c; };
+  const bool lean = !env_is("PVSG_XATTN_LEAN", '0');
+  const bool bx = !env_is("PVSG_XATTN", 'f') && lean;
+  const bool hw4 = !env_is("PVSG_XATTN_HW", '8');
   if (bx) {
     const long long cb = (chunk + TKB - 1) / TKB * TKB;
     const int hw = hw4 ? 4 : 8;
     const size_t ldsb = (size_t)xbx_lds_floats(hw) * sizeof(float);
     const void* kern = hw4 ? reinterpret_cast<const void*>(&xattn_partial_bf16x3_kernel<4>)
                            : reinterpret_cast<const void*>(&xattn_partial_bf16x3_kernel<8>);
-    static std::atomic<unsigned long long> attr_done3;
-    const hipError_t e = ensure_dynamic_lds(kern, (int)ldsb, attr_done3);
+    static std::atomic<unsigned long long> attr_done3, attr_done4;
+    const hipError_t e = ensure_dynamic_lds(kern, (int)ldsb, hw4 ? attr_done4 : attr_done3);
     if (e != hipSuccess)
       return set_err(PVSG_ERR_HIP, "masked_xattn_partial: cannot reserve %zu bytes of LDS: %s", ldsb, hipGetErrorString(e));
     if (hw4)

@@ -11,6 +11,17 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
+@pytest.fixture(autouse=True, params=['bf16x3', 'bf16x3-hw8', 'f32'])
+def xattn_kernel(request, monkeypatch):
+    """Every test runs against the default kernel (exact three-limb bf16 split, half-head workgroups), its whole-row
+    form and the f32-MFMA kernel -- same oracle, same tolerances (the library reads the switches per call)."""
+    if request.param == 'f32':
+        monkeypatch.setenv('PVSG_XATTN', 'f32')
+    elif request.param == 'bf16x3-hw8':
+        monkeypatch.setenv('PVSG_XATTN_HW', '8')
+    return request.param
+
+
 def oracle_mha(mha, q_in, k_in, v_in, mask_bool):
     """q_in (B,Q,C), k_in/v_in (B,K,C), mask (B,Q,K) bool or None -> attention output before the
     residual, via torch's own nn.MultiheadAttention (the reference path)."""
