@@ -76,6 +76,20 @@ inline hipError_t ensure_dynamic_lds(const void* fn, int bytes, std::atomic<unsi
   return e;
 }
 
+// Zero a small device buffer with a KERNEL, never hipMemsetAsync: captured into a hipGraph, the memset node of these
+// 16-byte .. few-KiB buffers did not reliably run before the kernel node that follows it (ROCm 7.2, MI355X) -- replays kept
+// the previous call's 'has an unblocked key' flags and produced NaN rows (scripts/lab/graph_bisect.py found it).
+static __global__ void zero_words_kernel(unsigned* __restrict__ p, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+inline hipError_t zero_words_async(void* p, size_t bytes, hipStream_t stream) {
+  const long long n = (long long)(bytes / 4);
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, static_cast<unsigned*>(p), n);
+  return hipGetLastError();
+}
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

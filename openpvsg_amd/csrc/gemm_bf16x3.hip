@@ -533,7 +533,7 @@ extern "C" int pvsg_attn_mask_bits_bf16x3(const float* mask_embed, const float* 
     return set_err(PVSG_ERR_UNSUPPORTED, "attn_mask_bits_bf16x3: built for C %% 16 == 0, Q <= 128, C*N < 2^29, 16B-aligned bits (got Q=%d C=%d N=%lld)",
                    Q, C, N);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * 4 * sizeof(uint32_t), st);
+  hipError_t e = zero_words_async(flags, (size_t)B * 4 * sizeof(uint32_t), st);
   if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "attn_mask_bits_bf16x3: memset: %s", hipGetErrorString(e));
   const long long welems = pvsg_gemm_bf16x3_packed_elems(Q, C);
   const int tiles_p = (int)((N + GB_N - 1) / GB_N);

@@ -318,7 +318,7 @@ extern "C" int pvsg_attn_mask_bits_forward(const float* mask_embed, const float*
                    "attn_mask_bits_forward: needs Q<=112, C%%16==0, C<=320, 16B-aligned bits "
                    "(got Q=%d C=%d N=%d)", Q, C, N);
   const bool vec = !(N & 3) && !(reinterpret_cast<uintptr_t>(feature_lowres) & 15u);
-  hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * 4 * sizeof(uint32_t), stream);
+  hipError_t e = zero_words_async(flags, (size_t)B * 4 * sizeof(uint32_t), stream);
   if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "attn_mask_bits_forward: memset: %s", hipGetErrorString(e));
   int tpi, wpb;
   launch_cfg(B, T, N, &tpi, &wpb);
@@ -347,7 +347,7 @@ extern "C" int pvsg_attn_mask_pack(const float* logits_lowres, uint32_t* bits, u
   PVSG_REQUIRE(B > 0 && T > 0 && Q > 0 && HW > 0, "attn_mask_pack: non-positive dimension");
   PVSG_REQUIRE(Q <= 128, "attn_mask_pack: at most 128 queries (got %d)", Q);
   PVSG_REQUIRE((reinterpret_cast<uintptr_t>(bits) & 15u) == 0, "attn_mask_pack: bits must be 16B aligned");
-  hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * 4 * sizeof(uint32_t), stream);
+  hipError_t e = zero_words_async(flags, (size_t)B * 4 * sizeof(uint32_t), stream);
   if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "attn_mask_pack: memset: %s", hipGetErrorString(e));
   const long long K = (long long)T * HW;
   long long nb = (K + 255) / 256;

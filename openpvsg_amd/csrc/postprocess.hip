@@ -390,7 +390,7 @@ extern "C" int pvsg_panoptic_fuse(const float* mask_logits, const int* kept_idx,
   PVSG_REQUIRE(K >= 0 && K <= MAXK - 1, "panoptic_fuse: at most %d kept queries (got %d)", MAXK - 1, K);
   PVSG_REQUIRE(K == 0 || (kept_idx && kept_score && kept_class && seg_id), "panoptic_fuse: null kept-query tables");
   const long long npix = (long long)oh * ow;
-  hipError_t e = hipMemsetAsync(counter_ws, 0, (size_t)T * 3 * MAXK * sizeof(int), stream);
+  hipError_t e = zero_words_async(counter_ws, (size_t)T * 3 * MAXK * sizeof(int), stream);
   if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "panoptic_fuse: memset: %s", hipGetErrorString(e));
   if (K > 0) {
     if (oh != ih || ow != iw)

@@ -57,13 +57,12 @@ class _Base(BaseModule):
         self.num_classes = self.panoptic_head.num_classes
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
         self.fused_postprocess = True
-        # EXPERIMENTAL, off by default: replay backbone + pixel decoder + decoder of small calls as one hipGraph
-        # (PVSG_DETECTOR_GRAPH=on).  Measured 80 -> 96 frames/s for one 720p image per call, but the replay is NOT correct
-        # yet: on a second, different input the decoder's outputs differ from the eager ones unless every intermediate
-        # tensor of the captured region is kept alive (scripts/lab/graph_bisect.py: backbone and pixel decoder replay
-        # exactly, the first decoder layer does not) -- a buffer-lifetime issue under the graph's private pool that is
-        # still open.  The host cost per launch was cut instead (ops._stream_ptr, DecoderRows signature).
-        self.use_graph = os.environ.get('PVSG_DETECTOR_GRAPH', 'off') == 'on'
+        # Small calls (<= graph_max_frames frames) are limited by the host: backbone + pixel decoder + decoder are replayed as
+        # one hipGraph per input shape (PVSG_DETECTOR_GRAPH=off disables).  Replays are bit-equal to the eager run
+        # (tests/test_modules_gpu.py::test_detector_graph_replay_equals_eager).  History: an earlier version produced NaN
+        # rows from the second input on -- the library zeroed the attention-mask flags with hipMemsetAsync, and the
+        # captured memset node was not ordered before the kernel that ORs into them; it is a kernel now (csrc/common.h).
+        self.use_graph = os.environ.get('PVSG_DETECTOR_GRAPH', 'on') != 'off'
         self.graph_max_frames = 4
         self._graphs, self._graph_seen = {}, {}
 
