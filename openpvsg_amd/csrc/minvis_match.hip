@@ -11,6 +11,7 @@
 // scipy's solver, run by ONE wave: a lane owns columns lane and lane+64 (Q <= 128), the row potentials live
 // in LDS, the per-step arg-min is a wave reduction.  Ties are measure-zero on real embeddings.
 #include "common.h"
+#include <stdlib.h>
 
 namespace pvsg {
 
@@ -57,6 +58,75 @@ __global__ __launch_bounds__(128) void minvis_gram_kernel(const float* __restric
   }
 }
 
+// One wave: assignment of the Q x Q cost matrix in LDS (rows = target slots, columns = current queries) by shortest
+// augmenting paths in float64, rows taken in order like scipy's linear_sum_assignment ([3P], called from
+// mask2former_min_vis.py:257).  pnew[row] = column.  `u` = Q+1 row potentials in LDS.
+__device__ __forceinline__ void lap_wave(const float* __restrict__ cost, double* __restrict__ u, int* __restrict__ pnew,
+                                         int Q, int lane) {
+    const int c0 = lane + 1, c1 = lane + 65;          // 1-based columns owned by this lane
+    const bool has0 = c0 <= Q, has1 = c1 <= Q;
+    double v0 = 0.0, v1 = 0.0;                         // column potentials
+    int p0 = 0, p1 = 0;                                // row matched to the column (0 = free)
+    for (int r = lane; r <= Q; r += 64) u[r] = 0.0;
+    for (int i = 1; i <= Q; ++i) {
+      double minv0 = 1e300, minv1 = 1e300;
+      int way0 = 0, way1 = 0;
+      bool used0 = false, used1 = false;
+      int j0 = 0;                                      // current column (0 = virtual column holding row i)
+      int i0 = i;
+      for (;;) {
+        if (j0 == c0) used0 = true;
+        if (j0 == c1) used1 = true;
+        const double ui0 = u[i0];
+        double best = 1e300;
+        int bj = 0x7fffffff;
+        if (has0 && !used0) {
+          const double curv = (double)cost[(i0 - 1) * Q + (c0 - 1)] - ui0 - v0;
+          if (curv < minv0) { minv0 = curv; way0 = j0; }
+          if (minv0 < best) { best = minv0; bj = c0; }
+        }
+        if (has1 && !used1) {
+          const double curv = (double)cost[(i0 - 1) * Q + (c1 - 1)] - ui0 - v1;
+          if (curv < minv1) { minv1 = curv; way1 = j0; }
+          if (minv1 < best || (minv1 == best && c1 < bj)) { best = minv1; bj = c1; }
+        }
+        wave_argmin(best, bj);
+        const double delta = best;
+        // update potentials: used columns (and the virtual column 0 = row i)
+        if (used0) { u[p0] += delta; v0 -= delta; } else if (has0) minv0 -= delta;
+        if (used1) { u[p1] += delta; v1 -= delta; } else if (has1) minv1 -= delta;
+        if (lane == 0) u[i] += delta;                   // p[0] = i
+        __builtin_amdgcn_wave_barrier();
+        j0 = bj;
+        // row matched to column j0 (owned by one lane) -> broadcast
+        int pj = (j0 == c0) ? p0 : (j0 == c1 ? p1 : 0);
+        const int owner = (j0 - 1) & 63;
+        pj = __shfl(pj, owner);
+        if (pj == 0) break;
+        i0 = pj;
+      }
+      // augment along `way`: walk back from j0 to the virtual column
+      while (j0 != 0) {
+        const int owner = (j0 - 1) & 63;
+        int w = (j0 == c0) ? way0 : (j0 == c1 ? way1 : 0);
+        w = __shfl(w, owner);                          // previous column on the path
+        int pw = 0;                                    // row currently at column w (or i if w is virtual)
+        if (w == 0) pw = i;
+        else {
+          const int wo = (w - 1) & 63;
+          int t2 = (w == c0) ? p0 : (w == c1 ? p1 : 0);
+          pw = __shfl(t2, wo);
+        }
+        if (j0 == c0) p0 = pw;
+        if (j0 == c1) p1 = pw;
+        j0 = w;
+      }
+    }
+    // p[col] = row: perm[j = row-1] = i = col-1
+    if (has0) pnew[p0 - 1] = c0 - 1;
+    if (has1) pnew[p1 - 1] = c1 - 1;
+}
+
 __global__ __launch_bounds__(256) void minvis_chain_kernel(const float* __restrict__ embds, const float* __restrict__ gram,
                                                           int* __restrict__ perm_out, int T, int Q, int C) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -80,81 +150,52 @@ __global__ __launch_bounds__(256) void minvis_chain_kernel(const float* __restri
     }
     __syncthreads();
     // ---- assignment: one wave, shortest augmenting paths -------------------------------------------------
-    if (tid < 64) {
-      const int lane = tid;
-      const int c0 = lane + 1, c1 = lane + 65;          // 1-based columns owned by this lane
-      const bool has0 = c0 <= Q, has1 = c1 <= Q;
-      double v0 = 0.0, v1 = 0.0;                         // column potentials
-      int p0 = 0, p1 = 0;                                // row matched to the column (0 = free)
-      for (int r = lane; r <= Q; r += 64) u[r] = 0.0;
-      for (int i = 1; i <= Q; ++i) {
-        double minv0 = 1e300, minv1 = 1e300;
-        int way0 = 0, way1 = 0;
-        bool used0 = false, used1 = false;
-        int j0 = 0;                                      // current column (0 = virtual column holding row i)
-        int i0 = i;
-        for (;;) {
-          if (j0 == c0) used0 = true;
-          if (j0 == c1) used1 = true;
-          const double ui0 = u[i0];
-          double best = 1e300;
-          int bj = 0x7fffffff;
-          if (has0 && !used0) {
-            const double curv = (double)cost[(i0 - 1) * Q + (c0 - 1)] - ui0 - v0;
-            if (curv < minv0) { minv0 = curv; way0 = j0; }
-            if (minv0 < best) { best = minv0; bj = c0; }
-          }
-          if (has1 && !used1) {
-            const double curv = (double)cost[(i0 - 1) * Q + (c1 - 1)] - ui0 - v1;
-            if (curv < minv1) { minv1 = curv; way1 = j0; }
-            if (minv1 < best || (minv1 == best && c1 < bj)) { best = minv1; bj = c1; }
-          }
-          wave_argmin(best, bj);
-          const double delta = best;
-          // update potentials: used columns (and the virtual column 0 = row i)
-          if (used0) { u[p0] += delta; v0 -= delta; } else if (has0) minv0 -= delta;
-          if (used1) { u[p1] += delta; v1 -= delta; } else if (has1) minv1 -= delta;
-          if (lane == 0) u[i] += delta;                   // p[0] = i
-          __builtin_amdgcn_wave_barrier();
-          j0 = bj;
-          // row matched to column j0 (owned by one lane) -> broadcast
-          int pj = (j0 == c0) ? p0 : (j0 == c1 ? p1 : 0);
-          const int owner = (j0 - 1) & 63;
-          pj = __shfl(pj, owner);
-          if (pj == 0) break;
-          i0 = pj;
-        }
-        // augment along `way`: walk back from j0 to the virtual column
-        while (j0 != 0) {
-          const int owner = (j0 - 1) & 63;
-          int w = (j0 == c0) ? way0 : (j0 == c1 ? way1 : 0);
-          w = __shfl(w, owner);                          // previous column on the path
-          int pw = 0;                                    // row currently at column w (or i if w is virtual)
-          if (w == 0) pw = i;
-          else {
-            const int wo = (w - 1) & 63;
-            int t2 = (w == c0) ? p0 : (w == c1 ? p1 : 0);
-            pw = __shfl(t2, wo);
-          }
-          if (j0 == c0) p0 = pw;
-          if (j0 == c1) p1 = pw;
-          j0 = w;
-        }
-      }
-      // p[col] = row: perm[j = row-1] = i = col-1
-      if (has0) pnew[p0 - 1] = c0 - 1;
-      if (has1) pnew[p1 - 1] = c1 - 1;
-    }
+    if (tid < 64) lap_wave(cost, u, pnew, Q, tid);
     __syncthreads();
     for (int j = tid; j < Q; j += blockDim.x) { pprev[j] = pnew[j]; P[(long long)t * Q + j] = pnew[j]; }
     __syncthreads();
   }
 }
 
+
+// The chain without its serial dependency.  Step t of the reference solves the assignment of
+// cost[j][i] = G_t[pprev[j]][i] -- the raw frame-pair matrix G_t with its ROWS permuted by the previous step's result.  An
+// optimal assignment of a row-permuted matrix is the permuted optimal assignment of the matrix, so when the optimum is
+// unique (always, short of exactly tied float64 totals) the chain is  perm_t[j] = sigma_t[perm_{t-1}[j]]  with
+// sigma_t = assignment of the raw G_t: the T-1 solves are independent (one wave each, all in flight together) and the
+// chain is a composition of permutations.  26 ms -> 1 ms for 32 frames x 100 queries.  PVSG_MINVIS=chain selects the
+// literal serial form (it also fixes the order in which exact ties would break).
+__global__ __launch_bounds__(64) void minvis_pair_kernel(const float* __restrict__ gram, int* __restrict__ sigma, int Q) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* cost = sm;
+  double* u = reinterpret_cast<double*>(cost + ((Q * Q + 1) & ~1));
+  int* pnew = reinterpret_cast<int*>(u + MQ + 1);
+  const long long vt = blockIdx.x;
+  const float* G = gram + vt * Q * Q;
+  for (int e = threadIdx.x; e < Q * Q; e += 64) cost[e] = G[e];
+  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
+  lap_wave(cost, u, pnew, Q, threadIdx.x);
+  __syncthreads();
+  for (int j = threadIdx.x; j < Q; j += 64) sigma[vt * Q + j] = pnew[j];
+}
+
+__global__ void minvis_compose_kernel(const int* __restrict__ sigma, int* __restrict__ perm_out, int T, int Q) {
+  const int vid = blockIdx.x, j = threadIdx.x;
+  if (j >= Q) return;
+  int* P = perm_out + (long long)vid * T * Q;
+  int cur = j;
+  P[j] = j;
+  for (int t = 1; t < T; ++t) {
+    cur = sigma[((long long)vid * (T - 1) + (t - 1)) * Q + cur];
+    P[(long long)t * Q + j] = cur;
+  }
+}
+
 }  // namespace pvsg
 
 extern "C" long long pvsg_minvis_chain_workspace_bytes(int V, int T, int Q) {
-  return T > 1 ? (long long)V * (T - 1) * Q * Q * 4 : 4;
+  return T > 1 ? (long long)V * (T - 1) * Q * (Q + 1) * 4 : 4;      // frame-pair cost matrices + their assignments
 }
 
 extern "C" int pvsg_minvis_chain(const float* embds, int* perm, float* workspace, int V, int T, int Q, int C, hipStream_t stream) {
@@ -169,7 +210,17 @@ extern "C" int pvsg_minvis_chain(const float* embds, int* perm, float* workspace
   if (T > 1)
     hipLaunchKernelGGL(minvis_gram_kernel, dim3((unsigned)((long long)V * (T - 1) * Q)), dim3(128), 0, stream, embds, workspace, T,
                        Q, C);
-  hipLaunchKernelGGL(minvis_chain_kernel, dim3(V), dim3(256), lds, stream, embds, workspace, perm, T, Q, C);
+  const char* mode = getenv("PVSG_MINVIS");
+  if (T == 1 || (mode && mode[0] == 'c')) {
+    hipLaunchKernelGGL(minvis_chain_kernel, dim3(V), dim3(256), lds, stream, embds, workspace, perm, T, Q, C);
+  } else {
+    int* sigma = reinterpret_cast<int*>(workspace + (size_t)V * (T - 1) * Q * Q);
+    const size_t lds2 = (size_t)((Q * Q + 1) & ~1) * 4 + (MQ + 1) * 8 + MQ * 4 + 16;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&minvis_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds2);
+    hipLaunchKernelGGL(minvis_pair_kernel, dim3((unsigned)(V * (T - 1))), dim3(64), lds2, stream, workspace, sigma, Q);
+    hipLaunchKernelGGL(minvis_compose_kernel, dim3(V), dim3(MQ), 0, stream, sigma, perm, T, Q);
+  }
   PVSG_LAUNCH_CHECK("minvis_chain");
   return PVSG_OK;
 }

@@ -289,6 +289,12 @@ __global__ void inst_init_kernel(double* __restrict__ stat_sum, int* __restrict_
   b[0] = 0; b[1] = big; b[2] = big; b[3] = -1; b[4] = -1;
 }
 
+// A thread owns a column of IM_ROWS output pixels (its column taps are computed once; the five statistics are reduced over
+// the wave once per IM_ROWS pixels instead of per pixel -- the per-pixel form spent most of its 44 ms at 32 x 100 x 720p in
+// the 42 cross-lane shuffles).  ONE_STAGE: output size == crop size, the second resize is the identity and the composed
+// tap (sample2) degenerates to one bilinear tap with bit-identical arithmetic (its stage-2 weights are exactly 1 and 0).
+constexpr int IM_ROWS = 8;
+template <bool ONE_STAGE>
 __global__ __launch_bounds__(256) void inst_masks_kernel(
     const float* __restrict__ logits, const int* __restrict__ sel_idx, unsigned char* __restrict__ masks,
     double* __restrict__ stat_sum, int* __restrict__ stat_box, int Q, int n, int sel_per_frame, int h, int w,
@@ -296,16 +302,39 @@ __global__ __launch_bounds__(256) void inst_masks_kernel(
   __shared__ double s_sum[4];
   __shared__ int s_box[4][5];
   const int e = blockIdx.z % n, t = blockIdx.z / n;
+  const int wv = threadIdx.x >> 6;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const bool inside = x < ow && y < oh;
-  const Tap2 tp = make_tap2(inside ? y : 0, inside ? x : 0, h, w, H, W, ih, iw, oh, ow);
+  const int ybase = (blockIdx.y * 4 + wv) * IM_ROWS;
   const float* p = logits + ((long long)t * Q + sel_idx[sel_per_frame ? t * n + e : e]) * h * w;
-  const float v = inside ? sample2(p, w, tp) : -1.f;
-  const bool on = inside && v > 0.f;
-  if (masks && inside) masks[(((long long)t * n + e) * oh + y) * ow + x] = on ? 1 : 0;
-  double sg = on ? (double)(1.f / (1.f + expf(-v))) : 0.0;
-  int cnt = on ? 1 : 0, x0 = on ? x : 0x7fffffff, y0 = on ? y : 0x7fffffff, x1 = on ? x : -1, y1 = on ? y : -1;
+  const bool xin = x < ow;
+  const Tap tx = bilinear_tap(xin ? x : 0, w, W);                       // ONE_STAGE only
+  unsigned char* mrow = masks ? masks + (((long long)t * n + e) * oh) * ow + x : nullptr;
+  double sg = 0.0;
+  int cnt = 0, x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
+#pragma unroll
+  for (int i = 0; i < IM_ROWS; ++i) {
+    const int y = ybase + i;
+    const bool inside = xin && y < oh;
+    float v;
+    if (ONE_STAGE) {
+      const Tap ty = bilinear_tap(inside ? y : 0, h, H);
+      const float* r0 = p + (long long)ty.i0 * w;
+      const float* r1 = r0 + (long long)ty.ip * w;
+      v = ty.l0 * (tx.l0 * r0[tx.i0] + tx.l1 * r0[tx.i0 + tx.ip]) + ty.l1 * (tx.l0 * r1[tx.i0] + tx.l1 * r1[tx.i0 + tx.ip]);
+    } else {
+      const Tap2 tp = make_tap2(inside ? y : 0, xin ? x : 0, h, w, H, W, ih, iw, oh, ow);
+      v = sample2(p, w, tp);
+    }
+    const bool on = inside && v > 0.f;
+    if (mrow && inside) mrow[(long long)y * ow] = on ? 1 : 0;
+    if (on) {
+      sg += (double)(1.f / (1.f + expf(-v)));
+      ++cnt;
+      y0 = y0 < y ? y0 : y;           // rows ascend: first / last 'on' row of the column
+      y1 = y;
+    }
+  }
+  if (cnt) { x0 = x; x1 = x; }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     sg += __shfl_xor(sg, off);
@@ -313,7 +342,6 @@ __global__ __launch_bounds__(256) void inst_masks_kernel(
     x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
     x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
   }
-  const int wv = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
     s_sum[wv] = sg; s_box[wv][0] = cnt; s_box[wv][1] = x0; s_box[wv][2] = y0; s_box[wv][3] = x1; s_box[wv][4] = y1;
   }
@@ -430,8 +458,13 @@ extern "C" int pvsg_instance_masks(const float* mask_logits, const int* sel_idx,
   hipLaunchKernelGGL(inst_init_kernel, dim3((T * n + 255) / 256), dim3(256), 0, stream, stat_sum, stat_box, T * n,
                      0x7fffffff);
   PVSG_LAUNCH_CHECK("instance_masks(init)");
-  hipLaunchKernelGGL(inst_masks_kernel, dim3((ow + 63) / 64, (oh + 3) / 4, T * n), dim3(256), 0, stream,
-                     mask_logits, sel_idx, masks, stat_sum, stat_box, Q, n, sel_per_frame, h, w, H, W, ih, iw, oh, ow);
+  const dim3 grid((ow + 63) / 64, (oh + 4 * IM_ROWS - 1) / (4 * IM_ROWS), T * n);
+  if (oh == ih && ow == iw)
+    hipLaunchKernelGGL(inst_masks_kernel<true>, grid, dim3(256), 0, stream, mask_logits, sel_idx, masks, stat_sum, stat_box,
+                       Q, n, sel_per_frame, h, w, H, W, ih, iw, oh, ow);
+  else
+    hipLaunchKernelGGL(inst_masks_kernel<false>, grid, dim3(256), 0, stream, mask_logits, sel_idx, masks, stat_sum, stat_box,
+                       Q, n, sel_per_frame, h, w, H, W, ih, iw, oh, ow);
   PVSG_LAUNCH_CHECK("instance_masks");
   return PVSG_OK;
 }

@@ -1,0 +1,63 @@
+"""One 720p image per call through the shipped IPS detector: GPU time of the graphed forward vs the fused post-process,
+and the host wall time of each (where do the ~10 ms per image go?)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import bench
+from openpvsg_amd import backbone, blocks, detectors, fusion, heads, tuning  # noqa: F401
+from openpvsg_amd.model_zoo import mask2former_r50_model_cfg
+from openpvsg_amd.registry import build_detector
+dev = torch.device('cuda:0')
+torch.backends.cudnn.deterministic = True
+torch.manual_seed(0)
+det = build_detector(mask2former_r50_model_cfg(video=False)).eval()
+det.panoptic_head.init_weights()
+with torch.no_grad():
+    det.panoptic_head.cls_embed.weight.mul_(bench.CLS_GAIN)
+    det.panoptic_head.query_feat.weight.mul_(8.0)
+det = det.to(dev)
+clip, (Hp, Wp) = bench.make_clip(8, 720, 1280)
+clip = clip.to(dev)
+syn_cls, syn_off = bench.synthetic_head_outputs(1, Hp // 4, Wp // 4, n_keep=32)
+syn_cls, syn_off = syn_cls.to(dev), syn_off.to(dev)
+head = det.panoptic_head
+orig = head._decode
+
+
+def patched(feats, B, Tn, all_masks=False, **kw):
+    cls_list, mask_list, q = orig(feats, B, Tn, all_masks=all_masks, **kw)
+    m = mask_list[-1]
+    mask_list = list(mask_list[:-1]) + [m + syn_off[:m.shape[0]]]
+    cls_list = list(cls_list[:-1]) + [syn_cls.expand(cls_list[-1].shape[0], -1, -1).contiguous()]
+    return cls_list, mask_list, q
+
+
+head._decode = patched
+meta = dict(img_shape=(720, 1280, 3), ori_shape=(720, 1280, 3))
+rec = {}
+for name in ('_graphed', '_fused_frames'):
+    fn = getattr(det, name)
+
+    def wrap(*a, _fn=fn, _n=name, **k):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        s.record()
+        r = _fn(*a, **k)
+        e.record()
+        rec.setdefault(_n, []).append((time.perf_counter() - t0, s, e))
+        return r
+    setattr(det, name, wrap)
+for mode in ('on', 'off'):
+    det.use_graph = mode == 'on'
+    for i in range(6):
+        det.forward([clip[i % 8:i % 8 + 1]], [[dict(meta)]], return_loss=False, rescale=True)
+    torch.cuda.synchronize()
+    rec.clear()
+    t0 = time.perf_counter()
+    n = 24
+    for i in range(n):
+        det.forward([clip[i % 8:i % 8 + 1]], [[dict(meta)]], return_loss=False, rescale=True)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / n * 1e3
+    out = {k: (sum(x[0] for x in v) / len(v) * 1e3, sum(x[1].elapsed_time(x[2]) for x in v) / len(v)) for k, v in rec.items()}
+    print('graph', mode, 'wall ms/image %.2f' % wall, {k: 'host %.2f ms, gpu-span %.2f ms' % v for k, v in out.items()})

@@ -13,6 +13,15 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
+@pytest.fixture(autouse=True, params=['pairs', 'chain'])
+def minvis_form(request, monkeypatch):
+    """default: T-1 independent frame-pair assignments composed into the chain; 'chain': the literal serial form.  Both
+    against the same oracle (the library reads PVSG_MINVIS per call)."""
+    if request.param == 'chain':
+        monkeypatch.setenv('PVSG_MINVIS', 'chain')
+    return request.param
+
+
 def oracle_chain(embds):
     out = [embds[0]]
     perms = [np.arange(embds.shape[1])]
@@ -57,3 +66,15 @@ def test_batched_videos(hip_lib):
     perm = ops.minvis_chain(e.to(DEV)).cpu().numpy()
     for v in range(3):
         assert (perm[v] == oracle_chain(e[v])).all()
+
+
+def test_unstructured_embeddings_both_forms_agree(hip_lib, monkeypatch):
+    """Independent random embeddings per frame (no planted correspondence: the hardest case for the solver) -- the
+    composed frame-pair form and the serial chain give the same permutations, and both equal the oracle."""
+    from openpvsg_amd import ops
+    e = torch.stack([det_input('rnd%d' % t, (100, 256), 40 + t) for t in range(12)])
+    monkeypatch.delenv('PVSG_MINVIS', raising=False)
+    a = ops.minvis_chain(e.to(DEV)).cpu().numpy()
+    monkeypatch.setenv('PVSG_MINVIS', 'chain')
+    b = ops.minvis_chain(e.to(DEV)).cpu().numpy()
+    assert (a == b).all() and (a == oracle_chain(e)).all()
