@@ -72,7 +72,9 @@ class _AppearanceResNet(ResNet):
     def forward(self, x):
         if x.is_cuda and not torch.is_grad_enabled() and self.fuse_bn_act:
             aff = self._affines()
-            x = ops.stem_bn_relu_pool(self.conv1(x), *aff['stem'])
+            # contiguous first: a cropped VIEW of the padded frames sends MIOpen to its naive non-packed convolution
+            # (25 ms per 16 frames at 720p, a quarter of the whole association stage); then the detector's stem kernel
+            x = self._stem(x.contiguous(), aff)
             for li in (1, 2, 3):
                 for bi, blk in enumerate(getattr(self, 'layer%d' % li)):
                     x = blk.forward_fused(x, aff[(li, bi)])
