@@ -80,7 +80,8 @@ def parse():
                          'GPU, attention partials merged across GPUs every decoder layer; weak = one 32-frame segment '
                          'of a longer video per GPU, tube records all-gathered')
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL over xGMI); gloo only for same-device logic tests')
-    ap.add_argument('--graph', action='store_true', help='replay backbone+head as one hipGraph (experimental)')
+    ap.add_argument('--graph', choices=('auto', 'on', 'off'), nargs='?', const='on', default='auto',
+                    help='replay backbone + head as one hipGraph: auto = clips of <= 8 frames (host-bound)')
     ap.add_argument('--checksum', action='store_true', help='add a result checksum (sharding-invariance check)')
     return ap.parse_args()
 
@@ -245,7 +246,7 @@ class KernelTimer:
             B, Q = a[6:8]
             return 4.0 * (256 * 256 + 768 * 256) + 4.0 * B * Q * 256 * 6, 2.0 * B * Q * 256 * (256 + 768)
         if name == 'pvsg_decoder_rows_post':
-            B, Q = a[11:13]
+            B, Q = a[12:14]
             w_head = 128 * 256 + 3 * 256 * 256 + (256 * 256 if a[2] else 0)
             w_layer = (256 * 256 + 2 * 256 * 2048) if a[0] is not None else 0
             att = 4.0 * B * Q * Q * 256 if a[0] is not None else 0.0
@@ -568,7 +569,7 @@ def main():
     det = det.to(dev)
     rel = {k: m.to(dev) for k, m in rel.items()}
     pipe = PVSGPipeline(det, rel['subject_encoder'], rel['object_encoder'], rel['pair_model'],
-                        rel['relation_model'], use_graph=args.graph).eval()
+                        rel['relation_model'], use_graph={'auto': 'auto', 'on': True, 'off': False}[args.graph]).eval()
 
     T = args.frames
     weak = world > 1 and args.scaling == 'weak'
@@ -672,6 +673,9 @@ def main():
                                    'run per-frame; scripts/ips_pipeline_bench.py measures that flavour)',
                        'tubes': int(out['tube_feats'].shape[0]), 'frames_per_step': frames_per_step,
                        'library_gemm_table': 'openpvsg_amd/tuning/gemm_gfx950.csv (load only)' if gemm_table else 'off',
+                       'hipgraph': ('backbone + head replayed as one hipGraph' if (pipe.use_graph is True or (
+                           pipe.use_graph == 'auto' and t_local <= pipe.graph_max_frames)) and world == 1 else 'eager launches')
+                       + ' (--graph %s); relation head graph %s' % (args.graph, 'on' if pipe.relation_graph else 'off'),
                        'parallelism': ('%d x 32-frame segments, all-gather of tube records' % world) if weak
                        else ('frame-shard x%d, attention partials merged per layer' % world)},
         }

@@ -161,11 +161,16 @@ int pvsg_decoder_rows_pre(const pvsg_decoder_layer* layer, const float* attn_cor
 /* query_out = LN2(FFN(x2) + x2), x2 = LN1(selfattn(qkv) Wo^T + bo + x1);  cls_out (B*Q, num_cls_out) and
  * mask_embed_out (B*Q, 256) from post_norm(query_out);  next_q_out = ((query_out + pos) Wq'^T + bq')/sqrt(32) for the
  * next layer's cross-attention (next_q_w packed (256,256); NULL = last layer).
- * layer == NULL: head part only on x1 = the initial queries (the forward_head call before layer 0). */
+ * layer == NULL: head part only on x1 = the initial queries (the forward_head call before layer 0).
+ * workspace: NULL, or pvsg_decoder_rows_post_workspace_bytes(B, Q) bytes ZEROED ONCE by the caller and reused from call to
+ *   call (one stream at a time): with it, and at most 32 row tiles (B * ceil(Q/16)), the FFN of a tile is split over eight
+ *   workgroups that meet through it (a clip's 100 query rows would otherwise occupy 7 CUs); every launch leaves its
+ *   arrival counters at zero.  The byte count is 0 when the split does not apply. */
+long long pvsg_decoder_rows_post_workspace_bytes(int B, int Q);
 int pvsg_decoder_rows_post(const pvsg_decoder_layer* layer, const pvsg_decoder_head* head, const float* next_q_w,
                            const float* next_q_b, const float* x1, const float* qkv, const float* query_pos,
-                           float* query_out, float* cls_out, float* mask_embed_out, float* next_q_out, int B,
-                           int Q, void* stream);
+                           float* query_out, float* cls_out, float* mask_embed_out, float* next_q_out, void* workspace,
+                           int B, int Q, void* stream);
 
 /* ---- a11: pairwise relation proposal scorer -------------------------------------------------
  * Replaces models/relation_head/base.py:49-62 PairProposalNetwork.forward (N^2 Python loop).

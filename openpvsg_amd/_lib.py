@@ -50,7 +50,8 @@ SIGNATURES = {
     'pvsg_xattn_combine_packed': [_c_f, _c_f, _i, _i, _i, _i, _i, _c_f],
     'pvsg_pack_rows_weight': [_c_f, _c_f, _i, _i, _c_f],
     'pvsg_decoder_rows_pre': [ctypes.POINTER(DecoderLayer), _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _c_f],
-    'pvsg_decoder_rows_post': [ctypes.POINTER(DecoderLayer), ctypes.POINTER(DecoderHead)] + [_c_f] * 9 + [_i, _i, _c_f],
+    'pvsg_decoder_rows_post_workspace_bytes': [_i, _i],
+    'pvsg_decoder_rows_post': [ctypes.POINTER(DecoderLayer), ctypes.POINTER(DecoderHead)] + [_c_f] * 10 + [_i, _i, _c_f],
     'pvsg_pair_prepare_weights': [_c_f, _c_f, _i, _i, _c_f],
     'pvsg_pair_score_forward': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _c_f],
     'pvsg_panoptic_fuse': [_c_f] * 8 + [_i] * 13 + [ctypes.c_double, _i, _c_f],
@@ -81,7 +82,8 @@ SIGNATURES = {
     'pvsg_conv3x3s2_affine': [_c_f] * 5 + [_i] * 6 + [_c_f],
 }
 # entry points that return a value instead of a status code
-VALUE_RETURNING = ('pvsg_xattn_num_splits', 'pvsg_gemm_bf16x3_packed_elems', 'pvsg_minvis_chain_workspace_bytes')
+VALUE_RETURNING = ('pvsg_xattn_num_splits', 'pvsg_gemm_bf16x3_packed_elems', 'pvsg_minvis_chain_workspace_bytes',
+                   'pvsg_decoder_rows_post_workspace_bytes')
 
 _lib = None
 
@@ -109,7 +111,8 @@ def load():
             f = getattr(lib, name)
         except AttributeError as e:
             raise BackendMissingError('symbol %s missing from %s' % (name, LIB_PATH)) from e
-        f.restype = _ll if name in ('pvsg_gemm_bf16x3_packed_elems', 'pvsg_minvis_chain_workspace_bytes') else _i
+        f.restype = _ll if name in ('pvsg_gemm_bf16x3_packed_elems', 'pvsg_minvis_chain_workspace_bytes',
+                                   'pvsg_decoder_rows_post_workspace_bytes') else _i
         f.argtypes = argtypes
     _lib = lib
     return lib

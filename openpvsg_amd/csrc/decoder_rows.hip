@@ -31,6 +31,8 @@ constexpr int DR_LD = DR_C + 4;           // LDS row stride: rows 16 B apart mod
 constexpr int DR_FC = 512;                // FFN hidden chunk held in LDS
 constexpr int DR_LDH = DR_FC + 4;
 constexpr int DR_MAXQ = 128;
+constexpr int DR_SPLIT = 8;               // workgroups per row tile in the split form of decoder_rows_post (256 hidden units each)
+constexpr int DR_SPLIT_MAX_TILES = 32;    // above this many row tiles the chip is full without the split
 
 __global__ void pack_rows_weight_kernel(const float* __restrict__ W, float* __restrict__ P, int N, int K,
                                         long long total) {
@@ -249,13 +251,20 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
     pvsg_decoder_layer L, pvsg_decoder_head Hd, int has_layer, const float* __restrict__ next_q_w,
     const float* __restrict__ next_q_b, const float* __restrict__ x1, const float* __restrict__ qkv,
     const float* __restrict__ qpos, float* __restrict__ query_out, float* __restrict__ cls_out,
-    float* __restrict__ emb_out, float* __restrict__ next_q_out, int Q, int tiles_per_b, float scale, float eps) {
+    float* __restrict__ emb_out, float* __restrict__ next_q_out, int Q, int tiles_per_b, float scale, float eps,
+    float* __restrict__ ws_part, int* __restrict__ ws_count, int nspl) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int s_last;
   float* xa = smem;                       // [16][DR_LD]
   float* xb = xa + 16 * DR_LD;
   float* xc = xb + 16 * DR_LD;
   float* big = xc + 16 * DR_LD;           // attention probabilities [8][128][16]  /  FFN hidden chunk [16][DR_LDH]
-  const int b = blockIdx.x / tiles_per_b, tile = blockIdx.x - b * tiles_per_b;
+  // nspl > 1: `nspl` workgroups per 16-row tile.  Each repeats the (cheap) self-attention part and computes ONE 256-wide slice
+  // of the FFN hidden layer; the partial outputs meet in `ws_part`, and the workgroup that arrives last (ws_count, left at
+  // zero again) sums them in slice order and carries on alone.  With Q = 100 rows and one clip the un-split kernel keeps 7
+  // of 256 CUs busy for 126 us, 55 of them the FFN's matrix instructions.
+  const int bt = nspl > 1 ? blockIdx.x / nspl : blockIdx.x, slice = nspl > 1 ? blockIdx.x - bt * nspl : 0;
+  const int b = bt / tiles_per_b, tile = bt - b * tiles_per_b;
   const int q0 = tile * 16;
   const int valid = min(16, Q - q0);
   const long long row0 = (long long)b * Q + q0;
@@ -352,6 +361,49 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
     __syncthreads();
     rows_layernorm(xb, L.n1_g, L.n1_b, eps, xa, nullptr, nullptr, nullptr, valid);
     __syncthreads();
+    if (nspl > 1) {
+      // ---- FFN, hidden units [256 slice, 256 slice + 256) ------------------------------------------------------
+      const int wkc2 = L.ffn_dim >> 4;
+      {
+        f32x4 acc[2];
+        zero_acc(acc);
+        rows_gemm<2, 16, 8>(xa, DR_LD, L.f1_w, 16, 0, slice * 16 + w * 2, acc, lane);
+        store_tiles_lds<2>(acc, slice * 16 + w * 2, L.f1_b, nullptr, 0, big, DR_LD, slice * DR_C, true, lane);
+      }
+      __syncthreads();
+      f32x4 yacc[2];
+      zero_acc(yacc);
+      rows_gemm<2, 16, 8>(big, DR_LD, L.f2_w, wkc2, slice * 16, w * 2, yacc, lane);
+      float* part = ws_part + ((long long)bt * nspl + slice) * (16 * DR_C);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[(4 * g + e) * DR_C + (w * 2 + i) * 16 + j] = yacc[i][e];
+      __threadfence();                                           // the partial is visible device-wide before the count
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int old = atomicAdd(ws_count + bt, 1);
+        s_last = old == nspl - 1;
+        if (s_last) ws_count[bt] = 0;                            // ready for the next launch
+      }
+      __syncthreads();
+      if (!s_last) return;
+      __threadfence();
+      const float* pall = ws_part + (long long)bt * nspl * (16 * DR_C);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int idx = threadIdx.x + it * DR_THREADS;
+        const int r = idx >> 6, c = (idx & 63) * 4;
+        float4 v = ld4(L.f2_b + c);
+        const float4 x2 = *reinterpret_cast<const float4*>(xa + r * DR_LD + c);
+        v.x += x2.x; v.y += x2.y; v.z += x2.z; v.w += x2.w;
+        for (int sl = 0; sl < nspl; ++sl) {
+          const float4 p = ld4_stream(pall + (long long)sl * (16 * DR_C) + r * DR_C + c);
+          v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        *reinterpret_cast<float4*>(xb + r * DR_LD + c) = v;
+      }
+    } else
     // ---- FFN in hidden chunks of 512 -----------------------------------------------------------
     {
       f32x4 yacc[2];
@@ -453,6 +505,15 @@ static_assert(8 * DR_MAXQ * 16 >= 16 * DR_LDH, "FFN chunk must fit in the attent
 
 }  // namespace pvsg
 
+// workspace of pvsg_decoder_rows_post: FFN partials (B x tiles x 8 x 16 x 256 floats) + one arrival counter per tile.  The
+// CALLER zeroes it once; every launch leaves the counters at zero.  0 when the split is not used for this (B, Q).
+extern "C" long long pvsg_decoder_rows_post_workspace_bytes(int B, int Q) {
+  using namespace pvsg;
+  if (B <= 0 || Q <= 0) return 0;
+  const long long tiles = (long long)B * ((Q + 15) / 16);
+  return tiles <= DR_SPLIT_MAX_TILES ? tiles * (DR_SPLIT * 16 * DR_C * 4 + 4) : 0;
+}
+
 extern "C" int pvsg_pack_rows_weight(const float* W, float* packed, int N, int K, void* stream_) {
   using namespace pvsg;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -495,7 +556,8 @@ extern "C" int pvsg_decoder_rows_pre(const pvsg_decoder_layer* layer, const floa
 extern "C" int pvsg_decoder_rows_post(const pvsg_decoder_layer* layer, const pvsg_decoder_head* head,
                                       const float* next_q_w, const float* next_q_b, const float* x1,
                                       const float* qkv, const float* query_pos, float* query_out, float* cls_out,
-                                      float* mask_embed_out, float* next_q_out, int B, int Q, void* stream_) {
+                                      float* mask_embed_out, float* next_q_out, void* workspace, int B, int Q,
+                                      void* stream_) {
   using namespace pvsg;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   PVSG_REQUIRE(head && x1 && query_pos && cls_out && mask_embed_out, "decoder_rows_post: null pointer argument");
@@ -520,9 +582,13 @@ extern "C" int pvsg_decoder_rows_post(const pvsg_decoder_layer* layer, const pvs
     const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&decoder_rows_post_kernel), (int)DR_POST_LDS, attr_done);
     if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "decoder_rows_post: LDS attribute: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(decoder_rows_post_kernel, dim3(B * tiles), dim3(DR_THREADS), DR_POST_LDS, stream, L, *head,
+  // few row tiles (a clip, or a handful of frames): split the FFN over DR_SPLIT workgroups per tile (needs the workspace)
+  const int nspl = (layer && workspace && B * tiles <= DR_SPLIT_MAX_TILES && L.ffn_dim == DR_SPLIT * DR_C) ? DR_SPLIT : 1;
+  float* ws_part = static_cast<float*>(workspace);
+  int* ws_count = workspace ? reinterpret_cast<int*>(ws_part + (size_t)B * tiles * DR_SPLIT * 16 * DR_C) : nullptr;
+  hipLaunchKernelGGL(decoder_rows_post_kernel, dim3(B * tiles * nspl), dim3(DR_THREADS), DR_POST_LDS, stream, L, *head,
                      layer ? 1 : 0, next_q_w, next_q_b, x1, qkv, query_pos, query_out, cls_out, mask_embed_out,
-                     next_q_out, Q, tiles, 0.17677669529663687f, 1e-5f);
+                     next_q_out, Q, tiles, 0.17677669529663687f, 1e-5f, ws_part, ws_count, nspl);
   PVSG_LAUNCH_CHECK("decoder_rows_post");
   return PVSG_OK;
 }

@@ -105,6 +105,7 @@ class DecoderRows:
 
         C = 256
         self.layers, self.next_q = [], []
+        self._ws = {}                                # (B, Q, device) -> workspace of decoder_rows_post's split form
         for layer in head.transformer_decoder.layers:
             xa, sa, ffn = layer.attentions[0].attn, layer.attentions[1].attn, layer.ffns[0]
             f1, f2 = ffn.layers[0][0], ffn.layers[1]
@@ -136,7 +137,13 @@ class DecoderRows:
         """layer i after its cross-attention core -> (new queries, class logits, mask embeddings, next layer's q)."""
         x1, qkv = ops.decoder_rows_pre(self.layers[i], attn_core, q, q_pos)
         nxt = self.next_q[i + 1] if i + 1 < len(self.layers) else None
-        return ops.decoder_rows_post(self.layers[i], self.head, nxt, x1, qkv, q_pos, self.num_cls_out)
+        key = (x1.shape[0], x1.shape[1], str(x1.device))
+        ws = self._ws.get(key, False)
+        if ws is False:                              # zeroed once; the kernel leaves its arrival counters at zero
+            if len(self._ws) >= 8:
+                self._ws.pop(next(iter(self._ws)))
+            ws = self._ws[key] = ops.decoder_rows_post_workspace(x1.shape[0], x1.shape[1], x1.device)
+        return ops.decoder_rows_post(self.layers[i], self.head, nxt, x1, qkv, q_pos, self.num_cls_out, workspace=ws)
 
 
 class _Mask2FormerHeadBase(BaseModule):

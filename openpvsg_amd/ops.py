@@ -782,7 +782,13 @@ def decoder_rows_pre(layer_struct, attn_core, query, query_pos):
     return x1, qkv
 
 
-def decoder_rows_post(layer_struct, head_struct, next_q, x1, qkv, query_pos, num_cls_out):
+def decoder_rows_post_workspace(B, Q, device):
+    """Zeroed workspace for decoder_rows_post's split form (None where it does not apply): allocate once per (B, Q), reuse."""
+    n = int(_lib.load().pvsg_decoder_rows_post_workspace_bytes(B, Q))
+    return torch.zeros(((n + 3) // 4,), device=device, dtype=torch.float32) if n else None
+
+
+def decoder_rows_post(layer_struct, head_struct, next_q, x1, qkv, query_pos, num_cls_out, workspace=None):
     """Self-attention + FFN + norms (layer_struct None: skipped, x1 = the queries) and the query side of
     forward_head; next_q = (packed Wq, bq) of the next layer's cross-attention or None.
     -> query_out (B,Q,256) or None, cls (B,Q,num_cls_out), mask_embed (B,Q,256), next_q (B,Q,256) or None."""
@@ -799,5 +805,6 @@ def decoder_rows_post(layer_struct, head_struct, next_q, x1, qkv, query_pos, num
                   next_q[1].data_ptr() if next_q is not None else None, x1.data_ptr(),
                   _chk(qkv, 'qkv').data_ptr() if qkv is not None else None, pos.data_ptr(),
                   q_out.data_ptr() if q_out is not None else None, cls.data_ptr(), emb.data_ptr(),
-                  nq.data_ptr() if nq is not None else None, B, Q, _stream_ptr())
+                  nq.data_ptr() if nq is not None else None,
+                  workspace.data_ptr() if workspace is not None else None, B, Q, _stream_ptr())
     return q_out, cls, emb, nq

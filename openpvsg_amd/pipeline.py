@@ -65,10 +65,13 @@ class PVSGPipeline(torch.nn.Module):
     """detector (clip-level VPS) + fusion post-processing per frame + tube assembly + relation head."""
 
     def __init__(self, detector, subject_encoder, object_encoder, pair_model, relation_model,
-                 num_top_pairs=100, fused_postprocess=True, use_graph=False):
+                 num_top_pairs=100, fused_postprocess=True, use_graph='auto'):
         super().__init__()
         self.fused_postprocess = fused_postprocess
+        # True / False / 'auto': short clips (<= graph_max_frames) are limited by the host's launch rate, so backbone + head
+        # are replayed as one hipGraph; long clips are GPU-bound and the capture would only pin their buffers
         self.use_graph = use_graph
+        self.graph_max_frames = 8
         self._graphs = {}
         self.detector = detector
         self.subject_encoder, self.object_encoder = subject_encoder, object_encoder
@@ -179,7 +182,8 @@ class PVSGPipeline(torch.nn.Module):
         if parallel.is_dist(group) and not solo:
             shard = parallel.ClipShard(head, total_frames, group)
         try:
-            if self.use_graph and shard is None:
+            graph = self.use_graph is True or (self.use_graph == 'auto' and clip.shape[0] <= self.graph_max_frames)
+            if graph and shard is None:
                 cls, masks4, q = self._graphed_forward(clip)
             else:
                 feats = det.extract_feat(clip)

@@ -55,7 +55,7 @@ def _torch_head_side(head, x3, q_pos, next_layer):
     return cls, emb, nq
 
 
-@pytest.mark.parametrize('B,Q', [(1, 100), (3, 100), (2, 37), (1, 128), (5, 16)])
+@pytest.mark.parametrize('B,Q', [(1, 100), (3, 100), (2, 37), (1, 128), (5, 16), (8, 100)])   # (8,100): 56 row tiles, un-split FFN
 def test_rows_kernels_vs_torch(hip_lib, B, Q):
     from openpvsg_amd.heads import DecoderRows
     head = _head(True, 11)
