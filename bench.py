@@ -280,6 +280,8 @@ class KernelTimer:
             return 2.0 * M * N * K
         if name in ('pvsg_conv1x1_bf16x3', 'pvsg_mask_logits_bf16x3', 'pvsg_attn_mask_bits_bf16x3'):
             return cls.work(name, a)[1] / 6.0
+        if name == 'pvsg_masked_xattn_partial' and not XATTN_F32:
+            return cls.work(name, a)[1] / 6.0
         return cls.work(name, a)[1]
 
     @staticmethod
