@@ -115,6 +115,11 @@ def load():
                                    'pvsg_decoder_rows_post_workspace_bytes') else _i
         f.argtypes = argtypes
     _lib = lib
+    try:                                    # loud, once: a second tenant on the GPU without a CU partition (parallel.py)
+        from . import parallel
+        parallel.warn_if_gpu_shared()
+    except ImportError:
+        pass
     return lib
 
 

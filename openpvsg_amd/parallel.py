@@ -68,6 +68,42 @@ def isolate_shared_gpu(slot, slots, device_index=0, cus=None):
         os.environ['HSA_CU_MASK'] = '%d:%d-%d' % (device_index, slot * per, (slot + 1) * per - 1)
 
 
+KFD_PROC = '/sys/class/kfd/kfd/proc'
+
+
+def other_gpu_processes():
+    """PIDs of OTHER processes that hold compute queues on this node's GPUs right now (KFD sysfs; [] where it is not visible)."""
+    root = KFD_PROC
+    out = []
+    try:
+        for pid in os.listdir(root):
+            if not pid.isdigit() or int(pid) == os.getpid():
+                continue
+            try:
+                if os.listdir(os.path.join(root, pid, 'queues')):
+                    out.append(int(pid))
+            except OSError:
+                continue
+    except OSError:
+        pass
+    return out
+
+
+def warn_if_gpu_shared():
+    """Called once when the backend library is loaded: a second process with live queues on the GPU and no CU partition is
+    the one setting in which the bf16 matrix kernels were seen to corrupt a neighbour's results (see isolate_shared_gpu)."""
+    if 'HSA_CU_MASK' in os.environ or os.environ.get('PVSG_SHARED_GPU_WARNING', 'on') == 'off':
+        return
+    others = other_gpu_processes()
+    if others:
+        import warnings
+        warnings.warn('openpvsg_amd: %d other process(es) hold compute queues on this node\'s GPU(s) (pids %s) and HSA_CU_MASK is '
+                      'not set.  Waves of the bf16-MFMA kernels co-resident on a CU with another process\'s waves were observed to '
+                      'corrupt that process\'s results (DESIGN.md section 3.13): run one process per GPU, or give the processes '
+                      'disjoint CU ranges with openpvsg_amd.parallel.isolate_shared_gpu() before HIP starts '
+                      '(PVSG_SHARED_GPU_WARNING=off silences this).' % (len(others), others[:8]), RuntimeWarning, stacklevel=3)
+
+
 def shard_frames(num_frames, rank, world):
     """Contiguous frame range of `rank` (frames must divide evenly: 32 over 1/2/4/8)."""
     if num_frames % world:

@@ -170,3 +170,26 @@ def test_cu_mask_is_derived_from_the_kfd_topology(tmp_path, monkeypatch):
     parallel.isolate_shared_gpu(0, 4)
     assert os.environ['HSA_CU_MASK'] == '0:0-63'
     monkeypatch.delenv('HSA_CU_MASK', raising=False)
+
+
+def test_second_tenant_on_the_gpu_is_announced(tmp_path, monkeypatch):
+    """A second process with live compute queues and no CU partition: the library says so when it is loaded (ADVICE r2,
+    co-residency finding), and stays quiet with HSA_CU_MASK set or nobody else around."""
+    import os
+    import warnings
+    from openpvsg_amd import parallel
+    (tmp_path / str(os.getpid()) / 'queues' / '0').mkdir(parents=True)      # ourselves: ignored
+    (tmp_path / '4242' / 'queues').mkdir(parents=True)                      # a process without queues: ignored
+    monkeypatch.setattr(parallel, 'KFD_PROC', str(tmp_path))
+    monkeypatch.delenv('HSA_CU_MASK', raising=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        parallel.warn_if_gpu_shared()
+    (tmp_path / '4243' / 'queues' / '7').mkdir(parents=True)
+    assert parallel.other_gpu_processes() == [4243]
+    with pytest.warns(RuntimeWarning, match='isolate_shared_gpu'):
+        parallel.warn_if_gpu_shared()
+    monkeypatch.setenv('HSA_CU_MASK', '0:0-127')
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        parallel.warn_if_gpu_shared()
