@@ -140,6 +140,9 @@ void gemm_abl_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp,
   fetch(1, KT > 1 ? 1 : 0);
   fetch(0, KT > 2 ? 2 : KT - 1);
   bf16x8 av[3][2], wv[3][2];
+  f32x4 acc4[2][2][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc4[i >> 3][(i >> 2) & 1][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (ABL == 4 || ABL == 5) {   // operands: whatever the (never written) LDS holds once -- random-ish bits from A instead
 #pragma unroll
     for (int l = 0; l < 3; ++l)
@@ -165,6 +168,20 @@ void gemm_abl_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp,
       fetch(par ^ 1, kt + 3 < KT ? kt + 3 : KT - 1);
     }
     constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PW[6] = {1, 2, 0, 1, 0, 0};
+    if (ABL == 21) {
+      // TIMING ONLY (numerically meaningless): every v_mfma_f32_32x32x16_bf16 replaced by two v_mfma_f32_16x16x32_bf16 on the
+      // same operand registers -- same flops and matrix-pipe cycles, everything else of the kernel unchanged.  Does the
+      // instruction's lower energy per flop (mfma_lab: 0.85 vs 0.73 of the roof on limb data) survive inside the real kernel?
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            acc4[rb][cb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[PA[p]][rb], wv[PW[p]][cb], acc4[rb][cb][0], 0, 0, 0);
+            acc4[rb][cb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[PA[p]][rb], wv[PW[p]][cb], acc4[rb][cb][1], 0, 0, 0);
+          }
+    } else {
 #pragma unroll
     for (int p = 0; p < 6; ++p)
 #pragma unroll
@@ -172,6 +189,7 @@ void gemm_abl_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp,
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
           acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[p]][rb], wv[PW[p]][cb], acc[rb][cb], 0, 0, 0);
+    }
   };
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
@@ -189,7 +207,15 @@ void gemm_abl_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp,
   }
 
   unsigned long long tpe[2] = {0, 0};
-  if (ABL == 11 || ABL == 12 || ABL == 13) {
+  if (ABL == 21) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][cb][r] = acc4[rb][cb][r >> 2][r & 3] + acc4[rb][cb][(r >> 2) ^ 1][r & 3];
+  }
+  if (ABL == 11 || ABL == 12 || ABL == 13 || ABL == 21) {
     // full tiles: no per-element guards, bias fetched and waited for ONCE -> 64 stores issue back to back
     // (the guarded form makes the compiler put an s_waitcnt vmcnt(0) in front of every store: each waits for its predecessor)
     const bool full = (m0 + GB_M <= M) && (n0 + GB_N <= N);
@@ -199,7 +225,7 @@ void gemm_abl_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp,
       for (int cb = 0; cb < 2; ++cb) bv[cb] = bias ? bias[n0 + wc * 64 + cb * 32 + li] : 0.f;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned long long te0 = __builtin_readcyclecounter();
-      if (ABL == 11 || ABL == 13) {
+      if (ABL == 11 || ABL == 13 || ABL == 21) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
           float* op = out + (size_t)(m0 + wr * 64 + 4 * kg) * N + n0 + wc * 64 + cb * 32 + li;
@@ -897,7 +923,7 @@ int main(int argc, char** argv) {
   std::vector<Variant> vars = {
       {"shipped", launch_abl<0>},      {"abl1_nosplit", launch_abl<1>}, {"abl2_nostash", launch_abl<2>},
       {"abl3_noload", launch_abl<3>},  {"abl4_mfma_only", launch_abl<4>}, {"abl5_mfma_nostore", launch_abl<5>},
-      {"abl10_shipped_timed", launch_abl<10>}, {"abl11_fullpath_dword", launch_abl<11>}, {"abl12_fullpath_ldsT", launch_abl<12>}, {"epi1_swapped_x4", launch_epi<1>}, {"epi2_ldsT_x4", launch_epi<2>},
+      {"abl10_shipped_timed", launch_abl<10>}, {"abl11_fullpath_dword", launch_abl<11>}, {"abl21_fullpath_mfma16x16x32", launch_abl<21>}, {"abl12_fullpath_ldsT", launch_abl<12>}, {"epi1_swapped_x4", launch_epi<1>}, {"epi2_ldsT_x4", launch_epi<2>},
       {"v2_persist_defer", launch_v2<false>},
       {"ps_ns2_w3", launch_ps<2, false, 3>},
   };
