@@ -152,8 +152,38 @@ void gemm_abl_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp,
         wv[l][b] = *reinterpret_cast<const bf16x8*>(Wp + (size_t)(tid * 8 + l * 2 + b) * 8);
       }
   }
+  f32x4 acc16[4][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc16[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ABL 22: v_mfma_f32_16x16x32_bf16 on the K = 16 stages -- the 32-deep K of one instruction holds TWO limb products of the same
+  // 16 k values: lanes 0-31 (k slots 0..15) read one limb, lanes 32-63 (slots 16..31) another:
+  //   [a_h|a_h].[w_h|w_m] = hh + hm,   [a_m|a_l].[w_h|w_h] = mh + lh,   [a_h|a_m].[w_l|w_m] = hl + mm
+  const int l15 = lane & 15, kgp = (lane >> 4) & 1, hsel = lane >> 5;
+  const int a16 = (kgp * GB_M + wr * 64 + l15) * 8, w16 = GB_TILE + (kgp * GB_N + wc * 64 + l15) * 8;
+  const int la[3] = {0, (hsel ? 2 : 1) * GB_LIMB, (hsel ? 1 : 0) * GB_LIMB};      // A: [h|h], [m|l], [h|m]
+  const int lw[3] = {(hsel ? 1 : 0) * GB_LIMB, 0, (hsel ? 1 : 2) * GB_LIMB};      // W: [h|m], [h|h], [l|m]
   auto kstep = [&](int kt, auto PAR) {
     constexpr int par = decltype(PAR)::value;
+    if (ABL == 22) {
+      __syncthreads();
+      const __bf16* cur = lds + par * GB_STAGE;
+      stash(par ^ 1, lds + (par ^ 1) * GB_STAGE);
+      fetch(par ^ 1, kt + 3 < KT ? kt + 3 : KT - 1);
+#pragma unroll
+      for (int c = 2; c >= 0; --c) {             // small terms first
+        bf16x8 ap[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) ap[rb] = *reinterpret_cast<const bf16x8*>(cur + a16 + la[c] + rb * 16 * 8);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+          const bf16x8 wp = *reinterpret_cast<const bf16x8*>(cur + w16 + lw[c] + cb * 16 * 8);
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+            acc16[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[rb], wp, acc16[rb][cb], 0, 0, 0);
+        }
+      }
+      return;
+    }
     if (ABL != 4 && ABL != 5) {
       __syncthreads();
       const __bf16* cur = lds + par * GB_STAGE;
@@ -207,6 +237,39 @@ void gemm_abl_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp,
   }
 
   unsigned long long tpe[2] = {0, 0};
+  if (ABL == 22) {
+    const int g4 = lane >> 4;
+    const bool full = (m0 + GB_M <= M) && (n0 + GB_N <= N);
+    if (full) {                                   // no guards, bias waited for once: the 64 stores issue back to back
+      float bv[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) bv[cb] = bias ? bias[n0 + wc * 64 + cb * 16 + l15] : 0.f;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        float* op = out + (size_t)(m0 + wr * 64 + 4 * g4) * N + n0 + wc * 64 + cb * 16 + l15;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) op[(size_t)(rb * 16 + r) * N] = acc16[rb][cb][r] + bv[cb];
+      }
+      return;
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int col = n0 + wc * 64 + cb * 16 + l15;
+      if (col >= N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wr * 64 + rb * 16 + 4 * g4 + r;
+          if (row < M) out[(size_t)row * N + col] = acc16[rb][cb][r] + bv;
+        }
+    }
+    return;
+  }
   if (ABL == 21) {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -923,7 +986,7 @@ int main(int argc, char** argv) {
   std::vector<Variant> vars = {
       {"shipped", launch_abl<0>},      {"abl1_nosplit", launch_abl<1>}, {"abl2_nostash", launch_abl<2>},
       {"abl3_noload", launch_abl<3>},  {"abl4_mfma_only", launch_abl<4>}, {"abl5_mfma_nostore", launch_abl<5>},
-      {"abl10_shipped_timed", launch_abl<10>}, {"abl11_fullpath_dword", launch_abl<11>}, {"abl21_fullpath_mfma16x16x32", launch_abl<21>}, {"abl12_fullpath_ldsT", launch_abl<12>}, {"epi1_swapped_x4", launch_epi<1>}, {"epi2_ldsT_x4", launch_epi<2>},
+      {"abl10_shipped_timed", launch_abl<10>}, {"abl11_fullpath_dword", launch_abl<11>}, {"abl21_fullpath_mfma16x16x32", launch_abl<21>}, {"pair16_k16stages", launch_abl<22>}, {"abl12_fullpath_ldsT", launch_abl<12>}, {"epi1_swapped_x4", launch_epi<1>}, {"epi2_ldsT_x4", launch_epi<2>},
       {"v2_persist_defer", launch_v2<false>},
       {"ps_ns2_w3", launch_ps<2, false, 3>},
   };
