@@ -20,6 +20,7 @@
 // per element pair, hidden beside the bf16 MFMAs); W is split once by pvsg_gemm_bf16x3_pack into the staging order.
 // LDS tiles are [limb][k-group of 8][row][8 bf16]: consecutive lanes read consecutive 16-byte groups.
 #include "common.h"
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -172,6 +173,145 @@ void gemm_bf16x3_kernel(const float* __restrict__ A, const __bf16* __restrict__ 
           if (RELU) o = fmaxf(o, 0.f);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), orsrc,
                                                 vbase + (unsigned)(rb * 32 + (r & 3) + 8 * (r >> 2)) * rowpitch, 0, 0);
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same GEMM on v_mfma_f32_16x16x32_bf16 (default since the end of round 3 for K % 32 == 0).  The bf16 matrix pipe is
+// power-limited on real data, and the 16x16x32 instruction spends less energy per flop than 32x32x16 (register-only loops:
+// 0.85 vs 0.73 of the roof; swapped into the kernel above on the same operand registers: 5-9 % faster,
+// profiles/r03_lab_gemm_ablations.txt).  Its 32-deep fragments need K = 32 stages: ONE 48 KB stage per workgroup (three
+// workgroups per CU as before), A and W limbs as [limb][k-group 0..3][row][8 bf16]; the next step's operands travel from
+// HBM / L2 into registers while this step's 96 MFMAs run, and are split and written between two barriers -- the other two
+// workgroups of the CU cover that window.  Wave tile 64 x 64 = 4 x 4 blocks of 16 x 16; A's hi / mid fragments stay in
+// registers across the four column blocks, the low limb takes over the mid limb's registers for the (lo, hi) product, which
+// therefore comes last.  The packed weight layout is unchanged (two 16-deep sub-steps per stage).
+// Measured against the kernel above: FFN1 1.85 -> 1.63 ms, FFN2 1.63 -> 1.57, 544-wide projection 1.10 -> 1.01.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int K32_LIMB = 4 * GB_M * 8;          // bf16 elements of one limb of a 128 x 32 tile
+constexpr int K32_TILE = 3 * K32_LIMB;          // 24 KB per operand
+template <bool RELU>
+__global__ __launch_bounds__(256, 3)
+void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
+                            float* __restrict__ out, int M, int N, int K, int Npad, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * K32_TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tn = logical % tiles_n, tm = logical / tiles_n;
+  const int m0 = tm * GB_M, n0 = tn * GB_N;
+  // staging: A -- thread = (row tid/2, half tid%2), 16 consecutive floats; W -- (k-group tid/128, column tid%128) of both
+  // 16-deep sub-steps of the packed weight, 3 limbs each
+  const int ar = tid >> 1, ah2 = tid & 1;
+  const bool a_in = m0 + ar < M;
+  const unsigned a_voff = a_in ? (unsigned)((ar * K + 16 * ah2) * 4) : 0x80000000u;   // rows beyond M read as 0
+  const auto asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A) + (size_t)m0 * K * 4), 0,
+                                                      (unsigned)((size_t)GB_M * K * 4), 0x00020000);
+  const int wkg = tid >> 7, wcol = tid & 127;
+  const size_t w_limb_stride = (size_t)2 * Npad * 8;
+  const __bf16* wsrc = Wp + ((size_t)wkg * Npad + n0 + wcol) * 8;
+  f32x4 a_regs[4];
+  u32x4 w_regs[2][3];
+  auto fetch = [&](int kt) {                                     // kt counts 32-deep steps
+    const unsigned so = (unsigned)kt * (32 * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      a_regs[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc, a_voff + 16 * q, so, 0));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const __bf16* wk = wsrc + (size_t)(2 * kt + j) * 3 * w_limb_stride;
+#pragma unroll
+      for (int l = 0; l < 3; ++l) w_regs[j][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {                             // k-group 2*ah2 + gq = floats 8 gq .. 8 gq + 7 of this thread
+      unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 v = a_regs[2 * gq + q];
+        split2(v[0], v[1], hh[2 * q], mm[2 * q], ll[2 * q]);
+        split2(v[2], v[3], hh[2 * q + 1], mm[2 * q + 1], ll[2 * q + 1]);
+      }
+      __bf16* pa = lds + ((2 * ah2 + gq) * GB_M + ar) * 8;
+      *reinterpret_cast<u32x4*>(pa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
+      *reinterpret_cast<u32x4*>(pa + K32_LIMB) = u32x4{mm[0], mm[1], mm[2], mm[3]};
+      *reinterpret_cast<u32x4*>(pa + 2 * K32_LIMB) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __bf16* pw = lds + K32_TILE + ((2 * j + wkg) * GB_N + wcol) * 8;
+#pragma unroll
+      for (int l = 0; l < 3; ++l) *reinterpret_cast<u32x4*>(pw + l * K32_LIMB) = w_regs[j][l];
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int l15 = lane & 15, kg4 = lane >> 4;
+  const __bf16* afr = lds + (kg4 * GB_M + wr * 64 + l15) * 8;                 // + limb * K32_LIMB + row block * 128
+  const __bf16* wfr = lds + K32_TILE + (kg4 * GB_N + wc * 64 + l15) * 8;      // + limb * K32_LIMB + column block * 128
+  auto mf = [](bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); };
+  const int KT = K / 32;
+  fetch(0);
+  stash();
+  for (int kt = 0; kt < KT; ++kt) {
+    __syncthreads();                                             // step kt is in LDS
+    fetch(kt + 1 < KT ? kt + 1 : KT - 1);
+    bf16x8 ahf[4], amf[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      ahf[rb] = *reinterpret_cast<const bf16x8*>(afr + rb * 128);
+      amf[rb] = *reinterpret_cast<const bf16x8*>(afr + K32_LIMB + rb * 128);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {                             // small terms first: (m,m) (h,l) (h,m) (m,h) (h,h)
+      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wfr + cb * 128);
+      const bf16x8 wm = *reinterpret_cast<const bf16x8*>(wfr + K32_LIMB + cb * 128);
+      const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wfr + 2 * K32_LIMB + cb * 128);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wm, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wl, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wm, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wh, acc[rb][cb]);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) amf[rb] = *reinterpret_cast<const bf16x8*>(afr + 2 * K32_LIMB + rb * 128);   // A's low limb
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {                             // (l,h)
+      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wfr + cb * 128);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+    }
+    __syncthreads();                                             // everyone is done reading step kt
+    if (kt + 1 < KT) stash();
+  }
+  // bias / ReLU and store through a bounded buffer descriptor (see the kernel above): register r of block (rb, cb) = row
+  // rb*16 + 4*(lane>>4) + r, column cb*16 + (lane&15) of the wave's 64 x 64 tile; no branch, no wait between the 64 stores
+  {
+    const int rows = M - m0 < GB_M ? M - m0 : GB_M;
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)m0 * N, 0, (unsigned)((size_t)rows * N * 4), 0x00020000);
+    const unsigned rowpitch = (unsigned)N * 4u;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int col = n0 + wc * 64 + cb * 16 + l15;
+      const float bv = bias ? bias[col < N ? col : N - 1] : 0.f;
+      const unsigned vbase = col < N ? (unsigned)(wr * 64 + 4 * kg4) * rowpitch + (unsigned)col * 4u : 0x80000000u;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float o = acc[rb][cb][r] + bv;
+          if (RELU) o = fmaxf(o, 0.f);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), orsrc, vbase + (unsigned)(rb * 16 + r) * rowpitch, 0, 0);
         }
     }
   }
@@ -451,7 +591,13 @@ extern "C" int pvsg_gemm_bf16x3(const float* a, const void* w_packed, const floa
   const dim3 grid((unsigned)blocks), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const __bf16* wp = static_cast<const __bf16*>(w_packed);
-  if (relu)
+  const char* sel = getenv("PVSG_GEMM_K32");                    // =0: the 32x32x16 / K = 16 kernel for every shape (A/B tests)
+  const bool k32 = K % 32 == 0 && !(sel && sel[0] == '0');
+  if (k32 && relu)
+    hipLaunchKernelGGL((gemm_bf16x3_k32_kernel<true>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n);
+  else if (k32)
+    hipLaunchKernelGGL((gemm_bf16x3_k32_kernel<false>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n);
+  else if (relu)
     hipLaunchKernelGGL((gemm_bf16x3_kernel<true>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n);
   else
     hipLaunchKernelGGL((gemm_bf16x3_kernel<false>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n);

@@ -7,9 +7,18 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-# (M, N, K): encoder FFN / projections, ragged M and N, K = 16
+# (M, N, K): encoder FFN / projections, ragged M and N, K = 16 / 48 (the 16-deep kernel only), K = 32 / 96 (one / three 32-deep steps)
 CASES = [(1024, 1024, 256), (640, 256, 1024), (384, 544, 256), (1000, 256, 256), (77, 96, 16), (129, 130, 48), (1, 1, 16),
-         (300, 2048, 256)]
+         (300, 2048, 256), (130, 70, 32), (257, 129, 96)]
+
+
+@pytest.fixture(autouse=True, params=['k32', 'k16'])
+def gemm_kernel(request, monkeypatch):
+    """Every test runs on the default dispatch (v_mfma_f32_16x16x32_bf16 with K = 32 stages where K % 32 == 0) and with the
+    32x32x16 / K = 16 kernel forced for all shapes (PVSG_GEMM_K32=0, read per call)."""
+    if request.param == 'k16':
+        monkeypatch.setenv('PVSG_GEMM_K32', '0')
+    return request.param
 
 
 @pytest.mark.parametrize('M,N,K', CASES)
