@@ -531,6 +531,201 @@ void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict
   }
 }
 
+// The 1x1 convolution on v_mfma_f32_16x16x32_bf16 with K = 32 stages (see gemm_bf16x3_k32_kernel): the same operands, epilogues
+// and record formats as the kernel above; default for Cin % 32 == 0.
+template <bool RELU, bool RESIDUAL, bool IN_NORM, bool BITS = false>
+__global__ __launch_bounds__(256, 3)
+void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ scale,
+                               const float* __restrict__ shift, const float* __restrict__ residual,
+                               const float* __restrict__ in_scale, const float* __restrict__ in_shift, float* __restrict__ y,
+                               int Cin, int Cout, int Cpad, int HWin, int Win, int HWo, int Wo, int stride, int tiles_c,
+                               int tiles_p, unsigned* __restrict__ flags = nullptr) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * K32_TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tc = logical % tiles_c;
+  logical /= tiles_c;
+  const int tp = logical % tiles_p, img = logical / tiles_p;
+  const int c0 = tc * GB_M, p0 = tp * GB_N;
+  // staging: weights -- (k-group tid/128, row tid%128) of both 16-deep sub-steps, 3 limbs; pixels -- (k-group tid/128, pixel
+  // tid%128), the 8 channels of that k-group in each sub-step
+  const int skg = __builtin_amdgcn_readfirstlane(tid >> 7), srow = tid & 127;
+  const size_t w_limb_stride = (size_t)2 * Cpad * 8;
+  const __bf16* wsrc = Wp + ((size_t)skg * Cpad + c0 + srow) * 8;
+  const int pix = p0 + srow;
+  const int pin = stride == 1 ? pix : (2 * (pix / Wo)) * Win + 2 * (pix % Wo);
+  const unsigned x_voff = pix < HWo ? (unsigned)pin * 4u : 0x80000000u;            // beyond the map: read as 0
+  const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)img * Cin * HWin, 0,
+                                                      (unsigned)((size_t)Cin * HWin * 4), 0x00020000);
+  const unsigned plane = (unsigned)HWin * 4u;
+  float x_regs[2][8];                                 // [sub-step]
+  u32x4 w_regs[2][3];
+  auto fetch = [&](int kt) {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      const unsigned so = (unsigned)(kt * 32 + 16 * gq + 8 * skg) * plane;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        x_regs[gq][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, x_voff, so + j * plane, 0));
+      const __bf16* wk = wsrc + (size_t)(2 * kt + gq) * 3 * w_limb_stride;
+#pragma unroll
+      for (int l = 0; l < 3; ++l) w_regs[gq][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
+    }
+  };
+  auto stash = [&](int kt) {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      if (IN_NORM) {                                   // channel kt*32 + 16*gq + 8*skg + j of this image: wave-uniform scalars
+        const int ci = img * Cin + kt * 32 + 16 * gq + 8 * skg;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x_regs[gq][j] = fmaxf(fmaf(x_regs[gq][j], in_scale[ci + j], in_shift[ci + j]), 0.f);
+      }
+      unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) split2(x_regs[gq][2 * q], x_regs[gq][2 * q + 1], hh[q], mm[q], ll[q]);
+      __bf16* pw = lds + ((2 * gq + skg) * GB_M + srow) * 8;                  // row operand: weights
+#pragma unroll
+      for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(pw + i * K32_LIMB) = w_regs[gq][i];
+      __bf16* px = lds + K32_TILE + ((2 * gq + skg) * GB_N + srow) * 8;       // column operand: pixels
+      *reinterpret_cast<u32x4*>(px) = u32x4{hh[0], hh[1], hh[2], hh[3]};
+      *reinterpret_cast<u32x4*>(px + K32_LIMB) = u32x4{mm[0], mm[1], mm[2], mm[3]};
+      *reinterpret_cast<u32x4*>(px + 2 * K32_LIMB) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int l15 = lane & 15, kg4 = lane >> 4;
+  const __bf16* afr = lds + (kg4 * GB_M + wr * 64 + l15) * 8;
+  const __bf16* wfr = lds + K32_TILE + (kg4 * GB_N + wc * 64 + l15) * 8;
+  auto mf = [](bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); };
+  const int KT = Cin / 32;
+  fetch(0);
+  stash(0);
+  for (int kt = 0; kt < KT; ++kt) {
+    __syncthreads();
+    fetch(kt + 1 < KT ? kt + 1 : KT - 1);
+    bf16x8 ahf[4], amf[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      ahf[rb] = *reinterpret_cast<const bf16x8*>(afr + rb * 128);
+      amf[rb] = *reinterpret_cast<const bf16x8*>(afr + K32_LIMB + rb * 128);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wfr + cb * 128);
+      const bf16x8 wm = *reinterpret_cast<const bf16x8*>(wfr + K32_LIMB + cb * 128);
+      const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wfr + 2 * K32_LIMB + cb * 128);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wm, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wl, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wm, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wh, acc[rb][cb]);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) amf[rb] = *reinterpret_cast<const bf16x8*>(afr + 2 * K32_LIMB + rb * 128);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wfr + cb * 128);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+    }
+    __syncthreads();
+    if (kt + 1 < KT) stash(kt + 1);
+  }
+
+  if constexpr (BITS) {
+    // register r of block (rb, cb): query 64 wr + 16 rb + 4 kg4 + r = bit 16 (rb & 1) + 4 kg4 + r of word 2 wr + (rb >> 1);
+    // key = pixel 64 wc + 16 cb + l15.  The four lane groups of a wave hold complementary bits of the same words.
+    unsigned w[4][2];                                    // [cb][word]
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int ws = 0; ws < 2; ++ws) {
+        unsigned v = 0u;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (acc[2 * ws + h2][cb][r] < 0.f) v |= 1u << (16 * h2 + 4 * kg4 + r);
+        v |= (unsigned)__shfl_xor((int)v, 16);
+        v |= (unsigned)__shfl_xor((int)v, 32);
+        w[cb][ws] = v;
+      }
+    // lane (l15, kg4) stores the key of column block cb = kg4: words 2 wr, 2 wr + 1 of its 16-byte record
+    const int p = p0 + wc * 64 + kg4 * 16 + l15;
+    const unsigned w0 = kg4 == 0 ? w[0][0] : kg4 == 1 ? w[1][0] : kg4 == 2 ? w[2][0] : w[3][0];
+    const unsigned w1 = kg4 == 0 ? w[0][1] : kg4 == 1 ? w[1][1] : kg4 == 2 ? w[2][1] : w[3][1];
+    unsigned a0 = 0u, a1 = 0u;
+    if (p < HWo) {
+      unsigned* rec = reinterpret_cast<unsigned*>(y) + ((size_t)img * HWo + p) * 4 + 2 * wr;
+      *reinterpret_cast<uint2*>(rec) = make_uint2(w0, w1);
+      a0 = ~w0;
+      a1 = ~w1;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      a0 |= (unsigned)__shfl_xor((int)a0, off);
+      a1 |= (unsigned)__shfl_xor((int)a1, off);
+    }
+    if (lane == 0) {                                     // look before the atomic (see the kernel above)
+      const unsigned c0w = __hip_atomic_load(flags + 2 * wr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned c1w = __hip_atomic_load(flags + 2 * wr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a0 & ~c0w) atomicOr(flags + 2 * wr, a0);
+      if (a1 & ~c1w) atomicOr(flags + 2 * wr + 1, a1);
+    }
+    return;
+  }
+  // BN affine (+ identity) (+ ReLU), branch-free through buffer descriptors (see the kernel above): register r of block
+  // (rb, cb) = channel 16 rb + 4 kg4 + r, pixel 16 cb + l15 of the wave's 64 x 64 tile
+  {
+    const auto srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scale), 0, scale ? (unsigned)Cout * 4u : 0u, 0x00020000);
+    const auto hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(shift), 0, shift ? (unsigned)Cout * 4u : 0u, 0x00020000);
+    const size_t obase = (size_t)img * Cout * HWo;
+    const unsigned img_bytes = (unsigned)((size_t)Cout * HWo * 4);
+    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(y + obase, 0, img_bytes, 0x00020000);
+    const auto rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual) + (RESIDUAL ? obase : 0), 0,
+                                                       RESIDUAL ? img_bytes : 0u, 0x00020000);
+    const unsigned chpitch = (unsigned)HWo * 4u;
+    unsigned pvoff[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int p = p0 + wc * 64 + cb * 16 + l15;
+      pvoff[cb] = p < HWo ? (unsigned)p * 4u : 0x80000000u;
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const int chb = c0 + wr * 64 + rb * 16 + 4 * kg4;              // channels chb .. chb + 3
+      const f32x4 sc4 = scale ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)chb * 4u, 0, 0))
+                              : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 sh4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, (unsigned)chb * 4u, 0, 0));
+      float res[4][4];
+      if (RESIDUAL) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            res[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, pvoff[cb] + (unsigned)(chb + r) * chpitch, 0, 0));
+      }
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = fmaf(acc[rb][cb][r], sc4[r], sh4[r]);
+          if (RESIDUAL) v += res[cb][r];
+          if (RELU) v = fmaxf(v, 0.f);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, pvoff[cb] + (unsigned)(chb + r) * chpitch, 0, 0);
+        }
+    }
+  }
+}
+
 // W (N, K) f32 -> [k-tile K/16][limb 3][k-group 2][Npad][8] bf16, columns beyond N zero
 __global__ void gemm_bf16x3_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int N, int K, int Npad) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // one (column, k pair)
@@ -625,14 +820,29 @@ extern "C" int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const f
   const dim3 grid((unsigned)blocks), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const __bf16* wp = static_cast<const __bf16*>(w_packed);
+  // PVSG_GEMM_K32=0: the 32x32x16 / K = 16 kernel for every shape, =1: the K = 32 kernel wherever Cin allows (A/B tests);
+  // default: K = 32 except on the small stride-1 maps (23 x 40 at 720p: layer4 and its input convolution measured 3-5 %
+  // slower there, profiles/r03_conv1x1_bf16x3_bench.jsonl)
+  const char* sel = getenv("PVSG_GEMM_K32");
+  const bool k32 = Cin % 32 == 0 && !(sel && sel[0] == '0') && ((sel && sel[0] == '1') || stride == 2 || Ho * Wo >= 2048);
 #define PVSG_C1_LAUNCH(R, S)                                                                                            \
-  hipLaunchKernelGGL((conv1x1_bf16x3_kernel<R, S, false>), grid, block, 0, st, x, wp, scale, shift, residual, in_scale,   \
-                     in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p)
+  do {                                                                                                                  \
+    if (k32)                                                                                                            \
+      hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<R, S, false>), grid, block, 0, st, x, wp, scale, shift, residual,  \
+                         in_scale, in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p);       \
+    else                                                                                                                \
+      hipLaunchKernelGGL((conv1x1_bf16x3_kernel<R, S, false>), grid, block, 0, st, x, wp, scale, shift, residual,      \
+                         in_scale, in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p);       \
+  } while (0)
   if (in_scale) {          // normalised input: the pixel decoder's mask-feature convolution (no ReLU / identity behind it)
     if (relu || residual)
       return set_err(PVSG_ERR_UNSUPPORTED, "conv1x1_bf16x3: in_scale / in_shift come without relu / residual");
-    hipLaunchKernelGGL((conv1x1_bf16x3_kernel<false, false, true>), grid, block, 0, st, x, wp, scale, shift, residual, in_scale,
-                       in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p);
+    if (k32)
+      hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<false, false, true>), grid, block, 0, st, x, wp, scale, shift, residual,
+                         in_scale, in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p);
+    else
+      hipLaunchKernelGGL((conv1x1_bf16x3_kernel<false, false, true>), grid, block, 0, st, x, wp, scale, shift, residual, in_scale,
+                         in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p);
   } else if (relu) {
     if (residual) PVSG_C1_LAUNCH(true, true); else PVSG_C1_LAUNCH(true, false);
   } else {
@@ -687,6 +897,14 @@ extern "C" int pvsg_attn_mask_bits_bf16x3(const float* mask_embed, const float* 
     __bf16* wp = static_cast<__bf16*>(w_scratch) + (size_t)b * welems;
     const int rc = pvsg_gemm_bf16x3_pack(mask_embed + (size_t)b * Q * C, wp, Q, C, stream);
     if (rc != PVSG_OK) return rc;
+    const char* sel = getenv("PVSG_GEMM_K32");
+    if (C % 32 == 0 && !(sel && sel[0] == '0'))
+      hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<false, false, false, true>), dim3((unsigned)(T * tiles_p)), dim3(256), 0, st,
+                         feature_lowres + (size_t)b * T * C * N, wp, (const float*)nullptr, (const float*)nullptr,
+                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                         reinterpret_cast<float*>(bits + (size_t)b * T * N * 4), C, Q, GB_M, (int)N, (int)N, (int)N, (int)N, 1, 1,
+                         tiles_p, flags + (size_t)b * 4);
+    else
     hipLaunchKernelGGL((conv1x1_bf16x3_kernel<false, false, false, true>), dim3((unsigned)(T * tiles_p)), dim3(256), 0, st,
                        feature_lowres + (size_t)b * T * C * N, wp, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,

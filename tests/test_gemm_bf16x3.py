@@ -16,8 +16,7 @@ CASES = [(1024, 1024, 256), (640, 256, 1024), (384, 544, 256), (1000, 256, 256),
 def gemm_kernel(request, monkeypatch):
     """Every test runs on the default dispatch (v_mfma_f32_16x16x32_bf16 with K = 32 stages where K % 32 == 0) and with the
     32x32x16 / K = 16 kernel forced for all shapes (PVSG_GEMM_K32=0, read per call)."""
-    if request.param == 'k16':
-        monkeypatch.setenv('PVSG_GEMM_K32', '0')
+    monkeypatch.setenv('PVSG_GEMM_K32', '0' if request.param == 'k16' else '1')     # '1': K = 32 on every shape that allows it
     return request.param
 
 

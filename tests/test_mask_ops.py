@@ -11,6 +11,14 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
+@pytest.fixture(autouse=True, params=['k32', 'k16'])
+def split_kernel_shape(request, monkeypatch):
+    """The split-bf16 mask kernels on their default form (v_mfma_f32_16x16x32_bf16, K = 32 stages) and on the 32x32x16 / K = 16
+    form (PVSG_GEMM_K32=0, read per call): same oracle, same bounds."""
+    monkeypatch.setenv('PVSG_GEMM_K32', '0' if request.param == 'k16' else '1')
+    return request.param
+
+
 def oracle_forward_head_mask(emb, feat, target, heads=8):
     """oracle/heads.py forward_head, mask part only (image or video)."""
     if feat.dim() == 4:
