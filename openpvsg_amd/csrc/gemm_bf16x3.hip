@@ -226,9 +226,12 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
       for (int l = 0; l < 3; ++l) w_regs[j][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
     }
   };
-  auto stash = [&]() {
+  // the split of step kt+1 (VALU) runs under the MFMAs of step kt, on the registers its loads landed in; between the two
+  // barriers only the LDS writes remain
+  u32x4 limbs[2][3];                                            // [k-group 2*ah2 + gq][limb]
+  auto split = [&]() {
 #pragma unroll
-    for (int gq = 0; gq < 2; ++gq) {                             // k-group 2*ah2 + gq = floats 8 gq .. 8 gq + 7 of this thread
+    for (int gq = 0; gq < 2; ++gq) {                             // floats 8 gq .. 8 gq + 7 of this thread
       unsigned hh[4], mm[4], ll[4];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -236,10 +239,17 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
         split2(v[0], v[1], hh[2 * q], mm[2 * q], ll[2 * q]);
         split2(v[2], v[3], hh[2 * q + 1], mm[2 * q + 1], ll[2 * q + 1]);
       }
+      limbs[gq][0] = u32x4{hh[0], hh[1], hh[2], hh[3]};
+      limbs[gq][1] = u32x4{mm[0], mm[1], mm[2], mm[3]};
+      limbs[gq][2] = u32x4{ll[0], ll[1], ll[2], ll[3]};
+    }
+  };
+  auto write = [&]() {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
       __bf16* pa = lds + ((2 * ah2 + gq) * GB_M + ar) * 8;
-      *reinterpret_cast<u32x4*>(pa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
-      *reinterpret_cast<u32x4*>(pa + K32_LIMB) = u32x4{mm[0], mm[1], mm[2], mm[3]};
-      *reinterpret_cast<u32x4*>(pa + 2 * K32_LIMB) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+#pragma unroll
+      for (int l = 0; l < 3; ++l) *reinterpret_cast<u32x4*>(pa + l * K32_LIMB) = limbs[gq][l];
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -257,7 +267,8 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
   auto mf = [](bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); };
   const int KT = K / 32;
   fetch(0);
-  stash();
+  split();
+  write();
   for (int kt = 0; kt < KT; ++kt) {
     __syncthreads();                                             // step kt is in LDS
     fetch(kt + 1 < KT ? kt + 1 : KT - 1);
@@ -283,6 +294,7 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wh, acc[rb][cb]);
     }
+    split();                                                     // next step's A: VALU under the MFMAs still in flight
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) amf[rb] = *reinterpret_cast<const bf16x8*>(afr + 2 * K32_LIMB + rb * 128);   // A's low limb
 #pragma unroll
@@ -292,7 +304,7 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
       for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
     }
     __syncthreads();                                             // everyone is done reading step kt
-    if (kt + 1 < KT) stash();
+    if (kt + 1 < KT) write();
   }
   // bias / ReLU and store through a bounded buffer descriptor (see the kernel above): register r of block (rb, cb) = row
   // rb*16 + 4*(lane>>4) + r, column cb*16 + (lane&15) of the wave's 64 x 64 tile; no branch, no wait between the 64 stores
@@ -573,7 +585,8 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
       for (int l = 0; l < 3; ++l) w_regs[gq][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
     }
   };
-  auto stash = [&](int kt) {
+  u32x4 limbs[2][3];                                   // split of step kt+1 under the MFMAs of step kt (see the GEMM kernel)
+  auto split = [&](int kt) {
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
       if (IN_NORM) {                                   // channel kt*32 + 16*gq + 8*skg + j of this image: wave-uniform scalars
@@ -584,13 +597,20 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
       unsigned hh[4], mm[4], ll[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) split2(x_regs[gq][2 * q], x_regs[gq][2 * q + 1], hh[q], mm[q], ll[q]);
+      limbs[gq][0] = u32x4{hh[0], hh[1], hh[2], hh[3]};
+      limbs[gq][1] = u32x4{mm[0], mm[1], mm[2], mm[3]};
+      limbs[gq][2] = u32x4{ll[0], ll[1], ll[2], ll[3]};
+    }
+  };
+  auto write = [&]() {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
       __bf16* pw = lds + ((2 * gq + skg) * GB_M + srow) * 8;                  // row operand: weights
 #pragma unroll
       for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(pw + i * K32_LIMB) = w_regs[gq][i];
       __bf16* px = lds + K32_TILE + ((2 * gq + skg) * GB_N + srow) * 8;       // column operand: pixels
-      *reinterpret_cast<u32x4*>(px) = u32x4{hh[0], hh[1], hh[2], hh[3]};
-      *reinterpret_cast<u32x4*>(px + K32_LIMB) = u32x4{mm[0], mm[1], mm[2], mm[3]};
-      *reinterpret_cast<u32x4*>(px + 2 * K32_LIMB) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+#pragma unroll
+      for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(px + i * K32_LIMB) = limbs[gq][i];
     }
   };
   f32x4 acc[4][4];
@@ -602,7 +622,8 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
   auto mf = [](bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); };
   const int KT = Cin / 32;
   fetch(0);
-  stash(0);
+  split(0);
+  write();
   for (int kt = 0; kt < KT; ++kt) {
     __syncthreads();
     fetch(kt + 1 < KT ? kt + 1 : KT - 1);
@@ -628,6 +649,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wh, acc[rb][cb]);
     }
+    split(kt + 1 < KT ? kt + 1 : KT - 1);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) amf[rb] = *reinterpret_cast<const bf16x8*>(afr + 2 * K32_LIMB + rb * 128);
 #pragma unroll
@@ -637,7 +659,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
       for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
     }
     __syncthreads();
-    if (kt + 1 < KT) stash(kt + 1);
+    if (kt + 1 < KT) write();
   }
 
   if constexpr (BITS) {
