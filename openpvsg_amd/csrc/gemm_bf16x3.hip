@@ -269,9 +269,9 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
   fetch(0);
   split();
   write();
+  fetch(KT > 1 ? 1 : 0);                                        // loads run a whole step ahead of their split
   for (int kt = 0; kt < KT; ++kt) {
     __syncthreads();                                             // step kt is in LDS
-    fetch(kt + 1 < KT ? kt + 1 : KT - 1);
     bf16x8 ahf[4], amf[4];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
@@ -305,6 +305,7 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
     }
     __syncthreads();                                             // everyone is done reading step kt
     if (kt + 1 < KT) write();
+    fetch(kt + 2 < KT ? kt + 2 : KT - 1);                        // registers are free again: step kt+2 starts its trip
   }
   // bias / ReLU and store through a bounded buffer descriptor (see the kernel above): register r of block (rb, cb) = row
   // rb*16 + 4*(lane>>4) + r, column cb*16 + (lane&15) of the wave's 64 x 64 tile; no branch, no wait between the 64 stores
@@ -626,7 +627,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
   write();
   for (int kt = 0; kt < KT; ++kt) {
     __syncthreads();
-    fetch(kt + 1 < KT ? kt + 1 : KT - 1);
+    fetch(kt + 1 < KT ? kt + 1 : KT - 1);     // (issued a step earlier, behind write(), this kernel spills 46 registers)
     bf16x8 ahf[4], amf[4];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {

@@ -1383,6 +1383,156 @@ void gemm_k32e_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp
       }
   }
 }
+__global__ __launch_bounds__(256, 3)
+void gemm_k32f_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
+                     float* __restrict__ out, int M, int N, int K, int Npad, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * K32_TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tn = logical % tiles_n, tm = logical / tiles_n;
+  const int m0 = tm * GB_M, n0 = tn * GB_N;
+  // staging roles: A -- thread (row tid/2, half tid%2) 16 consecutive floats; W -- (k-group tid/128, column tid%128) of both
+  // 16-deep sub-steps, 3 limbs each (the packed layout of the shipped kernel: [kt16][limb][kg][Npad][8])
+  const int ar = tid >> 1, ah2 = tid & 1;
+  const bool a_in = m0 + ar < M;
+  const unsigned a_voff = a_in ? (unsigned)((ar * K + 16 * ah2) * 4) : 0x80000000u;
+  const auto asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A) + (size_t)m0 * K * 4), 0,
+                                                      (unsigned)((size_t)GB_M * K * 4), 0x00020000);
+  const int wkg = tid >> 7, wcol = tid & 127;
+  const size_t w_limb_stride = (size_t)2 * Npad * 8;
+  const __bf16* wsrc = Wp + ((size_t)wkg * Npad + n0 + wcol) * 8;
+  f32x4 a_regs[4];
+  u32x4 w_regs[2][3];
+  auto fetch = [&](int kt) {                                     // kt counts 32-deep steps
+    const unsigned so = (unsigned)kt * (32 * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      a_regs[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc, a_voff + 16 * q, so, 0));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const __bf16* wk = wsrc + (size_t)(2 * kt + j) * 3 * w_limb_stride;
+#pragma unroll
+      for (int l = 0; l < 3; ++l) w_regs[j][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
+    }
+  };
+  u32x4 limbs[2][3];                                            // next step's A limbs of this thread's two k-groups
+  auto split = [&]() {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 v = a_regs[2 * gq + q];
+        split2(v[0], v[1], hh[2 * q], mm[2 * q], ll[2 * q]);
+        split2(v[2], v[3], hh[2 * q + 1], mm[2 * q + 1], ll[2 * q + 1]);
+      }
+      limbs[gq][0] = u32x4{hh[0], hh[1], hh[2], hh[3]};
+      limbs[gq][1] = u32x4{mm[0], mm[1], mm[2], mm[3]};
+      limbs[gq][2] = u32x4{ll[0], ll[1], ll[2], ll[3]};
+    }
+  };
+  auto write = [&]() {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      __bf16* pa = lds + ((2 * ah2 + gq) * GB_M + ar) * 8;
+#pragma unroll
+      for (int l = 0; l < 3; ++l) *reinterpret_cast<u32x4*>(pa + l * K32_LIMB) = limbs[gq][l];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __bf16* pw = lds + K32_TILE + ((2 * j + wkg) * GB_N + wcol) * 8;
+#pragma unroll
+      for (int l = 0; l < 3; ++l) *reinterpret_cast<u32x4*>(pw + l * K32_LIMB) = w_regs[j][l];
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int l15 = lane & 15, kg4 = lane >> 4;
+  const __bf16* afr = lds + (kg4 * GB_M + wr * 64 + l15) * 8;                 // + limb * K32_LIMB + rb * 128
+  const __bf16* wfr = lds + K32_TILE + (kg4 * GB_N + wc * 64 + l15) * 8;      // + limb * K32_LIMB + cb * 128
+  auto mf = [](bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); };
+  const int KT = K / 32;
+  fetch(0);
+  split();
+  write();
+  fetch(KT > 1 ? 1 : 0);
+  for (int kt = 0; kt < KT; ++kt) {
+    __syncthreads();                                             // step kt is in LDS
+    bf16x8 ahf[4], amf[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      ahf[rb] = *reinterpret_cast<const bf16x8*>(afr + rb * 128);
+      amf[rb] = *reinterpret_cast<const bf16x8*>(afr + K32_LIMB + rb * 128);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wfr + cb * 128);
+      const bf16x8 wm = *reinterpret_cast<const bf16x8*>(wfr + K32_LIMB + cb * 128);
+      const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wfr + 2 * K32_LIMB + cb * 128);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wm, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wl, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wm, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wh, acc[rb][cb]);
+    }
+    split();                                                     // next step's A (registers): VALU under the MFMAs
+    {                                                            // the (lo, hi) product: A's low limb takes over amf's registers
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) amf[rb] = *reinterpret_cast<const bf16x8*>(afr + 2 * K32_LIMB + rb * 128);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wfr + cb * 128);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+      }
+    }
+    __syncthreads();                                             // everyone is done reading step kt
+    if (kt + 1 < KT) write();
+    fetch(kt + 2 < KT ? kt + 2 : KT - 1);
+  }
+  const int g4 = lane >> 4;
+  const bool full = (m0 + GB_M <= M) && (n0 + GB_N <= N);
+  if (full) {
+    float bv[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) bv[cb] = bias ? bias[n0 + wc * 64 + cb * 16 + l15] : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      float* op = out + (size_t)(m0 + wr * 64 + 4 * g4) * N + n0 + wc * 64 + cb * 16 + l15;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) op[(size_t)(rb * 16 + r) * N] = acc[rb][cb][r] + bv[cb];
+    }
+    return;
+  }
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const int col = n0 + wc * 64 + cb * 16 + l15;
+    if (col >= N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wr * 64 + rb * 16 + 4 * g4 + r;
+        if (row < M) out[(size_t)row * N + col] = acc[rb][cb][r] + bv;
+      }
+  }
+}
+void launch_k32f(const float* A, const __bf16* Ap, const __bf16* Wp, const float* bias, float* out, int M, int N, int K) {
+  const int Npad = (N + 127) / 128 * 128, tiles_n = Npad / 128;
+  const long long blocks = (long long)((M + 127) / 128) * tiles_n;
+  hipLaunchKernelGGL(gemm_k32f_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, A, Wp, bias, out, M, N, K, Npad, tiles_n);
+}
 void launch_k32e(const float* A, const __bf16* Ap, const __bf16* Wp, const float* bias, float* out, int M, int N, int K) {
   const int Npad = (N + 127) / 128 * 128, tiles_n = Npad / 128;
   const long long blocks = (long long)((M + 127) / 128) * tiles_n;
@@ -1436,7 +1586,7 @@ int main(int argc, char** argv) {
   std::vector<Variant> vars = {
       {"shipped", launch_abl<0>},      {"abl1_nosplit", launch_abl<1>}, {"abl2_nostash", launch_abl<2>},
       {"abl3_noload", launch_abl<3>},  {"abl4_mfma_only", launch_abl<4>}, {"abl5_mfma_nostore", launch_abl<5>},
-      {"abl10_shipped_timed", launch_abl<10>}, {"abl11_fullpath_dword", launch_abl<11>}, {"abl21_fullpath_mfma16x16x32", launch_abl<21>}, {"pair16_k16stages", launch_abl<22>}, {"k32_single_stage", launch_k32}, {"k32_prefetchA2", launch_k32p2}, {"k32_split_early", launch_k32e}, {"abl12_fullpath_ldsT", launch_abl<12>}, {"epi1_swapped_x4", launch_epi<1>}, {"epi2_ldsT_x4", launch_epi<2>},
+      {"abl10_shipped_timed", launch_abl<10>}, {"abl11_fullpath_dword", launch_abl<11>}, {"abl21_fullpath_mfma16x16x32", launch_abl<21>}, {"pair16_k16stages", launch_abl<22>}, {"k32_single_stage", launch_k32}, {"k32_prefetchA2", launch_k32p2}, {"k32_split_early", launch_k32e}, {"k32_fetch_before_barrier", launch_k32f}, {"abl12_fullpath_ldsT", launch_abl<12>}, {"epi1_swapped_x4", launch_epi<1>}, {"epi2_ldsT_x4", launch_epi<2>},
       {"v2_persist_defer", launch_v2<false>},
       {"ps_ns2_w3", launch_ps<2, false, 3>},
   };
