@@ -1544,6 +1544,166 @@ void launch_k32(const float* A, const __bf16* Ap, const __bf16* Wp, const float*
   hipLaunchKernelGGL(gemm_k32_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, A, Wp, bias, out, M, N, K, Npad, tiles_n);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// W straight from L2 into MFMA fragments: the packed weight is fragment-major ([kt32][limb][16-column block][lane][8 bf16], lane =
+// (k-group, column)), every wave loads the fragments of its four column blocks itself (the two waves of a workgroup that share
+// them hit the vector L1).  LDS then holds only A: two 24 KB buffers, ONE barrier per step, the split / write of step kt+1
+// under the MFMAs of step kt.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void pack_w_frag_kernel(const float* __restrict__ w, __bf16* __restrict__ wf, int N, int K, int Npad) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // one (column, k pair)
+  const long long total = (long long)Npad * (K / 2);
+  if (idx >= total) return;
+  const int kp = (int)(idx % (K / 2)), n = (int)(idx / (K / 2));
+  const int k = 2 * kp;
+  float a0 = 0.f, a1 = 0.f;
+  if (n < N) { a0 = w[(size_t)n * K + k]; a1 = w[(size_t)n * K + k + 1]; }
+  unsigned h, m, l;
+  split2(a0, a1, h, m, l);
+  const int kt = k / 32, kg4 = (k % 32) / 8, e = k % 8, nb = n / 16, col = n % 16;
+  const size_t limb_stride = (size_t)(Npad / 16) * 64 * 8;                       // elements per (kt, limb)
+  unsigned* dst = reinterpret_cast<unsigned*>(wf + ((size_t)kt * 3) * limb_stride + ((size_t)nb * 64 + kg4 * 16 + col) * 8 + e);
+  dst[0] = h;
+  dst[limb_stride / 2] = m;
+  dst[limb_stride] = l;
+}
+
+__global__ __launch_bounds__(256, 3)
+void gemm_wdirect_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wf, const float* __restrict__ bias,
+                         float* __restrict__ out, int M, int N, int K, int Npad, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * K32_TILE];            // A only, two buffers
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tn = logical % tiles_n, tm = logical / tiles_n;
+  const int m0 = tm * GB_M, n0 = tn * GB_N;
+  const int ar = tid >> 1, ah2 = tid & 1;
+  const bool a_in = m0 + ar < M;
+  const unsigned a_voff = a_in ? (unsigned)((ar * K + 16 * ah2) * 4) : 0x80000000u;
+  const auto asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A) + (size_t)m0 * K * 4), 0,
+                                                      (unsigned)((size_t)GB_M * K * 4), 0x00020000);
+  f32x4 a_regs[4];
+  auto fetchA = [&](int kt) {
+    const unsigned so = (unsigned)kt * (32 * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      a_regs[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc, a_voff + 16 * q, so, 0));
+  };
+  auto stashA = [&](__bf16* buf) {                                // split + write (the write target is the OTHER buffer)
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 v = a_regs[2 * gq + q];
+        split2(v[0], v[1], hh[2 * q], mm[2 * q], ll[2 * q]);
+        split2(v[2], v[3], hh[2 * q + 1], mm[2 * q + 1], ll[2 * q + 1]);
+      }
+      __bf16* pa = buf + ((2 * ah2 + gq) * GB_M + ar) * 8;
+      *reinterpret_cast<u32x4*>(pa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
+      *reinterpret_cast<u32x4*>(pa + K32_LIMB) = u32x4{mm[0], mm[1], mm[2], mm[3]};
+      *reinterpret_cast<u32x4*>(pa + 2 * K32_LIMB) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+    }
+  };
+  // W fragments: this wave's column blocks nb0 .. nb0+3
+  const size_t wf_limb = (size_t)(Npad / 16) * 64 * 8;
+  const __bf16* wbase = Wf + ((size_t)((n0 + wc * 64) / 16) * 64 + lane) * 8;
+  bf16x8 wq[2][3];                                               // ring of two column blocks x three limbs
+  auto fetchW = [&](int slot, int kt, int cb) {
+    const __bf16* p = wbase + (size_t)kt * 3 * wf_limb + (size_t)cb * 64 * 8;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) wq[slot][l] = *reinterpret_cast<const bf16x8*>(p + l * wf_limb);
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int l15 = lane & 15, kg4 = lane >> 4;
+  const int afr_off = (kg4 * GB_M + wr * 64 + l15) * 8;
+  auto mf = [](bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); };
+  const int KT = K / 32;
+  fetchA(0);
+  fetchW(0, 0, 0);
+  stashA(lds);
+  fetchA(KT > 1 ? 1 : 0);
+  auto step = [&](int kt, auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    __syncthreads();                                             // A[kt] visible; the other buffer is free
+    if (kt + 1 < KT) stashA(lds + (par ^ 1) * K32_TILE);         // next step's A first: its registers die here
+    const __bf16* afr = lds + par * K32_TILE + afr_off;
+    bf16x8 ahf[4], amf[4], alf[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      ahf[rb] = *reinterpret_cast<const bf16x8*>(afr + rb * 128);
+      amf[rb] = *reinterpret_cast<const bf16x8*>(afr + K32_LIMB + rb * 128);
+      alf[rb] = *reinterpret_cast<const bf16x8*>(afr + 2 * K32_LIMB + rb * 128);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      // prefetch the next column block (or the next step's first) into the other ring slot
+      if (cb < 3) fetchW((cb + 1) & 1, kt, cb + 1);
+      else fetchW(0, kt + 1 < KT ? kt + 1 : KT - 1, 0);
+      const bf16x8 wh = wq[cb & 1][0], wm = wq[cb & 1][1], wl = wq[cb & 1][2];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wm, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wl, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(alf[rb], wh, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wm, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wh, acc[rb][cb]);
+      if (cb == 2) fetchA(kt + 2 < KT ? kt + 2 : KT - 1);        // lands during the rest of this step and the next barrier
+    }
+  };
+  {
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    int kt = 0;
+    for (; kt + 2 <= KT; kt += 2) { step(kt, P0{}); step(kt + 1, P1{}); }
+    if (kt < KT) step(kt, P0{});
+  }
+  const int g4 = lane >> 4;
+  const bool full = (m0 + GB_M <= M) && (n0 + GB_N <= N);
+  if (full) {
+    float bv[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) bv[cb] = bias ? bias[n0 + wc * 64 + cb * 16 + l15] : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      float* op = out + (size_t)(m0 + wr * 64 + 4 * g4) * N + n0 + wc * 64 + cb * 16 + l15;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) op[(size_t)(rb * 16 + r) * N] = acc[rb][cb][r] + bv[cb];
+    }
+    return;
+  }
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const int col = n0 + wc * 64 + cb * 16 + l15;
+    if (col >= N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wr * 64 + rb * 16 + 4 * g4 + r;
+        if (row < M) out[(size_t)row * N + col] = acc[rb][cb][r] + bv;
+      }
+  }
+}
+static __bf16* g_wf = nullptr;       // fragment-major pack of the current shape's weights (filled by main)
+void launch_wdirect(const float* A, const __bf16* Ap, const __bf16* Wp, const float* bias, float* out, int M, int N, int K) {
+  const int Npad = (N + 127) / 128 * 128, tiles_n = Npad / 128;
+  const long long blocks = (long long)((M + 127) / 128) * tiles_n;
+  hipLaunchKernelGGL(gemm_wdirect_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, A, g_wf, bias, out, M, N, K, Npad, tiles_n);
+}
+
 struct Variant {
   std::string name;
   void (*launch)(const float*, const __bf16*, const __bf16*, const float*, float*, int, int, int);
@@ -1586,7 +1746,7 @@ int main(int argc, char** argv) {
   std::vector<Variant> vars = {
       {"shipped", launch_abl<0>},      {"abl1_nosplit", launch_abl<1>}, {"abl2_nostash", launch_abl<2>},
       {"abl3_noload", launch_abl<3>},  {"abl4_mfma_only", launch_abl<4>}, {"abl5_mfma_nostore", launch_abl<5>},
-      {"abl10_shipped_timed", launch_abl<10>}, {"abl11_fullpath_dword", launch_abl<11>}, {"abl21_fullpath_mfma16x16x32", launch_abl<21>}, {"pair16_k16stages", launch_abl<22>}, {"k32_single_stage", launch_k32}, {"k32_prefetchA2", launch_k32p2}, {"k32_split_early", launch_k32e}, {"k32_fetch_before_barrier", launch_k32f}, {"abl12_fullpath_ldsT", launch_abl<12>}, {"epi1_swapped_x4", launch_epi<1>}, {"epi2_ldsT_x4", launch_epi<2>},
+      {"abl10_shipped_timed", launch_abl<10>}, {"abl11_fullpath_dword", launch_abl<11>}, {"abl21_fullpath_mfma16x16x32", launch_abl<21>}, {"pair16_k16stages", launch_abl<22>}, {"k32_single_stage", launch_k32}, {"k32_prefetchA2", launch_k32p2}, {"k32_split_early", launch_k32e}, {"k32_fetch_before_barrier", launch_k32f}, {"wdirect_A2buf", launch_wdirect}, {"abl12_fullpath_ldsT", launch_abl<12>}, {"epi1_swapped_x4", launch_epi<1>}, {"epi2_ldsT_x4", launch_epi<2>},
       {"v2_persist_defer", launch_v2<false>},
       {"ps_ns2_w3", launch_ps<2, false, 3>},
   };
@@ -1608,6 +1768,9 @@ int main(int argc, char** argv) {
     fill_kernel<<<16, 256>>>(bias, N, 0x5555u, 1.0f);
     split_tiles_kernel<<<(unsigned)((Mp * (K / 2) + 255) / 256), 256>>>(A, Ap, M, K);
     pack_w_kernel<<<(unsigned)(((long long)Npad * (K / 2) + 255) / 256), 256>>>(W, Wp, N, K, Npad);
+    if (g_wf) CK(hipFree(g_wf));
+    CK(hipMalloc(&g_wf, (size_t)Npad * K * 6));
+    pack_w_frag_kernel<<<(unsigned)(((long long)Npad * (K / 2) + 255) / 256), 256>>>(W, g_wf, N, K, Npad);
     CK(hipDeviceSynchronize());
     launch_abl<0>(A, Ap, Wp, bias, ref, M, N, K);
     CK(hipDeviceSynchronize());
