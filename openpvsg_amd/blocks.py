@@ -95,8 +95,7 @@ def conv3x3_fast(conv, x, scale=None, shift=None, relu=False, out=None):
 def conv1x1_fast(conv, x, scale=None, shift=None, residual=None, relu=False, out=None, always=False, in_norm=None):
     """1x1 convolution (stride 1 or 2, NCHW) with BN affine / bias (`shift`), identity and ReLU in the epilogue on the
     split-bf16 matrix-core kernel (csrc/gemm_bf16x3.hip: conv1x1_bf16x3), or None where another path is at least as fast
-    (measured at 32 x 720p, scripts/conv1x1_bf16x3_bench.py: 256 -> 64 and the layers with <= 128 input channels that do
-    not expand + add an identity stay on csrc/conv1x1.hip) or the shape is unsupported.  A convolution bias is
+    (fewer than 64 input channels stay on csrc/conv1x1.hip) or the shape is unsupported.  A convolution bias is
     folded into `shift`."""
     w = conv.weight
     cout, cin = w.shape[:2]
@@ -105,12 +104,11 @@ def conv1x1_fast(conv, x, scale=None, shift=None, residual=None, relu=False, out
             os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and ops.conv1x1_bf16x3_supported(cout, cin, x.shape[2], x.shape[3])):
         return None
     stride = conv.stride[0]
-    # per shape at 32 x 720p (scripts/conv1x1_bf16x3_bench.py, profiles/r03_conv1x1_bf16x3_bench.jsonl): with the guard-free
-    # epilogue this kernel also wins the bottleneck's expanding convolutions with identity (64->256, 128->512, 256->1024:
-    # 0.90 / 0.63 / 0.50 ms vs 0.95 / 0.70 / 0.65 on csrc/conv1x1.hip); 256->64 (0.97 vs 0.72) and the other layers with
-    # fewer than 256 input channels stay on the f32 kernel
-    if not always and stride == 1 and not (cin >= 512 or (cin == 256 and cout >= 128) or
-                                           (cin >= 64 and cout >= 4 * cin and residual is not None)):
+    # per shape at 32 x 720p (scripts/conv1x1_bf16x3_bench.py, scripts/lab/conv_small_ab.py): with the K = 32 form and its 64-row
+    # tile for <= 64 output channels the split kernel wins every bottleneck 1x1 from 64 input channels up (256->64 0.56 vs
+    # 0.70 ms, 64->256 0.59 vs 0.74, 64->64 0.23 vs 0.24 on csrc/conv1x1.hip); below 64 input channels (K < 64: one or two
+    # steps per tile) the f32 kernel stays
+    if not always and stride == 1 and (cin < 64 or cin % 32):
         return None
     if conv.bias is not None:
         shift = conv.bias if shift is None else shift + conv.bias * (scale if scale is not None else 1.0)

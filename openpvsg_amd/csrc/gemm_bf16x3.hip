@@ -546,7 +546,10 @@ void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict
 
 // The 1x1 convolution on v_mfma_f32_16x16x32_bf16 with K = 32 stages (see gemm_bf16x3_k32_kernel): the same operands, epilogues
 // and record formats as the kernel above; default for Cin % 32 == 0.
-template <bool RELU, bool RESIDUAL, bool IN_NORM, bool BITS = false>
+// TM = 64: layers with at most 64 output channels (the bottleneck's reducing 1x1 of layer1).  The packed weight is padded to 128
+// rows and is staged whole, but only rows 0..63 are multiplied: the four waves each take 32 pixel columns of the 64 rows, half
+// the matrix work of a 128-row tile, which leaves these layers to their HBM traffic.
+template <bool RELU, bool RESIDUAL, bool IN_NORM, bool BITS = false, int TM = 128>
 __global__ __launch_bounds__(256, 3)
 void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ scale,
                                const float* __restrict__ shift, const float* __restrict__ residual,
@@ -555,7 +558,10 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
                                int tiles_p, unsigned* __restrict__ flags = nullptr) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * K32_TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  static_assert(TM == 128 || (TM == 64 && !BITS), "64-row tiles: plain convolution only");
+  constexpr int CB = TM == 128 ? 4 : 2;                          // 16-pixel column blocks per wave
+  const int wr = TM == 128 ? wave >> 1 : 0, wc = wave & 1;
+  const int wcol0 = TM == 128 ? wc * 64 : wave * 32;            // first pixel column of this wave in the tile
   unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int tc = logical % tiles_c;
   logical /= tiles_c;
@@ -614,12 +620,14 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
       for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(px + i * K32_LIMB) = limbs[gq][i];
     }
   };
-  f32x4 acc[4][4];
+  f32x4 acc[4][CB];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int l15 = lane & 15, kg4 = lane >> 4;
   const __bf16* afr = lds + (kg4 * GB_M + wr * 64 + l15) * 8;
-  const __bf16* wfr = lds + K32_TILE + (kg4 * GB_N + wc * 64 + l15) * 8;
+  const __bf16* wfr = lds + K32_TILE + (kg4 * GB_N + wcol0 + l15) * 8;
   auto mf = [](bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); };
   const int KT = Cin / 32;
   fetch(0);
@@ -635,7 +643,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
       amf[rb] = *reinterpret_cast<const bf16x8*>(afr + K32_LIMB + rb * 128);
     }
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
+    for (int cb = 0; cb < CB; ++cb) {
       const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wfr + cb * 128);
       const bf16x8 wm = *reinterpret_cast<const bf16x8*>(wfr + K32_LIMB + cb * 128);
       const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wfr + 2 * K32_LIMB + cb * 128);
@@ -654,7 +662,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) amf[rb] = *reinterpret_cast<const bf16x8*>(afr + 2 * K32_LIMB + rb * 128);
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
+    for (int cb = 0; cb < CB; ++cb) {
       const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wfr + cb * 128);
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
@@ -716,10 +724,10 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
     const auto rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual) + (RESIDUAL ? obase : 0), 0,
                                                        RESIDUAL ? img_bytes : 0u, 0x00020000);
     const unsigned chpitch = (unsigned)HWo * 4u;
-    unsigned pvoff[4];
+    unsigned pvoff[CB];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-      const int p = p0 + wc * 64 + cb * 16 + l15;
+    for (int cb = 0; cb < CB; ++cb) {
+      const int p = p0 + wcol0 + cb * 16 + l15;
       pvoff[cb] = p < HWo ? (unsigned)p * 4u : 0x80000000u;
     }
 #pragma unroll
@@ -728,16 +736,16 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
       const f32x4 sc4 = scale ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)chb * 4u, 0, 0))
                               : f32x4{1.f, 1.f, 1.f, 1.f};
       const f32x4 sh4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, (unsigned)chb * 4u, 0, 0));
-      float res[4][4];
+      float res[CB][4];
       if (RESIDUAL) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             res[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, pvoff[cb] + (unsigned)(chb + r) * chpitch, 0, 0));
       }
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
+      for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = fmaf(acc[rb][cb][r], sc4[r], sh4[r]);
@@ -848,9 +856,13 @@ extern "C" int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const f
   // slower there, profiles/r03_conv1x1_bf16x3_bench.jsonl)
   const char* sel = getenv("PVSG_GEMM_K32");
   const bool k32 = Cin % 32 == 0 && !(sel && sel[0] == '0') && ((sel && sel[0] == '1') || stride == 2 || Ho * Wo >= 2048);
+  const bool tm64 = k32 && Cout <= 64;
 #define PVSG_C1_LAUNCH(R, S)                                                                                            \
   do {                                                                                                                  \
-    if (k32)                                                                                                            \
+    if (tm64)                                                                                                           \
+      hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<R, S, false, false, 64>), grid, block, 0, st, x, wp, scale, shift,   \
+                         residual, in_scale, in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p); \
+    else if (k32)                                                                                                       \
       hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<R, S, false>), grid, block, 0, st, x, wp, scale, shift, residual,  \
                          in_scale, in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p);       \
     else                                                                                                                \

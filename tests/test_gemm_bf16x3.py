@@ -80,7 +80,8 @@ def test_gemm_bf16x3_deterministic_and_guards(hip_lib):
 
 # ---- NCHW 1x1 convolution on the same arithmetic (backbone bottleneck convs, pixel decoder 1x1 convs) ---------------
 C1_CASES = [(2, 256, 64, 16, 24, 1), (1, 512, 128, 23, 40, 1), (2, 256, 512, 23, 41, 2), (1, 1024, 2048, 7, 9, 2),
-            (1, 2048, 256, 5, 8, 1), (3, 64, 256, 9, 13, 1), (1, 16, 8, 3, 3, 1)]
+            (1, 2048, 256, 5, 8, 1), (3, 64, 256, 9, 13, 1), (1, 16, 8, 3, 3, 1),
+            (1, 64, 64, 20, 33, 1), (2, 128, 32, 9, 11, 2)]            # <= 64 output channels: the 64-row tile of the K = 32 form
 
 
 @pytest.mark.parametrize('B,Cin,Cout,H,W,stride', C1_CASES)
