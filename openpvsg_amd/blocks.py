@@ -79,12 +79,16 @@ def conv3x3_fast(conv, x, scale=None, shift=None, relu=False, out=None):
         return None
     if conv.stride == (1, 1) and ops.conv3x3_winograd_supported(w.shape[0], w.shape[1], x.shape[2], x.shape[3]):
         pack, run = ops.conv3x3_winograd_pack, ops.conv3x3_winograd
+    elif (conv.stride == (2, 2) and scale is not None and os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and
+          os.environ.get('PVSG_CONV3X3S2', 'bf16x3') != 'f32' and
+          ops.conv3x3s2_bf16x3_supported(w.shape[0], w.shape[1], x.shape[2], x.shape[3])):
+        pack, run = ops.conv3x3s2_bf16x3_pack, ops.conv3x3s2_bf16x3  # implicit GEMM over the nine taps on the split kernel
     elif (conv.stride == (2, 2) and scale is not None and
           ops.conv3x3s2_supported(w.shape[0], w.shape[1], x.shape[2], x.shape[3])):
-        pack, run = ops.conv3x3s2_pack, ops.conv3x3s2_affine          # direct convolution, csrc/conv3x3s2.hip
+        pack, run = ops.conv3x3s2_pack, ops.conv3x3s2_affine          # direct convolution on the f32 MFMA, csrc/conv3x3s2.hip
     else:
         return None
-    key = (w.data_ptr(), w._version, str(w.device))
+    key = (w.data_ptr(), w._version, str(w.device), pack.__name__)
     cache = getattr(conv, '_pvsg_packed', None)
     if cache is None or cache[0] != key:
         cache = (key, pack(w.detach()))

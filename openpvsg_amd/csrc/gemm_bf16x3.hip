@@ -549,7 +549,10 @@ void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict
 // TM = 64: layers with at most 64 output channels (the bottleneck's reducing 1x1 of layer1).  The packed weight is padded to 128
 // rows and is staged whole, but only rows 0..63 are multiplied: the four waves each take 32 pixel columns of the 64 rows, half
 // the matrix work of a 128-row tile, which leaves these layers to their HBM traffic.
-template <bool RELU, bool RESIDUAL, bool IN_NORM, bool BITS = false, int TM = 128>
+// TAPS = 9: the stride-2 3x3 convolution (pad 1) as an implicit GEMM over K = 9 * Cin, tap-major (weight packed from
+// w.permute(0, 2, 3, 1)): a 32-deep step lies inside one tap (Cin % 32 == 0), whose pixel offset replaces the 1x1 one;
+// out-of-image taps read 0 through the descriptor's bounds check.
+template <bool RELU, bool RESIDUAL, bool IN_NORM, bool BITS = false, int TM = 128, int TAPS = 1>
 __global__ __launch_bounds__(256, 3)
 void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ scale,
                                const float* __restrict__ shift, const float* __restrict__ residual,
@@ -559,6 +562,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * K32_TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   static_assert(TM == 128 || (TM == 64 && !BITS), "64-row tiles: plain convolution only");
+  static_assert(TAPS == 1 || (TAPS == 9 && !BITS && !IN_NORM && !RESIDUAL), "3x3 taps: affine / ReLU epilogue only");
   constexpr int CB = TM == 128 ? 4 : 2;                          // 16-pixel column blocks per wave
   const int wr = TM == 128 ? wave >> 1 : 0, wc = wave & 1;
   const int wcol0 = TM == 128 ? wc * 64 : wave * 32;            // first pixel column of this wave in the tile
@@ -573,7 +577,8 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
   const size_t w_limb_stride = (size_t)2 * Cpad * 8;
   const __bf16* wsrc = Wp + ((size_t)skg * Cpad + c0 + srow) * 8;
   const int pix = p0 + srow;
-  const int pin = stride == 1 ? pix : (2 * (pix / Wo)) * Win + 2 * (pix % Wo);
+  const int oy = pix / Wo, ox = pix - oy * Wo, Hin = HWin / Win;
+  const int pin = stride == 1 ? pix : (2 * oy) * Win + 2 * ox;
   const unsigned x_voff = pix < HWo ? (unsigned)pin * 4u : 0x80000000u;            // beyond the map: read as 0
   const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)img * Cin * HWin, 0,
                                                       (unsigned)((size_t)Cin * HWin * 4), 0x00020000);
@@ -581,12 +586,21 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
   float x_regs[2][8];                                 // [sub-step]
   u32x4 w_regs[2][3];
   auto fetch = [&](int kt) {
+    int cstep = kt * 32;                               // first input channel of this step
+    unsigned voff = x_voff;
+    if (TAPS == 9) {
+      const int tap = cstep / Cin;
+      cstep -= tap * Cin;
+      const int dy = tap / 3, dx = tap - 3 * dy;
+      const int iy = 2 * oy + dy - 1, ix = 2 * ox + dx - 1;
+      voff = (pix < HWo && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) ? (unsigned)(iy * Win + ix) * 4u : 0x80000000u;
+    }
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
-      const unsigned so = (unsigned)(kt * 32 + 16 * gq + 8 * skg) * plane;
+      const unsigned so = (unsigned)(cstep + 16 * gq + 8 * skg) * plane;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        x_regs[gq][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, x_voff, so + j * plane, 0));
+        x_regs[gq][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff, so + j * plane, 0));
       const __bf16* wk = wsrc + (size_t)(2 * kt + gq) * 3 * w_limb_stride;
 #pragma unroll
       for (int l = 0; l < 3; ++l) w_regs[gq][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
@@ -629,7 +643,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
   const __bf16* afr = lds + (kg4 * GB_M + wr * 64 + l15) * 8;
   const __bf16* wfr = lds + K32_TILE + (kg4 * GB_N + wcol0 + l15) * 8;
   auto mf = [](bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); };
-  const int KT = Cin / 32;
+  const int KT = TAPS * Cin / 32;
   fetch(0);
   split(0);
   write();
@@ -885,6 +899,38 @@ extern "C" int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const f
   }
 #undef PVSG_C1_LAUNCH
   PVSG_LAUNCH_CHECK("conv1x1_bf16x3");
+  return PVSG_OK;
+}
+
+// [3P] mmdet ResNet Bottleneck.conv2 with stride 2 (first block of layers 2-4, style='pytorch') + frozen BN + ReLU on the split
+// kernel: implicit GEMM over the nine taps (K = 9 * Cin).  w_packed = pvsg_gemm_bf16x3_pack of the (Cout, 9 * Cin) matrix
+// w.permute(0, 2, 3, 1) (tap-major, channel-minor).  The f32-MFMA form stays as pvsg_conv3x3s2_affine (csrc/conv3x3s2.hip).
+extern "C" int pvsg_conv3x3s2_bf16x3(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B,
+                                     int Cin, int Cout, int H, int W, int relu, void* stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(x && w_packed && scale && shift && y, "conv3x3s2_bf16x3: null pointer argument");
+  PVSG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3s2_bf16x3: bad shape");
+  if (Cin % 32 || Cout % 4 || (long long)Cin * H * W >= (1LL << 29) || (long long)Cout * H * W >= (1LL << 29))
+    return set_err(PVSG_ERR_UNSUPPORTED, "conv3x3s2_bf16x3: built for Cin %% 32 == 0, Cout %% 4 == 0, C*H*W < 2^29 (got Cin=%d Cout=%d H=%d W=%d)",
+                   Cin, Cout, H, W);
+  PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15u),
+               "conv3x3s2_bf16x3: w_packed, scale and shift must be 16-byte aligned");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int Cpad = (Cout + 127) / 128 * 128;
+  const int tiles_c = Cpad / GB_M, tiles_p = (Ho * Wo + GB_N - 1) / GB_N;
+  const long long blocks = (long long)B * tiles_c * tiles_p;
+  PVSG_REQUIRE(blocks < (1LL << 31), "conv3x3s2_bf16x3: too many blocks");
+  const dim3 grid((unsigned)blocks), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const __bf16* wp = static_cast<const __bf16*>(w_packed);
+  const float* nul = nullptr;
+  if (relu)
+    hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<true, false, false, false, 128, 9>), grid, block, 0, st, x, wp, scale, shift, nul, nul,
+                       nul, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, 2, tiles_c, tiles_p);
+  else
+    hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<false, false, false, false, 128, 9>), grid, block, 0, st, x, wp, scale, shift, nul, nul,
+                       nul, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, 2, tiles_c, tiles_p);
+  PVSG_LAUNCH_CHECK("conv3x3s2_bf16x3");
   return PVSG_OK;
 }
 

@@ -16,4 +16,4 @@ int set_err(int code, const char* fmt, ...) {
 
 extern "C" const char* pvsg_last_error(void) { return pvsg::err_buf(); }
 extern "C" const char* pvsg_version(void) { return "openpvsg_amd-hip 0.1 (gfx950)"; }
-extern "C" int pvsg_abi_version(void) { return 5; }
+extern "C" int pvsg_abi_version(void) { return 6; }
