@@ -236,9 +236,9 @@ class KernelTimer:
             N, Cin, Cout, H, W = a[5:10]
             ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
             return 4.0 * N * (Cin * H * W + Cout * ho * wo) + 36.0 * Cin * Cout, 18.0 * N * Cin * Cout * ho * wo
-        if name == 'pvsg_conv3x3s2_bf16x3':          # flops = bf16 limb products issued (6 per f32 multiply-add)
-            N, Cin, Cout, H, W = a[5:10]
-            ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        if name == 'pvsg_conv3x3_bf16x3':            # flops = bf16 limb products issued (6 per f32 multiply-add)
+            N, Cin, Cout, H, W, st = a[5:11]
+            ho, wo = (H - 1) // st + 1, (W - 1) // st + 1
             return 4.0 * N * (Cin * H * W + Cout * ho * wo) + 54.0 * Cin * Cout, 6.0 * 18.0 * N * Cin * Cout * ho * wo
         if name == 'pvsg_fpn_merge_up2x':
             planes, h, w = a[5:8]
@@ -282,7 +282,7 @@ class KernelTimer:
         if name == 'pvsg_gemm_bf16x3':
             M, N, K = a[4:7]
             return 2.0 * M * N * K
-        if name in ('pvsg_conv1x1_bf16x3', 'pvsg_conv3x3s2_bf16x3', 'pvsg_mask_logits_bf16x3', 'pvsg_attn_mask_bits_bf16x3'):
+        if name in ('pvsg_conv1x1_bf16x3', 'pvsg_conv3x3_bf16x3', 'pvsg_mask_logits_bf16x3', 'pvsg_attn_mask_bits_bf16x3'):
             return cls.work(name, a)[1] / 6.0
         if name == 'pvsg_masked_xattn_partial' and not XATTN_F32:
             return cls.work(name, a)[1] / 6.0
@@ -291,7 +291,7 @@ class KernelTimer:
     @staticmethod
     def mfma_peak(name):
         """(peak TFLOP/s, what the flops of work() count) of the matrix pipe a kernel runs on."""
-        if name.startswith(('pvsg_gemm_bf16x3', 'pvsg_conv1x1_bf16x3', 'pvsg_conv3x3s2_bf16x3', 'pvsg_mask_logits_bf16x3',
+        if name.startswith(('pvsg_gemm_bf16x3', 'pvsg_conv1x1_bf16x3', 'pvsg_conv3x3_bf16x3', 'pvsg_mask_logits_bf16x3',
                             'pvsg_attn_mask_bits_bf16x3')) \
                 or (name.startswith('pvsg_masked_xattn_partial') and not XATTN_F32):
             return BF16_MFMA_PEAK_TF, 'bf16 limb products issued (6 per f32 multiply-add), dense bf16 MFMA peak'

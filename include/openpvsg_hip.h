@@ -348,11 +348,11 @@ int pvsg_gemm_bf16x3(const float* a, const void* w_packed, const float* bias, fl
 int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const float* scale, const float* shift,
                         const float* residual, const float* in_scale, const float* in_shift, float* y, int B, int Cin,
                         int Cout, int H, int W, int stride, int relu, void* stream);
-/* [3P] mmdet ResNet Bottleneck.conv2 with stride 2 (3x3, pad 1; first block of layers 2-4, style='pytorch') -> frozen BN ->
- * ReLU on the split-bf16 kernel: implicit GEMM over the nine taps.  w_packed = pvsg_gemm_bf16x3_pack of the (Cout, 9*Cin)
- * matrix w.permute(0, 2, 3, 1) (tap-major).  Cin % 32 == 0.  The f32-MFMA form: pvsg_conv3x3s2_affine. */
-int pvsg_conv3x3s2_bf16x3(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B, int Cin,
-                          int Cout, int H, int W, int relu, void* stream);
+/* [3P] mmdet ResNet Bottleneck.conv2 (3x3, pad 1, stride 1 or 2) -> frozen BN -> ReLU on the split-bf16 kernel: implicit GEMM
+ * over the nine taps.  w_packed = pvsg_gemm_bf16x3_pack of the (Cout, 9*Cin) matrix w.permute(0, 2, 3, 1) (tap-major).
+ * Cin % 32 == 0.  f32-MFMA forms: pvsg_conv3x3_winograd (stride 1), pvsg_conv3x3s2_affine (stride 2). */
+int pvsg_conv3x3_bf16x3(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B, int Cin,
+                        int Cout, int H, int W, int stride, int relu, void* stream);
 
 /* [3P] mmdet ResNet stem in one launch: conv1 (7x7 / 2, pad 3, 3 -> 64, no bias) -> frozen BN (scale, shift) -> ReLU ->
  * MaxPool2d(3, 2, 1):  x (N, 3, H, W) -> out (N, 64, Hp, Wp), Hc = (H-1)/2+1, Hp = (Hc-1)/2+1 (same for W).

@@ -76,7 +76,7 @@ SIGNATURES = {
     'pvsg_gemm_bf16x3_pack': [_c_f, _c_f, _i, _i, _c_f],
     'pvsg_gemm_bf16x3': [_c_f, _c_f, _c_f, _c_f, _ll, _i, _i, _i, _c_f],
     'pvsg_conv1x1_bf16x3': [_c_f] * 8 + [_i] * 7 + [_c_f],
-    'pvsg_conv3x3s2_bf16x3': [_c_f] * 5 + [_i] * 6 + [_c_f],
+    'pvsg_conv3x3_bf16x3': [_c_f] * 5 + [_i] * 7 + [_c_f],
     'pvsg_stem7x7_pack': [_c_f, _c_f, _c_f],
     'pvsg_group_norm_affine': [_c_f] * 6 + [_i, _i, _i, _ll, _f, _c_f],
     'pvsg_stem7x7_bn_relu_pool': [_c_f] * 5 + [_i, _i, _i, _c_f],

@@ -77,12 +77,17 @@ def conv3x3_fast(conv, x, scale=None, shift=None, relu=False, out=None):
             conv.groups == 1 and conv.bias is None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and
             x.is_contiguous() and not torch.is_grad_enabled() and os.environ.get('PVSG_WINOGRAD', 'on') != 'off'):
         return None
-    if conv.stride == (1, 1) and ops.conv3x3_winograd_supported(w.shape[0], w.shape[1], x.shape[2], x.shape[3]):
+    split_ok = (scale is not None and os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and
+                os.environ.get('PVSG_CONV3X3', 'bf16x3') != 'f32' and
+                ops.conv3x3_bf16x3_supported(w.shape[0], w.shape[1], x.shape[2], x.shape[3]))
+    if conv.stride == (1, 1) and split_ok and w.shape[1] >= 512:
+        # direct form on the split kernel: at 32 x 720p it beats Winograd on the 512-channel layers only (0.77 vs 0.86 ms;
+        # 64 / 128 / 256 channels: 0.93 / 0.70 / 0.66 vs 0.82 / 0.72 / 0.63, scripts/lab/conv3x3_ab.py)
+        pack, run = ops.conv3x3_bf16x3_pack, ops.conv3x3_bf16x3
+    elif conv.stride == (1, 1) and ops.conv3x3_winograd_supported(w.shape[0], w.shape[1], x.shape[2], x.shape[3]):
         pack, run = ops.conv3x3_winograd_pack, ops.conv3x3_winograd
-    elif (conv.stride == (2, 2) and scale is not None and os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and
-          os.environ.get('PVSG_CONV3X3S2', 'bf16x3') != 'f32' and
-          ops.conv3x3s2_bf16x3_supported(w.shape[0], w.shape[1], x.shape[2], x.shape[3])):
-        pack, run = ops.conv3x3s2_bf16x3_pack, ops.conv3x3s2_bf16x3  # implicit GEMM over the nine taps on the split kernel
+    elif conv.stride == (2, 2) and split_ok:
+        pack, run = ops.conv3x3_bf16x3_pack, ops.conv3x3s2_bf16x3    # implicit GEMM over the nine taps on the split kernel
     elif (conv.stride == (2, 2) and scale is not None and
           ops.conv3x3s2_supported(w.shape[0], w.shape[1], x.shape[2], x.shape[3])):
         pack, run = ops.conv3x3s2_pack, ops.conv3x3s2_affine          # direct convolution on the f32 MFMA, csrc/conv3x3s2.hip

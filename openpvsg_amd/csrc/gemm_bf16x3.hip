@@ -549,7 +549,7 @@ void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict
 // TM = 64: layers with at most 64 output channels (the bottleneck's reducing 1x1 of layer1).  The packed weight is padded to 128
 // rows and is staged whole, but only rows 0..63 are multiplied: the four waves each take 32 pixel columns of the 64 rows, half
 // the matrix work of a 128-row tile, which leaves these layers to their HBM traffic.
-// TAPS = 9: the stride-2 3x3 convolution (pad 1) as an implicit GEMM over K = 9 * Cin, tap-major (weight packed from
+// TAPS = 9: the 3x3 convolution (pad 1, stride 1 or 2) as an implicit GEMM over K = 9 * Cin, tap-major (weight packed from
 // w.permute(0, 2, 3, 1)): a 32-deep step lies inside one tap (Cin % 32 == 0), whose pixel offset replaces the 1x1 one;
 // out-of-image taps read 0 through the descriptor's bounds check.
 template <bool RELU, bool RESIDUAL, bool IN_NORM, bool BITS = false, int TM = 128, int TAPS = 1>
@@ -592,7 +592,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
       const int tap = cstep / Cin;
       cstep -= tap * Cin;
       const int dy = tap / 3, dx = tap - 3 * dy;
-      const int iy = 2 * oy + dy - 1, ix = 2 * ox + dx - 1;
+      const int iy = stride * oy + dy - 1, ix = stride * ox + dx - 1;
       voff = (pix < HWo && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) ? (unsigned)(iy * Win + ix) * 4u : 0x80000000u;
     }
 #pragma unroll
@@ -902,35 +902,36 @@ extern "C" int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const f
   return PVSG_OK;
 }
 
-// [3P] mmdet ResNet Bottleneck.conv2 with stride 2 (first block of layers 2-4, style='pytorch') + frozen BN + ReLU on the split
-// kernel: implicit GEMM over the nine taps (K = 9 * Cin).  w_packed = pvsg_gemm_bf16x3_pack of the (Cout, 9 * Cin) matrix
-// w.permute(0, 2, 3, 1) (tap-major, channel-minor).  The f32-MFMA form stays as pvsg_conv3x3s2_affine (csrc/conv3x3s2.hip).
-extern "C" int pvsg_conv3x3s2_bf16x3(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B,
-                                     int Cin, int Cout, int H, int W, int relu, void* stream) {
+// [3P] mmdet ResNet Bottleneck.conv2 (3x3, pad 1, stride 1 or 2) + frozen BN + ReLU on the split kernel: implicit GEMM over the
+// nine taps (K = 9 * Cin).  w_packed = pvsg_gemm_bf16x3_pack of the (Cout, 9 * Cin) matrix w.permute(0, 2, 3, 1) (tap-major,
+// channel-minor).  Direct-form arithmetic (18 Cin Cout flop per output pixel): it wins where the f32 kernels are weakest -- the
+// stride-2 layers (pvsg_conv3x3s2_affine) and, against Winograd (pvsg_conv3x3_winograd), the 64- and 512-channel layers.
+extern "C" int pvsg_conv3x3_bf16x3(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B,
+                                   int Cin, int Cout, int H, int W, int stride, int relu, void* stream) {
   using namespace pvsg;
-  PVSG_REQUIRE(x && w_packed && scale && shift && y, "conv3x3s2_bf16x3: null pointer argument");
-  PVSG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3s2_bf16x3: bad shape");
+  PVSG_REQUIRE(x && w_packed && scale && shift && y, "conv3x3_bf16x3: null pointer argument");
+  PVSG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "conv3x3_bf16x3: bad shape");
   if (Cin % 32 || Cout % 4 || (long long)Cin * H * W >= (1LL << 29) || (long long)Cout * H * W >= (1LL << 29))
-    return set_err(PVSG_ERR_UNSUPPORTED, "conv3x3s2_bf16x3: built for Cin %% 32 == 0, Cout %% 4 == 0, C*H*W < 2^29 (got Cin=%d Cout=%d H=%d W=%d)",
+    return set_err(PVSG_ERR_UNSUPPORTED, "conv3x3_bf16x3: built for Cin %% 32 == 0, Cout %% 4 == 0, C*H*W < 2^29 (got Cin=%d Cout=%d H=%d W=%d)",
                    Cin, Cout, H, W);
   PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15u),
-               "conv3x3s2_bf16x3: w_packed, scale and shift must be 16-byte aligned");
-  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+               "conv3x3_bf16x3: w_packed, scale and shift must be 16-byte aligned");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const int Cpad = (Cout + 127) / 128 * 128;
   const int tiles_c = Cpad / GB_M, tiles_p = (Ho * Wo + GB_N - 1) / GB_N;
   const long long blocks = (long long)B * tiles_c * tiles_p;
-  PVSG_REQUIRE(blocks < (1LL << 31), "conv3x3s2_bf16x3: too many blocks");
+  PVSG_REQUIRE(blocks < (1LL << 31), "conv3x3_bf16x3: too many blocks");
   const dim3 grid((unsigned)blocks), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const __bf16* wp = static_cast<const __bf16*>(w_packed);
   const float* nul = nullptr;
-  if (relu)
-    hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<true, false, false, false, 128, 9>), grid, block, 0, st, x, wp, scale, shift, nul, nul,
-                       nul, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, 2, tiles_c, tiles_p);
-  else
-    hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<false, false, false, false, 128, 9>), grid, block, 0, st, x, wp, scale, shift, nul, nul,
-                       nul, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, 2, tiles_c, tiles_p);
-  PVSG_LAUNCH_CHECK("conv3x3s2_bf16x3");
+#define PVSG_C3_LAUNCH(R, TMV)                                                                                                  \
+  hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<R, false, false, false, TMV, 9>), grid, block, 0, st, x, wp, scale, shift, nul, nul, \
+                     nul, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p)
+  if (Cout <= 64) { if (relu) PVSG_C3_LAUNCH(true, 64); else PVSG_C3_LAUNCH(false, 64); }
+  else { if (relu) PVSG_C3_LAUNCH(true, 128); else PVSG_C3_LAUNCH(false, 128); }
+#undef PVSG_C3_LAUNCH
+  PVSG_LAUNCH_CHECK("conv3x3_bf16x3");
   return PVSG_OK;
 }
 

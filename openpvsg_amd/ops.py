@@ -640,36 +640,40 @@ def conv3x3s2_affine(x, w_packed, cout, scale, shift, relu=True, out=None):
     return out
 
 
-def conv3x3s2_bf16x3_supported(cout, cin, h, w):
+def conv3x3s2_bf16x3(x, w_packed, cout, scale, shift, relu=True, out=None):
+    return conv3x3_bf16x3(x, w_packed, cout, scale, shift, relu=relu, out=out, stride=2)
+
+
+def conv3x3_bf16x3_supported(cout, cin, h, w):
     return cin % 32 == 0 and cout % 4 == 0 and cin * h * w < 2 ** 29 and cout * h * w < 2 ** 29 and 9 * cin <= 8192
 
 
-def conv3x3s2_bf16x3_pack(weight):
-    """(Cout,Cin,3,3) -> limbs of the (Cout, 9*Cin) tap-major matrix for pvsg_conv3x3s2_bf16x3 (once per weight)."""
+def conv3x3_bf16x3_pack(weight):
+    """(Cout,Cin,3,3) -> limbs of the (Cout, 9*Cin) tap-major matrix for pvsg_conv3x3_bf16x3 (once per weight)."""
     w = _chk(weight, 'weight')
     Cout, Cin = w.shape[:2]
-    if tuple(w.shape[2:]) != (3, 3) or not conv3x3s2_bf16x3_supported(Cout, Cin, 2, 2):
-        raise RuntimeError('conv3x3s2_bf16x3_pack: unsupported weight shape %s' % (tuple(w.shape),))
+    if tuple(w.shape[2:]) != (3, 3) or not conv3x3_bf16x3_supported(Cout, Cin, 2, 2):
+        raise RuntimeError('conv3x3_bf16x3_pack: unsupported weight shape %s' % (tuple(w.shape),))
     return gemm_bf16x3_pack(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous())
 
 
-def conv3x3s2_bf16x3(x, w_packed, cout, scale, shift, relu=True, out=None):
-    """act(conv3x3(x, w, stride 2, pad 1) * scale[c] + shift[c]) on the split-bf16 kernel (implicit GEMM over the nine taps,
-    csrc/gemm_bf16x3.hip); w_packed = conv3x3s2_bf16x3_pack(w)."""
+def conv3x3_bf16x3(x, w_packed, cout, scale, shift, relu=True, out=None, stride=1):
+    """act(conv3x3(x, w, stride 1 or 2, pad 1) * scale[c] + shift[c]) on the split-bf16 kernel (implicit GEMM over the nine
+    taps, csrc/gemm_bf16x3.hip); w_packed = conv3x3_bf16x3_pack(w)."""
     x = _chk(x, 'x')
     N, Cin, H, W = x.shape
-    if not conv3x3s2_bf16x3_supported(cout, Cin, H, W):
-        raise RuntimeError('conv3x3s2_bf16x3: unsupported shape Cout=%d Cin=%d H=%d W=%d' % (cout, Cin, H, W))
+    if stride not in (1, 2) or not conv3x3_bf16x3_supported(cout, Cin, H, W):
+        raise RuntimeError('conv3x3_bf16x3: unsupported shape Cout=%d Cin=%d H=%d W=%d stride=%d' % (cout, Cin, H, W, stride))
     if w_packed.numel() != _lib.load().pvsg_gemm_bf16x3_packed_elems(cout, 9 * Cin):
-        raise RuntimeError('conv3x3s2_bf16x3: packed weight does not match Cout=%d Cin=%d' % (cout, Cin))
-    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        raise RuntimeError('conv3x3_bf16x3: packed weight does not match Cout=%d Cin=%d' % (cout, Cin))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     if out is None:
         out = torch.empty((N, cout, Ho, Wo), device=x.device, dtype=torch.float32)
     elif not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (N, cout, Ho, Wo)):
-        raise RuntimeError('conv3x3s2_bf16x3: out must be a contiguous float32 HIP tensor (N,Cout,Ho,Wo)')
+        raise RuntimeError('conv3x3_bf16x3: out must be a contiguous float32 HIP tensor (N,Cout,Ho,Wo)')
     with _on(x.device):
-        _lib.call('pvsg_conv3x3s2_bf16x3', x.data_ptr(), w_packed.data_ptr(), _chk(scale, 'scale').data_ptr(),
-                  _chk(shift, 'shift').data_ptr(), out.data_ptr(), N, Cin, cout, H, W, int(bool(relu)), _stream_ptr())
+        _lib.call('pvsg_conv3x3_bf16x3', x.data_ptr(), w_packed.data_ptr(), _chk(scale, 'scale').data_ptr(),
+                  _chk(shift, 'shift').data_ptr(), out.data_ptr(), N, Cin, cout, H, W, stride, int(bool(relu)), _stream_ptr())
     return out
 
 
@@ -841,3 +845,7 @@ def decoder_rows_post(layer_struct, head_struct, next_q, x1, qkv, query_pos, num
                   nq.data_ptr() if nq is not None else None,
                   workspace.data_ptr() if workspace is not None else None, B, Q, _stream_ptr())
     return q_out, cls, emb, nq
+
+
+conv3x3s2_bf16x3_pack = conv3x3_bf16x3_pack
+conv3x3s2_bf16x3_supported = conv3x3_bf16x3_supported

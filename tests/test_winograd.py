@@ -92,14 +92,15 @@ def test_conv3x3s2_matches_direct_convolution(hip_lib, N, Cin, Cout, H, W, relu)
     assert err < 1e-5 * max(1.0, ref.abs().max().item()), err              # plain f32 fma chain of length 9 Cin
 
 
-# ---- the same convolution as an implicit GEMM over the nine taps on the split-bf16 kernel (csrc/gemm_bf16x3.hip) -------------
+# ---- 3x3 convolutions (stride 1 and 2) as an implicit GEMM over the nine taps on the split-bf16 kernel (csrc/gemm_bf16x3.hip) ----
 S2X_CASES = [(2, 128, 128, 32, 32), (1, 128, 128, 23, 41), (2, 256, 256, 46, 80), (1, 512, 512, 17, 19), (1, 32, 100, 5, 3),
              (1, 64, 8, 1, 1), (1, 64, 128, 92, 160), (1, 96, 260, 9, 9)]
 
 
 @pytest.mark.parametrize('N,Cin,Cout,H,W', S2X_CASES)
 @pytest.mark.parametrize('relu', [True, False])
-def test_conv3x3s2_bf16x3_matches_direct_convolution(hip_lib, N, Cin, Cout, H, W, relu):
+@pytest.mark.parametrize('stride', [2, 1])
+def test_conv3x3_bf16x3_matches_direct_convolution(hip_lib, N, Cin, Cout, H, W, relu, stride):
     """Odd and even maps (the last row / column tap falls outside for even sizes only), ragged pixel and channel tiles;
     against float64, at the f32 kernel's bound, and next to the library's own f32 convolution."""
     from openpvsg_amd import ops
@@ -107,21 +108,21 @@ def test_conv3x3s2_bf16x3_matches_direct_convolution(hip_lib, N, Cin, Cout, H, W
     x = torch.randn(N, Cin, H, W, generator=g).cuda()
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).cuda()
     scale, shift = (torch.rand(Cout, generator=g) + 0.5).cuda(), torch.randn(Cout, generator=g).cuda()
-    y = ops.conv3x3s2_bf16x3(x, ops.conv3x3s2_bf16x3_pack(w), Cout, scale, shift, relu=relu)
-    ref = F.conv2d(x.double().cpu(), w.double().cpu(), stride=2, padding=1)
+    y = ops.conv3x3_bf16x3(x, ops.conv3x3_bf16x3_pack(w), Cout, scale, shift, relu=relu, stride=stride)
+    ref = F.conv2d(x.double().cpu(), w.double().cpu(), stride=stride, padding=1)
     ref = ref * scale.double().cpu().view(1, -1, 1, 1) + shift.double().cpu().view(1, -1, 1, 1)
     ref = F.relu(ref) if relu else ref
-    lib = F.conv2d(x, w, stride=2, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    lib = F.conv2d(x, w, stride=stride, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     lib = F.relu(lib) if relu else lib
     assert tuple(y.shape) == tuple(ref.shape)
     err = (y.double().cpu() - ref).abs().max().item()
     err_lib = (lib.double().cpu() - ref).abs().max().item()
     # the split GEMM's bound (tests/test_gemm_bf16x3.py): a few f32 ulps of the accumulated magnitude sum |x||w| (* scale)
-    mag = (F.conv2d(x.abs().double().cpu(), w.abs().double().cpu(), stride=2, padding=1).max().item() + 1.0) * scale.max().item()
+    mag = (F.conv2d(x.abs().double().cpu(), w.abs().double().cpu(), stride=stride, padding=1).max().item() + 1.0) * scale.max().item()
     assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
     assert err < 4e-7 * mag, (err, mag)
     assert err < 3 * err_lib + 2e-7 * mag, (err, err_lib, mag)
-    assert torch.equal(y, ops.conv3x3s2_bf16x3(x, ops.conv3x3s2_bf16x3_pack(w), Cout, scale, shift, relu=relu))
+    assert torch.equal(y, ops.conv3x3_bf16x3(x, ops.conv3x3_bf16x3_pack(w), Cout, scale, shift, relu=relu, stride=stride))
 
 
 def test_conv3x3s2_is_deterministic_and_rejects_unsupported(hip_lib):
