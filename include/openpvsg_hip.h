@@ -354,6 +354,34 @@ int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const float* scale
 int pvsg_conv3x3_bf16x3(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B, int Cin,
                         int Cout, int H, int W, int stride, int relu, void* stream);
 
+/* ---- the same five entry points on a TWO-limb f16 split (csrc/gemm_bf16x3.hip, F16 kernels) ------------------------------
+ * An f16 carries 11 significant bits: a = a_h + a_l with a_h = f16(a), a_l = f16(a - a_h) is good to 2^-24 |a|, and a product
+ * needs three limb products (hh, hl, lh) instead of six -- half the matrix work for the same f32-class dot product
+ * (tests/test_gemm_f16x2.py measures both forms and the library's f32 GEMM against float64).  The missing exponent range of f16
+ * is handled by exact power-of-two factors: the packed weight is scaled so that max|w| 2^e lies in [2^13, 2^14) (2^-e is
+ * applied to the accumulator), the activation's low limb is staged as 2^11 (a - a_h) against a third weight array 2^-11 w_h.
+ * Full accuracy for activations 2^-13 <= |a| <= 65504 (absolute error <= 2^-36 below), weights down to 2^-16 max|w|.
+ * |a| > 65504 is NOT representable: the results of such a call are invalid and every kernel adds the number of staging
+ * threads that met such an operand to *overflow (a device uint32 owned by the caller; may be NULL = not reported).  The host
+ * mirror checks the counter at its next synchronisation point (openpvsg_amd/ops.py: split_overflow_check) and refuses to
+ * hand out results; PVSG_SPLIT=bf16x3 selects the three-limb form, which has the whole f32 range.
+ *   w_packed   pvsg_gemm_f16x2_packed_elems(N, K) 16-bit elements written by pvsg_gemm_f16x2_pack (arrays w_h, w_l, 2^-11 w_h
+ *              in the staging order of the bf16 form, then max|w| and 2^-e as floats); K % 32 == 0
+ * Arguments, layouts and the interfaces replaced are those of the _bf16x3 entry points above. */
+long long pvsg_gemm_f16x2_packed_elems(int N, int K);
+int pvsg_gemm_f16x2_pack(const float* weight, void* w_packed, int N, int K, void* stream);
+int pvsg_gemm_f16x2(const float* a, const void* w_packed, const float* bias, float* out, long long M, int N, int K,
+                    int relu, uint32_t* overflow, void* stream);
+int pvsg_conv1x1_f16x2(const float* x, const void* w_packed, const float* scale, const float* shift,
+                       const float* residual, const float* in_scale, const float* in_shift, float* y, int B, int Cin,
+                       int Cout, int H, int W, int stride, int relu, uint32_t* overflow, void* stream);
+int pvsg_conv3x3_f16x2(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B, int Cin,
+                       int Cout, int H, int W, int stride, int relu, uint32_t* overflow, void* stream);
+int pvsg_mask_logits_f16x2(const float* mask_embed, const float* mask_feature, void* w_scratch, float* out, int B, int T,
+                           int Q, int C, long long N, uint32_t* overflow, void* stream);
+int pvsg_attn_mask_bits_f16x2(const float* mask_embed, const float* feature_lowres, void* w_scratch, uint32_t* bits,
+                              uint32_t* flags, int B, int T, int Q, int C, long long N, uint32_t* overflow, void* stream);
+
 /* [3P] mmdet ResNet stem in one launch: conv1 (7x7 / 2, pad 3, 3 -> 64, no bias) -> frozen BN (scale, shift) -> ReLU ->
  * MaxPool2d(3, 2, 1):  x (N, 3, H, W) -> out (N, 64, Hp, Wp), Hc = (H-1)/2+1, Hp = (Hc-1)/2+1 (same for W).
  * `w_packed` = 21*64*8 floats written by pvsg_stem7x7_pack from the (64, 3, 7, 7) weight (once per weight). */

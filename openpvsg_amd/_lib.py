@@ -77,13 +77,21 @@ SIGNATURES = {
     'pvsg_gemm_bf16x3': [_c_f, _c_f, _c_f, _c_f, _ll, _i, _i, _i, _c_f],
     'pvsg_conv1x1_bf16x3': [_c_f] * 8 + [_i] * 7 + [_c_f],
     'pvsg_conv3x3_bf16x3': [_c_f] * 5 + [_i] * 7 + [_c_f],
+    'pvsg_gemm_f16x2_packed_elems': [_i, _i],
+    'pvsg_gemm_f16x2_pack': [_c_f, _c_f, _i, _i, _c_f],
+    'pvsg_gemm_f16x2': [_c_f, _c_f, _c_f, _c_f, _ll, _i, _i, _i, _c_f, _c_f],
+    'pvsg_conv1x1_f16x2': [_c_f] * 8 + [_i] * 7 + [_c_f, _c_f],
+    'pvsg_conv3x3_f16x2': [_c_f] * 5 + [_i] * 7 + [_c_f, _c_f],
+    'pvsg_mask_logits_f16x2': [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _ll, _c_f, _c_f],
+    'pvsg_attn_mask_bits_f16x2': [_c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _ll, _c_f, _c_f],
     'pvsg_stem7x7_pack': [_c_f, _c_f, _c_f],
     'pvsg_group_norm_affine': [_c_f] * 6 + [_i, _i, _i, _ll, _f, _c_f],
     'pvsg_stem7x7_bn_relu_pool': [_c_f] * 5 + [_i, _i, _i, _c_f],
     'pvsg_conv3x3s2_affine': [_c_f] * 5 + [_i] * 6 + [_c_f],
 }
 # entry points that return a value instead of a status code
-VALUE_RETURNING = ('pvsg_xattn_num_splits', 'pvsg_gemm_bf16x3_packed_elems', 'pvsg_minvis_chain_workspace_bytes',
+VALUE_RETURNING = ('pvsg_xattn_num_splits', 'pvsg_gemm_bf16x3_packed_elems', 'pvsg_gemm_f16x2_packed_elems',
+                   'pvsg_minvis_chain_workspace_bytes',
                    'pvsg_decoder_rows_post_workspace_bytes')
 
 _lib = None
@@ -112,7 +120,7 @@ def load():
             f = getattr(lib, name)
         except AttributeError as e:
             raise BackendMissingError('symbol %s missing from %s' % (name, LIB_PATH)) from e
-        f.restype = _ll if name in ('pvsg_gemm_bf16x3_packed_elems', 'pvsg_minvis_chain_workspace_bytes',
+        f.restype = _ll if name in ('pvsg_gemm_bf16x3_packed_elems', 'pvsg_gemm_f16x2_packed_elems', 'pvsg_minvis_chain_workspace_bytes',
                                    'pvsg_decoder_rows_post_workspace_bytes') else _i
         f.argtypes = argtypes
     _lib = lib

@@ -93,7 +93,7 @@ def conv3x3_fast(conv, x, scale=None, shift=None, relu=False, out=None):
         pack, run = ops.conv3x3s2_pack, ops.conv3x3s2_affine          # direct convolution on the f32 MFMA, csrc/conv3x3s2.hip
     else:
         return None
-    key = (w.data_ptr(), w._version, str(w.device), pack.__name__)
+    key = (w.data_ptr(), w._version, str(w.device), pack.__name__, ops.split_mode())
     cache = getattr(conv, '_pvsg_packed', None)
     if cache is None or cache[0] != key:
         cache = (key, pack(w.detach()))
@@ -121,7 +121,7 @@ def conv1x1_fast(conv, x, scale=None, shift=None, residual=None, relu=False, out
         return None
     if conv.bias is not None:
         shift = conv.bias if shift is None else shift + conv.bias * (scale if scale is not None else 1.0)
-    key = (w.data_ptr(), w._version, str(w.device))
+    key = (w.data_ptr(), w._version, str(w.device), ops.split_mode())
     cache = getattr(conv, '_pvsg_packed', None)
     if cache is None or cache[0] != key:
         cache = (key, ops.gemm_bf16x3_pack(w.detach().reshape(cout, cin).contiguous()))
@@ -142,7 +142,7 @@ def linear_fast(owner, tag, weights, x, bias=None, relu=False):
             os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and ops.gemm_bf16x3_supported(n, k)):
         y = F.linear(x, ws[0] if len(ws) == 1 else torch.cat(ws, 0), bias)
         return F.relu(y, inplace=True) if relu else y
-    key = tuple((w.data_ptr(), w._version, str(w.device)) for w in ws)
+    key = tuple((w.data_ptr(), w._version, str(w.device)) for w in ws) + (ops.split_mode(),)
     cache = owner.__dict__.setdefault('_pvsg_gemm', {})
     ent = cache.get(tag)
     if ent is None or ent[0] != key:

@@ -47,6 +47,44 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& h, unsigned
   l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Two-limb f16 split (F16 = true in the K = 32 kernels below; csrc header of the f16x2 entry points at the end of the file).
+// An f16 carries 11 significant bits, so a = a_h + a_l with a_h = f16(a), a_l = f16(a - a_h) is good to 2^-24 |a| (half an
+// ulp of the f32 itself) and a product needs THREE limb products (hh, hl, lh; ll < 2^-24 |a w|) instead of six: half the
+// matrix work for an f32-class dot product.  What f16 lacks is exponent range (2^-14 .. 65504), so the low limbs are kept
+// away from the subnormals by power-of-two factors that cancel exactly:
+//   weights (packed once):  ws = w * 2^e with max|ws| in [2^13, 2^14);  w_h = f16(ws), w_l = f16(ws - w_h), w_h2 = 2^-11 w_h
+//   activations (on the fly): a_h = f16(a), a_l' = f16(2^11 (a - a_h))      (a - a_h is exact in f32)
+//   acc += a_l' w_h2 + a_h w_l + a_h w_h      (f32 accumulator of v_mfma_f32_16x16x32_f16),   out = 2^-e acc
+// Full accuracy for 2^-13 <= |a| <= 65504 (29 binades; below that the absolute error is <= 2^-36), weights down to 2^-16 of
+// the tensor's largest.  |a| > 65504 cannot be represented: every kernel counts such operands into `overflow` (the caller's
+// device counter, checked by the host mirror at its next synchronisation point: openpvsg_amd/ops.py).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float F16X2_LO = 2048.f;                    // 2^11
+
+__device__ __forceinline__ void split2h(float a0, float a1, unsigned& h, unsigned& l, float& amax) {
+  const f16x2 hh = __builtin_convertvector(f32x2{a0, a1}, f16x2);
+  h = __builtin_bit_cast(unsigned, hh);
+  const float r0 = __builtin_fmaf((float)hh[0], -F16X2_LO, a0 * F16X2_LO), r1 = __builtin_fmaf((float)hh[1], -F16X2_LO, a1 * F16X2_LO);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, f16x2));
+  amax = fmaxf(fmaxf(amax, __builtin_fabsf(a0)), __builtin_fabsf(a1));
+}
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_k32(u32x4 a, u32x4 b, f32x4 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// per-tensor factor of an f16x2-packed weight: the two floats behind its 3 * Npad * K limb elements (amax, 2^-e)
+__device__ __forceinline__ float f16x2_unscale(const __bf16* Wp, int Npad, int K) {
+  return reinterpret_cast<const float*>(Wp + (size_t)3 * Npad * K)[1];
+}
+__device__ __forceinline__ void f16x2_count_overflow(float amax, unsigned* overflow) {
+  if (overflow && !(amax <= 65504.f)) atomicAdd(overflow, 1u);          // also counts NaN operands
+}
+
 template <bool RELU>
 __global__ __launch_bounds__(256, 2)
 void gemm_bf16x3_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
@@ -190,13 +228,17 @@ void gemm_bf16x3_kernel(const float* __restrict__ A, const __bf16* __restrict__ 
 // therefore comes last.  The packed weight layout is unchanged (two 16-deep sub-steps per stage).
 // Measured against the kernel above: FFN1 1.85 -> 1.63 ms, FFN2 1.63 -> 1.57, 544-wide projection 1.10 -> 1.01.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int K32_LIMB = 4 * GB_M * 8;          // bf16 elements of one limb of a 128 x 32 tile
+constexpr int K32_LIMB = 4 * GB_M * 8;          // bf16 / f16 elements of one limb of a 128 x 32 tile
 constexpr int K32_TILE = 3 * K32_LIMB;          // 24 KB per operand
-template <bool RELU>
+// F16: the two-limb f16 form (see split2h): A as (a_h, a_l'), W as (w_h, w_l, w_h2), three MFMAs per block instead of six,
+// 40 KB of LDS; `overflow` counts staged operands beyond the f16 range.
+template <bool RELU, bool F16 = false>
 __global__ __launch_bounds__(256, 3)
 void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
-                            float* __restrict__ out, int M, int N, int K, int Npad, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * K32_TILE];
+                            float* __restrict__ out, int M, int N, int K, int Npad, int tiles_n, unsigned* __restrict__ overflow = nullptr) {
+  constexpr int AL = F16 ? 2 : 3;                                // limbs of the on-the-fly operand
+  constexpr int W_AT = AL * K32_LIMB;                            // where the weight tile starts
+  __shared__ __attribute__((aligned(16))) __bf16 lds[W_AT + K32_TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -228,7 +270,8 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
   };
   // the split of step kt+1 (VALU) runs under the MFMAs of step kt, on the registers its loads landed in; between the two
   // barriers only the LDS writes remain
-  u32x4 limbs[2][3];                                            // [k-group 2*ah2 + gq][limb]
+  u32x4 limbs[2][AL];                                           // [k-group 2*ah2 + gq][limb]
+  float amax = 0.f;
   auto split = [&]() {
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {                             // floats 8 gq .. 8 gq + 7 of this thread
@@ -236,12 +279,17 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const f32x4 v = a_regs[2 * gq + q];
-        split2(v[0], v[1], hh[2 * q], mm[2 * q], ll[2 * q]);
-        split2(v[2], v[3], hh[2 * q + 1], mm[2 * q + 1], ll[2 * q + 1]);
+        if constexpr (F16) {
+          split2h(v[0], v[1], hh[2 * q], mm[2 * q], amax);
+          split2h(v[2], v[3], hh[2 * q + 1], mm[2 * q + 1], amax);
+        } else {
+          split2(v[0], v[1], hh[2 * q], mm[2 * q], ll[2 * q]);
+          split2(v[2], v[3], hh[2 * q + 1], mm[2 * q + 1], ll[2 * q + 1]);
+        }
       }
       limbs[gq][0] = u32x4{hh[0], hh[1], hh[2], hh[3]};
       limbs[gq][1] = u32x4{mm[0], mm[1], mm[2], mm[3]};
-      limbs[gq][2] = u32x4{ll[0], ll[1], ll[2], ll[3]};
+      if constexpr (!F16) limbs[gq][2] = u32x4{ll[0], ll[1], ll[2], ll[3]};
     }
   };
   auto write = [&]() {
@@ -249,11 +297,11 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
     for (int gq = 0; gq < 2; ++gq) {
       __bf16* pa = lds + ((2 * ah2 + gq) * GB_M + ar) * 8;
 #pragma unroll
-      for (int l = 0; l < 3; ++l) *reinterpret_cast<u32x4*>(pa + l * K32_LIMB) = limbs[gq][l];
+      for (int l = 0; l < AL; ++l) *reinterpret_cast<u32x4*>(pa + l * K32_LIMB) = limbs[gq][l];
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      __bf16* pw = lds + K32_TILE + ((2 * j + wkg) * GB_N + wcol) * 8;
+      __bf16* pw = lds + W_AT + ((2 * j + wkg) * GB_N + wcol) * 8;
 #pragma unroll
       for (int l = 0; l < 3; ++l) *reinterpret_cast<u32x4*>(pw + l * K32_LIMB) = w_regs[j][l];
     }
@@ -263,8 +311,9 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
   for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int l15 = lane & 15, kg4 = lane >> 4;
   const __bf16* afr = lds + (kg4 * GB_M + wr * 64 + l15) * 8;                 // + limb * K32_LIMB + row block * 128
-  const __bf16* wfr = lds + K32_TILE + (kg4 * GB_N + wc * 64 + l15) * 8;      // + limb * K32_LIMB + column block * 128
-  auto mf = [](bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); };
+  const __bf16* wfr = lds + W_AT + (kg4 * GB_N + wc * 64 + l15) * 8;          // + limb * K32_LIMB + column block * 128
+  auto frag = [](const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); };
+  auto mf = [](u32x4 a, u32x4 b, f32x4 c) { return mfma_k32<F16>(a, b, c); };
   const int KT = K / 32;
   fetch(0);
   split();
@@ -272,36 +321,48 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
   fetch(KT > 1 ? 1 : 0);                                        // loads run a whole step ahead of their split
   for (int kt = 0; kt < KT; ++kt) {
     __syncthreads();                                             // step kt is in LDS
-    bf16x8 ahf[4], amf[4];
+    u32x4 ahf[4], amf[4];                                        // A's first two limbs: (hi, mid) or (a_h, a_l')
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
-      ahf[rb] = *reinterpret_cast<const bf16x8*>(afr + rb * 128);
-      amf[rb] = *reinterpret_cast<const bf16x8*>(afr + K32_LIMB + rb * 128);
+      ahf[rb] = frag(afr + rb * 128);
+      amf[rb] = frag(afr + K32_LIMB + rb * 128);
     }
+    if constexpr (F16) {
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {                             // small terms first: (m,m) (h,l) (h,m) (m,h) (h,h)
-      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wfr + cb * 128);
-      const bf16x8 wm = *reinterpret_cast<const bf16x8*>(wfr + K32_LIMB + cb * 128);
-      const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wfr + 2 * K32_LIMB + cb * 128);
+      for (int cb = 0; cb < 4; ++cb) {                           // small terms first: (l', h2) (h, l) (h, h)
+        const u32x4 wh = frag(wfr + cb * 128), wl = frag(wfr + K32_LIMB + cb * 128), wh2 = frag(wfr + 2 * K32_LIMB + cb * 128);
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wm, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh2, acc[rb][cb]);
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wl, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wl, acc[rb][cb]);
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wm, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wh, acc[rb][cb]);
+      }
+      split();                                                   // next step's A: VALU under the MFMAs still in flight
+    } else {
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+      for (int cb = 0; cb < 4; ++cb) {                           // small terms first: (m,m) (h,l) (h,m) (m,h) (h,h)
+        const u32x4 wh = frag(wfr + cb * 128), wm = frag(wfr + K32_LIMB + cb * 128), wl = frag(wfr + 2 * K32_LIMB + cb * 128);
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wh, acc[rb][cb]);
-    }
-    split();                                                     // next step's A: VALU under the MFMAs still in flight
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wm, acc[rb][cb]);
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) amf[rb] = *reinterpret_cast<const bf16x8*>(afr + 2 * K32_LIMB + rb * 128);   // A's low limb
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wl, acc[rb][cb]);
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {                             // (l,h)
-      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wfr + cb * 128);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wm, acc[rb][cb]);
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wh, acc[rb][cb]);
+      }
+      split();                                                   // next step's A: VALU under the MFMAs still in flight
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) amf[rb] = frag(afr + 2 * K32_LIMB + rb * 128);   // A's low limb
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {                           // (l,h)
+        const u32x4 wh = frag(wfr + cb * 128);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+      }
     }
     __syncthreads();                                             // everyone is done reading step kt
     if (kt + 1 < KT) write();
@@ -310,6 +371,7 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
   // bias / ReLU and store through a bounded buffer descriptor (see the kernel above): register r of block (rb, cb) = row
   // rb*16 + 4*(lane>>4) + r, column cb*16 + (lane&15) of the wave's 64 x 64 tile; no branch, no wait between the 64 stores
   {
+    const float unscale = F16 ? f16x2_unscale(Wp, Npad, K) : 1.f;
     const int rows = M - m0 < GB_M ? M - m0 : GB_M;
     const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)m0 * N, 0, (unsigned)((size_t)rows * N * 4), 0x00020000);
     const unsigned rowpitch = (unsigned)N * 4u;
@@ -322,12 +384,13 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float o = acc[rb][cb][r] + bv;
+          float o = F16 ? __builtin_fmaf(acc[rb][cb][r], unscale, bv) : acc[rb][cb][r] + bv;
           if (RELU) o = fmaxf(o, 0.f);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), orsrc, vbase + (unsigned)(rb * 16 + r) * rowpitch, 0, 0);
         }
     }
   }
+  if constexpr (F16) f16x2_count_overflow(amax, overflow);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -552,14 +615,16 @@ void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict
 // TAPS = 9: the 3x3 convolution (pad 1, stride 1 or 2) as an implicit GEMM over K = 9 * Cin, tap-major (weight packed from
 // w.permute(0, 2, 3, 1)): a 32-deep step lies inside one tap (Cin % 32 == 0), whose pixel offset replaces the 1x1 one;
 // out-of-image taps read 0 through the descriptor's bounds check.
-template <bool RELU, bool RESIDUAL, bool IN_NORM, bool BITS = false, int TM = 128, int TAPS = 1>
+// F16: the two-limb f16 form (see split2h): weights (w_h, w_l, w_h2) resident in registers, pixels as (x_h, x_l').
+template <bool RELU, bool RESIDUAL, bool IN_NORM, bool BITS = false, int TM = 128, int TAPS = 1, bool F16 = false>
 __global__ __launch_bounds__(256, 3)
 void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ scale,
                                const float* __restrict__ shift, const float* __restrict__ residual,
                                const float* __restrict__ in_scale, const float* __restrict__ in_shift, float* __restrict__ y,
                                int Cin, int Cout, int Cpad, int HWin, int Win, int HWo, int Wo, int stride, int tiles_c,
-                               int tiles_p, unsigned* __restrict__ flags = nullptr) {
-  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * K32_TILE];
+                               int tiles_p, unsigned* __restrict__ flags = nullptr, unsigned* __restrict__ overflow = nullptr) {
+  constexpr int XL = F16 ? 2 : 3;                                // limbs of the on-the-fly (pixel) operand
+  __shared__ __attribute__((aligned(16))) __bf16 lds[K32_TILE + XL * K32_LIMB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   static_assert(TM == 128 || (TM == 64 && !BITS), "64-row tiles: plain convolution only");
   static_assert(TAPS == 1 || (TAPS == 9 && !BITS && !IN_NORM && !RESIDUAL), "3x3 taps: affine / ReLU epilogue only");
@@ -606,7 +671,8 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
       for (int l = 0; l < 3; ++l) w_regs[gq][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
     }
   };
-  u32x4 limbs[2][3];                                   // split of step kt+1 under the MFMAs of step kt (see the GEMM kernel)
+  u32x4 limbs[2][XL];                                  // split of step kt+1 under the MFMAs of step kt (see the GEMM kernel)
+  float amax = 0.f;
   auto split = [&](int kt) {
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
@@ -617,10 +683,13 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
       }
       unsigned hh[4], mm[4], ll[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) split2(x_regs[gq][2 * q], x_regs[gq][2 * q + 1], hh[q], mm[q], ll[q]);
+      for (int q = 0; q < 4; ++q) {
+        if constexpr (F16) split2h(x_regs[gq][2 * q], x_regs[gq][2 * q + 1], hh[q], mm[q], amax);
+        else split2(x_regs[gq][2 * q], x_regs[gq][2 * q + 1], hh[q], mm[q], ll[q]);
+      }
       limbs[gq][0] = u32x4{hh[0], hh[1], hh[2], hh[3]};
       limbs[gq][1] = u32x4{mm[0], mm[1], mm[2], mm[3]};
-      limbs[gq][2] = u32x4{ll[0], ll[1], ll[2], ll[3]};
+      if constexpr (!F16) limbs[gq][2] = u32x4{ll[0], ll[1], ll[2], ll[3]};
     }
   };
   auto write = [&]() {
@@ -631,7 +700,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
       for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(pw + i * K32_LIMB) = w_regs[gq][i];
       __bf16* px = lds + K32_TILE + ((2 * gq + skg) * GB_N + srow) * 8;       // column operand: pixels
 #pragma unroll
-      for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(px + i * K32_LIMB) = limbs[gq][i];
+      for (int i = 0; i < XL; ++i) *reinterpret_cast<u32x4*>(px + i * K32_LIMB) = limbs[gq][i];
     }
   };
   f32x4 acc[4][CB];
@@ -642,7 +711,8 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
   const int l15 = lane & 15, kg4 = lane >> 4;
   const __bf16* afr = lds + (kg4 * GB_M + wr * 64 + l15) * 8;
   const __bf16* wfr = lds + K32_TILE + (kg4 * GB_N + wcol0 + l15) * 8;
-  auto mf = [](bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); };
+  auto frag = [](const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); };
+  auto mf = [](u32x4 a, u32x4 b, f32x4 c) { return mfma_k32<F16>(a, b, c); };
   const int KT = TAPS * Cin / 32;
   fetch(0);
   split(0);
@@ -650,40 +720,56 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
   for (int kt = 0; kt < KT; ++kt) {
     __syncthreads();
     fetch(kt + 1 < KT ? kt + 1 : KT - 1);     // (issued a step earlier, behind write(), this kernel spills 46 registers)
-    bf16x8 ahf[4], amf[4];
+    u32x4 ahf[4], amf[4];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
-      ahf[rb] = *reinterpret_cast<const bf16x8*>(afr + rb * 128);
-      amf[rb] = *reinterpret_cast<const bf16x8*>(afr + K32_LIMB + rb * 128);
+      ahf[rb] = frag(afr + rb * 128);
+      amf[rb] = frag(afr + K32_LIMB + rb * 128);
     }
+    if constexpr (F16) {                       // weights (w_h, w_l, w_h2) all resident; pixels (x_h, x_l') per column block
+      u32x4 a2f[4];
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wfr + cb * 128);
-      const bf16x8 wm = *reinterpret_cast<const bf16x8*>(wfr + K32_LIMB + cb * 128);
-      const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wfr + 2 * K32_LIMB + cb * 128);
+      for (int rb = 0; rb < 4; ++rb) a2f[rb] = frag(afr + 2 * K32_LIMB + rb * 128);
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wm, acc[rb][cb]);
+      for (int cb = 0; cb < CB; ++cb) {
+        const u32x4 xh = frag(wfr + cb * 128), xl = frag(wfr + K32_LIMB + cb * 128);
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wl, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(a2f[rb], xl, acc[rb][cb]);
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wm, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], xh, acc[rb][cb]);
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], xh, acc[rb][cb]);
+      }
+      split(kt + 1 < KT ? kt + 1 : KT - 1);
+    } else {
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wh, acc[rb][cb]);
-    }
-    split(kt + 1 < KT ? kt + 1 : KT - 1);
+      for (int cb = 0; cb < CB; ++cb) {
+        const u32x4 wh = frag(wfr + cb * 128), wm = frag(wfr + K32_LIMB + cb * 128), wl = frag(wfr + 2 * K32_LIMB + cb * 128);
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) amf[rb] = *reinterpret_cast<const bf16x8*>(afr + 2 * K32_LIMB + rb * 128);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wm, acc[rb][cb]);
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wfr + cb * 128);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wl, acc[rb][cb]);
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wm, acc[rb][cb]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wh, acc[rb][cb]);
+      }
+      split(kt + 1 < KT ? kt + 1 : KT - 1);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) amf[rb] = frag(afr + 2 * K32_LIMB + rb * 128);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const u32x4 wh = frag(wfr + cb * 128);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+      }
     }
     __syncthreads();
     if (kt + 1 < KT) write();
   }
+  if constexpr (F16) f16x2_count_overflow(amax, overflow);
 
   if constexpr (BITS) {
     // register r of block (rb, cb): query 64 wr + 16 rb + 4 kg4 + r = bit 16 (rb & 1) + 4 kg4 + r of word 2 wr + (rb >> 1);
@@ -738,6 +824,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
     const auto rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual) + (RESIDUAL ? obase : 0), 0,
                                                        RESIDUAL ? img_bytes : 0u, 0x00020000);
     const unsigned chpitch = (unsigned)HWo * 4u;
+    const float unscale = F16 ? f16x2_unscale(Wp, Cpad, TAPS * Cin) : 1.f;
     unsigned pvoff[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
@@ -747,8 +834,9 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
       const int chb = c0 + wr * 64 + rb * 16 + 4 * kg4;              // channels chb .. chb + 3
-      const f32x4 sc4 = scale ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)chb * 4u, 0, 0))
-                              : f32x4{1.f, 1.f, 1.f, 1.f};
+      f32x4 sc4 = scale ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)chb * 4u, 0, 0))
+                        : f32x4{1.f, 1.f, 1.f, 1.f};
+      if constexpr (F16) sc4 *= unscale;                             // the packed weight's 2^-e (exact)
       const f32x4 sh4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, (unsigned)chb * 4u, 0, 0));
       float res[CB][4];
       if (RESIDUAL) {
@@ -793,8 +881,75 @@ __global__ void gemm_bf16x3_pack_kernel(const float* __restrict__ w, __bf16* __r
   dst[limb_stride] = l;
 }
 
+// f16x2 pack: same element layout as above with the arrays (w_h, w_l, w_h2) in the three limb slots, followed by four floats
+// (max|w|, 2^-e, 0, 0).  max|w| is reduced on the device first (mask embeddings are packed per call).
+__global__ void f16x2_amax_kernel(const float* __restrict__ w, long long n, unsigned* __restrict__ tail) {
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    m = fmaxf(m, __builtin_fabsf(w[i]));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(tail, __builtin_bit_cast(unsigned, m));   // non-negative floats order as uints
+}
+__device__ __forceinline__ int f16x2_exponent(float amax) {
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 0;
+  int e = 13 - ilogbf(amax);                               // max|w| 2^e in [2^13, 2^14)
+  return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+__global__ void gemm_f16x2_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int N, int K, int Npad) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // one (column, k pair)
+  const long long total = (long long)Npad * (K / 2);
+  if (idx >= total) return;
+  float* tail = reinterpret_cast<float*>(wp + (size_t)3 * Npad * K);
+  const int e = f16x2_exponent(tail[0]);
+  if (idx == 0) tail[1] = ldexpf(1.f, -e);
+  const float sc = ldexpf(1.f, e);
+  const int kp = (int)(idx % (K / 2)), n = (int)(idx / (K / 2));
+  const int k = 2 * kp;
+  float a0 = 0.f, a1 = 0.f;
+  if (n < N) {
+    a0 = w[(size_t)n * K + k] * sc;
+    a1 = w[(size_t)n * K + k + 1] * sc;
+  }
+  const f16x2 hh = __builtin_convertvector(f32x2{a0, a1}, f16x2);
+  const f16x2 ll = __builtin_convertvector(f32x2{a0 - (float)hh[0], a1 - (float)hh[1]}, f16x2);
+  const f16x2 h2 = __builtin_convertvector(f32x2{(float)hh[0] * (1.f / F16X2_LO), (float)hh[1] * (1.f / F16X2_LO)}, f16x2);
+  const int kt = k / GB_K, kg = (k % GB_K) / 8, el = k % 8;
+  const size_t limb_stride = (size_t)2 * Npad * 8;
+  unsigned* dst = reinterpret_cast<unsigned*>(wp + ((size_t)kt * 3 * limb_stride + ((size_t)kg * Npad + n) * 8 + el));
+  dst[0] = __builtin_bit_cast(unsigned, hh);
+  dst[limb_stride / 2] = __builtin_bit_cast(unsigned, ll);
+  dst[limb_stride] = __builtin_bit_cast(unsigned, h2);
+}
+
 }  // namespace
 }  // namespace pvsg
+
+extern "C" long long pvsg_gemm_f16x2_packed_elems(int N, int K) {
+  const long long npad = (N + 127) / 128 * 128;
+  return 3LL * npad * K + 8;                              // 16-bit elements; the last 8 hold (max|w|, 2^-e, 0, 0) as floats
+}
+
+extern "C" int pvsg_gemm_f16x2_pack(const float* weight, void* w_packed, int N, int K, void* stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(weight && w_packed, "gemm_f16x2_pack: null pointer argument");
+  PVSG_REQUIRE(N > 0 && K > 0, "gemm_f16x2_pack: bad shape");
+  if (K % 32) return set_err(PVSG_ERR_UNSUPPORTED, "gemm_f16x2: built for K %% 32 == 0 (got %d)", K);
+  PVSG_REQUIRE(!(reinterpret_cast<uintptr_t>(w_packed) & 15u), "gemm_f16x2_pack: w_packed must be 16-byte aligned");
+  const int Npad = (N + 127) / 128 * 128;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  __bf16* wp = static_cast<__bf16*>(w_packed);
+  unsigned* tail = reinterpret_cast<unsigned*>(wp + (size_t)3 * Npad * K);
+  hipError_t e = zero_words_async(tail, 16, st);
+  if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "gemm_f16x2_pack: %s", hipGetErrorString(e));
+  const long long n = (long long)N * K;
+  const unsigned ablocks = (unsigned)(n / 1024 + 1 < 512 ? n / 1024 + 1 : 512);
+  hipLaunchKernelGGL(f16x2_amax_kernel, dim3(ablocks), dim3(256), 0, st, weight, n, tail);
+  const long long total = (long long)Npad * (K / 2);
+  hipLaunchKernelGGL(gemm_f16x2_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight, wp, N, K, Npad);
+  PVSG_LAUNCH_CHECK("gemm_f16x2_pack");
+  return PVSG_OK;
+}
 
 extern "C" long long pvsg_gemm_bf16x3_packed_elems(int N, int K) {
   const long long npad = (N + 127) / 128 * 128;
@@ -814,81 +969,101 @@ extern "C" int pvsg_gemm_bf16x3_pack(const float* weight, void* w_packed, int N,
   return PVSG_OK;
 }
 
-extern "C" int pvsg_gemm_bf16x3(const float* a, const void* w_packed, const float* bias, float* out, long long M, int N, int K,
-                                int relu, void* stream) {
+static int gemm_split_run(const float* a, const void* w_packed, const float* bias, float* out, long long M, int N, int K,
+                          int relu, bool f16, uint32_t* overflow, void* stream) {
   using namespace pvsg;
-  PVSG_REQUIRE(a && w_packed && out, "gemm_bf16x3: null pointer argument");
-  PVSG_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_bf16x3: bad shape");
-  if (K % GB_K || M >= (1LL << 31) || (long long)GB_M * K * 4 >= (1LL << 31) || (long long)GB_M * N * 4 >= (1LL << 31))
-    return set_err(PVSG_ERR_UNSUPPORTED, "gemm_bf16x3: built for K %% 16 == 0, M < 2^31, 128 rows < 2 GiB (got M=%lld N=%d K=%d)", M, N, K);
+  const char* nm = f16 ? "gemm_f16x2" : "gemm_bf16x3";
+  PVSG_REQUIRE(a && w_packed && out, "%s: null pointer argument", nm);
+  PVSG_REQUIRE(M > 0 && N > 0 && K > 0, "%s: bad shape", nm);
+  if (K % (f16 ? 32 : GB_K) || M >= (1LL << 31) || (long long)GB_M * K * 4 >= (1LL << 31) || (long long)GB_M * N * 4 >= (1LL << 31))
+    return set_err(PVSG_ERR_UNSUPPORTED, "%s: built for K %% %d == 0, M < 2^31, 128 rows < 2 GiB (got M=%lld N=%d K=%d)", nm,
+                   f16 ? 32 : GB_K, M, N, K);
   PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w_packed)) & 15u),
-               "gemm_bf16x3: a and w_packed must be 16-byte aligned");
+               "%s: a and w_packed must be 16-byte aligned", nm);
   const int Npad = (N + 127) / 128 * 128;
   const int tiles_n = Npad / GB_N;
   const long long tiles_m = (M + GB_M - 1) / GB_M;
   const long long blocks = tiles_m * tiles_n;
-  PVSG_REQUIRE(blocks < (1LL << 31), "gemm_bf16x3: too many blocks");
+  PVSG_REQUIRE(blocks < (1LL << 31), "%s: too many blocks", nm);
   const dim3 grid((unsigned)blocks), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const __bf16* wp = static_cast<const __bf16*>(w_packed);
   const char* sel = getenv("PVSG_GEMM_K32");                    // =0: the 32x32x16 / K = 16 kernel for every shape (A/B tests)
   const bool k32 = K % 32 == 0 && !(sel && sel[0] == '0');
-  if (k32 && relu)
-    hipLaunchKernelGGL((gemm_bf16x3_k32_kernel<true>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n);
+  if (f16 && relu)
+    hipLaunchKernelGGL((gemm_bf16x3_k32_kernel<true, true>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n, overflow);
+  else if (f16)
+    hipLaunchKernelGGL((gemm_bf16x3_k32_kernel<false, true>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n, overflow);
+  else if (k32 && relu)
+    hipLaunchKernelGGL((gemm_bf16x3_k32_kernel<true>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n, nullptr);
   else if (k32)
-    hipLaunchKernelGGL((gemm_bf16x3_k32_kernel<false>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n);
+    hipLaunchKernelGGL((gemm_bf16x3_k32_kernel<false>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n, nullptr);
   else if (relu)
     hipLaunchKernelGGL((gemm_bf16x3_kernel<true>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n);
   else
     hipLaunchKernelGGL((gemm_bf16x3_kernel<false>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n);
-  PVSG_LAUNCH_CHECK("gemm_bf16x3");
+  PVSG_LAUNCH_CHECK(nm);
   return PVSG_OK;
 }
 
-extern "C" int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const float* scale, const float* shift,
-                                   const float* residual, const float* in_scale, const float* in_shift, float* y, int B,
-                                   int Cin, int Cout, int H, int W, int stride, int relu, void* stream) {
+extern "C" int pvsg_gemm_bf16x3(const float* a, const void* w_packed, const float* bias, float* out, long long M, int N, int K,
+                                int relu, void* stream) {
+  return gemm_split_run(a, w_packed, bias, out, M, N, K, relu, false, nullptr, stream);
+}
+
+extern "C" int pvsg_gemm_f16x2(const float* a, const void* w_packed, const float* bias, float* out, long long M, int N, int K,
+                               int relu, uint32_t* overflow, void* stream) {
+  return gemm_split_run(a, w_packed, bias, out, M, N, K, relu, true, overflow, stream);
+}
+
+static int conv1x1_split_run(const float* x, const void* w_packed, const float* scale, const float* shift,
+                             const float* residual, const float* in_scale, const float* in_shift, float* y, int B, int Cin,
+                             int Cout, int H, int W, int stride, int relu, bool f16, uint32_t* overflow, void* stream) {
   using namespace pvsg;
-  PVSG_REQUIRE(x && w_packed && y, "conv1x1_bf16x3: null pointer argument");
-  PVSG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "conv1x1_bf16x3: bad shape");
-  PVSG_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv1x1_bf16x3: in_scale and in_shift go together");
-  if (Cin % GB_K || Cout % 4 || (long long)Cin * H * W >= (1LL << 29) || (long long)Cout * H * W >= (1LL << 29))
-    return set_err(PVSG_ERR_UNSUPPORTED, "conv1x1_bf16x3: built for Cin %% 16 == 0, Cout %% 4 == 0, C*H*W < 2^29 (got Cin=%d Cout=%d H=%d W=%d)",
-                   Cin, Cout, H, W);
-  PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15u),
-               "conv1x1_bf16x3: w_packed, scale and shift must be 16-byte aligned");
+  const char* nm = f16 ? "conv1x1_f16x2" : "conv1x1_bf16x3";
+  PVSG_REQUIRE(x && w_packed && y, "%s: null pointer argument", nm);
+  PVSG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "%s: bad shape", nm);
+  PVSG_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "%s: in_scale and in_shift go together", nm);
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const int Cpad = (Cout + 127) / 128 * 128;
+  // the epilogue's 32-bit store offsets: pixel offset + padded channel row * plane must stay below 2^31 (out-of-range pixels
+  // carry 0x80000000 and rely on the bounds check)
+  if (Cin % (f16 ? 32 : GB_K) || Cout % 4 || (long long)Cin * H * W >= (1LL << 29) || (long long)Cpad * Ho * Wo >= (1LL << 29))
+    return set_err(PVSG_ERR_UNSUPPORTED, "%s: built for Cin %% %d == 0, Cout %% 4 == 0, C*H*W < 2^29 (got Cin=%d Cout=%d H=%d W=%d)",
+                   nm, f16 ? 32 : GB_K, Cin, Cout, H, W);
+  PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15u),
+               "%s: w_packed, scale and shift must be 16-byte aligned", nm);
   const int tiles_c = Cpad / GB_M, tiles_p = (Ho * Wo + GB_N - 1) / GB_N;
   const long long blocks = (long long)B * tiles_c * tiles_p;
-  PVSG_REQUIRE(blocks < (1LL << 31), "conv1x1_bf16x3: too many blocks");
+  PVSG_REQUIRE(blocks < (1LL << 31), "%s: too many blocks", nm);
   const dim3 grid((unsigned)blocks), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const __bf16* wp = static_cast<const __bf16*>(w_packed);
+  unsigned* const noflags = nullptr;
   // PVSG_GEMM_K32=0: the 32x32x16 / K = 16 kernel for every shape, =1: the K = 32 kernel wherever Cin allows (A/B tests);
   // default: K = 32 except on the small stride-1 maps (23 x 40 at 720p: layer4 and its input convolution measured 3-5 %
-  // slower there, profiles/r03_conv1x1_bf16x3_bench.jsonl)
+  // slower there, profiles/r03_conv1x1_bf16x3_bench.jsonl).  The f16 form exists on the K = 32 kernel only.
   const char* sel = getenv("PVSG_GEMM_K32");
-  const bool k32 = Cin % 32 == 0 && !(sel && sel[0] == '0') && ((sel && sel[0] == '1') || stride == 2 || Ho * Wo >= 2048);
+  const bool k32 = f16 || (Cin % 32 == 0 && !(sel && sel[0] == '0') && ((sel && sel[0] == '1') || stride == 2 || Ho * Wo >= 2048));
   const bool tm64 = k32 && Cout <= 64;
+#define PVSG_C1_K32(R, S, NORM, TMV, F)                                                                                  \
+  hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<R, S, NORM, false, TMV, 1, F>), grid, block, 0, st, x, wp, scale, shift,  \
+                     residual, in_scale, in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p, \
+                     noflags, overflow)
 #define PVSG_C1_LAUNCH(R, S)                                                                                            \
   do {                                                                                                                  \
-    if (tm64)                                                                                                           \
-      hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<R, S, false, false, 64>), grid, block, 0, st, x, wp, scale, shift,   \
-                         residual, in_scale, in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p); \
-    else if (k32)                                                                                                       \
-      hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<R, S, false>), grid, block, 0, st, x, wp, scale, shift, residual,  \
-                         in_scale, in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p);       \
+    if (f16) { if (tm64) PVSG_C1_K32(R, S, false, 64, true); else PVSG_C1_K32(R, S, false, 128, true); }                 \
+    else if (tm64) PVSG_C1_K32(R, S, false, 64, false);                                                                 \
+    else if (k32) PVSG_C1_K32(R, S, false, 128, false);                                                                 \
     else                                                                                                                \
       hipLaunchKernelGGL((conv1x1_bf16x3_kernel<R, S, false>), grid, block, 0, st, x, wp, scale, shift, residual,      \
                          in_scale, in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p);       \
   } while (0)
   if (in_scale) {          // normalised input: the pixel decoder's mask-feature convolution (no ReLU / identity behind it)
     if (relu || residual)
-      return set_err(PVSG_ERR_UNSUPPORTED, "conv1x1_bf16x3: in_scale / in_shift come without relu / residual");
-    if (k32)
-      hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<false, false, true>), grid, block, 0, st, x, wp, scale, shift, residual,
-                         in_scale, in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p);
+      return set_err(PVSG_ERR_UNSUPPORTED, "%s: in_scale / in_shift come without relu / residual", nm);
+    if (f16) PVSG_C1_K32(false, false, true, 128, true);
+    else if (k32) PVSG_C1_K32(false, false, true, 128, false);
     else
       hipLaunchKernelGGL((conv1x1_bf16x3_kernel<false, false, true>), grid, block, 0, st, x, wp, scale, shift, residual, in_scale,
                          in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p);
@@ -898,101 +1073,160 @@ extern "C" int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const f
     if (residual) PVSG_C1_LAUNCH(false, true); else PVSG_C1_LAUNCH(false, false);
   }
 #undef PVSG_C1_LAUNCH
-  PVSG_LAUNCH_CHECK("conv1x1_bf16x3");
+#undef PVSG_C1_K32
+  PVSG_LAUNCH_CHECK(nm);
   return PVSG_OK;
+}
+
+extern "C" int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const float* scale, const float* shift,
+                                   const float* residual, const float* in_scale, const float* in_shift, float* y, int B,
+                                   int Cin, int Cout, int H, int W, int stride, int relu, void* stream) {
+  return conv1x1_split_run(x, w_packed, scale, shift, residual, in_scale, in_shift, y, B, Cin, Cout, H, W, stride, relu, false,
+                           nullptr, stream);
+}
+
+extern "C" int pvsg_conv1x1_f16x2(const float* x, const void* w_packed, const float* scale, const float* shift,
+                                  const float* residual, const float* in_scale, const float* in_shift, float* y, int B,
+                                  int Cin, int Cout, int H, int W, int stride, int relu, uint32_t* overflow, void* stream) {
+  return conv1x1_split_run(x, w_packed, scale, shift, residual, in_scale, in_shift, y, B, Cin, Cout, H, W, stride, relu, true,
+                           overflow, stream);
 }
 
 // [3P] mmdet ResNet Bottleneck.conv2 (3x3, pad 1, stride 1 or 2) + frozen BN + ReLU on the split kernel: implicit GEMM over the
 // nine taps (K = 9 * Cin).  w_packed = pvsg_gemm_bf16x3_pack of the (Cout, 9 * Cin) matrix w.permute(0, 2, 3, 1) (tap-major,
 // channel-minor).  Direct-form arithmetic (18 Cin Cout flop per output pixel): it wins where the f32 kernels are weakest -- the
 // stride-2 layers (pvsg_conv3x3s2_affine) and, against Winograd (pvsg_conv3x3_winograd), the 64- and 512-channel layers.
-extern "C" int pvsg_conv3x3_bf16x3(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B,
-                                   int Cin, int Cout, int H, int W, int stride, int relu, void* stream) {
+static int conv3x3_split_run(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B,
+                             int Cin, int Cout, int H, int W, int stride, int relu, bool f16, uint32_t* overflow, void* stream) {
   using namespace pvsg;
-  PVSG_REQUIRE(x && w_packed && scale && shift && y, "conv3x3_bf16x3: null pointer argument");
-  PVSG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "conv3x3_bf16x3: bad shape");
-  if (Cin % 32 || Cout % 4 || (long long)Cin * H * W >= (1LL << 29) || (long long)Cout * H * W >= (1LL << 29))
-    return set_err(PVSG_ERR_UNSUPPORTED, "conv3x3_bf16x3: built for Cin %% 32 == 0, Cout %% 4 == 0, C*H*W < 2^29 (got Cin=%d Cout=%d H=%d W=%d)",
-                   Cin, Cout, H, W);
-  PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15u),
-               "conv3x3_bf16x3: w_packed, scale and shift must be 16-byte aligned");
+  const char* nm = f16 ? "conv3x3_f16x2" : "conv3x3_bf16x3";
+  PVSG_REQUIRE(x && w_packed && scale && shift && y, "%s: null pointer argument", nm);
+  PVSG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "%s: bad shape", nm);
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const int Cpad = (Cout + 127) / 128 * 128;
+  if (Cin % 32 || Cout % 4 || (long long)Cin * H * W >= (1LL << 29) || (long long)Cpad * Ho * Wo >= (1LL << 29))
+    return set_err(PVSG_ERR_UNSUPPORTED, "%s: built for Cin %% 32 == 0, Cout %% 4 == 0, C*H*W < 2^29 (got Cin=%d Cout=%d H=%d W=%d)",
+                   nm, Cin, Cout, H, W);
+  PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15u),
+               "%s: w_packed, scale and shift must be 16-byte aligned", nm);
   const int tiles_c = Cpad / GB_M, tiles_p = (Ho * Wo + GB_N - 1) / GB_N;
   const long long blocks = (long long)B * tiles_c * tiles_p;
-  PVSG_REQUIRE(blocks < (1LL << 31), "conv3x3_bf16x3: too many blocks");
+  PVSG_REQUIRE(blocks < (1LL << 31), "%s: too many blocks", nm);
   const dim3 grid((unsigned)blocks), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const __bf16* wp = static_cast<const __bf16*>(w_packed);
   const float* nul = nullptr;
-#define PVSG_C3_LAUNCH(R, TMV)                                                                                                  \
-  hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<R, false, false, false, TMV, 9>), grid, block, 0, st, x, wp, scale, shift, nul, nul, \
-                     nul, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p)
-  if (Cout <= 64) { if (relu) PVSG_C3_LAUNCH(true, 64); else PVSG_C3_LAUNCH(false, 64); }
-  else { if (relu) PVSG_C3_LAUNCH(true, 128); else PVSG_C3_LAUNCH(false, 128); }
+  unsigned* const noflags = nullptr;
+#define PVSG_C3_LAUNCH(R, TMV, F)                                                                                               \
+  hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<R, false, false, false, TMV, 9, F>), grid, block, 0, st, x, wp, scale, shift, nul, \
+                     nul, nul, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p, noflags, overflow)
+#define PVSG_C3_PICK(F)                                                                       \
+  do {                                                                                        \
+    if (Cout <= 64) { if (relu) PVSG_C3_LAUNCH(true, 64, F); else PVSG_C3_LAUNCH(false, 64, F); } \
+    else { if (relu) PVSG_C3_LAUNCH(true, 128, F); else PVSG_C3_LAUNCH(false, 128, F); }        \
+  } while (0)
+  if (f16) PVSG_C3_PICK(true); else PVSG_C3_PICK(false);
+#undef PVSG_C3_PICK
 #undef PVSG_C3_LAUNCH
-  PVSG_LAUNCH_CHECK("conv3x3_bf16x3");
+  PVSG_LAUNCH_CHECK(nm);
   return PVSG_OK;
 }
 
-// einsum('bqc,b[t]chw->b[t]qhw') (mask2former_head.py:382, mask2former_video_head.py:344) on the split-bf16 kernel: per batch
+extern "C" int pvsg_conv3x3_bf16x3(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B,
+                                   int Cin, int Cout, int H, int W, int stride, int relu, void* stream) {
+  return conv3x3_split_run(x, w_packed, scale, shift, y, B, Cin, Cout, H, W, stride, relu, false, nullptr, stream);
+}
+
+extern "C" int pvsg_conv3x3_f16x2(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B,
+                                  int Cin, int Cout, int H, int W, int stride, int relu, uint32_t* overflow, void* stream) {
+  return conv3x3_split_run(x, w_packed, scale, shift, y, B, Cin, Cout, H, W, stride, relu, true, overflow, stream);
+}
+
+// einsum('bqc,b[t]chw->b[t]qhw') (mask2former_head.py:382, mask2former_video_head.py:344) on the split kernels: per batch
 // element a 1x1 "convolution" of the (T, C, N) mask features with the Q mask embeddings as the weight (packed on the fly:
 // Q x C is 100 x 256), output (T, Q, N).  Same f32-class arithmetic as above; the f32-MFMA form stays as
-// pvsg_mask_logits_forward (csrc/mask_gemm.hip).  w_scratch: B * pvsg_gemm_bf16x3_packed_elems(Q, C) bf16 elements.
-extern "C" int pvsg_mask_logits_bf16x3(const float* mask_embed, const float* mask_feature, void* w_scratch, float* out, int B,
-                                       int T, int Q, int C, long long N, void* stream) {
+// pvsg_mask_logits_forward (csrc/mask_gemm.hip).  w_scratch: B * pvsg_gemm_{bf16x3,f16x2}_packed_elems(Q, C) 16-bit elements.
+static int mask_logits_split_run(const float* mask_embed, const float* mask_feature, void* w_scratch, float* out, int B, int T,
+                                 int Q, int C, long long N, bool f16, uint32_t* overflow, void* stream) {
   using namespace pvsg;
-  PVSG_REQUIRE(mask_embed && mask_feature && w_scratch && out, "mask_logits_bf16x3: null pointer argument");
-  PVSG_REQUIRE(B > 0 && T > 0 && Q > 0 && C > 0 && N > 0, "mask_logits_bf16x3: bad shape");
-  if (C % GB_K || Q % 4 || N >= (1LL << 31) || (long long)C * N >= (1LL << 29) || (long long)Q * N >= (1LL << 29))
-    return set_err(PVSG_ERR_UNSUPPORTED, "mask_logits_bf16x3: built for C %% 16 == 0, Q %% 4 == 0, C*N and Q*N < 2^29 (got Q=%d C=%d N=%lld)",
-                   Q, C, N);
-  const long long welems = pvsg_gemm_bf16x3_packed_elems(Q, C);
+  const char* nm = f16 ? "mask_logits_f16x2" : "mask_logits_bf16x3";
+  PVSG_REQUIRE(mask_embed && mask_feature && w_scratch && out, "%s: null pointer argument", nm);
+  PVSG_REQUIRE(B > 0 && T > 0 && Q > 0 && C > 0 && N > 0, "%s: bad shape", nm);
+  const long long Qpad = (Q + 127) / 128 * 128;
+  if (C % (f16 ? 32 : GB_K) || Q % 4 || N >= (1LL << 31) || (long long)C * N >= (1LL << 29) || Qpad * N >= (1LL << 29))
+    return set_err(PVSG_ERR_UNSUPPORTED, "%s: built for C %% %d == 0, Q %% 4 == 0, C*N and pad128(Q)*N < 2^29 (got Q=%d C=%d N=%lld)",
+                   nm, f16 ? 32 : GB_K, Q, C, N);
+  const long long welems = f16 ? pvsg_gemm_f16x2_packed_elems(Q, C) : pvsg_gemm_bf16x3_packed_elems(Q, C);
   for (int b = 0; b < B; ++b) {
     __bf16* wp = static_cast<__bf16*>(w_scratch) + (size_t)b * welems;
-    int rc = pvsg_gemm_bf16x3_pack(mask_embed + (size_t)b * Q * C, wp, Q, C, stream);
+    int rc = f16 ? pvsg_gemm_f16x2_pack(mask_embed + (size_t)b * Q * C, wp, Q, C, stream)
+                 : pvsg_gemm_bf16x3_pack(mask_embed + (size_t)b * Q * C, wp, Q, C, stream);
     if (rc != PVSG_OK) return rc;
-    rc = pvsg_conv1x1_bf16x3(mask_feature + (size_t)b * T * C * N, wp, nullptr, nullptr, nullptr, nullptr, nullptr,
-                             out + (size_t)b * T * Q * N, T, C, Q, 1, (int)N, 1, 0, stream);
+    rc = conv1x1_split_run(mask_feature + (size_t)b * T * C * N, wp, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           out + (size_t)b * T * Q * N, T, C, Q, 1, (int)N, 1, 0, f16, overflow, stream);
     if (rc != PVSG_OK) return rc;
   }
   return PVSG_OK;
+}
+
+extern "C" int pvsg_mask_logits_bf16x3(const float* mask_embed, const float* mask_feature, void* w_scratch, float* out, int B,
+                                       int T, int Q, int C, long long N, void* stream) {
+  return mask_logits_split_run(mask_embed, mask_feature, w_scratch, out, B, T, Q, C, N, false, nullptr, stream);
+}
+
+extern "C" int pvsg_mask_logits_f16x2(const float* mask_embed, const float* mask_feature, void* w_scratch, float* out, int B,
+                                      int T, int Q, int C, long long N, uint32_t* overflow, void* stream) {
+  return mask_logits_split_run(mask_embed, mask_feature, w_scratch, out, B, T, Q, C, N, true, overflow, stream);
 }
 
 // Attention-mask bits of a decoder level straight from the down-sampled mask features (mask2former_head.py:383-393,
-// video_head.py:346-357; the all-masked-row test of mask2former_head.py:453-454 becomes the flag words) on the split-bf16
-// kernel: same record format as pvsg_attn_mask_bits_forward (csrc/mask_gemm.hip), which stays as the f32-MFMA form.
-extern "C" int pvsg_attn_mask_bits_bf16x3(const float* mask_embed, const float* feature_lowres, void* w_scratch, uint32_t* bits,
-                                          uint32_t* flags, int B, int T, int Q, int C, long long N, void* stream) {
+// video_head.py:346-357; the all-masked-row test of mask2former_head.py:453-454 becomes the flag words) on the split
+// kernels: same record format as pvsg_attn_mask_bits_forward (csrc/mask_gemm.hip), which stays as the f32-MFMA form.
+static int attn_mask_bits_split_run(const float* mask_embed, const float* feature_lowres, void* w_scratch, uint32_t* bits,
+                                    uint32_t* flags, int B, int T, int Q, int C, long long N, bool f16, uint32_t* overflow,
+                                    void* stream) {
   using namespace pvsg;
-  PVSG_REQUIRE(mask_embed && feature_lowres && w_scratch && bits && flags, "attn_mask_bits_bf16x3: null pointer argument");
-  PVSG_REQUIRE(B > 0 && T > 0 && Q > 0 && C > 0 && N > 0, "attn_mask_bits_bf16x3: bad shape");
-  if (C % GB_K || Q > GB_M || (long long)C * N >= (1LL << 29) || (reinterpret_cast<uintptr_t>(bits) & 15u))
-    return set_err(PVSG_ERR_UNSUPPORTED, "attn_mask_bits_bf16x3: built for C %% 16 == 0, Q <= 128, C*N < 2^29, 16B-aligned bits (got Q=%d C=%d N=%lld)",
-                   Q, C, N);
+  const char* nm = f16 ? "attn_mask_bits_f16x2" : "attn_mask_bits_bf16x3";
+  PVSG_REQUIRE(mask_embed && feature_lowres && w_scratch && bits && flags, "%s: null pointer argument", nm);
+  PVSG_REQUIRE(B > 0 && T > 0 && Q > 0 && C > 0 && N > 0, "%s: bad shape", nm);
+  if (C % (f16 ? 32 : GB_K) || Q > GB_M || (long long)C * N >= (1LL << 29) || (reinterpret_cast<uintptr_t>(bits) & 15u))
+    return set_err(PVSG_ERR_UNSUPPORTED, "%s: built for C %% %d == 0, Q <= 128, C*N < 2^29, 16B-aligned bits (got Q=%d C=%d N=%lld)",
+                   nm, f16 ? 32 : GB_K, Q, C, N);
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipError_t e = zero_words_async(flags, (size_t)B * 4 * sizeof(uint32_t), st);
-  if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "attn_mask_bits_bf16x3: memset: %s", hipGetErrorString(e));
-  const long long welems = pvsg_gemm_bf16x3_packed_elems(Q, C);
+  if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "%s: memset: %s", nm, hipGetErrorString(e));
+  const long long welems = f16 ? pvsg_gemm_f16x2_packed_elems(Q, C) : pvsg_gemm_bf16x3_packed_elems(Q, C);
   const int tiles_p = (int)((N + GB_N - 1) / GB_N);
+  const float* nul = nullptr;
   for (int b = 0; b < B; ++b) {
     __bf16* wp = static_cast<__bf16*>(w_scratch) + (size_t)b * welems;
-    const int rc = pvsg_gemm_bf16x3_pack(mask_embed + (size_t)b * Q * C, wp, Q, C, stream);
+    const int rc = f16 ? pvsg_gemm_f16x2_pack(mask_embed + (size_t)b * Q * C, wp, Q, C, stream)
+                       : pvsg_gemm_bf16x3_pack(mask_embed + (size_t)b * Q * C, wp, Q, C, stream);
     if (rc != PVSG_OK) return rc;
     const char* sel = getenv("PVSG_GEMM_K32");
-    if (C % 32 == 0 && !(sel && sel[0] == '0'))
-      hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<false, false, false, true>), dim3((unsigned)(T * tiles_p)), dim3(256), 0, st,
-                         feature_lowres + (size_t)b * T * C * N, wp, (const float*)nullptr, (const float*)nullptr,
-                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                         reinterpret_cast<float*>(bits + (size_t)b * T * N * 4), C, Q, GB_M, (int)N, (int)N, (int)N, (int)N, 1, 1,
-                         tiles_p, flags + (size_t)b * 4);
+    const float* fl = feature_lowres + (size_t)b * T * C * N;
+    float* rec = reinterpret_cast<float*>(bits + (size_t)b * T * N * 4);
+    const dim3 grid((unsigned)(T * tiles_p)), block(256);
+    if (f16)
+      hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<false, false, false, true, 128, 1, true>), grid, block, 0, st, fl, wp, nul, nul,
+                         nul, nul, nul, rec, C, Q, GB_M, (int)N, (int)N, (int)N, (int)N, 1, 1, tiles_p, flags + (size_t)b * 4, overflow);
+    else if (C % 32 == 0 && !(sel && sel[0] == '0'))
+      hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<false, false, false, true>), grid, block, 0, st, fl, wp, nul, nul, nul, nul, nul,
+                         rec, C, Q, GB_M, (int)N, (int)N, (int)N, (int)N, 1, 1, tiles_p, flags + (size_t)b * 4, (unsigned*)nullptr);
     else
-    hipLaunchKernelGGL((conv1x1_bf16x3_kernel<false, false, false, true>), dim3((unsigned)(T * tiles_p)), dim3(256), 0, st,
-                       feature_lowres + (size_t)b * T * C * N, wp, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       reinterpret_cast<float*>(bits + (size_t)b * T * N * 4), C, Q, GB_M, (int)N, (int)N, (int)N, (int)N, 1, 1,
-                       tiles_p, flags + (size_t)b * 4);
-    PVSG_LAUNCH_CHECK("attn_mask_bits_bf16x3");
+      hipLaunchKernelGGL((conv1x1_bf16x3_kernel<false, false, false, true>), grid, block, 0, st, fl, wp, nul, nul, nul, nul, nul,
+                         rec, C, Q, GB_M, (int)N, (int)N, (int)N, (int)N, 1, 1, tiles_p, flags + (size_t)b * 4);
+    PVSG_LAUNCH_CHECK(nm);
   }
   return PVSG_OK;
+}
+
+extern "C" int pvsg_attn_mask_bits_bf16x3(const float* mask_embed, const float* feature_lowres, void* w_scratch, uint32_t* bits,
+                                          uint32_t* flags, int B, int T, int Q, int C, long long N, void* stream) {
+  return attn_mask_bits_split_run(mask_embed, feature_lowres, w_scratch, bits, flags, B, T, Q, C, N, false, nullptr, stream);
+}
+
+extern "C" int pvsg_attn_mask_bits_f16x2(const float* mask_embed, const float* feature_lowres, void* w_scratch, uint32_t* bits,
+                                         uint32_t* flags, int B, int T, int Q, int C, long long N, uint32_t* overflow, void* stream) {
+  return attn_mask_bits_split_run(mask_embed, feature_lowres, w_scratch, bits, flags, B, T, Q, C, N, true, overflow, stream);
 }

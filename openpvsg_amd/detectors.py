@@ -126,7 +126,9 @@ class _Base(BaseModule):
         if return_loss:
             raise NotImplementedError('training is outside the MI355X inference hot path')
         with torch.no_grad():
-            return self.forward_test(img, img_metas, **kwargs)
+            out = self.forward_test(img, img_metas, **kwargs)
+        ops.split_overflow_check()      # f16x2 kernels: an operand beyond the f16 range invalidates the results (ops.py)
+        return out
 
     def forward_train(self, *a, **k):
         raise NotImplementedError('training is outside the MI355X inference hot path')

@@ -104,11 +104,16 @@ def mask_logits(mask_embed, mask_feature):
     N = h * w
     with _on(e.device):
         if (os.environ.get('PVSG_MASK_GEMM', 'bf16x3') != 'f32' and C % 16 == 0 and Q % 4 == 0 and C * N < 2 ** 29 and
-                Q * N < 2 ** 29):
-            # exact three-limb bf16 split on the bf16 matrix cores (f32-class result; csrc/gemm_bf16x3.hip)
-            scratch = torch.empty((B * _lib.load().pvsg_gemm_bf16x3_packed_elems(Q, C),), device=e.device, dtype=torch.bfloat16)
-            _lib.call('pvsg_mask_logits_bf16x3', e.data_ptr(), f.data_ptr(), scratch.data_ptr(), out.data_ptr(), B, T, Q, C,
-                      N, _stream_ptr())
+                (Q + 127) // 128 * 128 * N < 2 ** 29):
+            # split arithmetic on the 16-bit matrix cores (f32-class result; csrc/gemm_bf16x3.hip)
+            if split_mode() == 'f16x2' and C % 32 == 0:
+                scratch = torch.empty((B * _lib.load().pvsg_gemm_f16x2_packed_elems(Q, C),), device=e.device, dtype=torch.bfloat16)
+                _lib.call('pvsg_mask_logits_f16x2', e.data_ptr(), f.data_ptr(), scratch.data_ptr(), out.data_ptr(), B, T, Q, C,
+                          N, _overflow_counter(e.device).data_ptr(), _stream_ptr())
+            else:
+                scratch = torch.empty((B * _lib.load().pvsg_gemm_bf16x3_packed_elems(Q, C),), device=e.device, dtype=torch.bfloat16)
+                _lib.call('pvsg_mask_logits_bf16x3', e.data_ptr(), f.data_ptr(), scratch.data_ptr(), out.data_ptr(), B, T, Q, C,
+                          N, _stream_ptr())
         else:
             _lib.call('pvsg_mask_logits_forward', e.data_ptr(), f.data_ptr(), out.data_ptr(), B, T, Q, C, N, _stream_ptr())
     return out if video else out[:, 0]
@@ -161,9 +166,14 @@ def attn_mask_from_lowres_feature(mask_embed, feature_lowres):
     flags = torch.empty((B, 4), device=e.device, dtype=torch.int32)
     with _on(e.device):
         if os.environ.get('PVSG_MASK_GEMM', 'bf16x3') != 'f32' and C % 16 == 0 and Q <= 128 and C * N < 2 ** 29:
-            scratch = torch.empty((B * _lib.load().pvsg_gemm_bf16x3_packed_elems(Q, C),), device=e.device, dtype=torch.bfloat16)
-            _lib.call('pvsg_attn_mask_bits_bf16x3', e.data_ptr(), f.data_ptr(), scratch.data_ptr(), bits.data_ptr(),
-                      flags.data_ptr(), B, T, Q, C, N, _stream_ptr())
+            if split_mode() == 'f16x2' and C % 32 == 0:
+                scratch = torch.empty((B * _lib.load().pvsg_gemm_f16x2_packed_elems(Q, C),), device=e.device, dtype=torch.bfloat16)
+                _lib.call('pvsg_attn_mask_bits_f16x2', e.data_ptr(), f.data_ptr(), scratch.data_ptr(), bits.data_ptr(),
+                          flags.data_ptr(), B, T, Q, C, N, _overflow_counter(e.device).data_ptr(), _stream_ptr())
+            else:
+                scratch = torch.empty((B * _lib.load().pvsg_gemm_bf16x3_packed_elems(Q, C),), device=e.device, dtype=torch.bfloat16)
+                _lib.call('pvsg_attn_mask_bits_bf16x3', e.data_ptr(), f.data_ptr(), scratch.data_ptr(), bits.data_ptr(),
+                          flags.data_ptr(), B, T, Q, C, N, _stream_ptr())
         else:
             _lib.call('pvsg_attn_mask_bits_forward', e.data_ptr(), f.data_ptr(), bits.data_ptr(),
                       flags.data_ptr(), B, T, Q, C, N, _stream_ptr())
@@ -664,33 +674,97 @@ def conv3x3_bf16x3(x, w_packed, cout, scale, shift, relu=True, out=None, stride=
     N, Cin, H, W = x.shape
     if stride not in (1, 2) or not conv3x3_bf16x3_supported(cout, Cin, H, W):
         raise RuntimeError('conv3x3_bf16x3: unsupported shape Cout=%d Cin=%d H=%d W=%d stride=%d' % (cout, Cin, H, W, stride))
-    if w_packed.numel() != _lib.load().pvsg_gemm_bf16x3_packed_elems(cout, 9 * Cin):
-        raise RuntimeError('conv3x3_bf16x3: packed weight does not match Cout=%d Cin=%d' % (cout, Cin))
+    f16 = _is_f16x2(w_packed, cout, 9 * Cin)
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     if out is None:
         out = torch.empty((N, cout, Ho, Wo), device=x.device, dtype=torch.float32)
     elif not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (N, cout, Ho, Wo)):
         raise RuntimeError('conv3x3_bf16x3: out must be a contiguous float32 HIP tensor (N,Cout,Ho,Wo)')
     with _on(x.device):
-        _lib.call('pvsg_conv3x3_bf16x3', x.data_ptr(), w_packed.data_ptr(), _chk(scale, 'scale').data_ptr(),
-                  _chk(shift, 'shift').data_ptr(), out.data_ptr(), N, Cin, cout, H, W, stride, int(bool(relu)), _stream_ptr())
+        args = (x.data_ptr(), w_packed.data_ptr(), _chk(scale, 'scale').data_ptr(), _chk(shift, 'shift').data_ptr(),
+                out.data_ptr(), N, Cin, cout, H, W, stride, int(bool(relu)))
+        if f16:
+            _lib.call('pvsg_conv3x3_f16x2', *args, _overflow_counter(x.device).data_ptr(), _stream_ptr())
+        else:
+            _lib.call('pvsg_conv3x3_bf16x3', *args, _stream_ptr())
     return out
+
+
+# ---- split arithmetic of the matrix-core GEMM / convolution kernels (csrc/gemm_bf16x3.hip) ---------------------------------
+# 'f16x2' (default): two f16 limbs per operand, three limb products per multiply (half the matrix work of 'bf16x3'), the
+#   low limbs kept out of the f16 subnormals by exact power-of-two factors; f32-class like the other (tests/test_gemm_f16x2.py
+#   measures both against f64).  Operands must lie within the f16 range, |a| <= 65504: every kernel counts violations into a
+#   per-device counter which `split_overflow_check()` turns into an error at the caller's next synchronisation point.
+# 'bf16x3': three bf16 limbs, six limb products, the full f32 exponent range.
+# A packed weight knows its form (the f16x2 pack carries 8 more elements), so the run functions below take either.
+def split_mode():
+    m = os.environ.get('PVSG_SPLIT', 'f16x2')
+    if m not in ('f16x2', 'bf16x3'):
+        raise RuntimeError("PVSG_SPLIT must be 'f16x2' or 'bf16x3' (got %r)" % m)
+    return m
+
+
+_overflow = {}
+
+
+def _overflow_counter(device):
+    t = _overflow.get(device.index)
+    if t is None:
+        t = _overflow[device.index] = torch.zeros(4, device=device, dtype=torch.int32)
+    return t
+
+
+def split_overflow_count(device=None, reset=True):
+    """staging threads of f16x2 kernels that met an operand beyond the f16 range since the last reset, on `device` or (None) on
+    every device that ran such a kernel (synchronises with those devices)"""
+    devs = list(_overflow) if device is None else [torch.device(device).index]
+    n = 0
+    for d in devs:
+        t = _overflow.get(d)
+        if t is None:
+            continue
+        c = int(t[0].item())
+        if reset and c:
+            t.zero_()
+        n += c
+    return n
+
+
+def split_overflow_check(device=None):
+    """Raise if an f16x2 kernel saw |operand| > 65504 since the last check: what it produced is not the product.  Called by the
+    detectors and the pipeline where they synchronise with the device anyway (results going to the host)."""
+    n = split_overflow_count(device)
+    if n:
+        raise RuntimeError('f16x2 split kernels met operands beyond the f16 range (|a| > 65504; %d staging threads): the results of '
+                           'this call are invalid. Set PVSG_SPLIT=bf16x3 for inputs of that magnitude.' % n)
+
+
+def _is_f16x2(wp, n, k):
+    lib = _lib.load()
+    if wp.numel() == lib.pvsg_gemm_bf16x3_packed_elems(n, k):
+        return False
+    if k % 32 == 0 and wp.numel() == lib.pvsg_gemm_f16x2_packed_elems(n, k):
+        return True
+    raise RuntimeError('packed weight does not match N=%d K=%d' % (n, k))
 
 
 def gemm_bf16x3_supported(n, k):
     return k % 16 == 0 and k <= 8192
 
 
-def gemm_bf16x3_pack(weight):
-    """(N,K) f32 linear weight -> its three bf16 limbs in the staging order of csrc/gemm_bf16x3.hip (once per weight)."""
+def gemm_bf16x3_pack(weight, mode=None):
+    """(N,K) f32 linear weight -> its limbs in the staging order of csrc/gemm_bf16x3.hip (once per weight): the two-limb f16
+    form (K % 32 == 0, `split_mode()`) or the three-limb bf16 form."""
     w = _chk(weight, 'weight')
     if w.dim() != 2 or not gemm_bf16x3_supported(w.shape[0], w.shape[1]):
         raise RuntimeError('gemm_bf16x3_pack: unsupported weight shape %s' % (tuple(w.shape),))
     N, K = w.shape
-    n = _lib.load().pvsg_gemm_bf16x3_packed_elems(N, K)
+    f16 = (mode or split_mode()) == 'f16x2' and K % 32 == 0
+    lib = _lib.load()
+    n = lib.pvsg_gemm_f16x2_packed_elems(N, K) if f16 else lib.pvsg_gemm_bf16x3_packed_elems(N, K)
     wp = torch.empty(n, device=w.device, dtype=torch.bfloat16)
     with _on(w.device):
-        _lib.call('pvsg_gemm_bf16x3_pack', w.data_ptr(), wp.data_ptr(), N, K, _stream_ptr())
+        _lib.call('pvsg_gemm_f16x2_pack' if f16 else 'pvsg_gemm_bf16x3_pack', w.data_ptr(), wp.data_ptr(), N, K, _stream_ptr())
     return wp
 
 
@@ -702,8 +776,7 @@ def gemm_bf16x3(a, w_packed, n, bias=None, relu=False, out=None):
         raise RuntimeError('gemm_bf16x3: unsupported shape %s x %d' % (tuple(a.shape), n))
     M, K = a.shape
     wp = _chk(w_packed, 'w_packed', torch.bfloat16)
-    if wp.numel() != _lib.load().pvsg_gemm_bf16x3_packed_elems(n, K):
-        raise RuntimeError('gemm_bf16x3: w_packed does not match N=%d K=%d' % (n, K))
+    f16 = _is_f16x2(wp, n, K)
     if out is None:
         out = torch.empty((M, n), device=a.device, dtype=torch.float32)
     elif not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (M, n)):
@@ -711,8 +784,12 @@ def gemm_bf16x3(a, w_packed, n, bias=None, relu=False, out=None):
     if M == 0:
         return out
     with _on(a.device):
-        _lib.call('pvsg_gemm_bf16x3', a.data_ptr(), wp.data_ptr(), _chk(bias, 'bias').data_ptr() if bias is not None else None,
-                  out.data_ptr(), M, n, K, int(bool(relu)), _stream_ptr())
+        bp = _chk(bias, 'bias').data_ptr() if bias is not None else None
+        if f16:
+            _lib.call('pvsg_gemm_f16x2', a.data_ptr(), wp.data_ptr(), bp, out.data_ptr(), M, n, K, int(bool(relu)),
+                      _overflow_counter(a.device).data_ptr(), _stream_ptr())
+        else:
+            _lib.call('pvsg_gemm_bf16x3', a.data_ptr(), wp.data_ptr(), bp, out.data_ptr(), M, n, K, int(bool(relu)), _stream_ptr())
     return out
 
 
@@ -728,9 +805,9 @@ def conv1x1_bf16x3(x, w_packed, cout, scale=None, shift=None, residual=None, rel
     x = _chk(x, 'x')
     B, Cin, H, W = x.shape
     wp = _chk(w_packed, 'w_packed', torch.bfloat16)
-    if stride not in (1, 2) or not conv1x1_bf16x3_supported(cout, Cin, H, W) or \
-            wp.numel() != _lib.load().pvsg_gemm_bf16x3_packed_elems(cout, Cin):
+    if stride not in (1, 2) or not conv1x1_bf16x3_supported(cout, Cin, H, W):
         raise RuntimeError('conv1x1_bf16x3: unsupported shape Cout=%d Cin=%d H=%d W=%d stride=%d' % (cout, Cin, H, W, stride))
+    f16 = _is_f16x2(wp, cout, Cin)
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     if out is None:
         out = torch.empty((B, cout, Ho, Wo), device=x.device, dtype=torch.float32)
@@ -742,13 +819,17 @@ def conv1x1_bf16x3(x, w_packed, cout, scale=None, shift=None, residual=None, rel
     if (in_scale is None) != (in_shift is None) or (in_scale is not None and (in_scale.numel() != B * Cin or in_shift.numel() != B * Cin)):
         raise RuntimeError('conv1x1_bf16x3: in_scale / in_shift must both be (B*Cin,)')
     with _on(x.device):
-        _lib.call('pvsg_conv1x1_bf16x3', x.data_ptr(), wp.data_ptr(),
-                  _chk(scale, 'scale').data_ptr() if scale is not None else None,
-                  _chk(shift, 'shift').data_ptr() if shift is not None else None,
-                  r.data_ptr() if r is not None else None,
-                  _chk(in_scale, 'in_scale').data_ptr() if in_scale is not None else None,
-                  _chk(in_shift, 'in_shift').data_ptr() if in_shift is not None else None,
-                  out.data_ptr(), B, Cin, cout, H, W, stride, int(bool(relu)), _stream_ptr())
+        args = (x.data_ptr(), wp.data_ptr(),
+                _chk(scale, 'scale').data_ptr() if scale is not None else None,
+                _chk(shift, 'shift').data_ptr() if shift is not None else None,
+                r.data_ptr() if r is not None else None,
+                _chk(in_scale, 'in_scale').data_ptr() if in_scale is not None else None,
+                _chk(in_shift, 'in_shift').data_ptr() if in_shift is not None else None,
+                out.data_ptr(), B, Cin, cout, H, W, stride, int(bool(relu)))
+        if f16:
+            _lib.call('pvsg_conv1x1_f16x2', *args, _overflow_counter(x.device).data_ptr(), _stream_ptr())
+        else:
+            _lib.call('pvsg_conv1x1_bf16x3', *args, _stream_ptr())
     return out
 
 

@@ -13,7 +13,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import parallel
+from . import ops, parallel
 
 
 def assemble_tubes(seg_ids, kept_feats, num_frames):
@@ -27,6 +27,8 @@ def assemble_tubes(seg_ids, kept_feats, num_frames):
         host = torch.stack([s.reshape(-1) for s in seg_ids]).tolist()       # the one sync of the stage
     else:
         host = [s.tolist() for s in seg_ids]
+    if dev.type == 'cuda':
+        ops.split_overflow_check(dev)       # the detector's f16x2 kernels (ops.py); the stage is synchronised here anyway
     order = []
     seen = set()
     for ids in host:

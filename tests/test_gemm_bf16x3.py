@@ -12,12 +12,16 @@ CASES = [(1024, 1024, 256), (640, 256, 1024), (384, 544, 256), (1000, 256, 256),
          (300, 2048, 256), (130, 70, 32), (257, 129, 96)]
 
 
-@pytest.fixture(autouse=True, params=['k32', 'k16'])
+@pytest.fixture(autouse=True, params=['k32', 'k16', 'f16x2'])
 def gemm_kernel(request, monkeypatch):
-    """Every test runs on the default dispatch (v_mfma_f32_16x16x32_bf16 with K = 32 stages where K % 32 == 0) and with the
-    32x32x16 / K = 16 kernel forced for all shapes (PVSG_GEMM_K32=0, read per call)."""
+    """Every test runs on the three-limb bf16 form with the K = 32 kernel (v_mfma_f32_16x16x32_bf16 where K % 32 == 0), on the
+    same form with the 32x32x16 / K = 16 kernel forced for all shapes (PVSG_GEMM_K32=0, read per call), and on the two-limb f16
+    form (PVSG_SPLIT=f16x2, the default; shapes with K % 32 != 0 stay on the bf16 form there) -- at the same bars."""
+    monkeypatch.setenv('PVSG_SPLIT', 'f16x2' if request.param == 'f16x2' else 'bf16x3')
     monkeypatch.setenv('PVSG_GEMM_K32', '0' if request.param == 'k16' else '1')     # '1': K = 32 on every shape that allows it
-    return request.param
+    yield request.param
+    from openpvsg_amd import ops
+    assert ops.split_overflow_count() == 0
 
 
 @pytest.mark.parametrize('M,N,K', CASES)

@@ -11,12 +11,15 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-@pytest.fixture(autouse=True, params=['k32', 'k16'])
+@pytest.fixture(autouse=True, params=['k32', 'k16', 'f16x2'])
 def split_kernel_shape(request, monkeypatch):
-    """The split-bf16 mask kernels on their default form (v_mfma_f32_16x16x32_bf16, K = 32 stages) and on the 32x32x16 / K = 16
-    form (PVSG_GEMM_K32=0, read per call): same oracle, same bounds."""
+    """The split mask kernels on the three-limb bf16 form (v_mfma_f32_16x16x32_bf16, K = 32 stages), on its 32x32x16 / K = 16
+    form (PVSG_GEMM_K32=0, read per call) and on the two-limb f16 form (PVSG_SPLIT=f16x2, the default): same oracle, same bounds."""
+    monkeypatch.setenv('PVSG_SPLIT', 'f16x2' if request.param == 'f16x2' else 'bf16x3')
     monkeypatch.setenv('PVSG_GEMM_K32', '0' if request.param == 'k16' else '1')
-    return request.param
+    yield request.param
+    from openpvsg_amd import ops
+    assert ops.split_overflow_count() == 0
 
 
 def oracle_forward_head_mask(emb, feat, target, heads=8):

@@ -100,10 +100,13 @@ S2X_CASES = [(2, 128, 128, 32, 32), (1, 128, 128, 23, 41), (2, 256, 256, 46, 80)
 @pytest.mark.parametrize('N,Cin,Cout,H,W', S2X_CASES)
 @pytest.mark.parametrize('relu', [True, False])
 @pytest.mark.parametrize('stride', [2, 1])
-def test_conv3x3_bf16x3_matches_direct_convolution(hip_lib, N, Cin, Cout, H, W, relu, stride):
+@pytest.mark.parametrize('split', ['bf16x3', 'f16x2'])
+def test_conv3x3_bf16x3_matches_direct_convolution(hip_lib, monkeypatch, N, Cin, Cout, H, W, relu, stride, split):
     """Odd and even maps (the last row / column tap falls outside for even sizes only), ragged pixel and channel tiles;
-    against float64, at the f32 kernel's bound, and next to the library's own f32 convolution."""
+    against float64, at the f32 kernel's bound, and next to the library's own f32 convolution.  Both split forms (three bf16
+    limbs / two f16 limbs, PVSG_SPLIT) at the same bars."""
     from openpvsg_amd import ops
+    monkeypatch.setenv('PVSG_SPLIT', split)
     g = torch.Generator().manual_seed(N * 1000 + Cin + H)
     x = torch.randn(N, Cin, H, W, generator=g).cuda()
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).cuda()
