@@ -894,7 +894,7 @@ __global__ void f16x2_amax_kernel(const float* __restrict__ w, long long n, unsi
 __device__ __forceinline__ int f16x2_exponent(float amax) {
   if (!(amax > 0.f) || !(amax < 3.0e38f)) return 0;
   int e = 13 - ilogbf(amax);                               // max|w| 2^e in [2^13, 2^14)
-  return e > 100 ? 100 : (e < -100 ? -100 : e);
+  return e > 126 ? 126 : (e < -126 ? -126 : e);            // 2^-e stays a normal f32
 }
 __global__ void gemm_f16x2_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int N, int K, int Npad) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // one (column, k pair)
@@ -903,13 +903,12 @@ __global__ void gemm_f16x2_pack_kernel(const float* __restrict__ w, __bf16* __re
   float* tail = reinterpret_cast<float*>(wp + (size_t)3 * Npad * K);
   const int e = f16x2_exponent(tail[0]);
   if (idx == 0) tail[1] = ldexpf(1.f, -e);
-  const float sc = ldexpf(1.f, e);
   const int kp = (int)(idx % (K / 2)), n = (int)(idx / (K / 2));
   const int k = 2 * kp;
   float a0 = 0.f, a1 = 0.f;
   if (n < N) {
-    a0 = w[(size_t)n * K + k] * sc;
-    a1 = w[(size_t)n * K + k + 1] * sc;
+    a0 = ldexpf(w[(size_t)n * K + k], e);
+    a1 = ldexpf(w[(size_t)n * K + k + 1], e);
   }
   const f16x2 hh = __builtin_convertvector(f32x2{a0, a1}, f16x2);
   const f16x2 ll = __builtin_convertvector(f32x2{a0 - (float)hh[0], a1 - (float)hh[1]}, f16x2);

@@ -58,13 +58,19 @@ def test_mask_logits(hip_lib, monkeypatch, path, B, T, Q, C, hw):
     assert err <= 3 * err_lib + 1e-6 * scale, (err, err_lib)           # f32-class: no worse than a plain f32 contraction
 
 
-def test_mask_logits_identity_asymmetric(hip_lib):
+def test_mask_logits_identity_asymmetric(hip_lib, split_kernel_shape):
     """E = I (first 100 channels) with an asymmetric F catches a transposed C/D fragment map."""
     from openpvsg_amd import ops
     Q, C, N = 100, 256, 64 * 3
     emb = torch.zeros(1, Q, C)
     emb[0, torch.arange(Q), torch.arange(Q)] = 1.0
     feat = (torch.arange(C)[:, None] * 1000 + torch.arange(N)[None, :]).float().view(1, C, 8, 24)
+    if split_kernel_shape == 'f16x2':
+        # the f16 form holds |operand| <= 65504 (255 191 here): as given the call must be flagged, not trusted ...
+        ops.mask_logits(emb.to(DEV), feat.to(DEV))
+        with pytest.raises(RuntimeError, match='beyond the f16 range'):
+            ops.split_overflow_check()
+        feat = feat / 8                                   # ... and within the range it is exact like the others (21 bits)
     out = ops.mask_logits(emb.to(DEV), feat.to(DEV)).cpu()
     assert torch.equal(out[0].flatten(1), feat[0, :Q].flatten(1))
 
