@@ -56,6 +56,11 @@ def host_cores():
     return max(1, n)
 
 
+def ops_split_mode():
+    from openpvsg_amd import ops
+    return ops.split_mode()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -174,9 +179,21 @@ class KernelTimer:
         import openpvsg_amd.ops as ops
         ops._lib.call = timed
 
-    @staticmethod
-    def work(name, a):
+    SPLIT_F16X2 = ('pvsg_gemm_f16x2', 'pvsg_conv1x1_f16x2', 'pvsg_conv3x3_f16x2', 'pvsg_mask_logits_f16x2',
+                   'pvsg_attn_mask_bits_f16x2')
+
+    @classmethod
+    def work(cls, name, a):
         """(algorithmic bytes, flops) of one launch from its scalar arguments."""
+        if name in cls.SPLIT_F16X2:
+            # two-limb f16 form: same arguments up to the trailing (overflow, stream); flops = the f16 limb products issued,
+            # 3 per f32 multiply-add (the bf16 form issues 6)
+            by, fl = cls._work(name.replace('_f16x2', '_bf16x3'), a)
+            return by, fl / 2.0
+        return cls._work(name, a)
+
+    @staticmethod
+    def _work(name, a):
         if name == 'pvsg_ms_deform_attn_forward':
             B, S, M, D, Lq, L, P = a[6:13]
             return 4.0 * (B * S * M * D + B * Lq * M * D + 3 * B * Lq * M * L * P), 9.0 * B * Lq * M * L * P * D
@@ -284,6 +301,8 @@ class KernelTimer:
             return 2.0 * M * N * K
         if name in ('pvsg_conv1x1_bf16x3', 'pvsg_conv3x3_bf16x3', 'pvsg_mask_logits_bf16x3', 'pvsg_attn_mask_bits_bf16x3'):
             return cls.work(name, a)[1] / 6.0
+        if name in cls.SPLIT_F16X2:
+            return cls.work(name, a)[1] / 3.0
         if name == 'pvsg_masked_xattn_partial' and not XATTN_F32:
             return cls.work(name, a)[1] / 6.0
         return cls.work(name, a)[1]
@@ -291,6 +310,8 @@ class KernelTimer:
     @staticmethod
     def mfma_peak(name):
         """(peak TFLOP/s, what the flops of work() count) of the matrix pipe a kernel runs on."""
+        if name.startswith(KernelTimer.SPLIT_F16X2):
+            return BF16_MFMA_PEAK_TF, 'f16 limb products issued (3 per f32 multiply-add), dense f16 MFMA peak (= the bf16 peak)'
         if name.startswith(('pvsg_gemm_bf16x3', 'pvsg_conv1x1_bf16x3', 'pvsg_conv3x3_bf16x3', 'pvsg_mask_logits_bf16x3',
                             'pvsg_attn_mask_bits_bf16x3')) \
                 or (name.startswith('pvsg_masked_xattn_partial') and not XATTN_F32):
@@ -661,10 +682,14 @@ def main():
             'collectives': {'backend': dist.get_backend() if dist.is_initialized() else None,
                             'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
                             'exchanges_run': bool(parallel.is_dist()), 'forced_at_world_1': bool(force and world == 1)},
-            'dtype_note': ('every tensor, accumulation and result f32; the 3x3 convolutions run on the f32 MFMA, the large '
-                           'GEMMs / 1x1 convolutions issue an EXACT three-limb bf16 split of their f32 operands on the bf16 MFMA '
-                           '(6 limb products per multiply, f32 accumulate: error vs f64 at or below the library f32 GEMM, '
-                           'tests/test_gemm_bf16x3.py)' if os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' else
+            'dtype_note': (('every tensor, accumulation and result f32; the 3x3 convolutions run on the f32 MFMA, the large '
+                            'GEMMs / 1x1 convolutions / mask projections split their f32 operands into ' +
+                            ('two f16 limbs (3 limb products per multiply on the f16 MFMA, operands within the f16 range, '
+                             'low limbs kept normal by exact power-of-two factors; PVSG_SPLIT=bf16x3 selects the other form)'
+                             if ops_split_mode() == 'f16x2' else
+                             'three bf16 limbs (6 limb products per multiply on the bf16 MFMA, exact split)') +
+                            ', f32 accumulate: error vs f64 at or below the library f32 GEMM (tests/test_gemm_bf16x3.py, '
+                            'tests/test_gemm_f16x2.py)') if os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' else
                            'every tensor, accumulation and result f32 (PVSG_GEMM=lib: library f32 GEMMs)'),
             'config': {'workload': 'Mask2Former-VPS R50 clip-level forward, %d frames %dx%d (padded %dx%d), '
                                    '100 queries, 9 decoder layers over T*h*w keys, panoptic fusion per frame, '
@@ -715,6 +740,12 @@ def main():
                     achieved=f0 / (ms_per_step * 1e-3) / 1e12, frac=ideal_ms / ms_per_step, ideal_ms_per_step=ideal_ms,
                     handwritten_kernel_ms_per_step=hw_ms, other_ms_per_step=ms_per_step - hw_ms,
                     note='rank 0; other = library kernels (MIOpen / rocBLAS / hipBLASLt / ATen) + launch gaps + host syncs')
+                # the same step against the pipes its kernels actually issue on: every launch's ISSUED matrix flops (limb
+                # products for the split kernels, Winograd's transformed multiplies) over that pipe's dense peak, summed.
+                # `frac` above prices the model's f32 arithmetic at the f32 matrix peak although most of it executes as
+                # 3 (f16x2) or 6 (bf16x3) limb products on the 16-bit pipe; this is the honest utilisation figure.
+                pipe_ms = sum(d['flops'] / args.steps / (KernelTimer.mfma_peak(k.split('[')[0])[0] * 1e12) * 1e3 for k, d in agg.items())
+                line['roofline_step'].update(ideal_ms_on_pipes_used=pipe_ms, frac_of_pipe_used=pipe_ms / ms_per_step)
             dom = max((k for k in agg if agg[k]['bytes'] > 0), key=lambda k: agg[k]['ms'])
             d = agg[dom]
             per = d['ms'] / d['calls']
@@ -749,7 +780,9 @@ def main():
             named = []
             for key, bound in (('pvsg_msda_fused_forward', 'hbm'), ('pvsg_ms_deform_attn_forward', 'hbm'),
                                ('pvsg_mask_logits_forward', 'mfma'), ('pvsg_mask_logits_bf16x3', 'mfma'),
+                               ('pvsg_mask_logits_f16x2', 'mfma'),
                                ('pvsg_attn_mask_bits_forward', 'mfma'), ('pvsg_attn_mask_bits_bf16x3', 'mfma'),
+                               ('pvsg_attn_mask_bits_f16x2', 'mfma'),
                                ('pvsg_masked_xattn_partial', 'mfma'), ('pvsg_pair_score_forward', 'latency')):
                 ks = [k for k in agg if k.startswith(key)]
                 if not ks:
@@ -779,9 +812,10 @@ def main():
                     a_ = dd['flops'] / dd['calls'] / per_ms / 1e9
                     pk, what = KernelTimer.mfma_peak(k.split('[')[0])
                     ent = dict(kernel=k, bound='mfma', achieved=a_, peak=pk, unit='TFLOP/s', frac=a_ / pk, flops_counted=what)
-                    if pk != F32_MFMA_PEAK_TF:      # split-bf16 kernels: also the model's f32 arithmetic against the f32 matrix roof
-                        ent['f32_equivalent_TFLOPs'] = a_ / 6.0
-                        ent['f32_equivalent_frac_of_f32_mfma_peak'] = a_ / 6.0 / F32_MFMA_PEAK_TF
+                    if pk != F32_MFMA_PEAK_TF:      # split kernels: also the model's f32 arithmetic against the f32 matrix roof
+                        limb_products = 3.0 if k.split('[')[0] in KernelTimer.SPLIT_F16X2 else 6.0
+                        ent['f32_equivalent_TFLOPs'] = a_ / limb_products
+                        ent['f32_equivalent_frac_of_f32_mfma_peak'] = a_ / limb_products / F32_MFMA_PEAK_TF
                     named.append(ent)
                 else:
                     named.append(dict(kernel=k, bound='launch-latency', avg_launch_us=per_ms * 1e3))
