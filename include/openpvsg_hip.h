@@ -359,14 +359,15 @@ int pvsg_conv3x3_bf16x3(const float* x, const void* w_packed, const float* scale
  * needs three limb products (hh, hl, lh) instead of six -- half the matrix work for the same f32-class dot product
  * (tests/test_gemm_f16x2.py measures both forms and the library's f32 GEMM against float64).  The missing exponent range of f16
  * is handled by exact power-of-two factors: the packed weight is scaled so that max|w| 2^e lies in [2^13, 2^14) (2^-e is
- * applied to the accumulator), the activation's low limb is staged as 2^11 (a - a_h) against a third weight array 2^-11 w_h.
+ * applied to the accumulator), the activation's low limb is staged as 2^11 (a - a_h) and multiplied by 2^-11 w_h, which the
+ * kernels derive from the w_h fragment in registers.
  * Full accuracy for activations 2^-13 <= |a| <= 65504 (absolute error <= 2^-36 below), weights down to 2^-16 max|w|.
  * |a| > 65504 is NOT representable: the results of such a call are invalid and every kernel adds the number of staging
  * threads that met such an operand to *overflow (a device uint32 owned by the caller; may be NULL = not reported).  The host
  * mirror checks the counter at its next synchronisation point (openpvsg_amd/ops.py: split_overflow_check) and refuses to
  * hand out results; PVSG_SPLIT=bf16x3 selects the three-limb form, which has the whole f32 range.
- *   w_packed   pvsg_gemm_f16x2_packed_elems(N, K) 16-bit elements written by pvsg_gemm_f16x2_pack (arrays w_h, w_l, 2^-11 w_h
- *              in the staging order of the bf16 form, then max|w| and 2^-e as floats); K % 32 == 0
+ *   w_packed   pvsg_gemm_f16x2_packed_elems(N, K) = 2 * pad128(N) * K + 8 16-bit elements written by pvsg_gemm_f16x2_pack
+ *              (arrays w_h, w_l in the staging order of the bf16 form, then max|w| and 2^-e as floats); K % 32 == 0
  * Arguments, layouts and the interfaces replaced are those of the _bf16x3 entry points above. */
 long long pvsg_gemm_f16x2_packed_elems(int N, int K);
 int pvsg_gemm_f16x2_pack(const float* weight, void* w_packed, int N, int K, void* stream);

@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libopenpvsg_hip.so')
+# PVSG_LIB_PATH: a lab build of the same library (scripts/lab/abl_split.sh); the product always loads the in-tree one
+LIB_PATH = os.environ.get('PVSG_LIB_PATH') or os.path.join(_HERE, 'lib', 'libopenpvsg_hip.so')
 
 _c_f = ctypes.c_void_p  # device pointers travel as raw addresses
 _i = ctypes.c_int

@@ -53,9 +53,11 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& h, unsigned
 // ulp of the f32 itself) and a product needs THREE limb products (hh, hl, lh; ll < 2^-24 |a w|) instead of six: half the
 // matrix work for an f32-class dot product.  What f16 lacks is exponent range (2^-14 .. 65504), so the low limbs are kept
 // away from the subnormals by power-of-two factors that cancel exactly:
-//   weights (packed once):  ws = w * 2^e with max|ws| in [2^13, 2^14);  w_h = f16(ws), w_l = f16(ws - w_h), w_h2 = 2^-11 w_h
+//   weights (packed once):  ws = w * 2^e with max|ws| in [2^13, 2^14);  w_h = f16(ws), w_l = f16(ws - w_h)
 //   activations (on the fly): a_h = f16(a), a_l' = f16(2^11 (a - a_h))      (a - a_h is exact in f32)
 //   acc += a_l' w_h2 + a_h w_l + a_h w_h      (f32 accumulator of v_mfma_f32_16x16x32_f16),   out = 2^-e acc
+//   with w_h2 = 2^-11 w_h made from the w_h fragment in registers (four v_pk_mul_f16 per fragment; exact down to the f16
+//   subnormals, below which the a_l' w_h2 term is < 2^-39 of |a| max|w|): two 16-bit arrays per operand travel and are staged
 // Full accuracy for 2^-13 <= |a| <= 65504 (29 binades; below that the absolute error is <= 2^-36), weights down to 2^-16 of
 // the tensor's largest.  |a| > 65504 cannot be represented: every kernel counts such operands into `overflow` (the caller's
 // device counter, checked by the host mirror at its next synchronisation point: openpvsg_amd/ops.py).
@@ -77,9 +79,21 @@ __device__ __forceinline__ f32x4 mfma_k32(u32x4 a, u32x4 b, f32x4 c) {
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// per-tensor factor of an f16x2-packed weight: the two floats behind its 3 * Npad * K limb elements (amax, 2^-e)
+// per-tensor factor of an f16x2-packed weight: the two floats behind its 2 * Npad * K limb elements (amax, 2^-e)
 __device__ __forceinline__ float f16x2_unscale(const __bf16* Wp, int Npad, int K) {
-  return reinterpret_cast<const float*>(Wp + (size_t)3 * Npad * K)[1];
+  return reinterpret_cast<const float*>(Wp + (size_t)2 * Npad * K)[1];
+}
+// 2^-11 w_h of a fragment of eight f16
+__device__ __forceinline__ u32x4 f16x2_lo_scale(u32x4 wh) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 k = {(_Float16)(1.f / F16X2_LO), (_Float16)(1.f / F16X2_LO)};
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned w = wh[i];               // (never bit_cast a vector ELEMENT expression: hipcc 7.2 then reads element 0)
+    r[i] = __builtin_bit_cast(unsigned, __builtin_bit_cast(h2, w) * k);
+  }
+  return r;
 }
 __device__ __forceinline__ void f16x2_count_overflow(float amax, unsigned* overflow) {
   if (overflow && !(amax <= 65504.f)) atomicAdd(overflow, 1u);          // also counts NaN operands
@@ -237,44 +251,60 @@ __global__ __launch_bounds__(256, 3)
 void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
                             float* __restrict__ out, int M, int N, int K, int Npad, int tiles_n, unsigned* __restrict__ overflow = nullptr) {
   constexpr int AL = F16 ? 2 : 3;                                // limbs of the on-the-fly operand
-  constexpr int W_AT = AL * K32_LIMB;                            // where the weight tile starts
-  __shared__ __attribute__((aligned(16))) __bf16 lds[W_AT + K32_TILE];
+  // A's k-groups are 130 rows apart in LDS (not 128): the staging threads of a wave write (row, k-group) = (lane / 4, lane % 4),
+  // and with a 2080-byte k-group stride the eight 16-byte records of a write cycle fall into eight different bank groups
+  constexpr int A_KG = (GB_M + 2) * 8, A_LIMB = 4 * A_KG;
+  constexpr int WL = F16 ? 2 : 3;                                // arrays of the packed operand
+  constexpr int W_AT = AL * A_LIMB;                              // where the weight tile starts
+  __shared__ __attribute__((aligned(16))) __bf16 lds[W_AT + WL * K32_LIMB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int tn = logical % tiles_n, tm = logical / tiles_n;
   const int m0 = tm * GB_M, n0 = tn * GB_N;
-  // staging: A -- thread = (row tid/2, half tid%2), 16 consecutive floats; W -- (k-group tid/128, column tid%128) of both
-  // 16-deep sub-steps of the packed weight, 3 limbs each
-  const int ar = tid >> 1, ah2 = tid & 1;
-  const bool a_in = m0 + ar < M;
-  const unsigned a_voff = a_in ? (unsigned)((ar * K + 16 * ah2) * 4) : 0x80000000u;   // rows beyond M read as 0
+  // staging: A -- thread = (rows tid/4 and 64 + tid/4, k-group tid%4), 8 consecutive floats of each: four lanes cover one
+  // 128-byte line of a row, a load instruction touches 16 lines (with two lanes per row and 64 bytes each it touched 32 and
+  // the texture addresser, not the matrix pipe, set the pace: scripts/lab/abl_split.sh); W -- (k-group tid/128, column
+  // tid%128) of both 16-deep sub-steps of the packed weight, 3 limbs each
+  const int ar = tid >> 2, akg = tid & 3;
+  unsigned a_voff[2];
+#pragma unroll
+  for (int p2 = 0; p2 < 2; ++p2)                                 // rows beyond M read as 0
+    a_voff[p2] = m0 + ar + 64 * p2 < M ? (unsigned)(((ar + 64 * p2) * K + 8 * akg) * 4) : 0x80000000u;
   const auto asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A) + (size_t)m0 * K * 4), 0,
                                                       (unsigned)((size_t)GB_M * K * 4), 0x00020000);
   const int wkg = tid >> 7, wcol = tid & 127;
   const size_t w_limb_stride = (size_t)2 * Npad * 8;
   const __bf16* wsrc = Wp + ((size_t)wkg * Npad + n0 + wcol) * 8;
   f32x4 a_regs[4];
-  u32x4 w_regs[2][3];
+  u32x4 w_regs[2][WL];
+#ifndef PVSG_ABL
+#define PVSG_ABL 0                                               // lab builds only (scripts/lab/abl_split.sh): timing ablations
+#endif
   auto fetch = [&](int kt) {                                     // kt counts 32-deep steps
     const unsigned so = (unsigned)kt * (32 * 4);
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      a_regs[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc, a_voff + 16 * q, so, 0));
+    for (int q = 0; q < 4; ++q) {                                // a_regs[2 p + h]: floats 4 h .. 4 h + 3 of row ar + 64 p
+      if (PVSG_ABL == 3 || PVSG_ABL == 4) a_regs[q] = f32x4{1.f + so, 2.f, 3.f, 4.f};
+      else a_regs[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc, a_voff[q >> 1] + 16 * (q & 1), so, 0));
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const __bf16* wk = wsrc + (size_t)(2 * kt + j) * 3 * w_limb_stride;
+      const __bf16* wk = wsrc + (size_t)(2 * kt + j) * WL * w_limb_stride;
 #pragma unroll
-      for (int l = 0; l < 3; ++l) w_regs[j][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
+      for (int l = 0; l < WL; ++l) {
+        if (PVSG_ABL == 2 || PVSG_ABL == 4 || PVSG_ABL == 5) w_regs[j][l] = u32x4{0x3c003c00u + (unsigned)kt, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+        else w_regs[j][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
+      }
     }
   };
   // the split of step kt+1 (VALU) runs under the MFMAs of step kt, on the registers its loads landed in; between the two
   // barriers only the LDS writes remain
-  u32x4 limbs[2][AL];                                           // [k-group 2*ah2 + gq][limb]
+  u32x4 limbs[2][AL];                                           // [row ar + 64 gq][limb]
   float amax = 0.f;
   auto split = [&]() {
 #pragma unroll
-    for (int gq = 0; gq < 2; ++gq) {                             // floats 8 gq .. 8 gq + 7 of this thread
+    for (int gq = 0; gq < 2; ++gq) {                             // the k-group of row ar + 64 gq
       unsigned hh[4], mm[4], ll[4];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -295,25 +325,29 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
   auto write = [&]() {
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
-      __bf16* pa = lds + ((2 * ah2 + gq) * GB_M + ar) * 8;
+      __bf16* pa = lds + akg * A_KG + (ar + 64 * gq) * 8;
 #pragma unroll
-      for (int l = 0; l < AL; ++l) *reinterpret_cast<u32x4*>(pa + l * K32_LIMB) = limbs[gq][l];
+      for (int l = 0; l < AL; ++l) *reinterpret_cast<u32x4*>(pa + l * A_LIMB) = limbs[gq][l];
     }
+    if (PVSG_ABL == 5) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       __bf16* pw = lds + W_AT + ((2 * j + wkg) * GB_N + wcol) * 8;
 #pragma unroll
-      for (int l = 0; l < 3; ++l) *reinterpret_cast<u32x4*>(pw + l * K32_LIMB) = w_regs[j][l];
+      for (int l = 0; l < WL; ++l) *reinterpret_cast<u32x4*>(pw + l * K32_LIMB) = w_regs[j][l];
     }
   };
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int l15 = lane & 15, kg4 = lane >> 4;
-  const __bf16* afr = lds + (kg4 * GB_M + wr * 64 + l15) * 8;                 // + limb * K32_LIMB + row block * 128
+  const __bf16* afr = lds + kg4 * A_KG + (wr * 64 + l15) * 8;                 // + limb * A_LIMB + row block * 128
   const __bf16* wfr = lds + W_AT + (kg4 * GB_N + wc * 64 + l15) * 8;          // + limb * K32_LIMB + column block * 128
   auto frag = [](const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); };
-  auto mf = [](u32x4 a, u32x4 b, f32x4 c) { return mfma_k32<F16>(a, b, c); };
+  auto mf = [](u32x4 a, u32x4 b, f32x4 c) {
+    if (PVSG_ABL == 6) { c[0] += __builtin_bit_cast(float, a[0] ^ b[0]); return c; }
+    return mfma_k32<F16>(a, b, c);
+  };
   const int KT = K / 32;
   fetch(0);
   split();
@@ -325,18 +359,18 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
       ahf[rb] = frag(afr + rb * 128);
-      amf[rb] = frag(afr + K32_LIMB + rb * 128);
+      amf[rb] = frag(afr + A_LIMB + rb * 128);
     }
     if constexpr (F16) {
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {                           // small terms first: (l', h2) (h, l) (h, h)
-        const u32x4 wh = frag(wfr + cb * 128), wl = frag(wfr + K32_LIMB + cb * 128), wh2 = frag(wfr + 2 * K32_LIMB + cb * 128);
+        const u32x4 wh = frag(wfr + cb * 128), wl = frag(wfr + K32_LIMB + cb * 128), wh2 = f16x2_lo_scale(wh);
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh2, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wh2, amf[rb], acc[rb][cb]);
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wl, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wl, ahf[rb], acc[rb][cb]);
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wh, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wh, ahf[rb], acc[rb][cb]);
       }
       split();                                                   // next step's A: VALU under the MFMAs still in flight
     } else {
@@ -344,50 +378,69 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
       for (int cb = 0; cb < 4; ++cb) {                           // small terms first: (m,m) (h,l) (h,m) (m,h) (h,h)
         const u32x4 wh = frag(wfr + cb * 128), wm = frag(wfr + K32_LIMB + cb * 128), wl = frag(wfr + 2 * K32_LIMB + cb * 128);
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wm, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wm, amf[rb], acc[rb][cb]);
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wl, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wl, ahf[rb], acc[rb][cb]);
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wm, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wm, ahf[rb], acc[rb][cb]);
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wh, amf[rb], acc[rb][cb]);
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wh, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wh, ahf[rb], acc[rb][cb]);
       }
       split();                                                   // next step's A: VALU under the MFMAs still in flight
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) amf[rb] = frag(afr + 2 * K32_LIMB + rb * 128);   // A's low limb
+      for (int rb = 0; rb < 4; ++rb) amf[rb] = frag(afr + 2 * A_LIMB + rb * 128);     // A's low limb
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {                           // (l,h)
         const u32x4 wh = frag(wfr + cb * 128);
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wh, amf[rb], acc[rb][cb]);
       }
     }
     __syncthreads();                                             // everyone is done reading step kt
     if (kt + 1 < KT) write();
     fetch(kt + 2 < KT ? kt + 2 : KT - 1);                        // registers are free again: step kt+2 starts its trip
   }
-  // bias / ReLU and store through a bounded buffer descriptor (see the kernel above): register r of block (rb, cb) = row
-  // rb*16 + 4*(lane>>4) + r, column cb*16 + (lane&15) of the wave's 64 x 64 tile; no branch, no wait between the 64 stores
+  // bias / ReLU and store through a bounded buffer descriptor (see the kernel above).  The MFMAs take the weight fragment as
+  // their row operand, so register r of block (rb, cb) = row rb*16 + (lane&15), column cb*16 + 4*(lane>>4) + r of the wave's
+  // 64 x 64 tile: a lane owns four consecutive columns of one row -- 16 sixteen-byte stores per lane instead of 64 dword
+  // stores (N % 4 == 0; otherwise element by element); no branch, no wait between the stores
   {
     const float unscale = F16 ? f16x2_unscale(Wp, Npad, K) : 1.f;
     const int rows = M - m0 < GB_M ? M - m0 : GB_M;
     const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)m0 * N, 0, (unsigned)((size_t)rows * N * 4), 0x00020000);
+    const auto brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, bias ? (unsigned)N * 4u : 0u, 0x00020000);
     const unsigned rowpitch = (unsigned)N * 4u;
+    const bool vec4 = (N & 3) == 0;
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
-      const int col = n0 + wc * 64 + cb * 16 + l15;
-      const float bv = bias ? bias[col < N ? col : N - 1] : 0.f;
-      const unsigned vbase = col < N ? (unsigned)(wr * 64 + 4 * kg4) * rowpitch + (unsigned)col * 4u : 0x80000000u;
+      const int col = n0 + wc * 64 + cb * 16 + 4 * kg4;
+      f32x4 bv;                                                  // columns >= N read 0 through the descriptor
+      if (vec4) bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, (unsigned)col * 4u, 0, 0));
+      else
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
+        for (int r = 0; r < 4; ++r) bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, (unsigned)(col + r) * 4u, 0, 0));
+      const unsigned vbase = (unsigned)(wr * 64 + l15) * rowpitch + (unsigned)col * 4u;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        f32x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float o = F16 ? __builtin_fmaf(acc[rb][cb][r], unscale, bv) : acc[rb][cb][r] + bv;
-          if (RELU) o = fmaxf(o, 0.f);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), orsrc, vbase + (unsigned)(rb * 16 + r) * rowpitch, 0, 0);
+          o[r] = F16 ? __builtin_fmaf(acc[rb][cb][r], unscale, bv[r]) : acc[rb][cb][r] + bv[r];
+          if (RELU) o[r] = fmaxf(o[r], 0.f);
         }
+        const unsigned vo = vbase + (unsigned)(rb * 16) * rowpitch;
+        if (PVSG_ABL == 1) { if (o[0] == 1.2345e33f) out[0] = o[1]; continue; }
+        if (vec4)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, col < N ? vo : 0x80000000u, 0, 0);
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float oe = o[r];              // (bit_cast of the vector element itself stored element 0 four times)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, oe), orsrc, col + r < N ? vo + 4u * r : 0x80000000u, 0, 0);
+          }
+      }
     }
   }
   if constexpr (F16) f16x2_count_overflow(amax, overflow);
@@ -624,7 +677,9 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
                                int Cin, int Cout, int Cpad, int HWin, int Win, int HWo, int Wo, int stride, int tiles_c,
                                int tiles_p, unsigned* __restrict__ flags = nullptr, unsigned* __restrict__ overflow = nullptr) {
   constexpr int XL = F16 ? 2 : 3;                                // limbs of the on-the-fly (pixel) operand
-  __shared__ __attribute__((aligned(16))) __bf16 lds[K32_TILE + XL * K32_LIMB];
+  constexpr int WL = F16 ? 2 : 3;                                // arrays of the packed weight
+  constexpr int X_AT = WL * K32_LIMB;                            // where the pixel tile starts
+  __shared__ __attribute__((aligned(16))) __bf16 lds[X_AT + XL * K32_LIMB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   static_assert(TM == 128 || (TM == 64 && !BITS), "64-row tiles: plain convolution only");
   static_assert(TAPS == 1 || (TAPS == 9 && !BITS && !IN_NORM && !RESIDUAL), "3x3 taps: affine / ReLU epilogue only");
@@ -649,7 +704,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
                                                       (unsigned)((size_t)Cin * HWin * 4), 0x00020000);
   const unsigned plane = (unsigned)HWin * 4u;
   float x_regs[2][8];                                 // [sub-step]
-  u32x4 w_regs[2][3];
+  u32x4 w_regs[2][WL];
   auto fetch = [&](int kt) {
     int cstep = kt * 32;                               // first input channel of this step
     unsigned voff = x_voff;
@@ -666,9 +721,9 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         x_regs[gq][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff, so + j * plane, 0));
-      const __bf16* wk = wsrc + (size_t)(2 * kt + gq) * 3 * w_limb_stride;
+      const __bf16* wk = wsrc + (size_t)(2 * kt + gq) * WL * w_limb_stride;
 #pragma unroll
-      for (int l = 0; l < 3; ++l) w_regs[gq][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
+      for (int l = 0; l < WL; ++l) w_regs[gq][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
     }
   };
   u32x4 limbs[2][XL];                                  // split of step kt+1 under the MFMAs of step kt (see the GEMM kernel)
@@ -697,8 +752,8 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
     for (int gq = 0; gq < 2; ++gq) {
       __bf16* pw = lds + ((2 * gq + skg) * GB_M + srow) * 8;                  // row operand: weights
 #pragma unroll
-      for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(pw + i * K32_LIMB) = w_regs[gq][i];
-      __bf16* px = lds + K32_TILE + ((2 * gq + skg) * GB_N + srow) * 8;       // column operand: pixels
+      for (int i = 0; i < WL; ++i) *reinterpret_cast<u32x4*>(pw + i * K32_LIMB) = w_regs[gq][i];
+      __bf16* px = lds + X_AT + ((2 * gq + skg) * GB_N + srow) * 8;           // column operand: pixels
 #pragma unroll
       for (int i = 0; i < XL; ++i) *reinterpret_cast<u32x4*>(px + i * K32_LIMB) = limbs[gq][i];
     }
@@ -710,7 +765,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
     for (int c = 0; c < CB; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int l15 = lane & 15, kg4 = lane >> 4;
   const __bf16* afr = lds + (kg4 * GB_M + wr * 64 + l15) * 8;
-  const __bf16* wfr = lds + K32_TILE + (kg4 * GB_N + wcol0 + l15) * 8;
+  const __bf16* wfr = lds + X_AT + (kg4 * GB_N + wcol0 + l15) * 8;
   auto frag = [](const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); };
   auto mf = [](u32x4 a, u32x4 b, f32x4 c) { return mfma_k32<F16>(a, b, c); };
   const int KT = TAPS * Cin / 32;
@@ -726,10 +781,10 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
       ahf[rb] = frag(afr + rb * 128);
       amf[rb] = frag(afr + K32_LIMB + rb * 128);
     }
-    if constexpr (F16) {                       // weights (w_h, w_l, w_h2) all resident; pixels (x_h, x_l') per column block
+    if constexpr (F16) {                       // weights (w_h, w_l, 2^-11 w_h) resident; pixels (x_h, x_l') per column block
       u32x4 a2f[4];
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) a2f[rb] = frag(afr + 2 * K32_LIMB + rb * 128);
+      for (int rb = 0; rb < 4; ++rb) a2f[rb] = f16x2_lo_scale(ahf[rb]);
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
         const u32x4 xh = frag(wfr + cb * 128), xl = frag(wfr + K32_LIMB + cb * 128);
@@ -881,8 +936,8 @@ __global__ void gemm_bf16x3_pack_kernel(const float* __restrict__ w, __bf16* __r
   dst[limb_stride] = l;
 }
 
-// f16x2 pack: same element layout as above with the arrays (w_h, w_l, w_h2) in the three limb slots, followed by four floats
-// (max|w|, 2^-e, 0, 0).  max|w| is reduced on the device first (mask embeddings are packed per call).
+// f16x2 pack: [k-tile K/16][array 2: w_h, w_l][k-group 2][Npad][8] f16, followed by four floats (max|w|, 2^-e, 0, 0).
+// max|w| is reduced on the device first (mask embeddings are packed per call).
 __global__ void f16x2_amax_kernel(const float* __restrict__ w, long long n, unsigned* __restrict__ tail) {
   float m = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -900,7 +955,7 @@ __global__ void gemm_f16x2_pack_kernel(const float* __restrict__ w, __bf16* __re
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // one (column, k pair)
   const long long total = (long long)Npad * (K / 2);
   if (idx >= total) return;
-  float* tail = reinterpret_cast<float*>(wp + (size_t)3 * Npad * K);
+  float* tail = reinterpret_cast<float*>(wp + (size_t)2 * Npad * K);
   const int e = f16x2_exponent(tail[0]);
   if (idx == 0) tail[1] = ldexpf(1.f, -e);
   const int kp = (int)(idx % (K / 2)), n = (int)(idx / (K / 2));
@@ -912,13 +967,11 @@ __global__ void gemm_f16x2_pack_kernel(const float* __restrict__ w, __bf16* __re
   }
   const f16x2 hh = __builtin_convertvector(f32x2{a0, a1}, f16x2);
   const f16x2 ll = __builtin_convertvector(f32x2{a0 - (float)hh[0], a1 - (float)hh[1]}, f16x2);
-  const f16x2 h2 = __builtin_convertvector(f32x2{(float)hh[0] * (1.f / F16X2_LO), (float)hh[1] * (1.f / F16X2_LO)}, f16x2);
   const int kt = k / GB_K, kg = (k % GB_K) / 8, el = k % 8;
   const size_t limb_stride = (size_t)2 * Npad * 8;
-  unsigned* dst = reinterpret_cast<unsigned*>(wp + ((size_t)kt * 3 * limb_stride + ((size_t)kg * Npad + n) * 8 + el));
+  unsigned* dst = reinterpret_cast<unsigned*>(wp + ((size_t)kt * 2 * limb_stride + ((size_t)kg * Npad + n) * 8 + el));
   dst[0] = __builtin_bit_cast(unsigned, hh);
   dst[limb_stride / 2] = __builtin_bit_cast(unsigned, ll);
-  dst[limb_stride] = __builtin_bit_cast(unsigned, h2);
 }
 
 }  // namespace
@@ -926,7 +979,7 @@ __global__ void gemm_f16x2_pack_kernel(const float* __restrict__ w, __bf16* __re
 
 extern "C" long long pvsg_gemm_f16x2_packed_elems(int N, int K) {
   const long long npad = (N + 127) / 128 * 128;
-  return 3LL * npad * K + 8;                              // 16-bit elements; the last 8 hold (max|w|, 2^-e, 0, 0) as floats
+  return 2LL * npad * K + 8;                              // 16-bit elements; the last 8 hold (max|w|, 2^-e, 0, 0) as floats
 }
 
 extern "C" int pvsg_gemm_f16x2_pack(const float* weight, void* w_packed, int N, int K, void* stream) {
@@ -938,7 +991,7 @@ extern "C" int pvsg_gemm_f16x2_pack(const float* weight, void* w_packed, int N, 
   const int Npad = (N + 127) / 128 * 128;
   hipStream_t st = static_cast<hipStream_t>(stream);
   __bf16* wp = static_cast<__bf16*>(w_packed);
-  unsigned* tail = reinterpret_cast<unsigned*>(wp + (size_t)3 * Npad * K);
+  unsigned* tail = reinterpret_cast<unsigned*>(wp + (size_t)2 * Npad * K);
   hipError_t e = zero_words_async(tail, 16, st);
   if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "gemm_f16x2_pack: %s", hipGetErrorString(e));
   const long long n = (long long)N * K;

@@ -696,7 +696,7 @@ def conv3x3_bf16x3(x, w_packed, cout, scale, shift, relu=True, out=None, stride=
 #   measures both against f64).  Operands must lie within the f16 range, |a| <= 65504: every kernel counts violations into a
 #   per-device counter which `split_overflow_check()` turns into an error at the caller's next synchronisation point.
 # 'bf16x3': three bf16 limbs, six limb products, the full f32 exponent range.
-# A packed weight knows its form (the f16x2 pack carries 8 more elements), so the run functions below take either.
+# A packed weight knows its form (two arrays + an 8-element trailer vs three arrays), so the run functions below take either.
 def split_mode():
     m = os.environ.get('PVSG_SPLIT', 'f16x2')
     if m not in ('f16x2', 'bf16x3'):

@@ -77,7 +77,7 @@ def test_f16x2_overflow_is_counted_and_raised(hip_lib):
 def test_f16x2_pack_trailer_and_zero_weight(hip_lib):
     from openpvsg_amd import _lib, ops
     lib = _lib.load()
-    assert lib.pvsg_gemm_f16x2_packed_elems(100, 256) == lib.pvsg_gemm_bf16x3_packed_elems(100, 256) + 8
+    assert lib.pvsg_gemm_f16x2_packed_elems(100, 256) == 2 * 128 * 256 + 8       # two arrays (w_h, w_l) + the trailer
     w = torch.zeros(100, 256, device='cuda')
     w[3, 5] = 0.75                                      # max|w| = 0.75 -> e = 14: 0.75 * 2^14 = 12288 in [2^13, 2^14)
     wp = ops.gemm_bf16x3_pack(w, mode='f16x2')
