@@ -77,12 +77,14 @@ def conv3x3_fast(conv, x, scale=None, shift=None, relu=False, out=None):
             conv.groups == 1 and conv.bias is None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and
             x.is_contiguous() and not torch.is_grad_enabled() and os.environ.get('PVSG_WINOGRAD', 'on') != 'off'):
         return None
-    split_ok = (scale is not None and os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and
-                os.environ.get('PVSG_CONV3X3', 'bf16x3') != 'f32' and
+    split_ok = (os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and os.environ.get('PVSG_CONV3X3', 'bf16x3') != 'f32' and
                 ops.conv3x3_bf16x3_supported(w.shape[0], w.shape[1], x.shape[2], x.shape[3]))
-    if conv.stride == (1, 1) and split_ok and w.shape[1] >= 512:
-        # direct form on the split kernel: at 32 x 720p it beats Winograd on the 512-channel layers only (0.77 vs 0.86 ms;
-        # 64 / 128 / 256 channels: 0.93 / 0.70 / 0.66 vs 0.82 / 0.72 / 0.63, scripts/lab/conv3x3_ab.py)
+    if conv.stride == (1, 1) and split_ok and w.shape[1] >= (64 if ops.split_mode() == 'f16x2' else 512):
+        # direct form (implicit GEMM over the nine taps) on the split kernel, scripts/lab/conv3x3_ab.py at 32 x 720p:
+        #   two-limb f16 split: beats Winograd on the f32 MFMA on every layer -- 64 / 128 / 256 / 512 channels 0.77 / 0.49 / 0.46 /
+        #   0.49 ms against 0.82 / 0.71 / 0.65 / 0.88, the FPN output convolution (256 channels, 184 x 320) 6.7 against 9.0 --
+        #   27 limb-product MFMA flops per multiply-add at the 16-bit rate against Winograd's 4 at 1/16 of it;
+        #   three-limb bf16 split: on the 512-channel layers only (0.77 vs 0.86 ms; 64 / 128 / 256 channels 0.93 / 0.70 / 0.66)
         pack, run = ops.conv3x3_bf16x3_pack, ops.conv3x3_bf16x3
     elif conv.stride == (1, 1) and ops.conv3x3_winograd_supported(w.shape[0], w.shape[1], x.shape[2], x.shape[3]):
         pack, run = ops.conv3x3_winograd_pack, ops.conv3x3_winograd

@@ -1152,7 +1152,8 @@ static int conv3x3_split_run(const float* x, const void* w_packed, const float* 
                              int Cin, int Cout, int H, int W, int stride, int relu, bool f16, uint32_t* overflow, void* stream) {
   using namespace pvsg;
   const char* nm = f16 ? "conv3x3_f16x2" : "conv3x3_bf16x3";
-  PVSG_REQUIRE(x && w_packed && scale && shift && y, "%s: null pointer argument", nm);
+  PVSG_REQUIRE(x && w_packed && y, "%s: null pointer argument", nm);
+  PVSG_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift go together (both NULL = no affine)", nm);
   PVSG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "%s: bad shape", nm);
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const int Cpad = (Cout + 127) / 128 * 128;

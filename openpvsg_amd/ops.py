@@ -667,7 +667,7 @@ def conv3x3_bf16x3_pack(weight):
     return gemm_bf16x3_pack(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous())
 
 
-def conv3x3_bf16x3(x, w_packed, cout, scale, shift, relu=True, out=None, stride=1):
+def conv3x3_bf16x3(x, w_packed, cout, scale=None, shift=None, relu=True, out=None, stride=1):
     """act(conv3x3(x, w, stride 1 or 2, pad 1) * scale[c] + shift[c]) on the split-bf16 kernel (implicit GEMM over the nine
     taps, csrc/gemm_bf16x3.hip); w_packed = conv3x3_bf16x3_pack(w)."""
     x = _chk(x, 'x')
@@ -680,8 +680,11 @@ def conv3x3_bf16x3(x, w_packed, cout, scale, shift, relu=True, out=None, stride=
         out = torch.empty((N, cout, Ho, Wo), device=x.device, dtype=torch.float32)
     elif not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (N, cout, Ho, Wo)):
         raise RuntimeError('conv3x3_bf16x3: out must be a contiguous float32 HIP tensor (N,Cout,Ho,Wo)')
+    if (scale is None) != (shift is None):
+        raise RuntimeError('conv3x3_bf16x3: scale and shift go together')
     with _on(x.device):
-        args = (x.data_ptr(), w_packed.data_ptr(), _chk(scale, 'scale').data_ptr(), _chk(shift, 'shift').data_ptr(),
+        args = (x.data_ptr(), w_packed.data_ptr(), _chk(scale, 'scale').data_ptr() if scale is not None else None,
+                _chk(shift, 'shift').data_ptr() if shift is not None else None,
                 out.data_ptr(), N, Cin, cout, H, W, stride, int(bool(relu)))
         if f16:
             _lib.call('pvsg_conv3x3_f16x2', *args, _overflow_counter(x.device).data_ptr(), _stream_ptr())

@@ -157,7 +157,9 @@ def test_conv3x3_fast_dispatch_follows_weight_updates(hip_lib):
             b = conv3x3_fast(conv, x, sc, sh, relu=False)
             assert torch.allclose(b, conv(x), atol=4e-5) and not torch.allclose(a, b, atol=1e-3)
         assert conv3x3_fast(nn.Conv2d(128, 128, 3, padding=1, bias=True).cuda(), x) is None      # bias: library path
-        assert conv3x3_fast(nn.Conv2d(128, 128, 3, stride=2, padding=1, bias=False).cuda(), x) is None   # stride 2 w/o affine
+        for stride in (1, 2):                                       # no affine (the FPN output convolution): the split kernel
+            conv = nn.Conv2d(128, 128, 3, stride=stride, padding=1, bias=False).cuda()
+            assert torch.allclose(conv3x3_fast(conv, x), conv(x), atol=2e-5)
 
 
 # ---- ResNet stem in one launch (csrc/stem7x7.hip): conv 7x7/2 -> BN -> ReLU -> max-pool 3x3/2 -------------------------
