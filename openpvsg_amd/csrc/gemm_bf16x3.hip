@@ -447,6 +447,391 @@ void gemm_bf16x3_k32_kernel(const float* __restrict__ A, const __bf16* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The f16x2 GEMM with the packed operand staged by LDS-DMA.  In the kernel above hipcc sinks the weight loads of a step down
+// to their LDS writes (the register budget of three workgroups per CU leaves it no room to keep them in flight): every step then
+// waits `vmcnt(0)` for an L2 round trip with nothing else to do (scripts/lab/abl_split.sh: "no W loads" -20 %).  Here the
+// weight tile of step kt+1 travels global -> LDS (global_load_lds_dwordx4, one 1 KB slab per wave instruction, no registers, no
+// ds_write) into the second of two weight buffers while step kt computes; A's loads run two steps ahead in registers as before.
+//   LDS: A [2 limbs][4 k-groups][130 rows][8] (16.3 KB) + W [2 buffers][2 arrays][4 k-groups][128 columns][8] (32 KB)
+//   per step: wait (everything issued a step ago) -> barrier -> split A(kt+1) -> DMA W(kt+1), load A(kt+2) -> fragments +
+//             48 MFMAs -> barrier -> write A(kt+1)
+// Past the last step the same addresses are fetched again (nothing reads them).
+#if defined(PVSG_ABL) && PVSG_ABL == 7
+// lab build (scripts/lab/abl_split.sh 7): where a wave's time goes.  Sums over wave 0 of every workgroup, in s_memtime ticks:
+// [0] prologue [1] wait + barrier at the top of a step [2] split / issue / (stage writes) [3] fragments + MFMAs [4] second barrier
+// + A writes (128 x 128 kernel) [5] epilogue [6] workgroups [7] steps
+__device__ unsigned long long g_split_phase[8];
+#define PVSG_TICK(v) const unsigned long long v = __builtin_readcyclecounter()
+#define PVSG_PHASE(i, d) do { if (tid == 0) atomicAdd(&g_split_phase[i], (unsigned long long)(d)); } while (0)
+#else
+#define PVSG_TICK(v) do {} while (0)
+#define PVSG_PHASE(i, d) do {} while (0)
+#endif
+template <bool RELU>
+__global__ __launch_bounds__(256, 3)
+void gemm_f16x2_dma_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
+                           float* __restrict__ out, int M, int N, int K, int Npad, int tiles_n, unsigned* __restrict__ overflow,
+                           int stagger_ticks, int ncu) {
+  // first-round workgroups of a CU start a third / two thirds of a tile period apart (100 MHz ticks): all tiles take the same
+  // time, so without it the three workgroups of a CU stay in phase -- all in their loops, then all in their store epilogues
+  if (stagger_ticks > 0 && blockIdx.x < 3u * (unsigned)ncu) {
+    const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)(blockIdx.x / (unsigned)ncu) * (unsigned)stagger_ticks;
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+  }
+  constexpr int A_KG = (GB_M + 2) * 8, A_LIMB = 4 * A_KG;        // (see gemm_bf16x3_k32_kernel: conflict-free staging writes)
+  constexpr int W_AT = 2 * A_LIMB, W_BUF = 2 * K32_LIMB;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[W_AT + 2 * W_BUF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  PVSG_TICK(tk0);
+  const unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tn = logical % tiles_n, tm = logical / tiles_n;
+  const int m0 = tm * GB_M, n0 = tn * GB_N;
+  const int ar = tid >> 2, akg = tid & 3;
+  unsigned a_voff[2];
+#pragma unroll
+  for (int p2 = 0; p2 < 2; ++p2)                                 // rows beyond M read as 0
+    a_voff[p2] = m0 + ar + 64 * p2 < M ? (unsigned)(((ar + 64 * p2) * K + 8 * akg) * 4) : 0x80000000u;
+  const auto asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A) + (size_t)m0 * K * 4), 0,
+                                                      (unsigned)((size_t)GB_M * K * 4), 0x00020000);
+  f32x4 a_regs[4];
+  auto loadA = [&](int kt) {
+    const unsigned so = (unsigned)kt * (32 * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)                                  // a_regs[2 p + h]: floats 4 h .. 4 h + 3 of row ar + 64 p
+      a_regs[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc, a_voff[q >> 1] + 16 * (q & 1), so, 0));
+  };
+  // weight slabs of a 32-deep step: (array l, k-group kg of 4, column half) = 16 x 1 KB; wave w brings slabs 4 w .. 4 w + 3.
+  // packed layout [k-tile of 16][array 2][k-group 2][Npad][8]: k-group kg of the step = k-tile 2 kt + (kg >> 1), group kg & 1
+  const size_t w_kg_stride = (size_t)Npad * 8;
+  auto dmaW = [&](int kt, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int sl = wave * 4 + i, l = sl >> 3, kg = (sl >> 1) & 3, half = sl & 1;
+      const __bf16* src = Wp + ((((size_t)(2 * kt + (kg >> 1)) * 2 + l) * 2 + (kg & 1)) * w_kg_stride) + (size_t)(n0 + half * 64 + lane) * 8;
+      __bf16* dst = lds + W_AT + buf * W_BUF + l * K32_LIMB + (kg * GB_N + half * 64) * 8;
+      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  u32x4 limbs[2][2];                                            // [row ar + 64 gq][limb]
+  float amax = 0.f;
+  auto split = [&]() {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      unsigned hh[4], mm[4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 v = a_regs[2 * gq + q];
+        split2h(v[0], v[1], hh[2 * q], mm[2 * q], amax);
+        split2h(v[2], v[3], hh[2 * q + 1], mm[2 * q + 1], amax);
+      }
+      limbs[gq][0] = u32x4{hh[0], hh[1], hh[2], hh[3]};
+      limbs[gq][1] = u32x4{mm[0], mm[1], mm[2], mm[3]};
+    }
+    // pin the running maximum here: left to itself the optimiser sinks the max chain below the next loads, the old A registers
+    // stay alive, the new loads land in other registers and a copy (with a `vmcnt(0)`) appears at the end of every step
+    asm volatile("" : "+v"(amax));
+  };
+  auto writeA = [&]() {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      __bf16* pa = lds + akg * A_KG + (ar + 64 * gq) * 8;
+#pragma unroll
+      for (int l = 0; l < 2; ++l) *reinterpret_cast<u32x4*>(pa + l * A_LIMB) = limbs[gq][l];
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int l15 = lane & 15, kg4 = lane >> 4;
+  const __bf16* afr = lds + kg4 * A_KG + (wr * 64 + l15) * 8;                  // + limb * A_LIMB + row block * 128
+  const __bf16* wfr0 = lds + W_AT + (kg4 * GB_N + wc * 64 + l15) * 8;          // + buffer * W_BUF + array * K32_LIMB + column block * 128
+  auto frag = [](const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); };
+  auto mf = [](u32x4 a, u32x4 b, f32x4 c) { return mfma_k32<true>(a, b, c); };
+  const int KT = K / 32;
+  dmaW(0, 0);
+  loadA(0);
+  split();
+  writeA();
+  loadA(KT > 1 ? 1 : 0);
+  PVSG_TICK(tk1);
+  PVSG_PHASE(0, tk1 - tk0);
+  for (int kt = 0; kt < KT; ++kt) {
+    PVSG_TICK(ts0);
+    // this wave's slabs of step kt, its A rows of step kt (LDS) and of step kt+1 (registers) have arrived -- all were issued a
+    // whole step ago.  (Consuming the A registers while newer DMA is in flight would need `vmcnt(4)`; hipcc's own count across
+    // the loop's back edge is `vmcnt(0)`, which would wait for the slabs just issued: so the split comes first.)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                 // ... everybody's have; buffer (kt+1)&1 is no longer read
+    PVSG_TICK(ts1);
+    split();                                                     // A of step kt+1
+    __builtin_amdgcn_sched_barrier(0);
+    dmaW(kt + 1 < KT ? kt + 1 : KT - 1, (kt + 1) & 1);
+    loadA(kt + 2 < KT ? kt + 2 : KT - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    PVSG_TICK(ts2);
+    const __bf16* wfr = wfr0 + (kt & 1) * W_BUF;
+    u32x4 ahf[4], alf[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      ahf[rb] = frag(afr + rb * 128);
+      alf[rb] = frag(afr + A_LIMB + rb * 128);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {                             // small terms first: (l', 2^-11 h) (h, l) (h, h)
+      const u32x4 wh = frag(wfr + cb * 128), wl = frag(wfr + K32_LIMB + cb * 128), wh2 = f16x2_lo_scale(wh);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wh2, alf[rb], acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wl, ahf[rb], acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wh, ahf[rb], acc[rb][cb]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PVSG_TICK(ts3);
+    __builtin_amdgcn_s_barrier();                                // everyone is done reading A of step kt
+    writeA();
+    PVSG_TICK(ts4);
+    PVSG_PHASE(1, ts1 - ts0); PVSG_PHASE(2, ts2 - ts1); PVSG_PHASE(3, ts3 - ts2); PVSG_PHASE(4, ts4 - ts3); PVSG_PHASE(7, 1);
+  }
+  PVSG_TICK(tk2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the repeated last slabs / rows: nothing may land after the end)
+  {
+    const float unscale = f16x2_unscale(Wp, Npad, K);
+    const int rows = M - m0 < GB_M ? M - m0 : GB_M;
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)m0 * N, 0, (unsigned)((size_t)rows * N * 4), 0x00020000);
+    const auto brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, bias ? (unsigned)N * 4u : 0u, 0x00020000);
+    const unsigned rowpitch = (unsigned)N * 4u;
+    const bool vec4 = (N & 3) == 0;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int col = n0 + wc * 64 + cb * 16 + 4 * kg4;
+      f32x4 bv;                                                  // columns >= N read 0 through the descriptor
+      if (vec4) bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, (unsigned)col * 4u, 0, 0));
+      else
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, (unsigned)(col + r) * 4u, 0, 0));
+      const unsigned vbase = (unsigned)(wr * 64 + l15) * rowpitch + (unsigned)col * 4u;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] = __builtin_fmaf(acc[rb][cb][r], unscale, bv[r]);
+          if (RELU) o[r] = fmaxf(o[r], 0.f);
+        }
+        const unsigned vo = vbase + (unsigned)(rb * 16) * rowpitch;
+        if (vec4)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, col < N ? vo : 0x80000000u, 0, 0);
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float oe = o[r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, oe), orsrc, col + r < N ? vo + 4u * r : 0x80000000u, 0, 0);
+          }
+      }
+    }
+  }
+  f16x2_count_overflow(amax, overflow);
+#if defined(PVSG_ABL) && PVSG_ABL == 7
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PVSG_TICK(tk3);
+  PVSG_PHASE(5, tk3 - tk2); PVSG_PHASE(6, 1);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The f16x2 GEMM on 256 x 256 tiles.  With half the matrix work of the bf16 form the 128 x 128 kernels above stop being
+// matrix-bound: what they move from L2 into the CUs -- M N K (4 / TN + 4 / TM) bytes, 10 GB for the encoder's first FFN layer,
+// every operand element re-read once per tile of the other operand -- sets their time at ~10 TB/s whatever the kernel does
+// inside (scripts/lab/abl_split.sh: time falls with every load removed, not with the MFMAs; profiles/r04_split_lab.txt).
+// A 256 x 256 tile halves that traffic.  One workgroup of 8 waves per CU (wave tile 64 rows x 128 columns: 128 accumulator
+// registers, A's fragments resident across the eight column blocks -- 24 LDS fragment reads per 96 MFMAs where two 64 x 64
+// waves need 32), two LDS stages of 64 KB and ONE barrier per 32-deep step:
+//   top of step kt: everything issued a step ago has arrived (own slabs of W(kt), own rows of A(kt+1) in registers, own LDS
+//   writes of A(kt)) -> barrier -> split A(kt+1) and write it to the other stage, DMA W(kt+1) into it, load A(kt+2) ->
+//   fragments + 96 MFMAs of stage kt.
+//   LDS stage: A [2 limbs][4 k-groups][258 rows][8] (33 KB; 258: conflict-free staging writes) + W [2 arrays][4][256 columns][8]
+template <bool RELU>
+__global__ __launch_bounds__(512)
+void gemm_f16x2_t256_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
+                            float* __restrict__ out, int M, int N, int K, int Npad, int tiles_n, unsigned* __restrict__ overflow) {
+  constexpr int TM = 256, TN = 256;
+  constexpr int A_KG = (TM + 2) * 8, A_LIMB = 4 * A_KG, A_STAGE = 2 * A_LIMB;
+  constexpr int W_LIMB = 4 * TN * 8, STAGE = A_STAGE + 2 * W_LIMB;
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds256[];
+  __bf16* lds = lds256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  PVSG_TICK(tk0);
+  const unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tn = logical % tiles_n, tm = logical / tiles_n;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int ar = tid >> 2, akg = tid & 3;                        // rows ar and ar + 128, k-group akg
+  unsigned a_voff[2];
+#pragma unroll
+  for (int p2 = 0; p2 < 2; ++p2)                                 // rows beyond M read as 0
+    a_voff[p2] = m0 + ar + 128 * p2 < M ? (unsigned)(((ar + 128 * p2) * K + 8 * akg) * 4) : 0x80000000u;
+  const auto asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A) + (size_t)m0 * K * 4), 0,
+                                                      (unsigned)((size_t)TM * K * 4), 0x00020000);
+  f32x4 a_regs[4];
+  auto loadA = [&](int kt) {
+    const unsigned so = (unsigned)kt * (32 * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      a_regs[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc, a_voff[q >> 1] + 16 * (q & 1), so, 0));
+  };
+  // weight slabs of a step: (array l, k-group kg of 4, column quarter) = 32 x 1 KB; wave w brings slabs 4 w .. 4 w + 3.  A
+  // quarter beyond the packed columns (Npad is a multiple of 128, not of 256) fetches other columns: its outputs are never stored.
+  const size_t w_kg_stride = (size_t)Npad * 8;
+  auto dmaW = [&](int kt, int st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int sl = wave * 4 + i, l = sl >> 4, kg = (sl >> 2) & 3, qt = sl & 3;
+      const int c0 = n0 + qt * 64 < Npad ? n0 + qt * 64 : Npad - 64;         // (branch-free: such a quarter re-reads valid columns)
+      const __bf16* src = Wp + ((((size_t)(2 * kt + (kg >> 1)) * 2 + l) * 2 + (kg & 1)) * w_kg_stride) + (size_t)(c0 + lane) * 8;
+      __bf16* dst = lds + st * STAGE + A_STAGE + l * W_LIMB + (kg * TN + qt * 64) * 8;
+      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  u32x4 limbs[2][2];                                            // [row ar + 128 gq][limb]
+  float amax = 0.f;
+  auto split = [&]() {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      unsigned hh[4], mm[4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 v = a_regs[2 * gq + q];
+        split2h(v[0], v[1], hh[2 * q], mm[2 * q], amax);
+        split2h(v[2], v[3], hh[2 * q + 1], mm[2 * q + 1], amax);
+      }
+      limbs[gq][0] = u32x4{hh[0], hh[1], hh[2], hh[3]};
+      limbs[gq][1] = u32x4{mm[0], mm[1], mm[2], mm[3]};
+    }
+    asm volatile("" : "+v"(amax));                                // (see gemm_f16x2_dma_kernel: keeps the A registers reusable)
+  };
+  auto writeA = [&](int st) {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      __bf16* pa = lds + st * STAGE + akg * A_KG + (ar + 128 * gq) * 8;
+#pragma unroll
+      for (int l = 0; l < 2; ++l) *reinterpret_cast<u32x4*>(pa + l * A_LIMB) = limbs[gq][l];
+    }
+  };
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i >> 3][i & 7] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int l15 = lane & 15, kg4 = lane >> 4;
+  const __bf16* afr0 = lds + kg4 * A_KG + (wr * 64 + l15) * 8;                 // + stage + limb * A_LIMB + row block * 128
+  const __bf16* wfr0 = lds + A_STAGE + (kg4 * TN + wc * 128 + l15) * 8;        // + stage + array * W_LIMB + column block * 128
+  auto frag = [](const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); };
+  auto mf = [](u32x4 a, u32x4 b, f32x4 c) { return mfma_k32<true>(a, b, c); };
+  const int KT = K / 32;
+  dmaW(0, 0);
+  loadA(0);
+  split();
+  writeA(0);
+  loadA(KT > 1 ? 1 : 0);
+  PVSG_TICK(tk1);
+  PVSG_PHASE(0, tk1 - tk0);
+  for (int kt = 0; kt < KT; ++kt) {
+    PVSG_TICK(ts0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // stage kt & 1 is complete; nobody reads the other stage any more
+    PVSG_TICK(ts1);
+    const int cur = kt & 1;
+    split();                                      // A of step kt+1 (a repeat of the last step past the end: never read)
+    __builtin_amdgcn_sched_barrier(0);
+    dmaW(kt + 1 < KT ? kt + 1 : KT - 1, cur ^ 1);
+    loadA(kt + 2 < KT ? kt + 2 : KT - 1);
+    writeA(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    PVSG_TICK(ts2);
+    const __bf16* afr = afr0 + cur * STAGE;
+    const __bf16* wfr = wfr0 + cur * STAGE;
+    u32x4 ahf[4], alf[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      ahf[rb] = frag(afr + rb * 128);
+      alf[rb] = frag(afr + A_LIMB + rb * 128);
+    }
+    // the weight fragments of column block cb+1 are requested before the 12 MFMAs of block cb are issued (left to itself the
+    // scheduler reads each pair just in time and waits lgkmcnt(0) in front of every four MFMAs)
+    u32x4 wh = frag(wfr), wl = frag(wfr + W_LIMB);
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {                             // small terms first: (l', 2^-11 h) (h, l) (h, h)
+      u32x4 whn = wh, wln = wl;
+      if (cb < 7) {
+        whn = frag(wfr + (cb + 1) * 128);
+        wln = frag(wfr + W_LIMB + (cb + 1) * 128);
+      }
+      const u32x4 wh2 = f16x2_lo_scale(wh);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wh2, alf[rb], acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wl, ahf[rb], acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wh, ahf[rb], acc[rb][cb]);
+      __builtin_amdgcn_sched_barrier(0);
+      wh = whn;
+      wl = wln;
+    }
+#if defined(PVSG_ABL) && PVSG_ABL == 7
+    asm volatile("" ::"v"(acc[3][7]));
+    PVSG_TICK(ts3);
+    PVSG_PHASE(1, ts1 - ts0); PVSG_PHASE(2, ts2 - ts1); PVSG_PHASE(3, ts3 - ts2); PVSG_PHASE(7, 1);
+#endif
+  }
+  PVSG_TICK(tk2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the repeated last slabs / rows: nothing may land after the end)
+  // register r of block (rb, cb) = row rb*16 + (lane&15), column cb*16 + 4*(lane>>4) + r of the wave's 64 x 128 tile
+  {
+    const float unscale = f16x2_unscale(Wp, Npad, K);
+    const int rows = M - m0 < TM ? M - m0 : TM;
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)m0 * N, 0, (unsigned)((size_t)rows * N * 4), 0x00020000);
+    const auto brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, bias ? (unsigned)N * 4u : 0u, 0x00020000);
+    const unsigned rowpitch = (unsigned)N * 4u;
+    const bool vec4 = (N & 3) == 0;
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      const int col = n0 + wc * 128 + cb * 16 + 4 * kg4;
+      f32x4 bv;                                                  // columns >= N read 0 through the descriptor
+      if (vec4) bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, (unsigned)col * 4u, 0, 0));
+      else
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, (unsigned)(col + r) * 4u, 0, 0));
+      const unsigned vbase = (unsigned)(wr * 64 + l15) * rowpitch + (unsigned)col * 4u;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] = __builtin_fmaf(acc[rb][cb][r], unscale, bv[r]);
+          if (RELU) o[r] = fmaxf(o[r], 0.f);
+        }
+        const unsigned vo = vbase + (unsigned)(rb * 16) * rowpitch;
+        if (vec4)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, col < N ? vo : 0x80000000u, 0, 0);
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float oe = o[r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, oe), orsrc, col + r < N ? vo + 4u * r : 0x80000000u, 0, 0);
+          }
+      }
+    }
+  }
+  f16x2_count_overflow(amax, overflow);
+#if defined(PVSG_ABL) && PVSG_ABL == 7
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PVSG_TICK(tk3);
+  PVSG_PHASE(5, tk3 - tk2); PVSG_PHASE(6, 1);
+#endif
+}
+constexpr int T256_LDS_BYTES = 2 * (2 * 4 * (256 + 2) * 8 + 2 * 4 * 256 * 8) * 2;
+
+// ------------------------------------------------------------------------------------------------------------------
 // 1x1 convolution in NCHW on the same arithmetic:  y[b, co, p] = act( (sum_ci w[co, ci] x[b, ci, pin(p)]) * scale[co]
 // + shift[co] (+ residual[b, co, p]) ), pin(p) = p (stride 1) or the stride-2 sub-sampled pixel.  Per image a GEMM with
 // rows = output channels (the packed weight, same pack as above), columns = pixels, K = input channels.  The pixel
@@ -977,6 +1362,14 @@ __global__ void gemm_f16x2_pack_kernel(const float* __restrict__ w, __bf16* __re
 }  // namespace
 }  // namespace pvsg
 
+#if defined(PVSG_ABL) && PVSG_ABL == 7
+extern "C" int pvsg_lab_split_phase(unsigned long long* host8, int reset) {      // lab builds only (scripts/lab/abl_split.sh 7)
+  if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(pvsg::g_split_phase), 64) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pvsg::g_split_phase), z, 64) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
+
 extern "C" long long pvsg_gemm_f16x2_packed_elems(int N, int K) {
   const long long npad = (N + 127) / 128 * 128;
   return 2LL * npad * K + 8;                              // 16-bit elements; the last 8 hold (max|w|, 2^-e, 0, 0) as floats
@@ -1042,7 +1435,40 @@ static int gemm_split_run(const float* a, const void* w_packed, const float* bia
   const __bf16* wp = static_cast<const __bf16*>(w_packed);
   const char* sel = getenv("PVSG_GEMM_K32");                    // =0: the 32x32x16 / K = 16 kernel for every shape (A/B tests)
   const bool k32 = K % 32 == 0 && !(sel && sel[0] == '0');
-  if (f16 && relu)
+  const char* dsel = getenv("PVSG_F16X2_DMA");                  // =0: the register-staged form (A/B tests)
+  const bool dma = !(dsel && dsel[0] == '0');
+  if (f16) {
+    // 256 x 256 tiles (half the L2 -> CU traffic) once they fill the chip: >= two workgroups per CU; PVSG_F16X2_TILE=128 / 256
+    // forces either form (A/B tests)
+    const char* tsel = getenv("PVSG_F16X2_TILE");
+    const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);
+    int ncu = 256;
+    { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; }
+    const bool big = tsel ? atoi(tsel) == 256 : t256 >= 2LL * ncu;
+    if (big && (long long)256 * N * 4 < (1LL << 31) && (long long)256 * K * 4 < (1LL << 31)) {
+      static std::atomic<unsigned long long> done_r{0}, done_n{0};
+      const int tn256 = (N + 255) / 256;
+      const dim3 g256((unsigned)(((M + 255) / 256) * tn256)), b512(512);
+      hipError_t e = relu ? ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f16x2_t256_kernel<true>), T256_LDS_BYTES, done_r)
+                          : ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f16x2_t256_kernel<false>), T256_LDS_BYTES, done_n);
+      if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "%s: dynamic LDS: %s", nm, hipGetErrorString(e));
+      if (relu)
+        hipLaunchKernelGGL((gemm_f16x2_t256_kernel<true>), g256, b512, T256_LDS_BYTES, st, a, wp, bias, out, (int)M, N, K, Npad, tn256, overflow);
+      else
+        hipLaunchKernelGGL((gemm_f16x2_t256_kernel<false>), g256, b512, T256_LDS_BYTES, st, a, wp, bias, out, (int)M, N, K, Npad, tn256, overflow);
+      PVSG_LAUNCH_CHECK(nm);
+      return PVSG_OK;
+    }
+  }
+  const char* ssel = getenv("PVSG_F16X2_STAGGER");              // 100 MHz ticks between the first-round workgroups of a CU (lab)
+  const int stag = ssel ? atoi(ssel) : 0;
+  int ncu_ = 256;
+  { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu_ = pr.multiProcessorCount; }
+  if (f16 && dma && relu)
+    hipLaunchKernelGGL((gemm_f16x2_dma_kernel<true>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n, overflow, stag, ncu_);
+  else if (f16 && dma)
+    hipLaunchKernelGGL((gemm_f16x2_dma_kernel<false>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n, overflow, stag, ncu_);
+  else if (f16 && relu)
     hipLaunchKernelGGL((gemm_bf16x3_k32_kernel<true, true>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n, overflow);
   else if (f16)
     hipLaunchKernelGGL((gemm_bf16x3_k32_kernel<false, true>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n, overflow);
