@@ -470,14 +470,7 @@ __device__ unsigned long long g_split_phase[8];
 template <bool RELU>
 __global__ __launch_bounds__(256, 3)
 void gemm_f16x2_dma_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
-                           float* __restrict__ out, int M, int N, int K, int Npad, int tiles_n, unsigned* __restrict__ overflow,
-                           int stagger_ticks, int ncu) {
-  // first-round workgroups of a CU start a third / two thirds of a tile period apart (100 MHz ticks): all tiles take the same
-  // time, so without it the three workgroups of a CU stay in phase -- all in their loops, then all in their store epilogues
-  if (stagger_ticks > 0 && blockIdx.x < 3u * (unsigned)ncu) {
-    const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)(blockIdx.x / (unsigned)ncu) * (unsigned)stagger_ticks;
-    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-  }
+                           float* __restrict__ out, int M, int N, int K, int Npad, int tiles_n, unsigned* __restrict__ overflow) {
   constexpr int A_KG = (GB_M + 2) * 8, A_LIMB = 4 * A_KG;        // (see gemm_bf16x3_k32_kernel: conflict-free staging writes)
   constexpr int W_AT = 2 * A_LIMB, W_BUF = 2 * K32_LIMB;
   __shared__ __attribute__((aligned(16))) __bf16 lds[W_AT + 2 * W_BUF];
@@ -1438,13 +1431,11 @@ static int gemm_split_run(const float* a, const void* w_packed, const float* bia
   const char* dsel = getenv("PVSG_F16X2_DMA");                  // =0: the register-staged form (A/B tests)
   const bool dma = !(dsel && dsel[0] == '0');
   if (f16) {
-    // 256 x 256 tiles (half the L2 -> CU traffic) once they fill the chip: >= two workgroups per CU; PVSG_F16X2_TILE=128 / 256
-    // forces either form (A/B tests)
+    // PVSG_F16X2_TILE=256: the 256 x 256-tile kernel (half the L2 -> CU traffic).  Opt-in: in a loop of one layer it is 6-10 %
+    // faster (1.28 vs 1.42 ms on the encoder's first FFN layer, both at the 1400 W socket limit), inside the step it ties
+    // (23.4 vs 23.2 ms over the 48 launches), so the default stays on the 128 x 128 kernels.
     const char* tsel = getenv("PVSG_F16X2_TILE");
-    const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);
-    int ncu = 256;
-    { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; }
-    const bool big = tsel ? atoi(tsel) == 256 : t256 >= 2LL * ncu;
+    const bool big = tsel && atoi(tsel) == 256;
     if (big && (long long)256 * N * 4 < (1LL << 31) && (long long)256 * K * 4 < (1LL << 31)) {
       static std::atomic<unsigned long long> done_r{0}, done_n{0};
       const int tn256 = (N + 255) / 256;
@@ -1460,14 +1451,10 @@ static int gemm_split_run(const float* a, const void* w_packed, const float* bia
       return PVSG_OK;
     }
   }
-  const char* ssel = getenv("PVSG_F16X2_STAGGER");              // 100 MHz ticks between the first-round workgroups of a CU (lab)
-  const int stag = ssel ? atoi(ssel) : 0;
-  int ncu_ = 256;
-  { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu_ = pr.multiProcessorCount; }
   if (f16 && dma && relu)
-    hipLaunchKernelGGL((gemm_f16x2_dma_kernel<true>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n, overflow, stag, ncu_);
+    hipLaunchKernelGGL((gemm_f16x2_dma_kernel<true>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n, overflow);
   else if (f16 && dma)
-    hipLaunchKernelGGL((gemm_f16x2_dma_kernel<false>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n, overflow, stag, ncu_);
+    hipLaunchKernelGGL((gemm_f16x2_dma_kernel<false>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n, overflow);
   else if (f16 && relu)
     hipLaunchKernelGGL((gemm_bf16x3_k32_kernel<true, true>), grid, block, 0, st, a, wp, bias, out, (int)M, N, K, Npad, tiles_n, overflow);
   else if (f16)
