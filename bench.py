@@ -334,7 +334,7 @@ class KernelTimer:
         return agg
 
 
-def cpu_baseline_and_parity(det_gpu, rel_gpu, pipe, args, dev, frames, reps, check=True):
+def cpu_baseline_and_parity(det_gpu, rel_gpu, pipe, args, dev, frames, reps, check=True, warmup=True):
     """Oracle (CPU restatement of the reference algorithm, oracle/) on a bounded sample: a `frames`-frame 720p clip
     through the same clip-level flow + relation head, 1 warm-up + `reps` timed repetitions; also compares the
     product's panoptic maps / pair matrix with the oracle's on that sample."""
@@ -386,7 +386,8 @@ def cpu_baseline_and_parity(det_gpu, rel_gpu, pipe, args, dev, frames, reps, che
                 rel_out = orel.evaluate_video(orl['se'], orl['oe'], orl['pp'], orl['rm'], feats, [], 100)
         return res, order, rel_out
 
-    run()                                                                # warm-up
+    if warmup:
+        run()                                                            # warm-up
     times = []
     for _ in range(max(1, reps)):
         t0 = time.perf_counter()

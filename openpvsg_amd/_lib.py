@@ -133,9 +133,60 @@ def load():
     return lib
 
 
+# ---- one stream at a time ------------------------------------------------------------------------------------------------
+# Waves of the 16-bit-MFMA kernels (split GEMM / convolution / attention) that share a CU with waves of ANOTHER kernel were
+# observed to corrupt that kernel's registers (scripts/coresidency_repro.hip) -- from another process
+# (parallel.warn_if_gpu_shared / isolate_shared_gpu) and just as well from a second stream of this process.  Inside one stream
+# kernels run back to back and nothing co-resides.  So launches of this backend may move from one stream to another (graph
+# capture warm-ups do), but never run on two at once: a launch on stream S while the stream that carried the previous launches
+# still has work pending is an error when either side is a 16-bit-MFMA kernel.  PVSG_MULTI_STREAM=allow switches the check off
+# (measurements of the effect itself).
+_MFMA16 = ('bf16x3', 'f16x2', 'masked_xattn')
+_MFMA16_NAMES = frozenset(n for n in SIGNATURES if any(k in n for k in _MFMA16))
+_cur = [None, False]        # [stream handle of the previous launch, has that stream run a 16-bit-MFMA kernel since it took over]
+_hip = None
+
+
+def _stream_busy(handle):
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL('libamdhip64.so')          # already mapped by torch: same runtime instance
+        _hip.hipStreamQuery.argtypes = [ctypes.c_void_p]
+        _hip.hipStreamQuery.restype = ctypes.c_int
+    return _hip.hipStreamQuery(ctypes.c_void_p(handle)) != 0        # hipErrorNotReady (or an error: treat as busy)
+
+
+class ConcurrentStreamError(RuntimeError):
+    pass
+
+
+def _stream_changed(name, stream):
+    """slow path of `call`: the launch goes to another stream than the previous one"""
+    if torch.cuda.is_current_stream_capturing():       # captured launches do not execute; the replay runs on ONE stream
+        return
+    mfma16 = name in _MFMA16_NAMES
+    prev = _cur[0]
+    if prev is not None and (mfma16 or _cur[1]) and _stream_busy(prev):
+        raise ConcurrentStreamError(
+            '%s launched on HIP stream %#x while stream %#x still runs kernels of this backend: 16-bit-MFMA kernels must not '
+            'share the GPU with other kernels (co-residency corruption, DESIGN.md section 3.13).  Keep the backend on one '
+            'stream, or order the streams (wait_stream + synchronize) before switching; PVSG_MULTI_STREAM=allow disables this '
+            'check.' % (name, stream, prev))
+    _cur[0], _cur[1] = stream, mfma16
+
+
+_CHECK_STREAMS = os.environ.get('PVSG_MULTI_STREAM', 'deny') != 'allow'
+
+
 def call(name, *args):
     """Invoke a C-ABI entry point; non-zero status -> RuntimeError with the library's message."""
     lib = load()
+    if _CHECK_STREAMS:
+        stream = args[-1] or 0
+        if stream != _cur[0]:
+            _stream_changed(name, stream)
+        elif not _cur[1] and name in _MFMA16_NAMES:
+            _cur[1] = True
     rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.pvsg_last_error()

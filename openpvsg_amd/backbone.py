@@ -194,6 +194,7 @@ class ResNet(BaseModule):
                 if getattr(self, '_side', None) is None or len(self._side) != n or self._side[0].device != x.device:
                     self._side = [torch.cuda.Stream(device=x.device) for _ in range(n)]
                 bounds = [x.shape[0] * i // n for i in range(n + 1)]
+                cur.synchronize()        # the backend's one-stream rule (_lib.call) sees streams, not events: hand over idle
                 for s, lo, hi in zip(self._side, bounds[:-1], bounds[1:]):
                     s.wait_stream(cur)
                     with torch.cuda.stream(s):
@@ -201,6 +202,7 @@ class ResNet(BaseModule):
                         self._forward_fused(x[lo:hi], aff, [f[lo:hi] for f in full], gemm=False)
                 for s in self._side:
                     cur.wait_stream(s)
+                    s.synchronize()      # (same rule: the 16-bit-MFMA kernels that follow on `cur` must find the side streams idle)
             return tuple(full[i] for i in range(4) if i in self.out_indices)
         x = F.max_pool2d(F.relu(self.bn1(self.conv1(x)), inplace=True), 3, stride=2, padding=1)
         outs = []

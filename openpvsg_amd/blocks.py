@@ -19,6 +19,7 @@ internally.  Nothing here runs on CPU tensors (ops.py raises).
 import copy
 import math
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -53,18 +54,34 @@ class ModuleList(BaseModule, nn.ModuleList):
 # ------------------------------------------------------------------------------------------------
 # positional encodings (cached per shape: the padding mask is all-False on this path)
 # ------------------------------------------------------------------------------------------------
+_GRAPH_CACHES = weakref.WeakSet()
+
+
 class _ShapeCache(dict):
     """Shape-keyed cache with a bound: inputs of varying size (keep_ratio resizing) must not grow it forever;
-    the oldest entry goes first."""
+    the oldest entry goes first.  Every instance is known to `pin_graph_caches`: a captured hipGraph references the cached
+    tensors BY ADDRESS, so it keeps them alive itself -- an eviction here must not free what a graph will read on replay."""
 
     def __init__(self, limit=16):
         super().__init__()
         self.limit = limit
+        _GRAPH_CACHES.add(self)
+
+    __hash__ = object.__hash__           # (dict is unhashable; the WeakSet keys by identity)
+    __eq__ = object.__eq__
 
     def __setitem__(self, k, v):
+        _GRAPH_CACHES.add(self)          # (a deep-copied instance never ran __init__)
         if k not in self and len(self) >= self.limit:
             del self[next(iter(self))]
         super().__setitem__(k, v)
+
+
+def pin_graph_caches():
+    """Strong references to everything the bounded shape caches hold right now.  Called right after a hipGraph capture
+    (detectors._graphed, pipeline._graphed_forward): the graph entry stores the result, so positional encodings, geometry
+    tables and kernel workspaces whose ADDRESSES the graph baked in outlive their cache slots."""
+    return [list(c.values()) for c in list(_GRAPH_CACHES)]
 
 
 def conv3x3_fast(conv, x, scale=None, shift=None, relu=False, out=None):

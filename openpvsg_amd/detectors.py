@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .blocks import BaseModule
+from .blocks import BaseModule, pin_graph_caches
 from .config import _wrap
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 
@@ -74,8 +74,25 @@ class _Base(BaseModule):
         x = self.backbone(img)
         return self.neck(x) if self.with_neck else x
 
+    def __setattr__(self, name, value):
+        if isinstance(value, torch.nn.Module):                     # a replaced sub-module: the tensor list below is stale
+            self.__dict__.pop('_sig_tensors', None)
+        super().__setattr__(name, value)
+
+    def invalidate_graphs(self):
+        """Drop every captured hipGraph and the cached parameter list (call after replacing a NESTED sub-module in place;
+        assignments on the detector itself, load_state_dict, in-place updates and .to() are noticed without it)."""
+        self._graphs.clear()
+        self._graph_seen.clear()
+        self.__dict__.pop('_sig_tensors', None)
+
     def _weights_signature(self):
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        """(address, version) of every parameter and buffer: what a captured graph baked in.  The tensor list is walked once
+        (the module-tree traversal was 3x the cost of reading the 800 address / version pairs on the host-bound small-batch path)."""
+        ts = self.__dict__.get('_sig_tensors')
+        if ts is None:
+            ts = self.__dict__['_sig_tensors'] = list(self.parameters()) + list(self.buffers())
+        return tuple((t.data_ptr(), t._version) for t in ts)
 
     def _graphed(self, tag, fn, x):
         """fn(x) -> tuple of tensors (no host sync inside).  Eager on the first sighting of (tag, shape), then two warm-up
@@ -99,15 +116,19 @@ class _Base(BaseModule):
             try:
                 static_in = x.clone()
                 side = torch.cuda.Stream(device=x.device)
+                torch.cuda.current_stream().synchronize()    # one-stream rule of _lib.call: hand over an idle stream
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     for _ in range(2):
                         fn(static_in)
                 torch.cuda.current_stream().wait_stream(side)
+                side.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                     static_out = fn(static_in)
-                ent = (graph, static_in, static_out, sig)
+                # the graph references the cached positional encodings / geometry tables / kernel workspaces by address:
+                # it keeps them alive itself (their bounded caches may evict them long before this entry goes)
+                ent = (graph, static_in, static_out, sig, pin_graph_caches())
             except Exception as e:      # an op that cannot be captured: stay eager for this key, say so once
                 import warnings
                 warnings.warn('hipGraph capture of the detector forward failed (%r); running eagerly' % (e,))
@@ -117,7 +138,7 @@ class _Base(BaseModule):
             self._graphs[key] = ent
         if ent is False:
             return fn(x)
-        graph, static_in, static_out, _ = ent
+        graph, static_in, static_out = ent[:3]
         static_in.copy_(x)
         graph.replay()
         return static_out

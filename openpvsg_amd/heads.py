@@ -27,7 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib, ops
-from .blocks import BaseModule, ModuleList
+from .blocks import BaseModule, ModuleList, _ShapeCache
 from .config import _wrap
 from .registry import (HEADS, build_plugin_layer, build_positional_encoding,
                        build_transformer_layer_sequence)
@@ -105,7 +105,7 @@ class DecoderRows:
 
         C = 256
         self.layers, self.next_q = [], []
-        self._ws = {}                                # (B, Q, device) -> workspace of decoder_rows_post's split form
+        self._ws = _ShapeCache(limit=8)              # (B, Q, device) -> workspace of decoder_rows_post's split form
         for layer in head.transformer_decoder.layers:
             xa, sa, ffn = layer.attentions[0].attn, layer.attentions[1].attn, layer.ffns[0]
             f1, f2 = ffn.layers[0][0], ffn.layers[1]
@@ -140,8 +140,6 @@ class DecoderRows:
         key = (x1.shape[0], x1.shape[1], str(x1.device))
         ws = self._ws.get(key, False)
         if ws is False:                              # zeroed once; the kernel leaves its arrival counters at zero
-            if len(self._ws) >= 8:
-                self._ws.pop(next(iter(self._ws)))
             ws = self._ws[key] = ops.decoder_rows_post_workspace(x1.shape[0], x1.shape[1], x1.device)
         return ops.decoder_rows_post(self.layers[i], self.head, nxt, x1, qkv, q_pos, self.num_cls_out, workspace=ws)
 
@@ -234,7 +232,9 @@ class _Mask2FormerHeadBase(BaseModule):
     def _pe_tokens(self, T, h, w, dev):
         """Decoder positional encoding of one level in token (key) order, cached per shape: the encodings depend on the
         geometry only, and re-laying (T,C,h,w) out as (T*h*w,C) every forward is a full pass over the level."""
-        cache = self.__dict__.setdefault('_pe_tok_cache', {})
+        cache = self.__dict__.get('_pe_tok_cache')
+        if cache is None:
+            cache = self.__dict__['_pe_tok_cache'] = _ShapeCache(limit=16)
         key = (T if self.video else 0, h, w, str(dev), self.clip_frame_offset, self.clip_total_frames)
         pe = cache.get(key)
         if pe is None:
@@ -243,8 +243,6 @@ class _Mask2FormerHeadBase(BaseModule):
                 pe = g.flatten(2).permute(0, 2, 1).reshape(T * h * w, -1).contiguous()
             else:
                 pe = self.decoder_positional_encoding.grid(h, w, dev).flatten(1).t().contiguous()
-            if len(cache) >= 16:
-                cache.pop(next(iter(cache)))
             cache[key] = pe
         return pe
 

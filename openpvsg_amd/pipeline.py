@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops, parallel
+from .blocks import pin_graph_caches
 
 
 def assemble_tubes(seg_ids, kept_feats, num_frames):
@@ -96,29 +97,39 @@ class PVSGPipeline(torch.nn.Module):
         entry = self._graphs.get(key)
         det, head = self.detector, self.detector.panoptic_head
         T = clip.shape[0]
+        # the graph bakes in parameter addresses and the tensors derived from them (packed limbs, BN affine tables): a weight
+        # change -- load_state_dict, an in-place update, .to() -- is seen through (address, version) and triggers a new capture
+        sig = det._weights_signature()
+        if entry is not None and entry is not False and entry[3] != sig:
+            entry = None
         if entry is None:
             def run(x):
                 return head.clip_logits(det.extract_feat(x), 1, T)
             try:
                 static_in = clip.clone()
                 side = torch.cuda.Stream(device=clip.device)
+                torch.cuda.current_stream().synchronize()    # one-stream rule of _lib.call: hand over an idle stream
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     for _ in range(2):
                         run(static_in)
                 torch.cuda.current_stream().wait_stream(side)
+                side.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                     static_out = run(static_in)
-                entry = (graph, static_in, static_out)
+                entry = (graph, static_in, static_out, sig, pin_graph_caches())   # (pins: see detectors._graphed)
             except Exception as e:   # capture unsupported for some op: stay eager, say so once
                 import warnings
                 warnings.warn('hipGraph capture of the VPS forward failed (%r); running eagerly' % (e,))
                 entry = False
+            self._graphs.pop(key, None)
+            if len(self._graphs) >= 4:                    # every shape pins a private memory pool: keep the four newest
+                self._graphs.pop(next(iter(self._graphs)))
             self._graphs[key] = entry
         if entry is False:
             return head.clip_logits(det.extract_feat(clip), 1, T)
-        graph, static_in, static_out = entry
+        graph, static_in, static_out = entry[:3]
         static_in.copy_(clip)
         graph.replay()
         cls, masks4, q = static_out
@@ -150,10 +161,12 @@ class PVSGPipeline(torch.nn.Module):
             try:
                 static_in = feats.clone()
                 side = torch.cuda.Stream(device=feats.device)
+                torch.cuda.current_stream().synchronize()    # one-stream rule of _lib.call: hand over an idle stream
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     run(static_in)
                 torch.cuda.current_stream().wait_stream(side)
+                side.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 # thread_local: CUDA calls of other threads (RCCL's watchdog polls events) must not invalidate the capture
                 with torch.cuda.graph(graph, capture_error_mode='thread_local'):

@@ -327,6 +327,47 @@ def test_detector_graph_replay_equals_eager(hip_lib, video, mode):
             np.testing.assert_array_equal(a, b)
 
 
+def test_graph_replay_survives_cache_eviction_and_follows_weight_updates(hip_lib):
+    """A captured graph reads the cached positional encodings / geometry tables / kernel workspaces BY ADDRESS, and those caches
+    are bounded (16 / 8 entries): after more than 16 other shapes have passed through, the old graph must still replay exactly
+    (it pins what it references, blocks.pin_graph_caches), and an in-place weight update must trigger a new capture instead
+    of a replay on stale packed weights."""
+    import gc
+    m = build_detector(False, 5, {'cls_embed.weight': 40.0})
+    meta = dict(img_shape=(64, 96, 3), ori_shape=(64, 96, 3))
+
+    def run(seed, hw=(64, 96)):
+        x = det_input('img', (1, 3) + hw, seed).to(DEV)
+        return m.forward([x], [[dict(meta, img_shape=hw + (3,), ori_shape=hw + (3,))]], return_loss=False, rescale=True)[0]
+
+    m.use_graph = False
+    want = np.asarray(run(31)['pan_results'])
+    m.use_graph = True
+    run(30)
+    run(30)                                                     # capture at 64 x 96
+    ent = m._graphs[('image', (1, 3, 64, 96), DEV)]
+    assert ent not in (None, False) and any(len(p) for p in ent[4]), 'the graph entry pins nothing'
+    m.use_graph = False                                         # 20 other shapes, eagerly: every bounded cache turns over
+    for i in range(20):
+        run(40 + i, (32 + 32 * (i % 5), 64 + 32 * (i // 5)))
+    gc.collect()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 20,), float('nan'), device=DEV) for _ in range(64)]      # reuse whatever was freed
+    del junk
+    m.use_graph = True
+    assert m._graphs.get(('image', (1, 3, 64, 96), DEV)) is ent
+    np.testing.assert_array_equal(np.asarray(run(31)['pan_results']), want)
+    # in-place weight update: new capture (two sightings), then replays of the NEW weights
+    with torch.no_grad():
+        m.panoptic_head.cls_embed.weight.mul_(0.5)
+    m.use_graph = False
+    want2 = np.asarray(run(31)['pan_results'])
+    m.use_graph = True
+    for _ in range(3):
+        np.testing.assert_array_equal(np.asarray(run(31)['pan_results']), want2)
+    assert m._graphs[('image', (1, 3, 64, 96), DEV)] is not ent
+
+
 def test_vps_detector_instance_on_and_rescale_vs_reference_golden(hip_lib, golden_dir):
     """Unmodified shipped test_cfg (instance_on=True, per-frame mode) with ori_shape != img_shape against the
     REFERENCE detector's own output: fused two-resize panoptic map + `ins_results` in the reference's format
