@@ -63,6 +63,10 @@ class _Base(BaseModule):
         # rows from the second input on -- the library zeroed the attention-mask flags with hipMemsetAsync, and the
         # captured memset node was not ordered before the kernel that ORs into them; it is a kernel now (csrc/common.h).
         self.use_graph = os.environ.get('PVSG_DETECTOR_GRAPH', 'on') != 'off'
+        # tests / benchmarks only: callable (cls (B,Q,classes+1), masks4 (B,Q,h/4,w/4)) -> (cls, masks4) applied to the head's
+        # last-layer outputs (B = images, or the T frames of a video) before chaining / fusion -- controlled keep counts and
+        # confident masks on random-init weights.  While set, calls run eagerly (no graph replay).
+        self.head_override = None
         self.graph_max_frames = 4
         self._graphs, self._graph_seen = {}, {}
 
@@ -101,7 +105,7 @@ class _Base(BaseModule):
         the graph's static buffers: valid until the next call with the same key (callers consume them within the call)."""
         # large batches are GPU-bound (launches run ahead of the device): the replay only pays where the host is the limit
         if (not self.use_graph or not x.is_cuda or x.shape[0] > self.graph_max_frames or torch.is_grad_enabled() or
-                torch.cuda.is_current_stream_capturing()):
+                torch.cuda.is_current_stream_capturing() or self.head_override is not None):
             return fn(x)
         key = (tag, tuple(x.shape), str(x.device))
         sig = self._weights_signature()
@@ -265,7 +269,10 @@ class Mask2FormerCustom(_Base):
             # one image per call (the reference's own limit)
             def logits(x):
                 cls_list, mask_list, q = self.panoptic_head._decode(self.extract_feat(x), 1, 1, all_masks=False)
-                return cls_list[-1], mask_list[-1], q
+                c, m4 = cls_list[-1], mask_list[-1]
+                if self.head_override is not None:
+                    c, m4 = self.head_override(c, m4)
+                return c, m4, q
             cls, masks4, q = self._graphed('image', logits, imgs)
             res = self._fused_frames(cls[0], masks4, q[:, 0], img_metas[0], rescale, video=False)
             if res is not None:
@@ -324,7 +331,10 @@ class Mask2FormerVideoCustom(_Base):
                 # all frames of the clip share the class logits -> one fused post-processing launch set
                 def clip_fn(x):
                     cls, m4, q = head.clip_logits(self.extract_feat(x), 1, T)
-                    return cls, q.permute(1, 0, 2), m4[0]
+                    m4 = m4[0]
+                    if self.head_override is not None:
+                        cls, m4 = self.head_override(cls, m4)
+                    return cls, q.permute(1, 0, 2), m4
                 logits, embds, masks4 = self._graphed('clip', clip_fn, frames)
             else:
                 feats = self.extract_feat(frames)
@@ -340,6 +350,8 @@ class Mask2FormerVideoCustom(_Base):
             def per_frame_fn(x):
                 cls_list, mask_list, qq = head._decode(self.extract_feat(x), T, 1, all_masks=False)
                 cls_t, m4 = cls_list[-1], mask_list[-1][:, 0]                     # (T,Q,C+1), (T,Q,h,w)
+                if self.head_override is not None:
+                    cls_t, m4 = self.head_override(cls_t, m4)
                 embds_t = qq.permute(1, 0, 2).contiguous()                        # (T,Q,C)
                 perm = ops.minvis_chain(embds_t)                                  # (T,Q)
                 ar = torch.arange(T, device=perm.device)[:, None]

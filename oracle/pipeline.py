@@ -25,10 +25,14 @@ class IPSDetectorOracle(nn.Module):
         self.num_things, self.num_stuff = num_things, num_stuff
         self.test_cfg = dict(DEFAULT_TEST_CFG, instance_on=True) if test_cfg is None else test_cfg
 
+    head_override = None        # tests: callable (cls (B,Q,C+1), masks (B,Q,H,W) full-resolution logits) -> (cls, masks)
+
     def simple_test(self, imgs, img_metas, rescale=True):
         feats = self.backbone(imgs)
         cls, masks, qf = self.panoptic_head.simple_test_with_query(
             feats, img_metas[0]['batch_input_shape'], batch_size=imgs.shape[0])
+        if self.head_override is not None:
+            cls, masks = self.head_override(cls, masks)
         return heads.fusion_simple_test_with_query(cls, masks, qf, img_metas, self.num_things,
                                                    self.num_stuff, self.test_cfg, rescale=rescale)
 
@@ -40,6 +44,7 @@ class VPSDetectorOracle(nn.Module):
         self.panoptic_head = heads.Mask2FormerHeadOracle(num_things, num_stuff, video=True)
         self.num_things, self.num_stuff = num_things, num_stuff
         self.test_cfg = dict(DEFAULT_TEST_CFG) if test_cfg is None else test_cfg
+        self.head_override = None
 
     def simple_test(self, ref_img, ref_img_metas, rescale=True):
         bs, T = ref_img.shape[:2]
@@ -49,6 +54,8 @@ class VPSDetectorOracle(nn.Module):
         for i in range(feats[0].size(0)):
             cur = [f[i].unsqueeze(0) for f in feats]
             cls, masks, q = self.panoptic_head.simple_test_with_query(cur, shape, 1, 1)
+            if self.head_override is not None:      # tests: (frame index, cls (1,Q,C+1), masks (1,1,Q,H,W)) -> (cls, masks)
+                cls, masks = self.head_override(i, cls, masks)
             f_logits.append(cls.squeeze())
             f_masks.append(masks.squeeze())
             f_embds.append(q.permute(0, 2, 1).squeeze())

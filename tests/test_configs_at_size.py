@@ -63,6 +63,50 @@ def test_config2_ips_8_frames_720p_vs_oracle(hip_lib):
             assert sorted(int(s) for s in seg[0].tolist() if s >= 0) == sorted(ref['query_feats'].keys())
 
 
+def test_config2_ips_8_frames_720p_north_star_bar(hip_lib):
+    """Config 2 at the real bar: the same 8 x 720p batch with CONTROLLED head outputs (bench.synthetic_head_outputs: 32 confident
+    queries, +/-40 mask-logit offsets on drifting rectangles, applied to product and oracle alike) -- panoptic maps of two
+    frames against the oracle with no decision-margin escape: pixel mismatch < 1e-3, mask IoU >= 1 - 1e-3, identical segment
+    ids, and the kept queries' features within 1e-3 (mask2former_fusion_head.py:96-171 on mask2former_head.py:397-479)."""
+    from tests.test_modules_gpu import _controlled, north_star_bar
+    seed, B = 21, 8
+    gains = {'cls_embed.weight': 40.0}
+    m = _detector(False, seed, gains)
+    m.panoptic_fusion_head.test_cfg = dict(m.panoptic_fusion_head.test_cfg, instance_on=False)
+    o = opipe.IPSDetectorOracle(test_cfg=dict(opipe.DEFAULT_TEST_CFG)).eval()
+    o.load_state_dict(det_state_dict(o, seed, gains))
+    g = torch.Generator().manual_seed(seed)
+    imgs = torch.randn(B, 3, 736, 1280, generator=g)
+    imgs[:, :, 720:] = 0.0
+    meta = dict(batch_input_shape=(736, 1280), img_shape=(720, 1280, 3), ori_shape=(720, 1280, 3))
+    cls_syn, off = _controlled(B, 184, 320, n_keep=32)
+    head, fusion = m.panoptic_head, m.panoptic_fusion_head
+    with torch.no_grad():
+        feats = m.extract_feat(imgs.to(DEV))
+        cls_list, mask_list, q = head._decode(feats, B, 1, all_masks=False)
+        masks4, q_g = mask_list[-1] + off.to(DEV), q                    # (B,Q,184,320), (Q,B,256)
+        cls_g = cls_syn.to(DEV)[0]
+        for b in (0, 5):
+            ob = off[b:b + 1]
+            o.head_override = lambda cls, masks: (cls_syn, masks + F.interpolate(ob, size=(736, 1280), mode='bilinear',
+                                                                                   align_corners=False))
+            ref = o.simple_test(imgs[b:b + 1], [meta], rescale=True)[0]
+            pan, seg, keep = fusion.panoptic_fused(cls_g, masks4[b:b + 1], (736, 1280), (720, 1280))
+            a, r = pan[0].cpu().numpy(), ref['pan_results'].numpy()
+            assert a.shape == (720, 1280)
+            north_star_bar(a, r)
+            ids = [int(s) for s in seg[0].tolist() if s >= 0]       # (queries of one stuff class share a segment id)
+            assert sorted(set(ids)) == sorted(ref['query_feats'].keys()) and len(set(ids)) >= 20
+            kf = q_g[:, b][keep].cpu()
+            seen = {}
+            for j, sid in enumerate(int(s) for s in seg[0].tolist()):
+                if sid >= 0:
+                    n = seen.get(sid, 0)                              # n-th query of this segment, in query order
+                    seen[sid] = n + 1
+                    np.testing.assert_allclose(kf[j].numpy(), ref['query_feats'][sid][n].reshape(-1).numpy(), rtol=1e-3, atol=1e-3)
+            assert {k: len(v) for k, v in ref['query_feats'].items()} == seen
+
+
 def test_config3_clip_720p_sample_vs_oracle_end_to_end(hip_lib):
     """Config 3 flow (clip-level VPS forward at 720p + fusion + tube assembly + relation head) on a 2-frame sample
     against the oracle, with the controlled keep count of the benchmark: the comparison `bench.py` prints as
@@ -81,6 +125,52 @@ def test_config3_clip_720p_sample_vs_oracle_end_to_end(hip_lib):
     assert parity['tubes'] == parity['tubes_oracle'] >= 30
     assert parity['pair_matrix_max_abs_diff'] < 1e-3 and parity['top20_pairs_equal']
     assert base['value'] > 0 and base['cores'] >= 1
+
+
+def test_config3_full_size_32_frames_graph_replay_and_key_split_invariance(hip_lib, monkeypatch):
+    """BASELINE config 3 at its full size -- 32 frames of 720p through backbone, pixel decoder, the clip-level decoder over
+    471 040 / 117 760 / 29 440 keys, fusion, tube assembly, relation head: (1) the hipGraph replay of backbone + head on a clip
+    the capture never saw equals the eager run bit for bit (panoptic maps, class logits, query features, pair matrix);
+    (2) cutting the key axis of the masked attention into another number of ranges (what frame shards do across GPUs) leaves
+    the panoptic maps, the tubes and the top pairs unchanged and moves the queries by float rounding only."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from openpvsg_amd import ops
+    from openpvsg_amd.pipeline import PVSGPipeline
+    dev = torch.device(DEV)
+    det, rel = bench.build_models(0)
+    det = det.to(dev)
+    rel = {k: v.to(dev) for k, v in rel.items()}
+    pipe = PVSGPipeline(det, rel['subject_encoder'], rel['object_encoder'], rel['pair_model'], rel['relation_model'],
+                        use_graph=False).eval()
+    T = 32
+    clip_a, (Hp, Wp) = bench.make_clip(T, 720, 1280, seed=0)
+    clip_b, _ = bench.make_clip(T, 720, 1280, seed=1)
+    pipe.head_override = bench.make_override(bench.synthetic_head_outputs(T, Hp // 4, Wp // 4, n_keep=32, seed=0), dev)
+    clip_b = clip_b.to(dev)
+
+    def snap(out):
+        return dict(pan=out['pan_results'].clone(), cls=out['cls'].clone(), query=out['query'].clone(),
+                    ids=out['tube_ids'].tolist(), pm=out['relation']['pred_matrix'].clone(), pairs=out['relation']['pairs'].tolist())
+    eager = snap(pipe(clip_b, (Hp, Wp), (720, 1280)))
+    assert len(eager['ids']) >= 30
+    pipe.use_graph = True
+    pipe(clip_a.to(dev), (Hp, Wp), (720, 1280))                   # warm-ups + capture + first replay, on another clip
+    assert any(e not in (None, False) for e in pipe._graphs.values()), 'no graph was captured'
+    replay = snap(pipe(clip_b, (Hp, Wp), (720, 1280)))
+    for k in ('pan', 'cls', 'query', 'pm'):
+        assert torch.equal(replay[k], eager[k]), k
+    assert replay['ids'] == eager['ids'] and replay['pairs'] == eager['pairs']
+    pipe.use_graph = False
+    pipe._graphs.clear()
+    default_ns = ops.xattn_num_splits(1, 32 * 14720)
+    for ns in (default_ns // 2, 8):
+        monkeypatch.setattr(ops, 'xattn_num_splits', lambda B, K, ns=ns: max(1, min(ns, (K + 63) // 64)))
+        other = snap(pipe(clip_b, (Hp, Wp), (720, 1280)))
+        assert torch.equal(other['pan'], eager['pan']) and other['ids'] == eager['ids']
+        assert other['pairs'][:20] == eager['pairs'][:20]
+        assert torch.allclose(other['query'], eager['query'], rtol=1e-4, atol=1e-4)
+        assert torch.allclose(other['pm'], eager['pm'], rtol=1e-3, atol=1e-4)
 
 
 @pytest.mark.parametrize('K', [32 * 14720])

@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import heads as oheads
 from oracle import pipeline as opipe
@@ -509,6 +510,55 @@ def test_vps_per_frame_fused_path_vs_oracle(hip_lib):
         for k in res[0][t]['query_feats']:
             np.testing.assert_allclose(res[0][t]['query_feats'][k][0], ref[0][t]['query_feats'][k][0].numpy(),
                                        rtol=1e-3, atol=1e-3)
+
+
+def _controlled(T, h4, w4, n_keep, seed=0):
+    """bench.synthetic_head_outputs: class logits with `n_keep` confident queries + additive +/-40 mask-logit offsets on
+    drifting rectangles -- decisions far from every threshold, so the north-star bar can be asserted without a margin escape"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.synthetic_head_outputs(T, h4, w4, n_keep=n_keep, seed=seed)
+
+
+def north_star_bar(a, b):
+    """mask IoU >= 1 - 1e-3 and < 1e-3 of the pixels differing (BASELINE.json north_star), segment ids identical"""
+    assert float((a != b).mean()) < 1e-3, float((a != b).mean())
+    assert mask_iou(a, b, 126) >= 1 - 1e-3
+    assert sorted(np.unique(a).tolist()) == sorted(np.unique(b).tolist())
+
+
+def test_vps_per_frame_minvis_flow_north_star_bar(hip_lib):
+    """The shipped flow -- per-frame heads, MinVIS chaining, fusion per frame (mask2former_vps/mask2former.py:125-200) -- against
+    the oracle at the real bar: controlled head outputs on both sides (same offsets, added before the chaining), no
+    decision-margin escape: pixel mismatch < 1e-3, mask IoU >= 1 - 1e-3, identical segment ids, kept query features at 1e-3."""
+    seed, T = 6, 3
+    gains = {'cls_embed.weight': 40.0, 'query_feat.weight': 30.0}
+    m = build_detector(True, seed, gains, 'per_frame')
+    m.panoptic_fusion_head.test_cfg = dict(m.panoptic_fusion_head.test_cfg, instance_on=False)
+    o = opipe.VPSDetectorOracle().eval()
+    o.load_state_dict(det_state_dict(o, seed, gains))
+    img = det_input('clip', (1, T, 3, 64, 96), seed)
+    meta = dict(batch_input_shape=(64, 96), img_shape=(64, 96, 3), ori_shape=(64, 96, 3))
+    cls_syn, off = _controlled(T, 16, 24, n_keep=8)
+    off_full = F.interpolate(off, size=(64, 96), mode='bilinear', align_corners=False)
+    o.head_override = lambda t, cls, masks: (cls_syn, masks + off_full[t][None, None])
+    cs, od = cls_syn.to(DEV), off.to(DEV)
+    m.head_override = lambda cls, m4: (cs.expand(cls.shape[0], -1, -1), m4 + od)
+    with torch.no_grad():
+        ref = o.simple_test(img, [[meta] * T], rescale=True)
+    res = m.forward(img=None, img_metas=None, return_loss=False, rescale=True, ref_img=img.to(DEV),
+                    ref_img_metas=[[dict(meta) for _ in range(T)]])
+    kept = 0
+    for t in range(T):
+        a, b = res[0][t]['pan_results'], ref[0][t]['pan_results'].numpy()
+        north_star_bar(a, b)
+        assert sorted(res[0][t]['query_feats'].keys()) == sorted(ref[0][t]['query_feats'].keys())
+        kept += len(res[0][t]['query_feats'])
+        for k in res[0][t]['query_feats']:
+            np.testing.assert_allclose(res[0][t]['query_feats'][k][0], ref[0][t]['query_feats'][k][0].numpy(),
+                                       rtol=1e-3, atol=1e-3)
+    assert kept >= 3 * T                                           # the controlled outputs really keep segments
 
 
 def test_rel_test_flow_with_dataset_and_dataloader(hip_lib, tmp_path):
