@@ -3,7 +3,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o coresidency_repro scripts/coresidency_repro.hip
 //   ./coresidency_repro [co-runner] [launches] [victim]
-//       co-runner: none | bf16_16x16x32 | bf16_32x32x16 | f16_32x32x16 | f32_32x32x2 | valu        (default bf16_16x16x32)
+//       co-runner: none | bf16_16x16x32 | f16_16x16x32 | bf16_32x32x16 | f16_32x32x16 | f32_32x32x2 | valu   (default bf16_16x16x32)
 //       victim:    msda | msdav<flags> | trans | imul | misc | gather | regs | both (= gather + regs) | all                (default both)
 //   HSA_CU_MASK is honoured per process through the environment variables REPRO_VICTIM_CU_MASK / REPRO_SPIN_CU_MASK
 //   (e.g. REPRO_VICTIM_CU_MASK=0:0-127 REPRO_SPIN_CU_MASK=0:128-255 -> disjoint CU sets -> no corruption expected).
@@ -72,6 +72,14 @@ __global__ __launch_bounds__(256) void spin_kernel(float* sink, int iters) {
     for (int it = 0; it < iters; ++it)
 #pragma unroll
       for (int u = 0; u < 16; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[u & 3], 0, 0, 0);
+    for (int u = 0; u < 4; ++u) total += acc[u][0];
+  } else if (KIND == 5) {                            // v_mfma_f32_16x16x32_f16 (round 4: the instruction of the f16x2 split kernels)
+    f16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.5f + 0.01f * (t + i)); b[i] = (_Float16)(1.0f - 0.02f * (t - i)); }
+    f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[u & 3], 0, 0, 0);
     for (int u = 0; u < 4; ++u) total += acc[u][0];
   } else if (KIND == 1) {                            // v_mfma_f32_32x32x16_bf16
     bf16x8 a, b;
@@ -294,6 +302,7 @@ static void spin_thread(const char* kind) {
   while (!g_stop.load()) {
     for (int i = 0; i < 4; ++i) {
       if (!strcmp(kind, "bf16_16x16x32")) spin_kernel<0><<<grid, 256, 0, st>>>(sink, 4000);
+      else if (!strcmp(kind, "f16_16x16x32")) spin_kernel<5><<<grid, 256, 0, st>>>(sink, 4000);
       else if (!strcmp(kind, "bf16_32x32x16")) spin_kernel<1><<<grid, 256, 0, st>>>(sink, 2000);
       else if (!strcmp(kind, "f16_32x32x16")) spin_kernel<2><<<grid, 256, 0, st>>>(sink, 2000);
       else if (!strcmp(kind, "f32_32x32x2")) spin_kernel<3><<<grid, 256, 0, st>>>(sink, 1000);
@@ -313,6 +322,7 @@ static void run_spinner(const char* kind, int readyfd) {
   const unsigned grid = (unsigned)p.multiProcessorCount * 3u;
   auto launch = [&]() {
     if (!strcmp(kind, "bf16_16x16x32")) spin_kernel<0><<<grid, 256>>>(sink, 4000);
+    else if (!strcmp(kind, "f16_16x16x32")) spin_kernel<5><<<grid, 256>>>(sink, 4000);
     else if (!strcmp(kind, "bf16_32x32x16")) spin_kernel<1><<<grid, 256>>>(sink, 2000);
     else if (!strcmp(kind, "f16_32x32x16")) spin_kernel<2><<<grid, 256>>>(sink, 2000);
     else if (!strcmp(kind, "f32_32x32x2")) spin_kernel<3><<<grid, 256>>>(sink, 1000);
