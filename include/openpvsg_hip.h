@@ -373,6 +373,13 @@ long long pvsg_gemm_f16x2_packed_elems(int N, int K);
 int pvsg_gemm_f16x2_pack(const float* weight, void* w_packed, int N, int K, void* stream);
 int pvsg_gemm_f16x2(const float* a, const void* w_packed, const float* bias, float* out, long long M, int N, int K,
                     int relu, uint32_t* overflow, void* stream);
+/* out = LayerNorm(residual + a w^T + bias) * gamma + beta over rows of N == 256: the [3P] mmcv encoder layer's projection (MSDA
+ * output_proj / second FFN layer) + identity + LayerNorm in ONE launch on the 256 x 256-tile f16x2 kernel (a workgroup owns whole
+ * rows; two-pass row statistics like F.layer_norm).  Replaces pvsg_gemm_* followed by pvsg_add_layernorm for those layers: the
+ * projection's output never reaches HBM un-normalised.  K % 32 == 0; every pointer 16-byte aligned. */
+int pvsg_gemm_f16x2_add_layernorm(const float* a, const void* w_packed, const float* bias, const float* residual,
+                                  const float* gamma, const float* beta, float eps, float* out, long long M, int N, int K,
+                                  uint32_t* overflow, void* stream);
 int pvsg_conv1x1_f16x2(const float* x, const void* w_packed, const float* scale, const float* shift,
                        const float* residual, const float* in_scale, const float* in_shift, float* y, int B, int Cin,
                        int Cout, int H, int W, int stride, int relu, uint32_t* overflow, void* stream);

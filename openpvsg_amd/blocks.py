@@ -171,6 +171,24 @@ def linear_fast(owner, tag, weights, x, bias=None, relu=False):
     return y.view(*x.shape[:-1], n)
 
 
+def linear_add_layernorm_fast(owner, tag, weight, x, bias, identity, norm):
+    """LayerNorm(identity + F.linear(x, weight, bias)): one launch where the fused kernel exists (f16x2 split, 256 output
+    columns: ops.gemm_add_layernorm), else the split GEMM followed by the add + LayerNorm kernel."""
+    n, k = weight.shape
+    if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and
+            n == 256 and k % 32 == 0 and ops.split_mode() == 'f16x2' and os.environ.get('PVSG_FUSE_LN', 'on') != 'off' and
+            isinstance(norm, nn.LayerNorm) and norm.normalized_shape == (256,)):
+        key = ((weight.data_ptr(), weight._version, str(weight.device)), 'f16x2')
+        cache = owner.__dict__.setdefault('_pvsg_gemm', {})
+        ent = cache.get(tag)
+        if ent is None or ent[0] != key:
+            ent = cache[tag] = (key, ops.gemm_bf16x3_pack(weight.detach().contiguous(), mode='f16x2'))
+        y = ops.gemm_add_layernorm(x.reshape(-1, k), ent[1], bias, identity.reshape(-1, 256), norm)
+        return y.view(*x.shape[:-1], 256)
+    t = linear_fast(owner, tag, weight, x)
+    return ops.add_layernorm(t, identity, bias, norm)
+
+
 def _interleave_sin_cos(p):
     return torch.stack((p[..., 0::2].sin(), p[..., 1::2].cos()), dim=-1).flatten(-2)
 
@@ -683,13 +701,11 @@ class MSDeformAttnPixelDecoder(BaseModule):
             x = ops.msda_proj_ln(y, pos_oa, ref2d, ss, lsi, a._wo_packed, a.output_proj.bias, x, layer.norms[0])
         else:
             core = ops.msda_fused(y, pos_oa, ref2d, ss, lsi)
-            t = linear_fast(a, 'output_proj', a.output_proj.weight, core)
-            x = ops.add_layernorm(t, x, a.output_proj.bias, layer.norms[0])
+            x = linear_add_layernorm_fast(a, 'output_proj', a.output_proj.weight, core, a.output_proj.bias, x, layer.norms[0])
         ffn = layer.ffns[0]
         fc1, fc2 = ffn.layers[0][0], ffn.layers[1]
         h = linear_fast(fc1, 'w', fc1.weight, x, fc1.bias, relu=True)              # bias + ReLU in the GEMM epilogue
-        t = linear_fast(fc2, 'w', fc2.weight, h)
-        return ops.add_layernorm(t, x, fc2.bias, layer.norms[1])
+        return linear_add_layernorm_fast(fc2, 'w', fc2.weight, h, fc2.bias, x, layer.norms[1])
 
     fuse_glue = True
 

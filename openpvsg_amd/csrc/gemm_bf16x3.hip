@@ -645,10 +645,17 @@ void gemm_f16x2_dma_kernel(const float* __restrict__ A, const __bf16* __restrict
 //   writes of A(kt)) -> barrier -> split A(kt+1) and write it to the other stage, DMA W(kt+1) into it, load A(kt+2) ->
 //   fragments + 96 MFMAs of stage kt.
 //   LDS stage: A [2 limbs][4 k-groups][258 rows][8] (33 KB; 258: conflict-free staging writes) + W [2 arrays][4][256 columns][8]
-template <bool RELU>
+// LN (N == 256 == one tile: a workgroup owns whole rows): out = LayerNorm(residual + A W^T + bias) * gamma + beta -- the
+// [3P] mmcv encoder layer's `identity + dropout(out)` followed by its `norm` ([3P] BaseTransformerLayer, 'self_attn', 'norm',
+// 'ffn', 'norm'), which otherwise costs a separate pass over three (rows, 256) tensors (pvsg_add_layernorm, 0.33 ms x 12 per
+// 32-frame clip).  Statistics in two passes like F.layer_norm: row mean, then the centred sum of squares; the four lane
+// groups of a wave hold 32 columns of a row each (shuffles), the two waves of a row pair meet through 2 KB of LDS.
+template <bool RELU, bool LN = false>
 __global__ __launch_bounds__(512)
 void gemm_f16x2_t256_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
-                            float* __restrict__ out, int M, int N, int K, int Npad, int tiles_n, unsigned* __restrict__ overflow) {
+                            float* __restrict__ out, int M, int N, int K, int Npad, int tiles_n, unsigned* __restrict__ overflow,
+                            const float* __restrict__ residual = nullptr, const float* __restrict__ gamma = nullptr,
+                            const float* __restrict__ beta = nullptr, float eps = 0.f) {
   constexpr int TM = 256, TN = 256;
   constexpr int A_KG = (TM + 2) * 8, A_LIMB = 4 * A_KG, A_STAGE = 2 * A_LIMB;
   constexpr int W_LIMB = 4 * TN * 8, STAGE = A_STAGE + 2 * W_LIMB;
@@ -779,7 +786,80 @@ void gemm_f16x2_t256_kernel(const float* __restrict__ A, const __bf16* __restric
   PVSG_TICK(tk2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the repeated last slabs / rows: nothing may land after the end)
   // register r of block (rb, cb) = row rb*16 + (lane&15), column cb*16 + 4*(lane>>4) + r of the wave's 64 x 128 tile
-  {
+  if constexpr (LN) {
+    const float unscale = f16x2_unscale(Wp, Npad, K);
+    const int rows = M - m0 < TM ? M - m0 : TM;
+    const unsigned tile_bytes = (unsigned)((size_t)rows * 256 * 4);
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)m0 * 256, 0, tile_bytes, 0x00020000);
+    const auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual) + (size_t)m0 * 256, 0, tile_bytes, 0x00020000);
+    // v = residual + acc 2^-e + bias (rows beyond M read 0 and are never stored), in place in the accumulators
+    float rsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      const int col = wc * 128 + cb * 16 + 4 * kg4;
+      const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const unsigned vo = (unsigned)(wr * 64 + rb * 16 + l15) * 1024u + (unsigned)col * 4u;
+        const f32x4 res = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, vo, 0, 0));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = __builtin_fmaf(acc[rb][cb][r], unscale, bv[r]) + res[r];
+          acc[rb][cb][r] = v;
+          rsum[rb] += v;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);                          // (one column block's residual loads in flight at a time: registers)
+    }
+    // row statistics: lanes l15, l15+16, +32, +48 hold the four 32-column parts of a row of this wave; waves (wr, 0) and (wr, 1)
+    // hold the two 128-column halves.  red[pass][wave][64 rows]
+    __builtin_amdgcn_s_barrier();                                 // everybody is done with the stages: LDS is free
+    float* red = reinterpret_cast<float*>(lds);
+    auto row_reduce = [&](float (&part)[4], int pass) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        part[rb] += __shfl_xor(part[rb], 16);
+        part[rb] += __shfl_xor(part[rb], 32);
+      }
+      if (kg4 == 0)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) red[(pass * 8 + wave) * 64 + rb * 16 + l15] = part[rb];
+      __syncthreads();
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) part[rb] += red[(pass * 8 + (wave ^ 1)) * 64 + rb * 16 + l15];
+    };
+    row_reduce(rsum, 0);
+    float mean[4], rstd[4], sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) mean[rb] = rsum[rb] * (1.f / 256.f);
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = acc[rb][cb][r] - mean[rb];
+          acc[rb][cb][r] = d;
+          sq[rb] = __builtin_fmaf(d, d, sq[rb]);
+        }
+    row_reduce(sq, 1);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) rstd[rb] = rsqrtf(sq[rb] * (1.f / 256.f) + eps);
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      const int col = wc * 128 + cb * 16 + 4 * kg4;
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + col), be = *reinterpret_cast<const f32x4*>(beta + col);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = __builtin_fmaf(acc[rb][cb][r] * rstd[rb], gv[r], be[r]);
+        const unsigned vo = (unsigned)(wr * 64 + rb * 16 + l15) * 1024u + (unsigned)col * 4u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, vo, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
     const float unscale = f16x2_unscale(Wp, Npad, K);
     const int rows = M - m0 < TM ? M - m0 : TM;
     const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)m0 * N, 0, (unsigned)((size_t)rows * N * 4), 0x00020000);
@@ -1479,6 +1559,29 @@ extern "C" int pvsg_gemm_bf16x3(const float* a, const void* w_packed, const floa
 extern "C" int pvsg_gemm_f16x2(const float* a, const void* w_packed, const float* bias, float* out, long long M, int N, int K,
                                int relu, uint32_t* overflow, void* stream) {
   return gemm_split_run(a, w_packed, bias, out, M, N, K, relu, true, overflow, stream);
+}
+
+// out = LayerNorm(residual + a w^T + bias) * gamma + beta for N == 256 (one 256-column tile = whole rows per workgroup): the
+// [3P] mmcv encoder layer's output_proj / second FFN layer + identity + norm in one launch (see gemm_f16x2_t256_kernel<.., LN>)
+extern "C" int pvsg_gemm_f16x2_add_layernorm(const float* a, const void* w_packed, const float* bias, const float* residual,
+                                             const float* gamma, const float* beta, float eps, float* out, long long M, int N,
+                                             int K, uint32_t* overflow, void* stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(a && w_packed && residual && gamma && beta && out, "gemm_f16x2_add_layernorm: null pointer argument");
+  PVSG_REQUIRE(M > 0 && K > 0, "gemm_f16x2_add_layernorm: bad shape");
+  if (N != 256 || K % 32 || M >= (1LL << 31) || (long long)256 * K * 4 >= (1LL << 31))
+    return set_err(PVSG_ERR_UNSUPPORTED, "gemm_f16x2_add_layernorm: built for N == 256, K %% 32 == 0 (got M=%lld N=%d K=%d)", M, N, K);
+  PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(bias) |
+                  reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
+                  reinterpret_cast<uintptr_t>(out)) & 15u), "gemm_f16x2_add_layernorm: pointers must be 16-byte aligned");
+  static std::atomic<unsigned long long> done{0};
+  const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f16x2_t256_kernel<false, true>), T256_LDS_BYTES, done);
+  if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "gemm_f16x2_add_layernorm: dynamic LDS: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL((gemm_f16x2_t256_kernel<false, true>), dim3((unsigned)((M + 255) / 256)), dim3(512), T256_LDS_BYTES,
+                     static_cast<hipStream_t>(stream), a, static_cast<const __bf16*>(w_packed), bias, out, (int)M, 256, K, 256, 1,
+                     overflow, residual, gamma, beta, eps);
+  PVSG_LAUNCH_CHECK("gemm_f16x2_add_layernorm");
+  return PVSG_OK;
 }
 
 static int conv1x1_split_run(const float* x, const void* w_packed, const float* scale, const float* shift,

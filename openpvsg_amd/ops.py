@@ -796,6 +796,31 @@ def gemm_bf16x3(a, w_packed, n, bias=None, relu=False, out=None):
     return out
 
 
+def gemm_add_layernorm_supported(w_packed, n, k):
+    """the fused projection + identity + LayerNorm exists for the f16x2 form with 256 output columns"""
+    return n == 256 and k % 32 == 0 and _is_f16x2(w_packed, n, k) and os.environ.get('PVSG_FUSE_LN', 'on') != 'off'
+
+
+def gemm_add_layernorm(a, w_packed, bias, residual, norm, out=None):
+    """LayerNorm(residual + a (M,K) @ w (256,K)^T + bias) with `norm` an nn.LayerNorm(256), in one launch
+    (csrc/gemm_bf16x3.hip: gemm_f16x2_t256_kernel<.., LN>); w given as gemm_bf16x3_pack(w, mode='f16x2')."""
+    a = _chk(a, 'a')
+    r = _chk(residual, 'residual')
+    M, K = a.shape
+    wp = _chk(w_packed, 'w_packed', torch.bfloat16)
+    if a.dim() != 2 or tuple(r.shape) != (M, 256) or not gemm_add_layernorm_supported(wp, 256, K):
+        raise RuntimeError('gemm_add_layernorm: unsupported shapes a=%s residual=%s' % (tuple(a.shape), tuple(r.shape)))
+    if out is None:
+        out = torch.empty((M, 256), device=a.device, dtype=torch.float32)
+    if M == 0:
+        return out
+    with _on(a.device):
+        _lib.call('pvsg_gemm_f16x2_add_layernorm', a.data_ptr(), wp.data_ptr(), _chk(bias, 'bias').data_ptr() if bias is not None else None,
+                  r.data_ptr(), _chk(norm.weight, 'gamma').data_ptr(), _chk(norm.bias, 'beta').data_ptr(), float(norm.eps),
+                  out.data_ptr(), M, 256, K, _overflow_counter(a.device).data_ptr(), _stream_ptr())
+    return out
+
+
 def conv1x1_bf16x3_supported(cout, cin, h, w):
     return cin % 16 == 0 and cin <= 4096 and cin * h * w < 2 ** 29
 

@@ -127,3 +127,28 @@ def test_f16x2_matches_bf16x3_at_encoder_size(hip_lib, N, K, relu):
     assert float((y - yb).abs().max()) < 1e-5 * max(1.0, float(yb.abs().max()))
     y2 = ops.gemm_bf16x3(a, ops.gemm_bf16x3_pack(w, mode='f16x2'), N, b, relu=relu)
     assert torch.equal(y, y2)                           # bitwise run to run
+
+
+@pytest.mark.parametrize('M,K', [(1000, 256), (257, 1024), (77280, 256), (64, 32)])
+def test_gemm_add_layernorm_matches_the_two_step_form(hip_lib, M, K):
+    """LayerNorm(identity + x W^T + b) in one launch (256-tile f16x2 kernel with the statistics in its epilogue) against the
+    float64 definition, next to the unfused pair (split GEMM, then pvsg_add_layernorm) -- ragged row tiles included."""
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(256, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(256, generator=g).cuda()
+    idn = torch.randn(M, 256, generator=g).cuda() * 2
+    ln = torch.nn.LayerNorm(256).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(torch.rand(256, generator=g) + 0.5)
+        ln.bias.copy_(torch.randn(256, generator=g))
+    wp = ops.gemm_bf16x3_pack(w, mode='f16x2')
+    y = ops.gemm_add_layernorm(x, wp, b, idn, ln)
+    two = ops.add_layernorm(ops.gemm_bf16x3(x, wp, 256), idn, b, ln)
+    ref = F.layer_norm((idn.double() + x.double() @ w.double().t() + b.double()).cpu(), (256,), ln.weight.double().cpu(),
+                       ln.bias.double().cpu(), ln.eps)
+    e1, e2 = (y.double().cpu() - ref).abs().max().item(), (two.double().cpu() - ref).abs().max().item()
+    assert e1 < 2e-5 and e1 < 3 * e2 + 2e-6, (e1, e2)
+    assert torch.equal(y, ops.gemm_add_layernorm(x, wp, b, idn, ln))
+    assert ops.split_overflow_count() == 0
