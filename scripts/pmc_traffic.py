@@ -43,16 +43,39 @@ def run_pass(counter, frames, workdir):
     return files[0], ' '.join(cmd[:7]) + ' <dir> -- python bench.py ' + ' '.join(cmd[11:])
 
 
+def split_entry(fn):
+    """C-ABI entry of the split kernels of csrc/gemm_bf16x3.hip from their template arguments (round 4: the f16x2 forms)"""
+    import re
+    m = re.search(r'(\w+_kernel)<([^>]*)>', fn)
+    if not m:
+        return None
+    name, targs = m.group(1), [t.strip() for t in m.group(2).split(',')]
+    if name == 'gemm_f16x2_t256_kernel':
+        return 'pvsg_gemm_f16x2_add_layernorm' if len(targs) > 1 and targs[1] == 'true' else 'pvsg_gemm_f16x2'
+    if name == 'gemm_f16x2_dma_kernel':
+        return 'pvsg_gemm_f16x2'
+    if name == 'gemm_bf16x3_k32_kernel':
+        return 'pvsg_gemm_f16x2' if len(targs) > 1 and targs[1] == 'true' else 'pvsg_gemm_bf16x3'
+    if name == 'conv1x1_bf16x3_k32_kernel':          # <RELU, RESIDUAL, IN_NORM, BITS, TM, TAPS, F16>
+        targs += ['false', '128', '1', 'false'][len(targs) - 3:] if len(targs) < 7 else []
+        sfx = '_f16x2' if targs[6] == 'true' else '_bf16x3'
+        if targs[3] == 'true':
+            return 'pvsg_attn_mask_bits' + sfx
+        return ('pvsg_conv3x3' if targs[5] == '9' else 'pvsg_conv1x1') + sfx
+    return None
+
+
 def reduce_csv(path, counter):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != counter or 'pvsg' not in r['Kernel_Name']:
             continue
         fn = r['Kernel_Name'].replace('void ', '')
-        for sub, entry in ENTRY:
-            if sub in fn:
-                agg[entry].append((float(r['Counter_Value']), fn.split('(')[0]))
-                break
+        entry = split_entry(fn)
+        if entry is None:
+            entry = next((e for sub, e in ENTRY if sub in fn), None)
+        if entry is not None:
+            agg[entry].append((float(r['Counter_Value']), fn.split('(')[0]))
     return agg
 
 
