@@ -179,12 +179,15 @@ class KernelTimer:
         import openpvsg_amd.ops as ops
         ops._lib.call = timed
 
-    SPLIT_F16X2 = ('pvsg_gemm_f16x2', 'pvsg_conv1x1_f16x2', 'pvsg_conv3x3_f16x2', 'pvsg_mask_logits_f16x2',
-                   'pvsg_attn_mask_bits_f16x2')
+    SPLIT_F16X2 = ('pvsg_gemm_f16x2', 'pvsg_gemm_f16x2_add_layernorm', 'pvsg_conv1x1_f16x2', 'pvsg_conv3x3_f16x2',
+                   'pvsg_mask_logits_f16x2', 'pvsg_attn_mask_bits_f16x2')
 
     @classmethod
     def work(cls, name, a):
         """(algorithmic bytes, flops) of one launch from its scalar arguments."""
+        if name == 'pvsg_gemm_f16x2_add_layernorm':     # projection + identity + LayerNorm: reads a, residual; writes the normalised rows
+            M, N, K = a[8:11]
+            return 4.0 * M * (K + 2 * N) + 4.0 * N * K, 6.0 * M * N * K
         if name in cls.SPLIT_F16X2:
             # two-limb f16 form: same arguments up to the trailing (overflow, stream); flops = the f16 limb products issued,
             # 3 per f32 multiply-add (the bf16 form issues 6)
@@ -779,7 +782,8 @@ def main():
                                         algorithmic_bytes_per_launch=d['bytes'] / d['calls'], scope=scope)
             # the four kernels the north-star names, each against its own roof (same HIP-event data)
             named = []
-            for key, bound in (('pvsg_msda_fused_forward', 'hbm'), ('pvsg_ms_deform_attn_forward', 'hbm'),
+            for key, bound in (('pvsg_gemm_f16x2', 'mfma'), ('pvsg_gemm_bf16x3', 'mfma'), ('pvsg_conv3x3_f16x2', 'mfma'),
+                               ('pvsg_msda_fused_forward', 'hbm'), ('pvsg_ms_deform_attn_forward', 'hbm'),
                                ('pvsg_mask_logits_forward', 'mfma'), ('pvsg_mask_logits_bf16x3', 'mfma'),
                                ('pvsg_mask_logits_f16x2', 'mfma'),
                                ('pvsg_attn_mask_bits_forward', 'mfma'), ('pvsg_attn_mask_bits_bf16x3', 'mfma'),
@@ -813,6 +817,10 @@ def main():
                     a_ = dd['flops'] / dd['calls'] / per_ms / 1e9
                     pk, what = KernelTimer.mfma_peak(k.split('[')[0])
                     ent = dict(kernel=k, bound='mfma', achieved=a_, peak=pk, unit='TFLOP/s', frac=a_ / pk, flops_counted=what)
+                    if k.split('[')[0] in KernelTimer.SPLIT_F16X2 or 'bf16x3' in k:
+                        # measured with rocm-smi while one layer loops (scripts/lab/power_probe.py, profiles/r04_power_probe.txt):
+                        # the split kernels run at the socket's 1400 W limit with the shader clock throttled to 1.6-2.2 GHz
+                        ent['limited_by'] = 'socket power (1400 W), profiles/r04_power_probe.txt'
                     if pk != F32_MFMA_PEAK_TF:      # split kernels: also the model's f32 arithmetic against the f32 matrix roof
                         limb_products = 3.0 if k.split('[')[0] in KernelTimer.SPLIT_F16X2 else 6.0
                         ent['f32_equivalent_TFLOPs'] = a_ / limb_products

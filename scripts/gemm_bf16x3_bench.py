@@ -30,6 +30,8 @@ def timed(fn, reps=10):
 
 
 def main():
+    global LIMBS
+    LIMBS = 3 if ops.split_mode() == 'f16x2' else 6          # limb products issued per f32 multiply-add
     tuning.enable()
     for name, M, N, K, relu in SHAPES:
         g = torch.Generator().manual_seed(1)
@@ -56,8 +58,9 @@ def main():
             t_lib, t_own = timed(lib), timed(own)
         print(json.dumps(dict(layer=name, M=M, N=N, K=K, lib_ms=round(t_lib, 3), own_ms=round(t_own, 3),
                               lib_tflops=round(flops / t_lib / 1e9, 1), own_tflops=round(flops / t_own / 1e9, 1),
-                              own_bf16_mfma_tflops=round(6 * flops / t_own / 1e9, 1),
-                              frac_bf16_roof=round(6 * flops / t_own / 1e9 / 2516.6, 3), max_err_own_lib_vs_f64=err)), flush=True)
+                              split=ops.split_mode(), limb_products=LIMBS,
+                              own_16bit_mfma_tflops=round(LIMBS * flops / t_own / 1e9, 1),
+                              frac_16bit_roof=round(LIMBS * flops / t_own / 1e9 / 2516.6, 3), max_err_own_lib_vs_f64=err)), flush=True)
 
 
 if __name__ == '__main__':
