@@ -349,7 +349,8 @@ int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const float* scale
                         const float* residual, const float* in_scale, const float* in_shift, float* y, int B, int Cin,
                         int Cout, int H, int W, int stride, int relu, void* stream);
 /* [3P] mmdet ResNet Bottleneck.conv2 (3x3, pad 1, stride 1 or 2) -> frozen BN -> ReLU on the split-bf16 kernel: implicit GEMM
- * over the nine taps.  w_packed = pvsg_gemm_bf16x3_pack of the (Cout, 9*Cin) matrix w.permute(0, 2, 3, 1) (tap-major).
+ * over the nine taps.  w_packed = pvsg_gemm_bf16x3_pack (pvsg_gemm_f16x2_pack for the _f16x2 entry) of the (Cout, 9*Cin) matrix whose
+ * K index runs [block of 32 input channels][tap ky*3+kx][32 channels]: w.reshape(Cout, Cin/32, 32, 3, 3).permute(0, 1, 3, 4, 2).
  * Cin % 32 == 0.  f32-MFMA forms: pvsg_conv3x3_winograd (stride 1), pvsg_conv3x3s2_affine (stride 2). */
 int pvsg_conv3x3_bf16x3(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B, int Cin,
                         int Cout, int H, int W, int stride, int relu, void* stream);

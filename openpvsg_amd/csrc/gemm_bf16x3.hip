@@ -1123,7 +1123,7 @@ void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict
 // TM = 64: layers with at most 64 output channels (the bottleneck's reducing 1x1 of layer1).  The packed weight is padded to 128
 // rows and is staged whole, but only rows 0..63 are multiplied: the four waves each take 32 pixel columns of the 64 rows, half
 // the matrix work of a 128-row tile, which leaves these layers to their HBM traffic.
-// TAPS = 9: the 3x3 convolution (pad 1, stride 1 or 2) as an implicit GEMM over K = 9 * Cin, tap-major (weight packed from
+// TAPS = 9: the 3x3 convolution (pad 1, stride 1 or 2) as an implicit GEMM over K = 9 * Cin, ordered [block of 32 input channels][tap][32 channels] (weight packed from
 // w.permute(0, 2, 3, 1)): a 32-deep step lies inside one tap (Cin % 32 == 0), whose pixel offset replaces the 1x1 one;
 // out-of-image taps read 0 through the descriptor's bounds check.
 // F16: the two-limb f16 form (see split2h): weights (w_h, w_l, w_h2) resident in registers, pixels as (x_h, x_l').
@@ -1166,9 +1166,9 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
   auto fetch = [&](int kt) {
     int cstep = kt * 32;                               // first input channel of this step
     unsigned voff = x_voff;
-    if (TAPS == 9) {
-      const int tap = cstep / Cin;
-      cstep -= tap * Cin;
+    if (TAPS == 9) {                                   // K order: [block of 32 input channels][tap][32 channels]
+      const int cib = kt / 9, tap = kt - 9 * cib;
+      cstep = cib * 32;
       const int dy = tap / 3, dx = tap - 3 * dy;
       const int iy = stride * oy + dy - 1, ix = stride * ox + dx - 1;
       voff = (pix < HWo && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) ? (unsigned)(iy * Win + ix) * 4u : 0x80000000u;
@@ -1177,8 +1177,13 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
     for (int gq = 0; gq < 2; ++gq) {
       const unsigned so = (unsigned)(cstep + 16 * gq + 8 * skg) * plane;
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+      for (int j = 0; j < 8; ++j) {
+#if defined(PVSG_ABL) && (PVSG_ABL == 8 || PVSG_ABL == 9)
+        x_regs[gq][j] = 0.5f + (float)(so + j);        // lab build: no pixel loads (timing only)
+#else
         x_regs[gq][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff, so + j * plane, 0));
+#endif
+      }
       const __bf16* wk = wsrc + (size_t)(2 * kt + gq) * WL * w_limb_stride;
 #pragma unroll
       for (int l = 0; l < WL; ++l) w_regs[gq][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
@@ -1197,8 +1202,12 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
       unsigned hh[4], mm[4], ll[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+#if defined(PVSG_ABL) && PVSG_ABL == 9
+        hh[q] = __builtin_bit_cast(unsigned, x_regs[gq][2 * q]); mm[q] = __builtin_bit_cast(unsigned, x_regs[gq][2 * q + 1]); ll[q] = hh[q];   // lab: no split either
+#else
         if constexpr (F16) split2h(x_regs[gq][2 * q], x_regs[gq][2 * q + 1], hh[q], mm[q], amax);
         else split2(x_regs[gq][2 * q], x_regs[gq][2 * q + 1], hh[q], mm[q], ll[q]);
+#endif
       }
       limbs[gq][0] = u32x4{hh[0], hh[1], hh[2], hh[3]};
       limbs[gq][1] = u32x4{mm[0], mm[1], mm[2], mm[3]};
@@ -1370,6 +1379,175 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
         }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 3x3 convolution (pad 1, stride 1), f16x2, with the input staged ONCE per block of 32 input channels.  The kernel above reads
+// and splits the pixel operand again for each of the nine taps; with the pixel loads removed it runs 25-33 % faster
+// (scripts/lab/abl_split.sh 8).  Here a workgroup owns 128 output channels x an 8 x 16 block of output pixels; per channel
+// block it stages the 10 x 18 input patch (zero halo through the descriptor's bounds check), split into its two f16 limbs, as
+// [limb][k-group 4][patch pixel 180][8 channels] -- 22.5 KB -- and runs the nine taps from it: a tap's pixel fragment is the
+// patch row (block row + dy), columns dx .. dx + 15, sixteen consecutive 16-byte records.  The weights of a tap (16 KB) arrive by
+// LDS-DMA into one of two buffers while the previous tap computes; one barrier per tap, two more per channel block.
+//   per channel block and thread: 24 dword loads + 12 split pairs (the tap-by-tap form: 144 + 72)
+template <bool RELU>
+__global__ __launch_bounds__(256, 2)
+void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ scale,
+                               const float* __restrict__ shift, float* __restrict__ y, int Cin, int Cout, int Cpad, int H, int W,
+                               int tiles_c, int tiles_x, int tiles_y, unsigned* __restrict__ overflow) {
+  constexpr int PH = 10, PW = 18, PP = PH * PW;                  // patch
+  constexpr int P_KG = PP * 8, P_LIMB = 4 * P_KG;                // elements
+  constexpr int W_AT = 2 * P_LIMB, W_BUF = 2 * K32_LIMB;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[W_AT + 2 * W_BUF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tc = logical % tiles_c;
+  logical /= tiles_c;
+  const int tx = logical % tiles_x;
+  logical /= tiles_x;
+  const int ty = logical % tiles_y, img = logical / tiles_y;
+  const int c0 = tc * GB_M, oy0 = ty * 8, ox0 = tx * 16;
+  const int HW = H * W;
+  const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)img * Cin * HW, 0,
+                                                      (unsigned)((size_t)Cin * HW * 4), 0x00020000);
+  const unsigned plane = (unsigned)HW * 4u;
+  // staging items (patch pixel, k-group): item i = round * 256 + tid, pixel i % 180, k-group i / 180; 720 items in 3 rounds
+  unsigned it_voff[3];
+  int it_lds[3];
+  unsigned it_kg[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int i = r * 256 + tid;
+    const int kg = i / PP, pp = i - kg * PP;
+    const int py = pp / PW, px = pp - py * PW;
+    const int iy = oy0 + py - 1, ix = ox0 + px - 1;
+    const bool ok = i < 4 * PP && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    it_voff[r] = ok ? (unsigned)(iy * W + ix) * 4u : 0x80000000u;          // halo / beyond the map: read as 0
+    it_kg[r] = (unsigned)(kg < 4 ? kg : 3);
+    it_lds[r] = i < 4 * PP ? kg * P_KG + pp * 8 : -1;
+  }
+  float xr[3][8];
+  auto loadX = [&](int cib) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const unsigned so = (unsigned)(cib * 32 + 8 * it_kg[r]) * plane;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xr[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, it_voff[r], so + j * plane, 0));
+    }
+  };
+  float amax = 0.f;
+  auto stashX = [&]() {                                          // split + write the patch of the channel block in xr
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      unsigned hh[4], ll[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) split2h(xr[r][2 * q], xr[r][2 * q + 1], hh[q], ll[q], amax);
+      if (it_lds[r] >= 0) {
+        *reinterpret_cast<u32x4*>(lds + it_lds[r]) = u32x4{hh[0], hh[1], hh[2], hh[3]};
+        *reinterpret_cast<u32x4*>(lds + P_LIMB + it_lds[r]) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+      }
+    }
+    asm volatile("" : "+v"(amax));
+  };
+  // weight slabs of a tap: (array l, k-group kg of 4, row half) = 16 x 1 KB; wave w brings 4 w .. 4 w + 3.  Packed K order
+  // [channel block][tap][32]: 32-deep step index = cib * 9 + tap.
+  const size_t w_kg_stride = (size_t)Cpad * 8;
+  auto dmaW = [&](int step, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int sl = wave * 4 + i, l = sl >> 3, kg = (sl >> 1) & 3, half = sl & 1;
+      const __bf16* src = Wp + ((((size_t)(2 * step + (kg >> 1)) * 2 + l) * 2 + (kg & 1)) * w_kg_stride) + (size_t)(c0 + half * 64 + lane) * 8;
+      __bf16* dst = lds + W_AT + buf * W_BUF + l * K32_LIMB + (kg * GB_M + half * 64) * 8;
+      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int l15 = lane & 15, kg4 = lane >> 4;
+  const __bf16* wfr0 = lds + W_AT + (kg4 * GB_M + wr * 64 + l15) * 8;          // + buffer + array * K32_LIMB + row block * 128
+  const __bf16* xfr0 = lds + kg4 * P_KG + ((wc * 4) * PW + l15) * 8;           // + limb * P_LIMB + ((cb + dy) * PW + dx) * 8
+  auto frag = [](const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); };
+  auto mf = [](u32x4 a, u32x4 b, f32x4 c) { return mfma_k32<true>(a, b, c); };
+  const int NCB = Cin / 32, NSTEP = NCB * 9;
+  loadX(0);
+  dmaW(0, 0);
+  stashX();
+  int step = 0;
+  for (int cib = 0; cib < NCB; ++cib) {
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap, ++step) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own slabs of this tap (and, at tap 0, own patch rows) are in LDS
+      __builtin_amdgcn_s_barrier();                               // ... everybody's are; the other weight buffer is free
+      dmaW(step + 1 < NSTEP ? step + 1 : step, (step + 1) & 1);
+      if (tap == 0) loadX(cib + 1 < NCB ? cib + 1 : cib);         // next channel block's patch: lands under the nine taps
+      const __bf16* wfr = wfr0 + (step & 1) * W_BUF;
+      const int dy = tap / 3, dx = tap - 3 * dy;
+      const __bf16* xfr = xfr0 + (dy * PW + dx) * 8;
+      u32x4 whf[4], wlf[4], w2f[4];
+      u32x4 xh = frag(xfr), xl = frag(xfr + P_LIMB);               // pixel fragments one column block ahead of their MFMAs
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        whf[rb] = frag(wfr + rb * 128);
+        wlf[rb] = frag(wfr + K32_LIMB + rb * 128);
+      }
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) w2f[rb] = f16x2_lo_scale(whf[rb]);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {                             // small terms first: (2^-11 w_h, x_l') (w_l, x_h) (w_h, x_h)
+        u32x4 xhn = xh, xln = xl;
+        if (cb < 3) {
+          xhn = frag(xfr + (cb + 1) * PW * 8);
+          xln = frag(xfr + P_LIMB + (cb + 1) * PW * 8);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(w2f[rb], xl, acc[rb][cb]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wlf[rb], xh, acc[rb][cb]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(whf[rb], xh, acc[rb][cb]);
+        __builtin_amdgcn_sched_barrier(0);
+        xh = xhn;
+        xl = xln;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                 // everyone is done with this channel block's patch
+    if (cib + 1 < NCB) stashX();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the repeated last slabs: nothing may land after the end)
+  // BN affine (+ ReLU): register r of block (rb, cb) = channel 16 rb + 4 kg4 + r, pixel (row wc*4 + cb, column l15) of the tile
+  {
+    const auto srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scale), 0, scale ? (unsigned)Cout * 4u : 0u, 0x00020000);
+    const auto hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(shift), 0, shift ? (unsigned)Cout * 4u : 0u, 0x00020000);
+    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(y + (size_t)img * Cout * HW, 0, (unsigned)((size_t)Cout * HW * 4), 0x00020000);
+    const unsigned chpitch = (unsigned)HW * 4u;
+    const float unscale = f16x2_unscale(Wp, Cpad, 9 * Cin);
+    unsigned pvoff[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int oy = oy0 + wc * 4 + cb, ox = ox0 + l15;
+      pvoff[cb] = (oy < H && ox < W) ? (unsigned)(oy * W + ox) * 4u : 0x80000000u;
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const int chb = c0 + wr * 64 + rb * 16 + 4 * kg4;              // channels chb .. chb + 3 (>= Cout: dropped by the descriptor)
+      f32x4 sc4 = scale ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)chb * 4u, 0, 0))
+                        : f32x4{1.f, 1.f, 1.f, 1.f};
+      sc4 *= unscale;
+      const f32x4 sh4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, (unsigned)chb * 4u, 0, 0));
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = fmaf(acc[rb][cb][r], sc4[r], sh4[r]);
+          if (RELU) v = fmaxf(v, 0.f);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, pvoff[cb] + (unsigned)(chb + r) * chpitch, 0, 0);
+        }
+    }
+  }
+  f16x2_count_overflow(amax, overflow);
 }
 
 // W (N, K) f32 -> [k-tile K/16][limb 3][k-group 2][Npad][8] bf16, columns beyond N zero
@@ -1661,7 +1839,7 @@ extern "C" int pvsg_conv1x1_f16x2(const float* x, const void* w_packed, const fl
 }
 
 // [3P] mmdet ResNet Bottleneck.conv2 (3x3, pad 1, stride 1 or 2) + frozen BN + ReLU on the split kernel: implicit GEMM over the
-// nine taps (K = 9 * Cin).  w_packed = pvsg_gemm_bf16x3_pack of the (Cout, 9 * Cin) matrix w.permute(0, 2, 3, 1) (tap-major,
+// nine taps (K = 9 * Cin).  w_packed = the pack of the (Cout, 9 * Cin) matrix ordered [block of 32 input channels][tap][32] (see ops.conv3x3_bf16x3_pack;
 // channel-minor).  Direct-form arithmetic (18 Cin Cout flop per output pixel): it wins where the f32 kernels are weakest -- the
 // stride-2 layers (pvsg_conv3x3s2_affine) and, against Winograd (pvsg_conv3x3_winograd), the 64- and 512-channel layers.
 static int conv3x3_split_run(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B,
@@ -1686,6 +1864,22 @@ static int conv3x3_split_run(const float* x, const void* w_packed, const float* 
   const __bf16* wp = static_cast<const __bf16*>(w_packed);
   const float* nul = nullptr;
   unsigned* const noflags = nullptr;
+  {
+    const char* hsel = getenv("PVSG_CONV3X3_HALO");               // =0: the tap-by-tap form for stride 1 too (A/B tests)
+    if (f16 && stride == 1 && Cout > 64 && !(hsel && hsel[0] == '0')) {   // (<= 64 output channels: the 64-row tile of the tap-by-tap kernel)
+      const int tiles_x = (W + 15) / 16, tiles_y = (H + 7) / 8;
+      const long long hb = (long long)B * tiles_c * tiles_x * tiles_y;
+      PVSG_REQUIRE(hb < (1LL << 31), "%s: too many blocks", nm);
+      if (relu)
+        hipLaunchKernelGGL((conv3x3_f16x2_halo_kernel<true>), dim3((unsigned)hb), block, 0, st, x, wp, scale, shift, y, Cin, Cout, Cpad,
+                           H, W, tiles_c, tiles_x, tiles_y, overflow);
+      else
+        hipLaunchKernelGGL((conv3x3_f16x2_halo_kernel<false>), dim3((unsigned)hb), block, 0, st, x, wp, scale, shift, y, Cin, Cout, Cpad,
+                           H, W, tiles_c, tiles_x, tiles_y, overflow);
+      PVSG_LAUNCH_CHECK(nm);
+      return PVSG_OK;
+    }
+  }
 #define PVSG_C3_LAUNCH(R, TMV, F)                                                                                               \
   hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<R, false, false, false, TMV, 9, F>), grid, block, 0, st, x, wp, scale, shift, nul, \
                      nul, nul, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p, noflags, overflow)

@@ -659,12 +659,14 @@ def conv3x3_bf16x3_supported(cout, cin, h, w):
 
 
 def conv3x3_bf16x3_pack(weight):
-    """(Cout,Cin,3,3) -> limbs of the (Cout, 9*Cin) tap-major matrix for pvsg_conv3x3_bf16x3 (once per weight)."""
+    """(Cout,Cin,3,3) -> limbs of the (Cout, 9*Cin) matrix for pvsg_conv3x3_bf16x3 / _f16x2 (once per weight)."""
     w = _chk(weight, 'weight')
     Cout, Cin = w.shape[:2]
     if tuple(w.shape[2:]) != (3, 3) or not conv3x3_bf16x3_supported(Cout, Cin, 2, 2):
         raise RuntimeError('conv3x3_bf16x3_pack: unsupported weight shape %s' % (tuple(w.shape),))
-    return gemm_bf16x3_pack(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous())
+    # K order of the implicit GEMM: [block of 32 input channels][tap 3x3][32 channels] -- the nine taps of a channel block are
+    # consecutive steps, so their (shifted) reads of the same pixels find each other in the vector L1
+    return gemm_bf16x3_pack(w.reshape(Cout, Cin // 32, 32, 3, 3).permute(0, 1, 3, 4, 2).reshape(Cout, 9 * Cin).contiguous())
 
 
 def conv3x3_bf16x3(x, w_packed, cout, scale=None, shift=None, relu=True, out=None, stride=1):
