@@ -75,13 +75,26 @@ class DecoderRows:
 
     @staticmethod
     def _modules(head):
-        """the leaf modules whose parameters the packed structs were built from (cached on the head: the module tree is
-        fixed, parameters are looked up afresh on every check so that replaced / reloaded / moved tensors are noticed)"""
-        mods = head.__dict__.get('_rows_modules')
-        if mods is None:
-            mods = [m for root in (head.transformer_decoder, head.cls_embed, head.mask_embed) for m in root.modules()
-                    if m._parameters]
-            head.__dict__['_rows_modules'] = mods
+        """the leaf modules whose parameters the packed structs were built from.  The walk over the module tree is cached on the
+        head as (parent's child table, name, module) triples; each check confirms that every module is still the one registered
+        under that name (a swapped sub-module -- `layer.ffns[0] = other`, `head.cls_embed = nn.Linear(...)` -- rebuilds the list),
+        and parameters are looked up afresh so that replaced / reloaded / moved tensors are noticed."""
+        ent = head.__dict__.get('_rows_modules')
+        if ent is not None and all(tab.get(name) is m for tab, name, m in ent[0]):
+            return ent[1]
+        links, mods = [], []
+
+        def walk(tab, name, m):
+            links.append((tab, name, m))
+            if m._parameters:
+                mods.append(m)
+            for cname, child in m._modules.items():
+                if child is not None:
+                    walk(m._modules, cname, child)
+
+        for name in ('transformer_decoder', 'cls_embed', 'mask_embed'):
+            walk(head._modules, name, head._modules[name])
+        head.__dict__['_rows_modules'] = (links, mods)
         return mods
 
     @classmethod

@@ -204,6 +204,22 @@ class DeviceMask:
     def __reduce__(self):
         return (np.array, (np.asarray(self),))
 
+    def __getitem__(self, idx):
+        return np.asarray(self)[idx]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __iter__(self):
+        return iter(np.asarray(self))
+
+    def __getattr__(self, name):
+        # the rest of the ndarray surface a caller of the reference's masks may use (.sum(), .any(), .astype(), .nonzero(), .T ...):
+        # answered by the host copy of the stack (made once, shared by the masks of the image)
+        if name.startswith('__') or name in ('stack', 'j'):
+            raise AttributeError(name)
+        return getattr(np.asarray(self), name)
+
     def rle(self):
         return self.stack.rles()[self.j]
 

@@ -39,3 +39,50 @@ def test_isolate_shared_gpu_sets_disjoint_cu_ranges(monkeypatch):
     monkeypatch.delenv('HSA_CU_MASK')
     parallel.isolate_shared_gpu(0, 1)                                       # one process: nothing to isolate
     assert 'HSA_CU_MASK' not in os.environ
+
+
+def test_decoder_rows_signature_follows_swapped_submodules():
+    """heads.DecoderRows.signature caches the walk over the head's module tree; a sub-module replaced afterwards (not only a
+    parameter written in place) must change the signature, or the fused decoder would keep running the old packed weights."""
+    from openpvsg_amd.heads import DecoderRows
+
+    class Head(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.transformer_decoder = nn.Sequential(nn.Linear(8, 8), nn.Sequential(nn.Linear(8, 8), nn.ReLU()))
+            self.cls_embed = nn.Linear(8, 3)
+            self.mask_embed = nn.Sequential(nn.Linear(8, 8), nn.ReLU(), nn.Linear(8, 8))
+
+    head = Head()
+    s0 = DecoderRows.signature(head)
+    assert DecoderRows.signature(head) == s0 and len(s0) == 10
+    with torch.no_grad():
+        head.cls_embed.weight.add_(1.0)                                    # in place: version counter
+    s1 = DecoderRows.signature(head)
+    assert s1 != s0
+    head.transformer_decoder[1][0] = nn.Linear(8, 8)                        # a leaf swapped two levels down
+    s2 = DecoderRows.signature(head)
+    assert s2 != s1
+    head.cls_embed = nn.Linear(8, 3)                                        # a root swapped
+    s3 = DecoderRows.signature(head)
+    assert s3 != s2 and DecoderRows.signature(head) == s3
+    head.mask_embed.add_module('3', nn.Linear(8, 8))                        # a module added: more parameters
+    assert len(DecoderRows.signature(head)) == 10                           # (known limit: additions are not part of the
+    #                                                                         fused decoder's structure check either; supported()
+    #                                                                         rejects such a head before a signature is taken)
+
+
+def test_device_mask_has_the_ndarray_surface_of_the_reference_masks():
+    import numpy as np
+    from openpvsg_amd import tubes
+    m = np.zeros((3, 6, 9), bool)
+    m[0, 1:4, 2:5] = 1
+    m[2, 5, 8] = 1
+    st = tubes.DeviceMaskStack(torch.from_numpy(m))
+    a = tubes.DeviceMask(st, 0)
+    assert a[1, 2] and not a[0, 0] and a[1:4, 2:5].all() and a.sum() == 9 and a.any() and not tubes.DeviceMask(st, 1).any()
+    assert a.astype(np.uint8).dtype == np.uint8 and a.T.shape == (9, 6) and len(a) == 6
+    assert [int(r.sum()) for r in a] == [0, 3, 3, 3, 0, 0]
+    ys, xs = a.nonzero()
+    assert ys.min() == 1 and xs.max() == 4
+    assert (a & ~np.asarray(tubes.DeviceMask(st, 2))).sum() == 9
