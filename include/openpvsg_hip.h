@@ -268,6 +268,19 @@ int pvsg_mask_embed_forward(const float* feat_hwd, const int* pan_low, const int
                             const float* obj_inv_scale, float* out, float* out_normalised, int h, int w, int d,
                             int k, int n_obj, void* stream);
 
+/* ---- 8f row 4: IPS tube association -- reconstruction distance of the first association ----------
+ * Replaces the tail of reconsdot_distance, models/unitrack/core/association/matching.py:194-225 (two soft-maxes over
+ * the cell affinities, the einsum reconstructions, their normalisation and the two dot products), without forming
+ * the soft-max matrices or the reconstructions (csrc/reconsdot.hip).  Ptp / Pdp = Pt / Pd rounded up to 32.
+ *   A  (Nt*Ptp, Nd*Pdp) = F_trk F_det^T, the L2-normalised cell features of the tracks (rows, object-major) and of the
+ *      observations (columns), each object zero-padded to Pt (Pd) cells as get_track_feat :174-191 pads them, then to Ptp
+ *      (Pdp); cells p >= Pt / s >= Pd are ignored, the zero cells below that take part in the soft-max as in the reference;
+ *   Gt (Nt, Ptp, Ptp) = F_trk[t] F_trk[t]^T,  Gd (Nd, Pdp, Pdp) likewise (zero in the padding);  tmp = 100 there;
+ *   workspace: pvsg_reconsdot_workspace_bytes(Nt, Pt, Nd, Pd) bytes;  cost (Nt, Nd). */
+long long pvsg_reconsdot_workspace_bytes(int Nt, int Pt, int Nd, int Pd);
+int pvsg_reconsdot_cost(const float* A, const float* Gt, const float* Gd, int Nt, int Pt, int Nd, int Pd, float tmp,
+                        float* workspace, float* cost, void* stream);
+
 /* ---- pixel-decoder / backbone glue around the library convolutions (HBM streaming) -----------------
  * [3P] mmdet MSDeformAttnPixelDecoder.forward FPN step:
  *   out = lateral * scale[plane] + shift[plane] + bilinear_x2(top)      (GroupNorm as per-(image,channel) affine,

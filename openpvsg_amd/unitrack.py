@@ -227,6 +227,29 @@ def mask2box(masks_low):
     return boxes
 
 
+def mask2box_grouped(oy, ox, obj, n):
+    """mask2box for the cells of ALL objects of a frame at once: (oy, ox) cell coordinates, obj their object index (0..n-1).
+    The coordinate sums are integers below 2^24, i.e. exact in float32 in any order, so the centres are the same floats as
+    mask2box's; the mean absolute deviations are accumulated in float64 and rounded once (mask2box: float32 pairwise)."""
+    boxes = np.empty((n, 4), dtype=np.float64)
+    boxes[:] = (-1, -1, 10, 10)
+    cnt = np.bincount(obj, minlength=n)
+    has = cnt > 0
+    if not has.any():
+        return boxes
+    c32 = cnt.astype(np.float32)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        cy = np.bincount(obj, weights=oy, minlength=n).astype(np.float32) / c32
+        cx = np.bincount(obj, weights=ox, minlength=n).astype(np.float32) / c32
+        ady = np.abs(oy.astype(np.float32) - cy[obj]).astype(np.float64)
+        adx = np.abs(ox.astype(np.float32) - cx[obj]).astype(np.float64)
+        dy = np.maximum((np.bincount(obj, weights=ady, minlength=n) / cnt).astype(np.float32), np.float32(1))
+        dx = np.maximum((np.bincount(obj, weights=adx, minlength=n) / cnt).astype(np.float32), np.float32(1))
+    b = np.stack([cx - dx * 2, cy - dy * 2, cx + dx * 2, cy + dy * 2], 1).astype(np.float64)
+    boxes[has] = b[has]
+    return boxes
+
+
 def remove_duplicated_box(boxes, iou_th=0.5):
     """utils/box.py:140-154 ([3P] torchvision.ops.box_iou = plain IoU): walk the boxes in order, a kept box
     suppresses every other box overlapping it by more than iou_th; placeholder boxes are dropped."""
@@ -503,12 +526,45 @@ def iou_distance(atracks, btracks):  # matching.py:44-81
     return 1 - bbox_ious(a, b)
 
 
+def _padded_cells(feats):
+    """[(n_i, d)] -> ((N * P32, d) zero-padded rows, object-major; P = longest object, get_track_feat matching.py:174-191; P32 = P
+    rounded up to 32).  One concatenation and one scatter instead of a copy per object."""
+    n = [int(f.shape[0]) for f in feats]
+    p = max(n)
+    pp = (p + 31) // 32 * 32
+    rows = np.concatenate([np.arange(c, dtype=np.int64) + i * pp for i, c in enumerate(n)])
+    out = torch.zeros((len(n) * pp, feats[0].shape[1]), device=feats[0].device, dtype=torch.float32)
+    out.index_copy_(0, torch.from_numpy(rows).to(out.device, non_blocking=True), torch.cat([f.float() for f in feats]))
+    return out, p, pp
+
+
 def reconsdot_cost(trk_feats, det_feats, tmp=100.0):
     """matching.py:179-225 on the device.  trk_feats / det_feats: lists of L2-normalised (n_cells_i, d) tensors.
     With A = F_trk F_det^T over all (zero-padded) cells, P = softmax_rows(tmp A), Pc = softmax_cols(tmp A):
       <recons_trk[t,d], f_trk[t]>  = sum over the (t,d) block of P * A
       ||recons_trk[t,d]||^2        = sum_p  P[(t,p),(d,:)] G_d P[(t,p),(d,:)]^T,   G_d = F_d F_d^T
-    and symmetrically with Pc and G_t, so the (cells, objects, d) reconstructions are never materialised."""
+    and symmetrically with Pc and G_t, so the (cells, objects, d) reconstructions are never materialised.  A and the Gram
+    matrices come from three GEMM calls; the rest (both soft-maxes, the block sums, the quadratic forms on the matrix cores,
+    the final normalisation) is `pvsg_reconsdot_cost` (csrc/reconsdot.hip): four passes over A instead of the fourteen the
+    tensor-op form below makes."""
+    Ft, Pt, Ptp = _padded_cells(trk_feats)
+    Fd, Pd, Pdp = _padded_cells(det_feats)
+    Nt, Nd, d = len(trk_feats), len(det_feats), Ft.shape[1]
+    if d % 32 == 0 and d >= 64:
+        # the affinities on the split-f16 matrix-core GEMM (f32-class, csrc/gemm_bf16x3.hip): normalised features are within
+        # its range by construction; 0.46 ms against the library's f32 GEMM's 1.0 for 28 x 27 objects of 300 cells
+        A = ops.gemm_bf16x3(Ft, ops.gemm_bf16x3_pack(Fd), Nd * Pdp)
+    else:
+        A = Ft @ Fd.t()
+    Ft3, Fd3 = Ft.view(Nt, Ptp, d), Fd.view(Nd, Pdp, d)
+    Gt = torch.bmm(Ft3, Ft3.transpose(1, 2))
+    Gd = torch.bmm(Fd3, Fd3.transpose(1, 2))
+    return ops.reconsdot_cost(A, Gt, Gd, Nt, Pt, Nd, Pd, tmp)
+
+
+def reconsdot_cost_tensor_ops(trk_feats, det_feats, tmp=100.0):
+    """The same quantity with torch tensor operations only (round 1-3 form; kept as the yardstick of tests/test_unitrack.py
+    and scripts/lab/reconsdot_profile.py, not called by the tracker)."""
     Ft = torch.nn.utils.rnn.pad_sequence(trk_feats, batch_first=True)
     Fd = torch.nn.utils.rnn.pad_sequence(det_feats, batch_first=True)
     Nt, Pt, d = Ft.shape
@@ -723,6 +779,7 @@ class PanopticObs:
         self.ids = [int(i) for i in ids]
         self._runs = None
         self._rles = None
+        self.prepared = None     # MaskAssociationTracker.prepare_frames: (cell maps, embeddings, boxes) made for a batch of frames
 
     def __len__(self):
         return len(self.ids)
@@ -878,11 +935,113 @@ class MaskAssociationTracker(AssociationTracker):
                 embs[i] = (r, F.normalize(r, dim=1))
         return low, embs
 
+    @staticmethod
+    def feature_size(H, W):
+        """rows, columns of the appearance features of an (H, W) frame: 7x7 /2 (pad 3), max-pool 3x3 /2 (pad 1), layer2 /2"""
+        f = lambda x: ((x + 6 - 7) // 2 + 1 + 2 - 3) // 2 + 1
+        g = lambda x: (x + 2 - 3) // 2 + 1
+        return g(f(H)), g(f(W))
+
+    def prepare_frames(self, feats, obs_list, images=None):
+        """Everything `prepare_obs` needs that does not depend on the tracks, for a batch of frames at once: the id maps at
+        the feature stride (one device->host copy for the batch instead of one per frame), the cells of every object from ONE
+        pass over each low-resolution map (the reference stacks n full masks and scans each), boxes from the grouped cells,
+        all cell lists in one upload, then one `pvsg_mask_embed_forward` launch per frame with nothing waiting on it.
+        Fills `obs.prepared`.  Same results as extract_emb + mask2box frame by frame (tests/test_unitrack.py).
+        With `images` (B,3,H,W) instead of `feats` the appearance CNN is launched here, after the low-resolution maps have come
+        back and before the host works through them, so that the two overlap; returns the list of `Features`."""
+        if images is not None:
+            hw = self.feature_size(*images.shape[-2:])
+        else:
+            hw = tuple(feats[0].hwd.shape[:2]) if feats else None
+        sel = [i for i, o in enumerate(obs_list) if len(o)]
+        same = sel and len({tuple(obs_list[i].pan.shape) for i in sel}) == 1 and \
+            (images is not None or len({tuple(feats[i].hwd.shape) for i in sel}) == 1)
+        low = None
+        if same:
+            pans = torch.stack([obs_list[i].pan for i in sel])                 # (F, H, W) int32
+            nf, H, W = pans.shape
+            h, w = hw
+            low_dev = pans[:, self._nearest(h, H)][:, :, self._nearest(w, W)].contiguous()
+            low = low_dev.cpu().numpy()
+        if images is not None:
+            feats = self.features(images)                                      # asynchronous: runs while the host plans below
+            if tuple(feats[0].hwd.shape[:2]) != hw:                            # an appearance model with another geometry
+                if same:
+                    return self.prepare_frames(feats, obs_list) or feats
+        if not same:
+            return feats
+        live = [(feats[i], obs_list[i]) for i in sel]
+        d = live[0][0].hwd.shape[2]
+        max_area = _get(self.mots, 'max_mask_area')
+        tmpl = int(np.prod(_get(self.mots, 'feat_size')))
+        plan, upload, off = [], [], 0
+        for f, (feat, obs) in enumerate(live):
+            ids = np.asarray(obs.ids, dtype=np.int64)
+            n = len(ids)
+            lm = low[f]
+            flat = lm.ravel()
+            by_id = np.argsort(ids, kind='stable')
+            sid = ids[by_id]
+            pos = np.minimum(np.searchsorted(sid, flat), n - 1)
+            cell = np.nonzero(sid[pos] == flat)[0]                             # row-major, like np.nonzero of each mask
+            obj = by_id[pos[cell]]
+            g = np.argsort(obj, kind='stable')
+            cell, obj = cell[g], obj[g]
+            oy, ox = cell // w, cell - (cell // w) * w
+            area = np.bincount(obj, minlength=n)
+            boxes = mask2box_grouped(oy, ox, obj, n)
+            starts = np.concatenate(([0], np.cumsum(area)))
+            scales, counts = np.ones(n, np.float32), area.copy()
+            if (area > max_area).any():
+                parts = []
+                for i in range(n):
+                    if area[i] == 0:
+                        continue
+                    if area[i] > max_area:                                     # mask.py:34-39: shrink to ~max_mask_area cells
+                        sf = math.sqrt(max_area / float(area[i]))
+                        inv = np.float32(1.0 / sf)
+                        scales[i] = inv
+                        sel = lm[nearest_index(int(math.floor(h * sf)), h, inv)][:, nearest_index(int(math.floor(w * sf)), w, inv)] == ids[i]
+                        yy, xx = np.nonzero(sel)
+                    else:
+                        yy, xx = oy[starts[i]:starts[i + 1]], ox[starts[i]:starts[i + 1]]
+                    counts[i] = len(yy)
+                    parts.append(np.stack([np.full(len(yy), i), yy, xx], 1))
+                ent = np.concatenate(parts) if parts else np.zeros((0, 3), np.int64)
+            else:
+                ent = np.stack([obj, oy, ox], 1)
+            k = len(ent)
+            upload += [ent.astype(np.int32).ravel(), ids.astype(np.int32), scales.view(np.int32)]
+            plan.append((feat, obs, boxes, counts, k, n, off))
+            off += 3 * k + 2 * n
+        buf = torch.from_numpy(np.concatenate(upload)).to(self.device)
+        for f, (feat, obs, boxes, counts, k, n, off) in enumerate(plan):
+            embs = [None] * n
+            if k:
+                raw, nrm = ops.mask_embed(feat.hwd, low_dev[f], buf[off:off + 3 * k].view(k, 3), buf[off + 3 * k:off + 3 * k + n],
+                                          buf[off + 3 * k + n:off + 3 * k + 2 * n].view(torch.float32))
+                o = 0
+                for i in range(n):
+                    if counts[i]:
+                        embs[i] = (raw[o:o + counts[i]], nrm[o:o + counts[i]])
+                        o += counts[i]
+            for i in range(n):
+                if embs[i] is None:       # vanished at the feature stride: mask.py:46 draws noise (unseeded there)
+                    r = torch.randn(tmpl, d, generator=self._empty_gen).to(self.device)
+                    embs[i] = (r, F.normalize(r, dim=1))
+            obs.prepared = (embs, boxes)
+        return feats
+
     def prepare_obs(self, img, img0, obs, embs=None):  # mask.py:49-63
         if obs.shape[0] == 0:
             return []
-        low, embs = self.extract_emb(img, obs)
-        boxes = mask2box(low)
+        if getattr(obs, 'prepared', None) is not None:
+            embs, boxes = obs.prepared
+            obs.prepared = None          # the tracks keep what they use; the rest of the frame's embeddings can go
+        else:
+            low, embs = self.extract_emb(img, obs)
+            boxes = mask2box(low)
         keep = remove_duplicated_box(boxes, iou_th=0.7)
         return [STrack(tlbr_to_tlwh(boxes[k]), 1, embs[k], self.buffer_size, obs[k], ac=True) for k in keep]
 
@@ -946,6 +1105,64 @@ class LoadOutputsFromMask2Former:
                                                     cls_id=i % INSTANCE_OFFSET) for i in ids]
 
 
+    def panoptic_obs_batch(self, indices, device):
+        """`panoptic_obs` for several frames with two device->host copies in all: the run boundaries of every map (their labels
+        are the ids; np.unique per frame: one sort and one wait each), the query features of every object in one block."""
+        pans = [torch.as_tensor(self.pan_masks_all_images[i]).to(device=device, dtype=torch.int32) for i in indices]
+        if not pans or len({tuple(p.shape) for p in pans}) != 1:
+            return [self.panoptic_obs(i, device) for i in indices]
+        # column-major run boundaries of every map in one scan: the MOTS codes are built from them (PanopticObs.runs), and the
+        # ids of a map are the labels of its runs -- no sort (np.unique) or histogram of the 0.9 M pixels of each frame
+        stack = torch.stack(pans)
+        nf, H, W = stack.shape
+        ft = stack.transpose(1, 2).reshape(nf, H * W)
+        idx = (ft[:, 1:] != ft[:, :-1]).nonzero()
+        host = torch.cat([idx.reshape(-1), ft[idx[:, 0], idx[:, 1] + 1].long(), ft[:, 0].long()]).cpu().numpy()
+        m = idx.shape[0]
+        run_f, run_p = host[:2 * m].reshape(m, 2).T
+        run_lab, first_lab = host[2 * m:3 * m], host[3 * m:]
+        bounds = np.searchsorted(run_f, np.arange(nf + 1))
+        ids_of, runs_of = [], []
+        for f in range(nf):
+            a, b = bounds[f], bounds[f + 1]
+            st = np.concatenate(([0], run_p[a:b] + 1))
+            lab = np.concatenate(([first_lab[f]], run_lab[a:b]))
+            runs_of.append((st, np.diff(np.r_[st, H * W]), lab))
+            ids_of.append([int(i) for i in np.unique(lab) if i != self.num_classes])      # ascending, like np.unique(pan)
+        flat, owner = [], []
+        for f, i in enumerate(indices):
+            qfd = self.query_feat_dicts_all_images[i]
+            if ids_of[f]:
+                assert len(qfd) == len(ids_of[f]), 'Masks and query feats should match!'
+            for oid in ids_of[f]:
+                for x in qfd[oid]:
+                    flat.append(x)
+                owner.append(len(qfd[oid]))
+        if flat and all(hasattr(x, 'detach') and x.device == flat[0].device and x.numel() == flat[0].numel() for x in flat):
+            block = torch.stack([x.detach().reshape(-1) for x in flat]).cpu().numpy()
+            shape = tuple(_squeezed(flat[0].shape))
+            arrs = [block[j].reshape(shape) for j in range(len(flat))]
+        else:
+            arrs = [_np(x).squeeze() for x in flat]
+        out, j, o = [], 0, 0
+        for f, i in enumerate(indices):
+            qfs = []
+            for oid in ids_of[f]:
+                c = owner[o]
+                o += 1
+                qf = arrs[j] if c == 1 else np.stack(arrs[j:j + c]).mean(axis=0)
+                j += c
+                qfs.append(dict(query_feat=qf, cls_id=oid % INSTANCE_OFFSET))
+            obs = PanopticObs(pans[f], ids_of[f], device)
+            obs._runs = runs_of[f]
+            out.append((obs, qfs))
+        return out
+
+
+def _squeezed(shape):
+    return [int(d) for d in shape if d != 1]
+
+
 def _np(x):
     return x.detach().cpu().numpy() if hasattr(x, 'detach') else np.asarray(x)
 
@@ -960,20 +1177,38 @@ def eval_seq(data_cfg, tracker_cfg, outputs, classes, save_root=None, return_res
     BaseTrack.reset_count()
     tracker = (tracker_cls or MaskAssociationTracker)(tracker_cfg, app_model)
     down = _get(tracker_cfg['common'] if isinstance(tracker_cfg, dict) else tracker_cfg.common, 'down_factor', 8)
-    feats = {}
-    need = [i for i in range(len(loader)) if bool((loader.pan_masks_all_images[i] != loader.num_classes).any())]
-    for s in range(0, len(need), batch):
-        idx = need[s:s + batch]
-        for i, f in zip(idx, tracker.features(torch.stack([loader.image(i).to(tracker.device) for i in idx]))):
-            feats[i] = f
+    pm = loader.pan_masks_all_images
+    if len(pm) and all(torch.is_tensor(p) and p.is_cuda and p.shape == pm[0].shape for p in pm):
+        flags = (torch.stack(list(pm)) != loader.num_classes).flatten(1).any(1).tolist()     # one wait for the video
+    else:
+        flags = [bool((p != loader.num_classes).any()) for p in pm]
+    need = [i for i, fl in enumerate(flags) if fl]
+    ready = {}
+
+    def prepare(idx):
+        """the part of the work that does not depend on the tracks, for `batch` frames at a time: appearance CNN, ids, query
+        features, cells / boxes / embeddings of every observation (MaskAssociationTracker.prepare_frames)"""
+        obs_qf = loader.panoptic_obs_batch(idx, tracker.device)
+        imgs = torch.stack([loader.image(i).to(tracker.device) for i in idx])
+        if hasattr(tracker, 'prepare_frames'):
+            fs = tracker.prepare_frames(None, [o for o, _ in obs_qf], images=imgs)
+        else:
+            fs = tracker.features(imgs)
+        for i, f, (o, q) in zip(idx, fs, obs_qf):
+            ready[i] = (f, o, q)
+
     results = []
     frame_id = -1
+    nxt = 0
     for frame_id in range(len(loader)):
-        if frame_id not in feats:              # nothing in this frame (the tracker's own frame counter stands still)
+        if nxt < len(need) and frame_id == need[nxt] and frame_id not in ready:
+            prepare(need[nxt:nxt + batch])
+        if frame_id not in ready:              # nothing in this frame (the tracker's own frame counter stands still)
             results.append((frame_id + 1, [], [], []))
             continue
-        obs, query_feats = loader.panoptic_obs(frame_id, tracker.device)
-        targets, _ = tracker.update(feats.pop(frame_id), None, obs, query_feats, 0)
+        nxt += 1
+        feat, obs, query_feats = ready.pop(frame_id)
+        targets, _ = tracker.update(feat, None, obs, query_feats, 0)
         tlwhs, ids, masks = [], [], []
         for t in targets:
             rle = t.mask.rle() if isinstance(t.mask, LazyMask) else rle_encode(np.asarray(t.mask).astype(np.uint8))

@@ -86,10 +86,11 @@ def step():
     return st
 
 
-for _ in range(3):
-    s = step()
-runs = [step() for _ in range(5)]
-avg = {k: float(np.mean([r[k] for r in runs])) for k in runs[0]}
-avg['frames'] = T
-avg['frames_per_s'] = T / (avg['total_ms'] / 1e3)
-print(json.dumps(avg))
+if __name__ == '__main__':
+    for _ in range(3):
+        s = step()
+    runs = [step() for _ in range(5)]
+    avg = {k: float(np.mean([r[k] for r in runs])) for k in runs[0]}
+    avg['frames'] = T
+    avg['frames_per_s'] = T / (avg['total_ms'] / 1e3)
+    print(json.dumps(avg))

@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COUNTERS = ['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'GRBM_GUI_ACTIVE']
 RUNS = [('conv3x3_bench.py', ['32', '', 'own']), ('gemm_bf16x3_bench.py', ['own'])]
-NAMES = ('winograd_f2x3_kernel', 'conv3x3s2_kernel', 'gemm_f16x2_dma_kernel', 'gemm_f16x2_t256_kernel', 'gemm_bf16x3_kernel', 'gemm_bf16x3_k32_kernel', 'conv1x1_bf16x3_kernel',
+NAMES = ('winograd_f2x3_kernel', 'conv3x3s2_kernel', 'gemm_f16x2_dma_kernel', 'gemm_f16x2_t256_kernel', 'conv3x3_f16x2_halo_kernel', 'gemm_bf16x3_kernel', 'gemm_bf16x3_k32_kernel', 'conv1x1_bf16x3_kernel',
          'conv1x1_bf16x3_k32_kernel', 'stem7x7_kernel')
 
 

@@ -50,15 +50,17 @@ def split_entry(fn):
     if m:
         name, targs = m.group(1), [t.strip() for t in m.group(2).split(',')]
     else:                                            # rocprofv3 leaves the long instantiations mangled: ...kernelILb1ELb0E...Li128E...E
-        m = re.search(r'(gemm_f16x2_t256_kernel|gemm_f16x2_dma_kernel|gemm_bf16x3_k32_kernel|conv1x1_bf16x3_k32_kernel)I((?:L[bi]\d+E)+)E', fn)
+        m = re.search(r'(gemm_f16x2_t256_kernel|gemm_f16x2_dma_kernel|gemm_bf16x3_k32_kernel|conv1x1_bf16x3_k32_kernel|conv3x3_f16x2_halo_kernel)I((?:L[bi]\d+E)+)E', fn)
         if not m:
             return None
         name = m.group(1)
         targs = [('true' if v == '1' else 'false') if t == 'b' else v for t, v in re.findall(r'L([bi])(\d+)E', m.group(2))]
     if name == 'gemm_f16x2_t256_kernel':
         return 'pvsg_gemm_f16x2_add_layernorm' if len(targs) > 1 and targs[1] == 'true' else 'pvsg_gemm_f16x2'
-    if name == 'gemm_f16x2_dma_kernel':
+    if name in ('gemm_f16x2_dma_kernel',):
         return 'pvsg_gemm_f16x2'
+    if name == 'conv3x3_f16x2_halo_kernel':
+        return 'pvsg_conv3x3_f16x2'
     if name == 'gemm_bf16x3_k32_kernel':
         return 'pvsg_gemm_f16x2' if len(targs) > 1 and targs[1] == 'true' else 'pvsg_gemm_bf16x3'
     if name == 'conv1x1_bf16x3_k32_kernel':          # <RELU, RESIDUAL, IN_NORM, BITS, TM, TAPS, F16>

@@ -75,6 +75,29 @@ def test_boxes_and_assignment_host_logic():
     assert m.shape == (0, 2) and ua == () and ub == (0, 1, 2)
 
 
+def test_boxes_from_grouped_cells_equal_mask2box():
+    """unitrack.mask2box_grouped (all objects of a frame from one pass over the low-resolution id map) against mask2box
+    (one mask at a time, the reference's form): same centres exactly, deviations within float32 rounding."""
+    from openpvsg_amd import unitrack as T
+    rs = np.random.RandomState(7)
+    h, w, n = 90, 160, 9
+    lab = np.full((h, w), -1)
+    for i in range(n - 2):
+        y, x = rs.randint(0, h - 10), rs.randint(0, w - 10)
+        lab[y:y + rs.randint(1, 60), x:x + rs.randint(1, 90)] = i
+    lab[rs.uniform(size=(h, w)) < 0.05] = n - 2                     # scattered cells; object n-1 has none
+    masks = np.stack([lab == i for i in range(n)])
+    cell = np.nonzero(lab.ravel() >= 0)[0]
+    obj = lab.ravel()[cell]
+    g = np.argsort(obj, kind='stable')
+    cell, obj = cell[g], obj[g]
+    got = T.mask2box_grouped(cell // w, cell % w, obj, n)
+    ref = T.mask2box(masks)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+    assert got[n - 1].tolist() == [-1, -1, 10, 10]
+    assert T.remove_duplicated_box(got, 0.7).tolist() == T.remove_duplicated_box(ref, 0.7).tolist()
+
+
 def test_tracker_refuses_cpu():
     from openpvsg_amd import unitrack as T
     with pytest.raises(RuntimeError, match='no CPU path'):
@@ -137,6 +160,38 @@ def test_mask_embed_kernel_matches_extract_emb(hip_lib):
 
 
 @pytest.mark.gpu
+def test_prepare_frames_equals_frame_by_frame_preparation(hip_lib):
+    """The batched preparation of eval_seq (ids from one histogram, cells from one pass per low-resolution map, one upload,
+    run lists of all maps from one scan) gives what panoptic_obs + extract_emb + mask2box give frame by frame."""
+    from openpvsg_amd import unitrack as T
+    frames, outputs = ips_video(T=6, H=720, W=1280, seed=5, empty_frames=(2,))
+    model, _ = _app_model()
+    tr = T.MaskAssociationTracker(tracker_cfg(), app_model=model)
+    tr2 = T.MaskAssociationTracker(tracker_cfg(), app_model=model)
+    loader = T.LoadOutputsFromMask2Former(None, outputs, tracker_cfg(), 126, frames=frames)
+    idx = [0, 1, 3, 4, 5]
+    feats = tr.features(torch.stack([loader.image(i) for i in idx]).cuda())
+    batch = loader.panoptic_obs_batch(idx, tr.device)
+    tr.prepare_frames(feats, [o for o, _ in batch])
+    big = 0
+    for i, f, (obs, qfs) in zip(idx, feats, batch):
+        o1, q1 = loader.panoptic_obs(i, tr.device)
+        assert obs.ids == o1.ids and len(qfs) == len(q1)
+        for a, b in zip(qfs, q1):
+            assert a['cls_id'] == b['cls_id'] and a['query_feat'].shape == b['query_feat'].shape
+            np.testing.assert_array_equal(a['query_feat'], b['query_feat'])
+        for x, y in zip(obs._runs, o1.runs()):
+            np.testing.assert_array_equal(x, y)
+        embs, boxes = obs.prepared
+        low, embs1 = tr2.extract_emb(f, o1)
+        np.testing.assert_allclose(boxes, T.mask2box(low), rtol=0, atol=2e-5)
+        for (r, nrm), (r1, n1) in zip(embs, embs1):
+            assert torch.equal(r, r1) and torch.equal(nrm, n1)
+            big += int(low.reshape(len(low), -1).sum(1).max() > 300)
+    assert big                                                        # the resampled (> max_mask_area) branch was taken
+
+
+@pytest.mark.gpu
 def test_reconsdot_cost_matches_reference_vector(hip_lib):
     from openpvsg_amd import unitrack as T
     g = np.load(os.path.join(G, 'unitrack_reconsdot.npz'))
@@ -167,6 +222,31 @@ def test_reconsdot_cost_matches_reference_vector(hip_lib):
     np.testing.assert_allclose(cost, ref, atol=5e-4)
     assert np.abs(cost - ref).mean() < 2e-5
     assert cost[0, 1] == cost[0].min() and cost[2, 3] == cost[2].min()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('trk_cells,det_cells', [((300, 41, 7, 180, 299, 64, 12), (120, 300, 33, 5, 210)),
+                                                 ((1,), (1,)), ((33,), (32, 31, 64)), ((5, 700), (2, 3)),
+                                                 (tuple(range(20, 300, 10)), tuple(range(25, 295, 10)))])
+def test_reconsdot_fused_kernels_equal_the_tensor_op_form(hip_lib, trk_cells, det_cells):
+    """pvsg_reconsdot_cost (soft-max statistics, block sums and the quadratic forms on the f32 matrix cores, csrc/reconsdot.hip)
+    against the same quantity from torch tensor operations: ragged objects, cell counts around the 32-cell strips, one cell,
+    more than 512 cells (LDS above 64 KB), the 28 x 27 objects of the 720p bench; and twice the same bits."""
+    from openpvsg_amd import unitrack as T
+    gen = torch.Generator().manual_seed(len(trk_cells) * 131 + len(det_cells))
+    f = lambda n: torch.nn.functional.normalize(torch.relu(torch.randn(n, 256, generator=gen)), dim=1).cuda()
+    trk, det = [f(n) for n in trk_cells], [f(n) for n in det_cells]
+    if len(trk) > 1 and len(det) > 1:
+        k = min(trk[0].shape[0], det[1].shape[0])
+        det[1] = torch.nn.functional.normalize(det[1] + 0, dim=1)
+        det[1][:k] = torch.nn.functional.normalize(trk[0][:k] + 0.2 * det[1][:k], dim=1)       # a planted pair
+    ref = T.reconsdot_cost_tensor_ops(trk, det, 100.0).double().cpu().numpy()
+    got = T.reconsdot_cost(trk, det, 100.0)
+    assert got.shape == (len(trk), len(det)) and got.dtype == torch.float32
+    np.testing.assert_allclose(got.double().cpu().numpy(), ref, rtol=0, atol=3e-6)
+    assert torch.equal(got, T.reconsdot_cost(trk, det, 100.0))
+    if len(trk) > 1 and len(det) > 1:
+        assert int(got[0].argmin()) == 1
 
 
 @pytest.mark.gpu
