@@ -35,6 +35,13 @@ const char* pvsg_last_error(void);
 const char* pvsg_version(void);
 int pvsg_abi_version(void);
 
+/* Host-side codec of the result formats (no device work): COCO compressed run-length strings of many masks at once, what
+ * [3P] pycocotools `mask.encode` / rleToString produce for models/unitrack/utils/io.py:14-36 (MOTS lines) and mmdet
+ * `encode_mask_results`.  counts: run lengths of all masks back to back (zeros first), seg[j] of them belong to mask j;
+ * out: >= 13 bytes per count; out_len[j] characters belong to mask j.  Returns the total number of characters (-1: bad args). */
+long long pvsg_rle_counts_to_chars(const long long* counts, const long long* seg, int nseg, unsigned char* out,
+                                   long long* out_len);
+
 /* ---- a1: multi-scale deformable attention sampling core ----------------------------------
  * Replaces [3P] mmcv.ops.multi_scale_deform_attn: ext_module.ms_deform_attn_forward(value,
  * spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step)

@@ -65,6 +65,7 @@ SIGNATURES = {
     'pvsg_minvis_chain': [_c_f, _c_f, _c_f, _i, _i, _i, _i, _c_f],
     'pvsg_mask_embed_forward': [_c_f] * 7 + [_i] * 5 + [_c_f],
     'pvsg_reconsdot_workspace_bytes': [_i, _i, _i, _i],
+    'pvsg_rle_counts_to_chars': [_c_f, _c_f, _i, _c_f, _c_f],
     'pvsg_reconsdot_cost': [_c_f] * 3 + [_i] * 4 + [_f, _c_f, _c_f, _c_f],
     'pvsg_fpn_merge_up2x': [_c_f] * 5 + [_ll, _i, _i, _c_f],
     'pvsg_stem_bn_relu_pool': [_c_f] * 4 + [_ll, _i, _i, _i, _c_f],
@@ -95,7 +96,7 @@ SIGNATURES = {
 }
 # entry points that return a value instead of a status code
 VALUE_RETURNING = ('pvsg_xattn_num_splits', 'pvsg_gemm_bf16x3_packed_elems', 'pvsg_gemm_f16x2_packed_elems',
-                   'pvsg_minvis_chain_workspace_bytes', 'pvsg_reconsdot_workspace_bytes',
+                   'pvsg_minvis_chain_workspace_bytes', 'pvsg_reconsdot_workspace_bytes', 'pvsg_rle_counts_to_chars',
                    'pvsg_decoder_rows_post_workspace_bytes')
 
 _lib = None
@@ -125,7 +126,8 @@ def load():
         except AttributeError as e:
             raise BackendMissingError('symbol %s missing from %s' % (name, LIB_PATH)) from e
         f.restype = _ll if name in ('pvsg_gemm_bf16x3_packed_elems', 'pvsg_gemm_f16x2_packed_elems', 'pvsg_minvis_chain_workspace_bytes',
-                                   'pvsg_decoder_rows_post_workspace_bytes', 'pvsg_reconsdot_workspace_bytes') else _i
+                                   'pvsg_decoder_rows_post_workspace_bytes', 'pvsg_reconsdot_workspace_bytes',
+                                   'pvsg_rle_counts_to_chars') else _i
         f.argtypes = argtypes
     _lib = lib
     try:                                    # loud, once: a second tenant on the GPU without a CU partition (parallel.py)

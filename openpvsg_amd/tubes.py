@@ -48,7 +48,39 @@ def rle_counts_to_string(counts):
 
 def rle_counts_to_strings(counts, seg_lengths):
     """The same for MANY masks at once: `counts` = the run lengths of all masks back to back, seg_lengths[j] of them belong
-    to mask j.  One vectorised pass instead of one per mask (100 instance masks per image)."""
+    to mask j.  Host code either way: the library's C codec (`pvsg_rle_counts_to_chars`, 0.05 ms for the 27 objects of a 720p
+    frame) or, where the library is not built, the vectorised numpy form below (0.65 ms); tests/test_tubes.py holds them equal."""
+    c = np.ascontiguousarray(counts, dtype=np.int64)
+    seg = np.ascontiguousarray(seg_lengths, dtype=np.int64)
+    if seg.size == 0:
+        return []
+    lib = _codec()
+    if lib is not None:
+        out = np.empty(13 * c.size + 1, np.uint8)
+        lens = np.empty(seg.size, np.int64)
+        total = lib.pvsg_rle_counts_to_chars(c.ctypes.data, seg.ctypes.data, int(seg.size), out.ctypes.data, lens.ctypes.data)
+        if total < 0:
+            raise RuntimeError('pvsg_rle_counts_to_chars failed')
+        raw = out[:total].tobytes().decode('ascii')
+        ends = np.cumsum(lens)
+        return [raw[e - n:e] for e, n in zip(ends.tolist(), lens.tolist())]
+    return rle_counts_to_strings_numpy(c, seg)
+
+
+_CODEC = []
+
+
+def _codec():
+    if not _CODEC:
+        try:
+            from . import _lib
+            _CODEC.append(_lib.load())
+        except Exception:                                     # library not built (host-only use of the formats)
+            _CODEC.append(None)
+    return _CODEC[0]
+
+
+def rle_counts_to_strings_numpy(counts, seg_lengths):
     c = np.asarray(counts, dtype=np.int64)
     seg = np.asarray(seg_lengths, dtype=np.int64)
     starts = np.concatenate(([0], np.cumsum(seg)[:-1]))

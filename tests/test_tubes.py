@@ -359,3 +359,22 @@ def test_device_tubes_to_files_to_relation_evaluate(hip_lib, tmp_path):
 def _masks_for(pipe, det, clip, T):
     with torch.no_grad():
         return det.panoptic_head.clip_logits(det.extract_feat(clip), 1, T)[1][0]
+
+
+def test_rle_string_codec_c_and_numpy_forms_agree():
+    """tubes.rle_counts_to_strings: the library's host codec (pvsg_rle_counts_to_chars) against the numpy form and the
+    one-mask-at-a-time form, on run lists with negative deltas, values needing up to 5 characters, empty masks."""
+    rs = np.random.RandomState(11)
+    segs, counts = [], []
+    for j in range(40):
+        n = int(rs.choice([0, 1, 2, 3, 4, 7, 50, 400]))
+        c = rs.randint(0, int(rs.choice([2, 40, 5000, 921600])), n).astype(np.int64)
+        segs.append(n)
+        counts.append(c)
+    flat = np.concatenate(counts) if counts else np.zeros(0, np.int64)
+    got = tubes.rle_counts_to_strings(flat, segs)
+    assert got == tubes.rle_counts_to_strings_numpy(flat, segs)
+    assert got == [tubes.rle_counts_to_string(c) for c in counts]
+    assert tubes.rle_counts_to_strings(np.zeros(0, np.int64), []) == []
+    m = rs.uniform(size=(45, 70)) < 0.3
+    assert tubes.rle_decode(tubes.rle_encode(m)).astype(bool).tolist() == m.tolist()
