@@ -294,15 +294,57 @@ __device__ __forceinline__ float4 msda_sample_query(const float* __restrict__ va
   return acc;
 }
 
-template <int L, int P>
+// Order in which the queries of one image are WORKED ON when they are the cells of the value pyramid themselves (encoder
+// self-attention: Lq == S, level-major).  Level-major order sweeps an image's value maps once per level of queries (3 x 19.8 MB
+// per 720p frame against 4 MB of L2 per XCD: rocprofv3 counted 4.6 GB of HBM traffic per launch for 2.0 GB of algorithmic bytes);
+// band order takes, for every row band of the coarsest level, the rows of ALL levels that cover it, so the cells a band samples
+// are fetched once.  position (0 .. Lq) -> query index; a bijection for any shapes (band b of level l = rows
+// [b H_l / nb, (b+1) H_l / nb), nb = rows of the last level).
+template <int L>
+__device__ __forceinline__ int msda_band_query(int pos, const long long* __restrict__ shapes, const long long* __restrict__ lsi) {
+  const int nb = (int)shapes[2 * (L - 1)];
+  const float inv_nb = 1.f / (float)nb;
+  int Hs[L], Ws[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) { Hs[l] = (int)shapes[2 * l]; Ws[l] = (int)shapes[2 * l + 1]; }
+  // floor(b H / nb) without an integer division: for integers x, nb the fraction of x / nb is a multiple of 1 / nb, so
+  // (x + 0.5) / nb has the same floor and sits 0.5 / nb away from every integer -- far more than the float rounding (x < 2^22)
+  auto row0 = [&](int b, int l) { return (int)(((float)(b * Hs[l]) + 0.5f) * inv_nb); };
+  auto start = [&](int b) {
+    int o = 0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) o += Ws[l] * row0(b, l);
+    return o;
+  };
+  int lo = 0, hi = nb - 1;                       // largest b with start(b) <= pos
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (start(mid) <= pos) lo = mid; else hi = mid - 1;
+  }
+  int r = pos - start(lo);
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int r0 = row0(lo, l), r1 = row0(lo + 1, l);
+    const int n = (r1 - r0) * Ws[l];
+    if (r < n) return (int)lsi[l] + r0 * Ws[l] + r;
+    r -= n;
+  }
+  return pos;                                     // not reached for consistent shapes
+}
+
+template <int L, int P, bool BANDS>
 __global__ __launch_bounds__(256) void msda_fused_m8d32(
     const float* __restrict__ value, long long value_stride, const float* __restrict__ oa,
     long long oa_stride, const float* __restrict__ pos_oa, const float* __restrict__ ref,
     const long long* __restrict__ shapes, const long long* __restrict__ lsi, float* __restrict__ out,
     int S, int Lq, long long nq_total, unsigned nblk) {
   const unsigned lb = xcd_contiguous_block(blockIdx.x, nblk);
-  const long long gq = (long long)lb * 4 + (threadIdx.x >> 6);
+  long long gq = (long long)lb * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (gq >= nq_total) return;
+  if (BANDS) {
+    const int b = (int)((unsigned long long)gq / (unsigned)Lq);
+    gq = (long long)b * Lq + msda_band_query<L>((int)(gq - (long long)b * Lq), shapes, lsi);
+  }
   const int lane = threadIdx.x & 63;
   const float4 acc = msda_sample_query<L, P>(value, value_stride, oa, oa_stride, pos_oa, ref, shapes, lsi, S, Lq, gq, lane);
   st4_stream(out + gq * 256 + lane * 4, acc);            // lane = (head, 4-channel quad): column 4*lane
@@ -488,9 +530,18 @@ extern "C" int pvsg_msda_fused_forward(const float* value, long long value_row_s
   const long long nblk_ll = (nq + 3) / 4;
   PVSG_REQUIRE(nblk_ll < (1ll << 31), "msda_fused_forward: too many queries");
   const unsigned nblk = (unsigned)nblk_ll;
-  hipLaunchKernelGGL((msda_fused_m8d32<3, 4>), dim3(nblk), dim3(256), 0, stream, value, value_row_stride, oa,
-                     oa_row_stride, pos_oa, ref_points, reinterpret_cast<const long long*>(spatial_shapes),
-                     reinterpret_cast<const long long*>(level_start_index), out, S, Lq, nq, nblk);
+  // queries = the cells of the value pyramid (encoder self-attention): band order (msda_band_query); PVSG_MSDA_ORDER=level keeps
+  // the level-major order for the A/B.  The results do not depend on the order.
+  const char* ord = getenv("PVSG_MSDA_ORDER");
+  const bool bands = Lq == S && !(ord && ord[0] == 'l');
+  if (bands)
+    hipLaunchKernelGGL((msda_fused_m8d32<3, 4, true>), dim3(nblk), dim3(256), 0, stream, value, value_row_stride, oa,
+                       oa_row_stride, pos_oa, ref_points, reinterpret_cast<const long long*>(spatial_shapes),
+                       reinterpret_cast<const long long*>(level_start_index), out, S, Lq, nq, nblk);
+  else
+    hipLaunchKernelGGL((msda_fused_m8d32<3, 4, false>), dim3(nblk), dim3(256), 0, stream, value, value_row_stride, oa,
+                       oa_row_stride, pos_oa, ref_points, reinterpret_cast<const long long*>(spatial_shapes),
+                       reinterpret_cast<const long long*>(level_start_index), out, S, Lq, nq, nblk);
   PVSG_LAUNCH_CHECK("msda_fused_forward");
   return PVSG_OK;
 }
