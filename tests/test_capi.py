@@ -42,6 +42,19 @@ def test_invalid_args_report_errors_without_gpu(hip_lib):
     assert rc == 2 and b'Q<=112' in hip_lib.pvsg_last_error()
     rc = hip_lib.pvsg_pair_score_forward(one, one, one, one, one, one, one, None, one, 0, 4, 256, 1024, None)
     assert rc == 1
+    # IPS association entries: sizes are checked before anything is launched
+    assert hip_lib.pvsg_reconsdot_workspace_bytes(0, 10, 3, 10) == 0 and hip_lib.pvsg_reconsdot_workspace_bytes(2, 33, 3, 64) > 0
+    rc = hip_lib.pvsg_reconsdot_cost(one, one, one, 2, 2000, 3, 64, ctypes.c_float(100.0), one, one, None)
+    assert rc == 1 and b'1024 cells' in hip_lib.pvsg_last_error()
+    rc = hip_lib.pvsg_reconsdot_cost(one, None, one, 2, 20, 3, 64, ctypes.c_float(100.0), one, one, None)
+    assert rc == 1 and b'null pointer' in hip_lib.pvsg_last_error()
+    counts = (ctypes.c_longlong * 5)(3, 2, 40, 1, 7)                  # host codec: runs of one mask
+    seg = (ctypes.c_longlong * 1)(5)
+    out, lens = (ctypes.c_ubyte * 80)(), (ctypes.c_longlong * 1)()
+    n = hip_lib.pvsg_rle_counts_to_chars(counts, seg, 1, out, lens)
+    from openpvsg_amd import tubes
+    assert bytes(out[:n]).decode() == tubes.rle_counts_to_string([3, 2, 40, 1, 7]) and lens[0] == n
+    assert hip_lib.pvsg_rle_counts_to_chars(None, None, 1, None, None) == -1
 
 
 def test_cpu_tensors_are_rejected(hip_lib):
