@@ -75,6 +75,25 @@ def test_boxes_and_assignment_host_logic():
     assert m.shape == (0, 2) and ua == () and ub == (0, 1, 2)
 
 
+def test_kalman_multi_update_equals_one_track_at_a_time():
+    """KalmanFilter.multi_update (the matched tracks of one association stage in one stack) against `update` per track"""
+    from openpvsg_amd.unitrack import KalmanFilter
+    kf, rs = KalmanFilter(), np.random.RandomState(0)
+    ms, cs, zs = [], [], []
+    for i in range(9):
+        m, c = kf.initiate(rs.uniform(10, 100, 4) * [1, 1, 0.01, 1])
+        for _ in range(i % 4):
+            m, c = kf.predict(m, c)
+            m, c = kf.update(m, c, m[:4] + rs.normal(0, 1, 4))
+        m, c = kf.predict(m, c)
+        ms.append(m), cs.append(c), zs.append(m[:4] + rs.normal(0, 1, 4))
+    bm, bc = kf.multi_update(np.stack(ms), np.stack(cs), np.stack(zs))
+    for i in range(9):
+        m, c = kf.update(ms[i], cs[i], zs[i])
+        np.testing.assert_allclose(bm[i], m, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(bc[i], c, rtol=1e-11, atol=1e-11)
+
+
 def test_boxes_from_grouped_cells_equal_mask2box():
     """unitrack.mask2box_grouped (all objects of a frame from one pass over the low-resolution id map) against mask2box
     (one mask at a time, the reference's form): same centres exactly, deviations within float32 rounding."""
