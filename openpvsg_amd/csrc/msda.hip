@@ -294,6 +294,111 @@ __device__ __forceinline__ float4 msda_sample_query(const float* __restrict__ va
   return acc;
 }
 
+// The same query with the per-point work SHARED by the eight lanes of a head.  In msda_sample_query every lane of a head repeats
+// the location / bilinear-weight / address arithmetic of all 12 (level, point) taps of its head -- 1 219 VALU instructions per
+// wave, i.e. 1.4 ms of pure VALU issue per launch at 32 x 720p (the kernel runs 1.9 ms).  Here lane c4 of a head works out taps
+// c4 and 8 + c4 only (token byte offsets of the four corners, their bilinear weights, the attention weight), and the gather
+// loop fetches each tap's nine numbers from its owner lane with ds_bpermute (the LDS crossbar, otherwise idle in this kernel).
+// Same formulas, same order of the floating-point operations per tap and over the taps.  32-bit byte offsets: the caller checks
+// that one image's value rows fit 2 GB.
+template <int L, int P>
+__device__ __forceinline__ float4 msda_sample_query_coop(const float* __restrict__ value, long long value_stride,
+                                                         const float* __restrict__ oa, long long oa_stride,
+                                                         const float* __restrict__ pos_oa, const float* __restrict__ ref,
+                                                         const long long* __restrict__ shapes,
+                                                         const long long* __restrict__ lsi, int S, int Lq, long long gq,
+                                                         int lane) {
+  constexpr int M = 8, D = 32, LP = L * P;
+  static_assert(LP > 8 && LP <= 16 && P == 4, "two taps per lane");
+  const int m = lane >> 3, c4 = lane & 7;
+  const int b = (int)(gq / Lq);
+  const int q = (int)(gq - (long long)b * Lq);
+  const float* offp = oa + gq * oa_stride + m * (LP * 2);
+  const float* logp = oa + gq * oa_stride + M * LP * 2 + m * LP;
+  const float* poff = pos_oa ? pos_oa + (long long)q * (M * LP * 3) + m * (LP * 2) : nullptr;
+  const float* plog = pos_oa ? pos_oa + (long long)q * (M * LP * 3) + M * LP * 2 + m * LP : nullptr;
+  float aw[LP];
+#pragma unroll
+  for (int i = 0; i < LP / 4; ++i) {
+    float4 t = ld4_stream(logp + 4 * i);
+    if (plog) { const float4 u = ld4(plog + 4 * i); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    aw[4 * i] = t.x; aw[4 * i + 1] = t.y; aw[4 * i + 2] = t.z; aw[4 * i + 3] = t.w;
+  }
+  float mx = aw[0];
+#pragma unroll
+  for (int i = 1; i < LP; ++i) mx = fmaxf(mx, aw[i]);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) sum += __expf(aw[i] - mx);
+  const float inv = 1.f / sum;
+  const float rx = ref[2 * q], ry = ref[2 * q + 1];
+  // ---- the lane's own taps ----------------------------------------------------------------------------------
+  int own_off[2][4];
+  float own_cw[2][4], own_a[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int p = (k == 0) ? c4 : min(8 + c4, LP - 1);            // lanes without a second tap repeat the last one (never read)
+    const int l = p >> 2;
+    float ox = offp[2 * p], oy = offp[2 * p + 1], lg = logp[p];
+    if (poff) { ox += poff[2 * p]; oy += poff[2 * p + 1]; lg += plog[p]; }
+    own_a[k] = __expf(lg - mx) * inv;
+    int H = (int)shapes[0], W = (int)shapes[1];
+    long long base = lsi[0];
+#pragma unroll
+    for (int j = 1; j < L; ++j)
+      if (l == j) { H = (int)shapes[2 * j]; W = (int)shapes[2 * j + 1]; base = lsi[j]; }
+    const float invW = 1.f / (float)W, invH = 1.f / (float)H;
+    const float locx = rx + ox * invW, locy = ry + oy * invH;
+    const float him = locy * (float)H - 0.5f, wim = locx * (float)W - 0.5f;
+    const float hf = floorf(him), wf = floorf(wim);
+    const float lh = him - hf, lw = wim - wf, hh = 1.f - lh, hw = 1.f - lw;
+    const float hfc = fminf(fmaxf(hf, -2.f), (float)H + 1.f);
+    const float wfc = fminf(fmaxf(wf, -2.f), (float)W + 1.f);
+    const int h0 = (int)hfc, w0 = (int)wfc, h1 = h0 + 1, w1 = w0 + 1;
+    const bool inside = (him > -1.f) && (wim > -1.f) && (him < (float)H) && (wim < (float)W);
+    const bool vh0 = inside && h0 >= 0, vh1 = inside && h1 <= H - 1;
+    const bool vw0 = w0 >= 0, vw1 = w1 <= W - 1;
+    const int h0c = min(max(h0, 0), H - 1), h1c = min(max(h1, 0), H - 1);
+    const int w0c = min(max(w0, 0), W - 1), w1c = min(max(w1, 0), W - 1);
+    own_cw[k][0] = (vh0 && vw0) ? hh * hw : 0.f;
+    own_cw[k][1] = (vh0 && vw1) ? hh * lw : 0.f;
+    own_cw[k][2] = (vh1 && vw0) ? lh * hw : 0.f;
+    own_cw[k][3] = (vh1 && vw1) ? lh * lw : 0.f;
+    const int vs4 = (int)value_stride * 4, b0 = (int)base;
+    own_off[k][0] = (b0 + h0c * W + w0c) * vs4;
+    own_off[k][1] = (b0 + h0c * W + w1c) * vs4;
+    own_off[k][2] = (b0 + h1c * W + w0c) * vs4;
+    own_off[k][3] = (b0 + h1c * W + w1c) * vs4;
+  }
+  // ---- gather: every tap of the head from its owner lane -----------------------------------------------------------
+  const char* vbase = reinterpret_cast<const char*>(value + (long long)b * S * value_stride);
+  const int lane_off = (m * D + c4 * 4) * 4;
+  const int grp = (lane & ~7) << 2;                                  // ds_bpermute takes byte addresses (lane * 4)
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int p = 0; p < LP; ++p) {
+    const int k = p >> 3, src = grp + ((p & 7) << 2);
+    int off[4];
+    float cw[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      off[c] = __builtin_amdgcn_ds_bpermute(src, own_off[k][c]);
+      cw[c] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(own_cw[k][c])));
+    }
+    const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(own_a[k])));
+    float4 v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const float4*>(vbase + (unsigned)(off[c] + lane_off));
+    float4 s4;
+    s4.x = cw[0] * v[0].x + cw[1] * v[1].x + cw[2] * v[2].x + cw[3] * v[3].x;
+    s4.y = cw[0] * v[0].y + cw[1] * v[1].y + cw[2] * v[2].y + cw[3] * v[3].y;
+    s4.z = cw[0] * v[0].z + cw[1] * v[1].z + cw[2] * v[2].z + cw[3] * v[3].z;
+    s4.w = cw[0] * v[0].w + cw[1] * v[1].w + cw[2] * v[2].w + cw[3] * v[3].w;
+    acc.x += a * s4.x; acc.y += a * s4.y; acc.z += a * s4.z; acc.w += a * s4.w;
+  }
+  return acc;
+}
+
 // Order in which the queries of one image are WORKED ON when they are the cells of the value pyramid themselves (encoder
 // self-attention: Lq == S, level-major).  Level-major order sweeps an image's value maps once per level of queries (3 x 19.8 MB
 // per 720p frame against 4 MB of L2 per XCD: rocprofv3 counted 4.6 GB of HBM traffic per launch for 2.0 GB of algorithmic bytes);
@@ -332,7 +437,7 @@ __device__ __forceinline__ int msda_band_query(int pos, const long long* __restr
   return pos;                                     // not reached for consistent shapes
 }
 
-template <int L, int P, bool BANDS>
+template <int L, int P, bool BANDS, bool COOP>
 __global__ __launch_bounds__(256) void msda_fused_m8d32(
     const float* __restrict__ value, long long value_stride, const float* __restrict__ oa,
     long long oa_stride, const float* __restrict__ pos_oa, const float* __restrict__ ref,
@@ -346,7 +451,8 @@ __global__ __launch_bounds__(256) void msda_fused_m8d32(
     gq = (long long)b * Lq + msda_band_query<L>((int)(gq - (long long)b * Lq), shapes, lsi);
   }
   const int lane = threadIdx.x & 63;
-  const float4 acc = msda_sample_query<L, P>(value, value_stride, oa, oa_stride, pos_oa, ref, shapes, lsi, S, Lq, gq, lane);
+  const float4 acc = COOP ? msda_sample_query_coop<L, P>(value, value_stride, oa, oa_stride, pos_oa, ref, shapes, lsi, S, Lq, gq, lane)
+                          : msda_sample_query<L, P>(value, value_stride, oa, oa_stride, pos_oa, ref, shapes, lsi, S, Lq, gq, lane);
   st4_stream(out + gq * 256 + lane * 4, acc);            // lane = (head, 4-channel quad): column 4*lane
 }
 
@@ -534,14 +640,19 @@ extern "C" int pvsg_msda_fused_forward(const float* value, long long value_row_s
   // the level-major order for the A/B.  The results do not depend on the order.
   const char* ord = getenv("PVSG_MSDA_ORDER");
   const bool bands = Lq == S && !(ord && ord[0] == 'l');
-  if (bands)
-    hipLaunchKernelGGL((msda_fused_m8d32<3, 4, true>), dim3(nblk), dim3(256), 0, stream, value, value_row_stride, oa,
-                       oa_row_stride, pos_oa, ref_points, reinterpret_cast<const long long*>(spatial_shapes),
-                       reinterpret_cast<const long long*>(level_start_index), out, S, Lq, nq, nblk);
-  else
-    hipLaunchKernelGGL((msda_fused_m8d32<3, 4, false>), dim3(nblk), dim3(256), 0, stream, value, value_row_stride, oa,
-                       oa_row_stride, pos_oa, ref_points, reinterpret_cast<const long long*>(spatial_shapes),
-                       reinterpret_cast<const long long*>(level_start_index), out, S, Lq, nq, nblk);
+  // the per-tap arithmetic shared by the lanes of a head (msda_sample_query_coop) where 32-bit byte offsets reach every value row
+  // of an image; PVSG_MSDA_COOP=0 keeps every lane computing every tap (A/B)
+  const char* cp = getenv("PVSG_MSDA_COOP");
+  const bool coop = (long long)S * value_row_stride * 4 < (1ll << 31) && !(cp && cp[0] == '0');
+#define PVSG_MSDA_LAUNCH(BANDS, COOP)                                                                                        \
+  hipLaunchKernelGGL((msda_fused_m8d32<3, 4, BANDS, COOP>), dim3(nblk), dim3(256), 0, stream, value, value_row_stride, oa,  \
+                     oa_row_stride, pos_oa, ref_points, reinterpret_cast<const long long*>(spatial_shapes),                \
+                     reinterpret_cast<const long long*>(level_start_index), out, S, Lq, nq, nblk)
+  if (bands && coop) PVSG_MSDA_LAUNCH(true, true);
+  else if (bands) PVSG_MSDA_LAUNCH(true, false);
+  else if (coop) PVSG_MSDA_LAUNCH(false, true);
+  else PVSG_MSDA_LAUNCH(false, false);
+#undef PVSG_MSDA_LAUNCH
   PVSG_LAUNCH_CHECK("msda_fused_forward");
   return PVSG_OK;
 }
