@@ -317,21 +317,18 @@ __device__ __forceinline__ float4 msda_sample_query_coop(const float* __restrict
   const float* logp = oa + gq * oa_stride + M * LP * 2 + m * LP;
   const float* poff = pos_oa ? pos_oa + (long long)q * (M * LP * 3) + m * (LP * 2) : nullptr;
   const float* plog = pos_oa ? pos_oa + (long long)q * (M * LP * 3) + M * LP * 2 + m * LP : nullptr;
-  float aw[LP];
-#pragma unroll
-  for (int i = 0; i < LP / 4; ++i) {
-    float4 t = ld4_stream(logp + 4 * i);
-    if (plog) { const float4 u = ld4(plog + 4 * i); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-    aw[4 * i] = t.x; aw[4 * i + 1] = t.y; aw[4 * i + 2] = t.z; aw[4 * i + 3] = t.w;
-  }
-  float mx = aw[0];
-#pragma unroll
-  for (int i = 1; i < LP; ++i) mx = fmaxf(mx, aw[i]);
-  float sum = 0.f;
-#pragma unroll
-  for (int i = 0; i < LP; ++i) sum += __expf(aw[i] - mx);
-  const float inv = 1.f / sum;
   const float rx = ref[2 * q], ry = ref[2 * q + 1];
+  // logits of the lane's own taps; their maximum over the head by three butterfly steps inside the 8-lane group
+  float own_lg[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int p = (k == 0) ? c4 : min(8 + c4, LP - 1);
+    own_lg[k] = logp[p] + (plog ? plog[p] : 0.f);
+  }
+  float mx = fmaxf(own_lg[0], own_lg[1]);                           // lanes without a second tap hold the last tap twice: harmless
+  mx = fmaxf(mx, __shfl_xor(mx, 1));
+  mx = fmaxf(mx, __shfl_xor(mx, 2));
+  mx = fmaxf(mx, __shfl_xor(mx, 4));
   // ---- the lane's own taps ----------------------------------------------------------------------------------
   int own_off[2][4];
   float own_cw[2][4], own_a[2];
@@ -339,9 +336,10 @@ __device__ __forceinline__ float4 msda_sample_query_coop(const float* __restrict
   for (int k = 0; k < 2; ++k) {
     const int p = (k == 0) ? c4 : min(8 + c4, LP - 1);            // lanes without a second tap repeat the last one (never read)
     const int l = p >> 2;
-    float ox = offp[2 * p], oy = offp[2 * p + 1], lg = logp[p];
-    if (poff) { ox += poff[2 * p]; oy += poff[2 * p + 1]; lg += plog[p]; }
-    own_a[k] = __expf(lg - mx) * inv;
+    float2 oxy = *reinterpret_cast<const float2*>(offp + 2 * p);
+    if (poff) { const float2 u = *reinterpret_cast<const float2*>(poff + 2 * p); oxy.x += u.x; oxy.y += u.y; }
+    const float ox = oxy.x, oy = oxy.y;
+    own_a[k] = __expf(own_lg[k] - mx);                              // normalised below, once the head's sum is known
     int H = (int)shapes[0], W = (int)shapes[1];
     long long base = lsi[0];
 #pragma unroll
@@ -369,6 +367,15 @@ __device__ __forceinline__ float4 msda_sample_query_coop(const float* __restrict
     own_off[k][1] = (b0 + h0c * W + w1c) * vs4;
     own_off[k][2] = (b0 + h1c * W + w0c) * vs4;
     own_off[k][3] = (b0 + h1c * W + w1c) * vs4;
+  }
+  {   // the soft-max denominator of the head: the 12 exponentials live one or two per lane
+    float e = own_a[0] + (8 + c4 < LP ? own_a[1] : 0.f);
+    e += __shfl_xor(e, 1);
+    e += __shfl_xor(e, 2);
+    e += __shfl_xor(e, 4);
+    const float inv = 1.f / e;
+    own_a[0] *= inv;
+    own_a[1] *= inv;
   }
   // ---- gather: every tap of the head from its owner lane -----------------------------------------------------------
   const char* vbase = reinterpret_cast<const char*>(value + (long long)b * S * value_stride);
