@@ -95,6 +95,33 @@ def test_msda_fused_equals_oracle(hip_lib, B, h0w0, scale):
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('shapes', [[(5, 7), (10, 14), (20, 28)], [(23, 40), (46, 80), (92, 160)], [(9, 4), (3, 2), (1, 1)]])
+def test_msda_fused_kernel_variants_agree(hip_lib, monkeypatch, shapes):
+    """The four forms of the fused sampling kernel -- queries level by level or in bands across the levels (msda_band_query),
+    every lane computing every tap or the taps of a head shared by its eight lanes (msda_sample_query_coop) -- give the same
+    rows: the band order only re-orders the work, the shared form keeps the per-tap arithmetic (the soft-max denominator is a
+    tree sum there: last-bit differences)."""
+    from openpvsg_amd import ops
+    B = 2
+    S = sum(h * w for h, w in shapes)
+    y = det_input('y', (B, S, 544), 11)
+    y[..., 256:448] *= 4.0
+    pos_oa = det_input('pos_oa', (S, 288), 12, 0.3)
+    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing='ij')[::-1], -1).reshape(-1, 2)
+                     for h, w in shapes], 0)
+    ss = torch.tensor(shapes, dtype=torch.long)
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    outs = {}
+    for order in ('level', 'band'):
+        for coop in ('0', '1'):
+            monkeypatch.setenv('PVSG_MSDA_ORDER', order)
+            monkeypatch.setenv('PVSG_MSDA_COOP', coop)
+            outs[order, coop] = ops.msda_fused(y.to(DEV), pos_oa.to(DEV), ref.to(DEV), ss.to(DEV), lsi.to(DEV)).cpu()
+    assert torch.equal(outs['level', '0'], outs['band', '0']) and torch.equal(outs['level', '1'], outs['band', '1'])
+    sc = float(outs['level', '0'].abs().max())
+    np.testing.assert_allclose(outs['level', '1'].numpy(), outs['level', '0'].numpy(), rtol=2e-6, atol=2e-6 * sc)
+
+
 def test_backbone_fused_bn_act_equals_plain(hip_lib):
     """ResNet-50 with the fused BN(+residual)(+ReLU) passes vs plain conv/BN/ReLU modules vs the oracle."""
     from openpvsg_amd.backbone import ResNet
