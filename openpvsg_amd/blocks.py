@@ -171,13 +171,31 @@ def linear_fast(owner, tag, weights, x, bias=None, relu=False):
     return y.view(*x.shape[:-1], n)
 
 
+_CU_COUNT = {}
+
+
+def _fused_ln_fills_the_gpu(x, k):
+    """The fused projection + LayerNorm kernel owns whole rows: 256-row tiles, one workgroup per CU.  With few rows the last
+    round of workgroups leaves most CUs idle (4 frames of 720p = 302 tiles on 256 CUs: 0.165 ms where 128 x 128 tiles + the
+    separate LayerNorm take 0.10); then the two-launch form is used.  PVSG_FUSE_LN=force keeps the fused kernel regardless."""
+    if os.environ.get('PVSG_FUSE_LN', 'on') == 'force':
+        return True
+    dev = x.device.index or 0
+    cus = _CU_COUNT.get(dev)
+    if cus is None:
+        cus = _CU_COUNT[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+    tiles = (x.numel() // k + 255) // 256
+    rounds = (tiles + cus - 1) // cus
+    return tiles >= float(os.environ.get('PVSG_FUSE_LN_MINEFF', '0.85')) * rounds * cus
+
+
 def linear_add_layernorm_fast(owner, tag, weight, x, bias, identity, norm):
     """LayerNorm(identity + F.linear(x, weight, bias)): one launch where the fused kernel exists (f16x2 split, 256 output
     columns: ops.gemm_add_layernorm), else the split GEMM followed by the add + LayerNorm kernel."""
     n, k = weight.shape
     if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and
             n == 256 and k % 32 == 0 and ops.split_mode() == 'f16x2' and os.environ.get('PVSG_FUSE_LN', 'on') != 'off' and
-            isinstance(norm, nn.LayerNorm) and norm.normalized_shape == (256,)):
+            isinstance(norm, nn.LayerNorm) and norm.normalized_shape == (256,) and _fused_ln_fills_the_gpu(x, k)):
         key = ((weight.data_ptr(), weight._version, str(weight.device)), 'f16x2')
         cache = owner.__dict__.setdefault('_pvsg_gemm', {})
         ent = cache.get(tag)
