@@ -91,6 +91,7 @@ class MaskFormerFusionHeadCustom(BaseModule):
         -> (panoptic (T,oh,ow) int32, seg_id (T,K) int32, keep (Q,) bool)."""
         scores, labels, keep = self.panoptic_select(mask_cls)
         idx = keep.nonzero()[:, 0]
+        self.last_kept_index = idx           # callers that gather per kept query use it instead of the mask (no second wait)
         pan, seg = ops.panoptic_fuse(mask_logits4, idx, scores[idx], labels[idx], batch_input_shape,
                                      img_shape[:2], self.num_things_classes, self.num_classes,
                                      self.test_cfg.get('iou_thr', 0.8),

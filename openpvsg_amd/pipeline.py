@@ -214,7 +214,7 @@ class PVSGPipeline(torch.nn.Module):
             pans, seg, keep = fusion.panoptic_fused(cls[0], masks4[0], (H, W), (ih, iw))
             self._last_keep = keep
             seg_ids = list(seg.to(torch.long).unbind(0))
-            k_feats = q[:, 0][keep]
+            k_feats = q[:, 0].index_select(0, fusion.last_kept_index)        # == q[:, 0][keep] without its device->host wait
             return pans, seg_ids, [k_feats] * T, cls, q
         scores, labels, keep = fusion.panoptic_select(cls[0])
         self._last_keep = keep
