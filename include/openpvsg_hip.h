@@ -283,10 +283,13 @@ int pvsg_mask_embed_forward(const float* feat_hwd, const int* pan_low, const int
  *      observations (columns), each object zero-padded to Pt (Pd) cells as get_track_feat :174-191 pads them, then to Ptp
  *      (Pdp); cells p >= Pt / s >= Pd are ignored, the zero cells below that take part in the soft-max as in the reference;
  *   Gt (Nt, Ptp, Ptp) = F_trk[t] F_trk[t]^T,  Gd (Nd, Pdp, Pdp) likewise (zero in the padding);  tmp = 100 there;
+ *   needed (Nt, Nd) bytes or NULL: pairs with 0 are not evaluated and get cost +inf -- the caller's class gate
+ *      (class_aware_distance, models/unitrack/core/multitracker.py:27-34, sets exactly those to inf afterwards); the soft-max
+ *      statistics still run over every cell, as in the reference;
  *   workspace: pvsg_reconsdot_workspace_bytes(Nt, Pt, Nd, Pd) bytes;  cost (Nt, Nd). */
 long long pvsg_reconsdot_workspace_bytes(int Nt, int Pt, int Nd, int Pd);
 int pvsg_reconsdot_cost(const float* A, const float* Gt, const float* Gd, int Nt, int Pt, int Nd, int Pd, float tmp,
-                        float* workspace, float* cost, void* stream);
+                        const unsigned char* needed, float* workspace, float* cost, void* stream);
 
 /* ---- pixel-decoder / backbone glue around the library convolutions (HBM streaming) -----------------
  * [3P] mmdet MSDeformAttnPixelDecoder.forward FPN step:

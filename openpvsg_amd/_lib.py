@@ -66,7 +66,7 @@ SIGNATURES = {
     'pvsg_mask_embed_forward': [_c_f] * 7 + [_i] * 5 + [_c_f],
     'pvsg_reconsdot_workspace_bytes': [_i, _i, _i, _i],
     'pvsg_rle_counts_to_chars': [_c_f, _c_f, _i, _c_f, _c_f],
-    'pvsg_reconsdot_cost': [_c_f] * 3 + [_i] * 4 + [_f, _c_f, _c_f, _c_f],
+    'pvsg_reconsdot_cost': [_c_f] * 3 + [_i] * 4 + [_f, _c_f, _c_f, _c_f, _c_f],
     'pvsg_fpn_merge_up2x': [_c_f] * 5 + [_ll, _i, _i, _c_f],
     'pvsg_stem_bn_relu_pool': [_c_f] * 4 + [_ll, _i, _i, _i, _c_f],
     'pvsg_nchw_to_tokens': [_c_f] * 4 + [_i, _i, _i, _ll, _c_f],

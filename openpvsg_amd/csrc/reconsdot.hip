@@ -137,10 +137,11 @@ __global__ __launch_bounds__(256) void reconsdot_col_finish(const float* __restr
 template <bool COLS>
 __global__ __launch_bounds__(256) void reconsdot_strip(const float* __restrict__ A, const float* __restrict__ G, const float* __restrict__ smax,
                                                         const float* __restrict__ ssum, float* __restrict__ part, int Pt, int Ptp, int Nd, int Pd,
-                                                        int Pdp, float tmp) {
+                                                        int Pdp, float tmp, const unsigned char* __restrict__ needed) {
   extern __shared__ float X[];                       // [32][Kp + pad]
   __shared__ float sh[4];
   const int strip = blockIdx.x, d = blockIdx.y, t = blockIdx.z;
+  if (needed && !needed[t * Nd + d]) return;        // a pair the caller gates away (another class): its cost is written as +inf
   const int Kp = COLS ? Ptp : Pdp, Kv = COLS ? Pt : Pd;          // length of a strip line, its valid part
   const int Sv = COLS ? Pd : Pt;                                   // valid strip lines of the block
   const int ld = Kp + RD_LDS_PAD;
@@ -212,10 +213,14 @@ __global__ __launch_bounds__(256) void reconsdot_strip(const float* __restrict__
 // one wave per (track, observation) pair: strip partials and Gram diagonals summed in a fixed lane order
 __global__ __launch_bounds__(256) void reconsdot_finish(const float* __restrict__ part_td, const float* __restrict__ part_dt, const float* __restrict__ Gt,
                                                          const float* __restrict__ Gd, float* __restrict__ cost, int Nt, int Pt, int Ptp, int Nd,
-                                                         int Pd, int Pdp, int nst, int nsd) {
+                                                         int Pd, int Pdp, int nst, int nsd, const unsigned char* __restrict__ needed) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= Nt * Nd) return;
   const int lane = threadIdx.x & 63;
+  if (needed && !needed[i]) {
+    if (lane == 0) cost[i] = INFINITY;
+    return;
+  }
   const int t = i / Nd, d = i - t * Nd;
   const float eps = 1e-12f;
   float nt = 0.f, nd = 0.f, num_td = 0.f, q_td = 0.f, num_dt = 0.f, q_dt = 0.f;
@@ -283,7 +288,7 @@ extern "C" long long pvsg_reconsdot_workspace_bytes(int Nt, int Pt, int Nd, int 
 }
 
 extern "C" int pvsg_reconsdot_cost(const float* A, const float* Gt, const float* Gd, int Nt, int Pt, int Nd, int Pd, float tmp,
-                                   float* workspace, float* cost, void* stream) {
+                                   const unsigned char* needed, float* workspace, float* cost, void* stream) {
   using namespace pvsg;
   PVSG_REQUIRE(A && Gt && Gd && workspace && cost, "pvsg_reconsdot_cost: null pointer");
   PVSG_REQUIRE(Nt > 0 && Nd > 0 && Pt > 0 && Pd > 0, "pvsg_reconsdot_cost: sizes must be positive (Nt %d, Pt %d, Nd %d, Pd %d)", Nt, Pt, Nd, Pd);
@@ -310,11 +315,11 @@ extern "C" int pvsg_reconsdot_cost(const float* A, const float* Gt, const float*
     const hipError_t e = ensure_dynamic_lds((const void*)reconsdot_strip<true>, lds_cols, g_lds_cols);
     if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "pvsg_reconsdot_cost: %d bytes of LDS: %s", lds_cols, hipGetErrorString(e));
   }
-  reconsdot_strip<false><<<dim3(L.nst, Nd, Nt), 256, lds_rows, st>>>(A, Gd, ws + L.rmax, ws + L.rsum, ws + L.ptd, Pt, Ptp, Nd, Pd, Pdp, tmp);
+  reconsdot_strip<false><<<dim3(L.nst, Nd, Nt), 256, lds_rows, st>>>(A, Gd, ws + L.rmax, ws + L.rsum, ws + L.ptd, Pt, Ptp, Nd, Pd, Pdp, tmp, needed);
   PVSG_LAUNCH_CHECK("reconsdot_strip<rows>");
-  reconsdot_strip<true><<<dim3(L.nsd, Nd, Nt), 256, lds_cols, st>>>(A, Gt, ws + L.cmax, ws + L.csum, ws + L.pdt, Pt, Ptp, Nd, Pd, Pdp, tmp);
+  reconsdot_strip<true><<<dim3(L.nsd, Nd, Nt), 256, lds_cols, st>>>(A, Gt, ws + L.cmax, ws + L.csum, ws + L.pdt, Pt, Ptp, Nd, Pd, Pdp, tmp, needed);
   PVSG_LAUNCH_CHECK("reconsdot_strip<cols>");
-  reconsdot_finish<<<(Nt * Nd + 3) / 4, 256, 0, st>>>(ws + L.ptd, ws + L.pdt, Gt, Gd, cost, Nt, Pt, Ptp, Nd, Pd, Pdp, L.nst, L.nsd);
+  reconsdot_finish<<<(Nt * Nd + 3) / 4, 256, 0, st>>>(ws + L.ptd, ws + L.pdt, Gt, Gd, cost, Nt, Pt, Ptp, Nd, Pd, Pdp, L.nst, L.nsd, needed);
   PVSG_LAUNCH_CHECK("reconsdot_finish");
   return PVSG_OK;
 }

@@ -476,11 +476,12 @@ def mask_embed(feat_hwd, pan_low, entries, obj_id, obj_inv_scale, normalised=Tru
     return out, out_n
 
 
-def reconsdot_cost(a, gt, gd, n_trk, cells_trk, n_det, cells_det, tmp=100.0):
+def reconsdot_cost(a, gt, gd, n_trk, cells_trk, n_det, cells_det, tmp=100.0, needed=None):
     """Reconstruction distance of the IPS tracker's first association (matching.py:194-225) from the cell affinities.
     a (n_trk * Ptp, n_det * Pdp) = F_trk F_det^T over the zero-padded, L2-normalised cell features (Ptp / Pdp: cells_trk /
     cells_det rounded up to 32), gt (n_trk, Ptp, Ptp) / gd (n_det, Pdp, Pdp) the Gram matrices of each object's cells
-    -> cost (n_trk, n_det) f32.  csrc/reconsdot.hip."""
+    -> cost (n_trk, n_det) f32.  needed: optional (n_trk, n_det) uint8 / bool device tensor, pairs with 0 are skipped and cost
+    +inf (the tracker's class gate).  csrc/reconsdot.hip."""
     ptp, pdp = (cells_trk + 31) // 32 * 32, (cells_det + 31) // 32 * 32
     a, gt, gd = _chk(a, 'a'), _chk(gt, 'gt'), _chk(gd, 'gd')
     for t, name, shape in ((a, 'a', (n_trk * ptp, n_det * pdp)), (gt, 'gt', (n_trk, ptp, ptp)), (gd, 'gd', (n_det, pdp, pdp))):
@@ -490,8 +491,13 @@ def reconsdot_cost(a, gt, gd, n_trk, cells_trk, n_det, cells_det, tmp=100.0):
     ws = torch.empty(((nbytes + 3) // 4,), device=a.device, dtype=torch.float32)
     cost = torch.empty((n_trk, n_det), device=a.device, dtype=torch.float32)
     with _on(a.device):
+        nd = None
+        if needed is not None:
+            nd = needed.to(device=a.device, dtype=torch.uint8).contiguous()
+            if tuple(nd.shape) != (n_trk, n_det):
+                raise RuntimeError('reconsdot_cost: needed has shape %s, expected %s' % (tuple(nd.shape), (n_trk, n_det)))
         _lib.call('pvsg_reconsdot_cost', a.data_ptr(), gt.data_ptr(), gd.data_ptr(), n_trk, cells_trk, n_det, cells_det, float(tmp),
-                  ws.data_ptr(), cost.data_ptr(), _stream_ptr())
+                  nd.data_ptr() if nd is not None else None, ws.data_ptr(), cost.data_ptr(), _stream_ptr())
     return cost
 
 

@@ -567,7 +567,7 @@ def _padded_cells(feats):
     return out, p, pp
 
 
-def reconsdot_cost(trk_feats, det_feats, tmp=100.0):
+def reconsdot_cost(trk_feats, det_feats, tmp=100.0, needed=None):
     """matching.py:179-225 on the device.  trk_feats / det_feats: lists of L2-normalised (n_cells_i, d) tensors.
     With A = F_trk F_det^T over all (zero-padded) cells, P = softmax_rows(tmp A), Pc = softmax_cols(tmp A):
       <recons_trk[t,d], f_trk[t]>  = sum over the (t,d) block of P * A
@@ -588,7 +588,7 @@ def reconsdot_cost(trk_feats, det_feats, tmp=100.0):
     Ft3, Fd3 = Ft.view(Nt, Ptp, d), Fd.view(Nd, Pdp, d)
     Gt = torch.bmm(Ft3, Ft3.transpose(1, 2))
     Gd = torch.bmm(Fd3, Fd3.transpose(1, 2))
-    return ops.reconsdot_cost(A, Gt, Gd, Nt, Pt, Nd, Pd, tmp)
+    return ops.reconsdot_cost(A, Gt, Gd, Nt, Pt, Nd, Pd, tmp, needed=needed)
 
 
 def reconsdot_cost_tensor_ops(trk_feats, det_feats, tmp=100.0):
@@ -626,19 +626,27 @@ def _feat_n(track):
     return F.normalize(f.float(), dim=1)
 
 
-def reconsdot_distance(tracks, detections, tmp=100):  # matching.py:179-225
+def reconsdot_distance(tracks, detections, tmp=100, needed=None):  # matching.py:179-225
+    """needed: optional (tracks, detections) bool array -- pairs the caller discards anyway are not evaluated (cost inf)"""
     if len(tracks) * len(detections) == 0:
         return np.zeros((len(tracks), len(detections)), dtype=np.float64), None
-    cost = reconsdot_cost([_feat_n(t) for t in tracks], [_feat_n(t) for t in detections], float(tmp))
+    nd = None
+    if needed is not None:
+        nd = torch.from_numpy(np.ascontiguousarray(needed, dtype=np.uint8)).to(_feat_n(tracks[0]).device, non_blocking=True)
+    cost = reconsdot_cost([_feat_n(t) for t in tracks], [_feat_n(t) for t in detections], float(tmp), needed=nd)
     return cost.double().cpu().numpy(), None
 
 
 def class_aware_distance(tracks, detections, query_feats):  # multitracker.py:27-34
-    dists, _ = reconsdot_distance(tracks, detections)
-    if dists.size:
-        tc = np.array([t.cls_id for t in tracks])
-        dc = np.array([query_feats[j]['cls_id'] % INSTANCE_OFFSET for j in range(len(detections))])
-        dists[tc[:, None] != dc[None, :]] = np.inf
+    """The reference computes every pair and then sets the pairs of different classes to inf; here the class gate is known first
+    and the gated pairs' quadratic forms (most of the distance's device time) are never evaluated -- same matrix."""
+    if len(tracks) * len(detections) == 0:
+        return reconsdot_distance(tracks, detections)[0]
+    tc = np.array([t.cls_id for t in tracks])
+    dc = np.array([query_feats[j]['cls_id'] % INSTANCE_OFFSET for j in range(len(detections))])
+    same = tc[:, None] == dc[None, :]
+    dists, _ = reconsdot_distance(tracks, detections, needed=same)
+    dists[~same] = np.inf
     return dists
 
 

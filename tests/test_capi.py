@@ -44,9 +44,9 @@ def test_invalid_args_report_errors_without_gpu(hip_lib):
     assert rc == 1
     # IPS association entries: sizes are checked before anything is launched
     assert hip_lib.pvsg_reconsdot_workspace_bytes(0, 10, 3, 10) == 0 and hip_lib.pvsg_reconsdot_workspace_bytes(2, 33, 3, 64) > 0
-    rc = hip_lib.pvsg_reconsdot_cost(one, one, one, 2, 2000, 3, 64, ctypes.c_float(100.0), one, one, None)
+    rc = hip_lib.pvsg_reconsdot_cost(one, one, one, 2, 2000, 3, 64, ctypes.c_float(100.0), None, one, one, None)
     assert rc == 1 and b'1024 cells' in hip_lib.pvsg_last_error()
-    rc = hip_lib.pvsg_reconsdot_cost(one, None, one, 2, 20, 3, 64, ctypes.c_float(100.0), one, one, None)
+    rc = hip_lib.pvsg_reconsdot_cost(one, None, one, 2, 20, 3, 64, ctypes.c_float(100.0), None, one, one, None)
     assert rc == 1 and b'null pointer' in hip_lib.pvsg_last_error()
     counts = (ctypes.c_longlong * 5)(3, 2, 40, 1, 7)                  # host codec: runs of one mask
     seg = (ctypes.c_longlong * 1)(5)

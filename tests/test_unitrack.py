@@ -266,6 +266,11 @@ def test_reconsdot_fused_kernels_equal_the_tensor_op_form(hip_lib, trk_cells, de
     assert torch.equal(got, T.reconsdot_cost(trk, det, 100.0))
     if len(trk) > 1 and len(det) > 1:
         assert int(got[0].argmin()) == 1
+    # the caller's class gate: gated pairs are skipped (+inf), the others are the same numbers (the soft-max statistics run
+    # over every cell either way)
+    need = (torch.arange(len(trk))[:, None] + torch.arange(len(det))[None, :]) % 3 != 1
+    part = T.reconsdot_cost(trk, det, 100.0, needed=need.cuda())
+    assert torch.equal(part.cpu()[need], got.cpu()[need]) and bool(torch.isinf(part.cpu()[~need]).all())
 
 
 @pytest.mark.gpu
