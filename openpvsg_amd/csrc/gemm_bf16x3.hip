@@ -1390,14 +1390,19 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
 // patch row (block row + dy), columns dx .. dx + 15, sixteen consecutive 16-byte records.  The weights of a tap (16 KB) arrive by
 // LDS-DMA into one of two buffers while the previous tap computes; one barrier per tap, two more per channel block.
 //   per channel block and thread: 24 dword loads + 12 split pairs (the tap-by-tap form: 144 + 72)
-template <bool RELU>
+// CT = 128: 128 output channels x 8 x 16 pixels (wave = 64 channels x 4 pixel rows); CT = 64 (the 64-channel layers): 64 output
+// channels x 16 x 16 pixels (wave = all 64 channels x 4 pixel rows), patch 18 x 18.
+template <bool RELU, int CT>
 __global__ __launch_bounds__(256, 2)
 void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ scale,
                                const float* __restrict__ shift, float* __restrict__ y, int Cin, int Cout, int Cpad, int H, int W,
                                int tiles_c, int tiles_x, int tiles_y, unsigned* __restrict__ overflow) {
-  constexpr int PH = 10, PW = 18, PP = PH * PW;                  // patch
+  constexpr int PR = CT == 128 ? 8 : 16;                         // pixel rows of the tile
+  constexpr int PH = PR + 2, PW = 18, PP = PH * PW;              // patch
   constexpr int P_KG = PP * 8, P_LIMB = 4 * P_KG;                // elements
-  constexpr int W_AT = 2 * P_LIMB, W_BUF = 2 * K32_LIMB;
+  constexpr int W_ARR = 4 * CT * 8;                              // one limb array of a tap: [k-group 4][CT][8]
+  constexpr int W_AT = 2 * P_LIMB, W_BUF = 2 * W_ARR;
+  constexpr int NR = (4 * PP + 255) / 256;                       // staging rounds
   __shared__ __attribute__((aligned(16))) __bf16 lds[W_AT + 2 * W_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -1407,17 +1412,19 @@ void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __rest
   const int tx = logical % tiles_x;
   logical /= tiles_x;
   const int ty = logical % tiles_y, img = logical / tiles_y;
-  const int c0 = tc * GB_M, oy0 = ty * 8, ox0 = tx * 16;
+  const int c0 = tc * CT, oy0 = ty * PR, ox0 = tx * 16;
+  const int ch_w = CT == 128 ? wr * 64 : 0;                       // the wave's first channel / pixel row inside the tile
+  const int pr_w = CT == 128 ? wc * 4 : wr * 8 + wc * 4;
   const int HW = H * W;
   const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)img * Cin * HW, 0,
                                                       (unsigned)((size_t)Cin * HW * 4), 0x00020000);
   const unsigned plane = (unsigned)HW * 4u;
-  // staging items (patch pixel, k-group): item i = round * 256 + tid, pixel i % 180, k-group i / 180; 720 items in 3 rounds
-  unsigned it_voff[3];
-  int it_lds[3];
-  unsigned it_kg[3];
+  // staging items (patch pixel, k-group): item i = round * 256 + tid, pixel i % PP, k-group i / PP; 4 PP items in NR rounds
+  unsigned it_voff[NR];
+  int it_lds[NR];
+  unsigned it_kg[NR];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
+  for (int r = 0; r < NR; ++r) {
     const int i = r * 256 + tid;
     const int kg = i / PP, pp = i - kg * PP;
     const int py = pp / PW, px = pp - py * PW;
@@ -1427,10 +1434,10 @@ void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __rest
     it_kg[r] = (unsigned)(kg < 4 ? kg : 3);
     it_lds[r] = i < 4 * PP ? kg * P_KG + pp * 8 : -1;
   }
-  float xr[3][8];
+  float xr[NR][8];
   auto loadX = [&](int cib) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < NR; ++r) {
       const unsigned so = (unsigned)(cib * 32 + 8 * it_kg[r]) * plane;
 #pragma unroll
       for (int j = 0; j < 8; ++j) xr[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, it_voff[r], so + j * plane, 0));
@@ -1439,7 +1446,7 @@ void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __rest
   float amax = 0.f;
   auto stashX = [&]() {                                          // split + write the patch of the channel block in xr
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < NR; ++r) {
       unsigned hh[4], ll[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) split2h(xr[r][2 * q], xr[r][2 * q + 1], hh[q], ll[q], amax);
@@ -1454,11 +1461,12 @@ void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __rest
   // [channel block][tap][32]: 32-deep step index = cib * 9 + tap.
   const size_t w_kg_stride = (size_t)Cpad * 8;
   auto dmaW = [&](int step, int buf) {
+    constexpr int HALVES = CT / 64, SLABS = 8 * HALVES / 4;        // (array, k-group, 64-channel half) slabs of 1 KB; per wave
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int sl = wave * 4 + i, l = sl >> 3, kg = (sl >> 1) & 3, half = sl & 1;
+    for (int i = 0; i < SLABS; ++i) {
+      const int sl = wave * SLABS + i, half = sl % HALVES, kg = (sl / HALVES) & 3, l = sl / (4 * HALVES);
       const __bf16* src = Wp + ((((size_t)(2 * step + (kg >> 1)) * 2 + l) * 2 + (kg & 1)) * w_kg_stride) + (size_t)(c0 + half * 64 + lane) * 8;
-      __bf16* dst = lds + W_AT + buf * W_BUF + l * K32_LIMB + (kg * GB_M + half * 64) * 8;
+      __bf16* dst = lds + W_AT + buf * W_BUF + l * W_ARR + (kg * CT + half * 64) * 8;
       __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
   };
@@ -1466,8 +1474,8 @@ void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __rest
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int l15 = lane & 15, kg4 = lane >> 4;
-  const __bf16* wfr0 = lds + W_AT + (kg4 * GB_M + wr * 64 + l15) * 8;          // + buffer + array * K32_LIMB + row block * 128
-  const __bf16* xfr0 = lds + kg4 * P_KG + ((wc * 4) * PW + l15) * 8;           // + limb * P_LIMB + ((cb + dy) * PW + dx) * 8
+  const __bf16* wfr0 = lds + W_AT + (kg4 * CT + ch_w + l15) * 8;               // + buffer + array * W_ARR + row block * 128
+  const __bf16* xfr0 = lds + kg4 * P_KG + (pr_w * PW + l15) * 8;               // + limb * P_LIMB + ((cb + dy) * PW + dx) * 8
   auto frag = [](const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); };
   auto mf = [](u32x4 a, u32x4 b, f32x4 c) { return mfma_k32<true>(a, b, c); };
   const int NCB = Cin / 32, NSTEP = NCB * 9;
@@ -1490,7 +1498,7 @@ void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __rest
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) {
         whf[rb] = frag(wfr + rb * 128);
-        wlf[rb] = frag(wfr + K32_LIMB + rb * 128);
+        wlf[rb] = frag(wfr + W_ARR + rb * 128);
       }
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) w2f[rb] = f16x2_lo_scale(whf[rb]);
@@ -1517,7 +1525,7 @@ void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __rest
     if (cib + 1 < NCB) stashX();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the repeated last slabs: nothing may land after the end)
-  // BN affine (+ ReLU): register r of block (rb, cb) = channel 16 rb + 4 kg4 + r, pixel (row wc*4 + cb, column l15) of the tile
+  // BN affine (+ ReLU): register r of block (rb, cb) = channel ch_w + 16 rb + 4 kg4 + r, pixel (row pr_w + cb, column l15) of the tile
   {
     const auto srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scale), 0, scale ? (unsigned)Cout * 4u : 0u, 0x00020000);
     const auto hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(shift), 0, shift ? (unsigned)Cout * 4u : 0u, 0x00020000);
@@ -1527,12 +1535,12 @@ void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __rest
     unsigned pvoff[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
-      const int oy = oy0 + wc * 4 + cb, ox = ox0 + l15;
+      const int oy = oy0 + pr_w + cb, ox = ox0 + l15;
       pvoff[cb] = (oy < H && ox < W) ? (unsigned)(oy * W + ox) * 4u : 0x80000000u;
     }
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
-      const int chb = c0 + wr * 64 + rb * 16 + 4 * kg4;              // channels chb .. chb + 3 (>= Cout: dropped by the descriptor)
+      const int chb = c0 + ch_w + rb * 16 + 4 * kg4;              // channels chb .. chb + 3 (>= Cout: dropped by the descriptor)
       f32x4 sc4 = scale ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)chb * 4u, 0, 0))
                         : f32x4{1.f, 1.f, 1.f, 1.f};
       sc4 *= unscale;
@@ -1866,16 +1874,18 @@ static int conv3x3_split_run(const float* x, const void* w_packed, const float* 
   unsigned* const noflags = nullptr;
   {
     const char* hsel = getenv("PVSG_CONV3X3_HALO");               // =0: the tap-by-tap form for stride 1 too (A/B tests)
-    if (f16 && stride == 1 && Cout > 64 && !(hsel && hsel[0] == '0')) {   // (<= 64 output channels: the 64-row tile of the tap-by-tap kernel)
-      const int tiles_x = (W + 15) / 16, tiles_y = (H + 7) / 8;
-      const long long hb = (long long)B * tiles_c * tiles_x * tiles_y;
+    if (f16 && stride == 1 && !(hsel && hsel[0] == '0')) {
+      const bool wide = Cout > 64;                                // <= 64 output channels: 64 x (16 x 16 pixels) tiles
+      const int tc = wide ? tiles_c : (Cout + 63) / 64;
+      const int tiles_x = (W + 15) / 16, tiles_y = wide ? (H + 7) / 8 : (H + 15) / 16;
+      const long long hb = (long long)B * tc * tiles_x * tiles_y;
       PVSG_REQUIRE(hb < (1LL << 31), "%s: too many blocks", nm);
-      if (relu)
-        hipLaunchKernelGGL((conv3x3_f16x2_halo_kernel<true>), dim3((unsigned)hb), block, 0, st, x, wp, scale, shift, y, Cin, Cout, Cpad,
-                           H, W, tiles_c, tiles_x, tiles_y, overflow);
-      else
-        hipLaunchKernelGGL((conv3x3_f16x2_halo_kernel<false>), dim3((unsigned)hb), block, 0, st, x, wp, scale, shift, y, Cin, Cout, Cpad,
-                           H, W, tiles_c, tiles_x, tiles_y, overflow);
+#define PVSG_HALO_LAUNCH(R, C)                                                                                                     \
+  hipLaunchKernelGGL((conv3x3_f16x2_halo_kernel<R, C>), dim3((unsigned)hb), block, 0, st, x, wp, scale, shift, y, Cin, Cout, Cpad, \
+                     H, W, tc, tiles_x, tiles_y, overflow)
+      if (wide) { if (relu) PVSG_HALO_LAUNCH(true, 128); else PVSG_HALO_LAUNCH(false, 128); }
+      else { if (relu) PVSG_HALO_LAUNCH(true, 64); else PVSG_HALO_LAUNCH(false, 64); }
+#undef PVSG_HALO_LAUNCH
       PVSG_LAUNCH_CHECK(nm);
       return PVSG_OK;
     }
