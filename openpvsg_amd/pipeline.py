@@ -10,11 +10,49 @@ Here the same records stay on the GPU: kept segment ids per frame -> tube index 
 """
 import os
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
 from . import ops, parallel
 from .blocks import pin_graph_caches
+
+
+def _first_appearances_numpy(host):
+    """host (T, K) segment ids, -1 = dropped -> (ids in order of first appearance, and for every (frame, id) present the
+    tube row, the frame and the FIRST query index carrying that id in the frame: `feat[0]` of the id's list, utils.py:48)."""
+    hh = np.asarray(host, dtype=np.int64)
+    tt, kk = np.nonzero(hh >= 0)                                             # frame-major, then query order
+    sid = hh[tt, kk]
+    uniq, first, inv = np.unique(sid, return_index=True, return_inverse=True)
+    by_first = np.argsort(first, kind='stable')
+    rank = np.empty(len(uniq), np.int64)
+    rank[by_first] = np.arange(len(uniq))                                    # position of an id in order of first appearance
+    _, firsts = np.unique(tt * max(len(uniq), 1) + inv, return_index=True)   # first (frame, id) occurrence = smallest k
+    return uniq[by_first].tolist(), rank[inv[firsts]].tolist(), tt[firsts].tolist(), kk[firsts].tolist()
+
+
+def _first_appearances_python(host):
+    """the same for ragged frames (lists of different lengths)"""
+    order = []
+    seen = set()
+    for ids in host:
+        for sid in ids:
+            if sid >= 0 and sid not in seen:
+                seen.add(sid)
+                order.append(sid)
+    index = {sid: i for i, sid in enumerate(order)}
+    rows, ts, cols = [], [], []
+    for t, ids in enumerate(host):
+        first = {}
+        for k, sid in enumerate(ids):
+            if sid >= 0 and sid not in first:
+                first[sid] = k
+        for sid, k in first.items():
+            rows.append(index[sid])
+            ts.append(t)
+            cols.append(k)
+    return order, rows, ts, cols
 
 
 def assemble_tubes(seg_ids, kept_feats, num_frames):
@@ -30,25 +68,11 @@ def assemble_tubes(seg_ids, kept_feats, num_frames):
         host = [s.tolist() for s in seg_ids]
     if dev.type == 'cuda':
         ops.split_overflow_check(dev)       # the detector's f16x2 kernels (ops.py); the stage is synchronised here anyway
-    order = []
-    seen = set()
-    for ids in host:
-        for sid in ids:
-            if sid >= 0 and sid not in seen:
-                seen.add(sid)
-                order.append(sid)
-    index = {sid: i for i, sid in enumerate(order)}
+    if seg_ids and same_k and len(host[0]):
+        order, rows, ts, cols = _first_appearances_numpy(host)
+    else:
+        order, rows, ts, cols = _first_appearances_python(host)
     feats = torch.zeros((len(order), num_frames, C), dtype=torch.float32, device=dev)
-    rows, ts, cols = [], [], []
-    for t, ids in enumerate(host):
-        first = {}
-        for k, sid in enumerate(ids):
-            if sid >= 0 and sid not in first:               # `feat[0]` of the id's list (utils.py:48)
-                first[sid] = k
-        for sid, k in first.items():
-            rows.append(index[sid])
-            ts.append(t)
-            cols.append(k)
     if rows:
         shared = all(f is kept_feats[0] for f in kept_feats)                 # clip mode: one kept set for all frames
         idx = torch.tensor([rows, ts, cols], dtype=torch.long, device=dev)

@@ -86,3 +86,19 @@ def test_device_mask_has_the_ndarray_surface_of_the_reference_masks():
     ys, xs = a.nonzero()
     assert ys.min() == 1 and xs.max() == 4
     assert (a & ~np.asarray(tubes.DeviceMask(st, 2))).sum() == 9
+
+
+def test_tube_assembly_first_appearances_numpy_equals_python():
+    """pipeline._first_appearances_numpy (clip mode: T x K ids in one array) against the loop form used for ragged frames"""
+    import numpy as np
+    from openpvsg_amd import pipeline
+    rs = np.random.RandomState(5)
+    for T, K in ((1, 1), (4, 7), (32, 32), (3, 100)):
+        for _ in range(5):
+            host = np.where(rs.rand(T, K) < 0.8, rs.randint(0, 9, (T, K)) * 1000 + rs.randint(0, 5, (T, K)), -1)
+            if rs.rand() < 0.3:
+                host[:] = -1
+            o1, r1, t1, c1 = pipeline._first_appearances_numpy(host.tolist())
+            o2, r2, t2, c2 = pipeline._first_appearances_python(host.tolist())
+            assert o1 == o2
+            assert sorted(zip(r1, t1, c1)) == sorted(zip(r2, t2, c2))
