@@ -854,6 +854,14 @@ def main():
                     a_ = dd['flops'] / dd['calls'] / per_ms / 1e9
                     pk, what = KernelTimer.mfma_peak(k.split('[')[0])
                     ent = dict(kernel=k, bound='mfma', achieved=a_, peak=pk, unit='TFLOP/s', frac=a_ / pk, flops_counted=what)
+                    # the roof that binds = the larger ideal time, as for `roofline`: the mask projection streams 2.7 GB per launch
+                    # through 0.2 TFLOP of limb products -- its matrix fraction says little, its HBM fraction is the bound
+                    gbs = dd['bytes'] / dd['calls'] / per_ms / 1e6
+                    if dd['bytes'] / (HBM_PEAK_GBS * 1e9) > dd['flops'] / (pk * 1e12):
+                        ent = dict(kernel=k, bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS,
+                                   mfma_TFLOPs=a_, mfma_frac=a_ / pk, flops_counted=what)
+                    else:
+                        ent['hbm_GBps'], ent['hbm_frac'] = gbs, gbs / HBM_PEAK_GBS
                     if k.split('[')[0] in KernelTimer.SPLIT_F16X2 or 'bf16x3' in k:
                         # measured with rocm-smi while one layer loops (scripts/lab/power_probe.py, profiles/r04_power_probe.txt):
                         # the split kernels run at the socket's 1400 W limit with the shader clock throttled to 1.6-2.2 GHz
