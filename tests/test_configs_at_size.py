@@ -197,3 +197,43 @@ def test_config3_attention_471040_keys_exact_properties(hip_lib, K):
     assert torch.allclose(out, expect.view(Q, 1).expand(Q, 256), rtol=1e-4, atol=1e-5)
     ones = ops.masked_xattn(torch.randn(1, Q, 256, device=DEV) * 0.3, k, torch.ones_like(k), mask, 8)
     assert torch.allclose(ones, torch.ones_like(ones), rtol=1e-4, atol=1e-4)
+
+
+def test_config5_1080p_through_the_backbone_sample_vs_oracle_and_8_frames_per_gpu(hip_lib, monkeypatch):
+    """BASELINE config 5 (full PVSG, 64 frames of 1080p over 8 GPUs = 8 frames of 1088 x 1920 per GPU) THROUGH THE BACKBONE:
+    (1) a 2-frame 1080p sample of the whole flow -- backbone, pixel decoder (34x60 / 68x120 / 136x240 levels), clip-level decoder,
+    fusion, tube assembly, relation head -- against the CPU oracle at the north-star bar; (2) the per-GPU size, 8 frames: the
+    key-split of the masked attention (what the frame shards of the other ranks change) leaves the panoptic maps, the tubes and
+    the top pairs unchanged."""
+    sys.path.insert(0, ROOT)
+    import argparse
+    import bench
+    from openpvsg_amd import ops
+    from openpvsg_amd.pipeline import PVSGPipeline
+    dev = torch.device(DEV)
+    det, rel = bench.build_models(0)
+    det = det.to(dev)
+    rel = {k: v.to(dev) for k, v in rel.items()}
+    pipe = PVSGPipeline(det, rel['subject_encoder'], rel['object_encoder'], rel['pair_model'], rel['relation_model'],
+                        use_graph=False).eval()
+    args = argparse.Namespace(height=1080, width=1920, head_outputs='synthetic', keep=32, frames=2)
+    base, parity = bench.cpu_baseline_and_parity(det, rel, pipe, args, dev, 2, 1, warmup=False)
+    assert parity['pixel_mismatch'] < 1e-3 and parity['mask_iou'] >= 1 - 1e-3
+    assert parity['tubes'] == parity['tubes_oracle'] >= 30
+    assert parity['pair_matrix_max_abs_diff'] < 1e-3 and parity['top20_pairs_equal']
+    T = 8
+    clip, (Hp, Wp) = bench.make_clip(T, 1080, 1920, seed=2)
+    assert (Hp, Wp) == (1088, 1920)
+    pipe.head_override = bench.make_override(bench.synthetic_head_outputs(T, Hp // 4, Wp // 4, n_keep=32, seed=0), dev)
+    clip = clip.to(dev)
+
+    def snap(out):
+        return dict(pan=out['pan_results'].clone(), query=out['query'].clone(), ids=out['tube_ids'].tolist(),
+                    pm=out['relation']['pred_matrix'].clone(), pairs=out['relation']['pairs'].tolist())
+    one = snap(pipe(clip, (Hp, Wp), (1080, 1920)))
+    assert one['pan'].shape == (T, 1080, 1920) and len(one['ids']) >= 30
+    monkeypatch.setattr(ops, 'xattn_num_splits', lambda B, K: max(1, min(8, (K + 63) // 64)))
+    other = snap(pipe(clip, (Hp, Wp), (1080, 1920)))
+    assert torch.equal(other['pan'], one['pan']) and other['ids'] == one['ids'] and other['pairs'][:20] == one['pairs'][:20]
+    assert torch.allclose(other['query'], one['query'], rtol=1e-4, atol=1e-4)
+    assert torch.allclose(other['pm'], one['pm'], rtol=1e-3, atol=1e-4)
