@@ -112,6 +112,88 @@ __global__ __launch_bounds__(256) void msda_fwd_m8d32(
   st4(out + gq * (M * D) + m * D + c4 * 4, acc);
 }
 
+// The same op with the per-tap arithmetic shared by the eight lanes of a head (see msda_sample_query_coop below: lane c4 of a
+// head works out taps c4 and 8 + c4 -- location, bilinear weights, 32-bit byte offsets of the four corners -- and the gather
+// loop fetches each tap's nine numbers from its owner lane with ds_bpermute).  848 -> ~500 VALU instructions per wave; same
+// per-tap formulas and summation order.  Needs one image's value rows within 2 GB (checked by the caller).
+template <int L, int P>
+__global__ __launch_bounds__(256) void msda_fwd_m8d32_coop(
+    const float* __restrict__ value, const long long* __restrict__ shapes,
+    const long long* __restrict__ lsi, const float* __restrict__ loc,
+    const float* __restrict__ attw, float* __restrict__ out, int S, int Lq,
+    long long nq_total, unsigned nblk) {
+  constexpr int M = 8, D = 32, LP = L * P, NT = (LP + 7) / 8;     // NT taps per lane
+  static_assert(LP <= 16, "at most two taps per lane");
+  const unsigned lb = xcd_contiguous_block(blockIdx.x, nblk);
+  const long long gq = (long long)lb * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (gq >= nq_total) return;
+  const int lane = threadIdx.x & 63;
+  const int m = lane >> 3, c4 = lane & 7;
+  const int b = (int)(gq / Lq);
+  const float* locp = loc + ((gq * M + m) * (long long)(LP * 2));
+  const float* wp = attw + ((gq * M + m) * (long long)LP);
+  int own_off[NT][4];
+  float own_cw[NT][4], own_a[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const int p = min(k * 8 + c4, LP - 1);                         // lanes without this tap repeat the last one (never read)
+    const int l = p / P;
+    const float2 xy = *reinterpret_cast<const float2*>(locp + 2 * p);
+    own_a[k] = wp[p];
+    int H = (int)shapes[0], W = (int)shapes[1];
+    long long base = lsi[0];
+#pragma unroll
+    for (int j = 1; j < L; ++j)
+      if (l == j) { H = (int)shapes[2 * j]; W = (int)shapes[2 * j + 1]; base = lsi[j]; }
+    const float him = xy.y * (float)H - 0.5f, wim = xy.x * (float)W - 0.5f;
+    const float hf = floorf(him), wf = floorf(wim);
+    const float lh = him - hf, lw = wim - wf, hh = 1.f - lh, hw = 1.f - lw;
+    const float hfc = fminf(fmaxf(hf, -2.f), (float)H + 1.f);
+    const float wfc = fminf(fmaxf(wf, -2.f), (float)W + 1.f);
+    const int h0 = (int)hfc, w0 = (int)wfc, h1 = h0 + 1, w1 = w0 + 1;
+    const bool inside = (him > -1.f) && (wim > -1.f) && (him < (float)H) && (wim < (float)W);
+    const bool vh0 = inside && h0 >= 0, vh1 = inside && h1 <= H - 1;
+    const bool vw0 = w0 >= 0, vw1 = w1 <= W - 1;
+    const int h0c = min(max(h0, 0), H - 1), h1c = min(max(h1, 0), H - 1);
+    const int w0c = min(max(w0, 0), W - 1), w1c = min(max(w1, 0), W - 1);
+    own_cw[k][0] = (vh0 && vw0) ? hh * hw : 0.f;
+    own_cw[k][1] = (vh0 && vw1) ? hh * lw : 0.f;
+    own_cw[k][2] = (vh1 && vw0) ? lh * hw : 0.f;
+    own_cw[k][3] = (vh1 && vw1) ? lh * lw : 0.f;
+    const int b0 = (int)base;
+    own_off[k][0] = (b0 + h0c * W + w0c) * (M * D * 4);
+    own_off[k][1] = (b0 + h0c * W + w1c) * (M * D * 4);
+    own_off[k][2] = (b0 + h1c * W + w0c) * (M * D * 4);
+    own_off[k][3] = (b0 + h1c * W + w1c) * (M * D * 4);
+  }
+  const char* vbase = reinterpret_cast<const char*>(value + (long long)b * S * (M * D));
+  const int lane_off = (m * D + c4 * 4) * 4;
+  const int grp = (lane & ~7) << 2;                                  // ds_bpermute takes byte addresses (lane * 4)
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int p = 0; p < LP; ++p) {
+    const int k = p >> 3, src = grp + ((p & 7) << 2);
+    int off[4];
+    float cw[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      off[c] = __builtin_amdgcn_ds_bpermute(src, own_off[k][c]);
+      cw[c] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(own_cw[k][c])));
+    }
+    const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(own_a[k])));
+    float4 v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const float4*>(vbase + (unsigned)(off[c] + lane_off));
+    float4 s4;
+    s4.x = cw[0] * v[0].x + cw[1] * v[1].x + cw[2] * v[2].x + cw[3] * v[3].x;
+    s4.y = cw[0] * v[0].y + cw[1] * v[1].y + cw[2] * v[2].y + cw[3] * v[3].y;
+    s4.z = cw[0] * v[0].z + cw[1] * v[1].z + cw[2] * v[2].z + cw[3] * v[3].z;
+    s4.w = cw[0] * v[0].w + cw[1] * v[1].w + cw[2] * v[2].w + cw[3] * v[3].w;
+    acc.x += a * s4.x; acc.y += a * s4.y; acc.z += a * s4.z; acc.w += a * s4.w;
+  }
+  st4(out + gq * (M * D) + m * D + c4 * 4, acc);
+}
+
 // Shape-generic path (any M, D, L, P): one lane per output scalar.  Only the
 // R50 configs' (M=8, D=32) shape is tuned; this keeps the op total.
 __global__ __launch_bounds__(256) void msda_fwd_generic(
@@ -180,7 +262,18 @@ extern "C" int pvsg_ms_deform_attn_forward(const float* value, const int64_t* sp
     const long long nblk_ll = (nq + 3) / 4;
     PVSG_REQUIRE(nblk_ll < (1ll << 31), "ms_deform_attn_forward: too many queries");
     const unsigned nblk = (unsigned)nblk_ll;
-    if (L == 3)
+    const char* cp = getenv("PVSG_MSDA_COOP");                       // =0: every lane of a head computes every tap (A/B)
+    const bool coop = (long long)S * M * D * 4 < (1ll << 31) && !(cp && cp[0] == '0');
+    if (coop && L == 3)
+      hipLaunchKernelGGL((msda_fwd_m8d32_coop<3, 4>), dim3(nblk), dim3(256), 0, stream, value, sh, ls,
+                         sampling_loc, attn_weight, out, S, Lq, nq, nblk);
+    else if (coop && L == 4)
+      hipLaunchKernelGGL((msda_fwd_m8d32_coop<4, 4>), dim3(nblk), dim3(256), 0, stream, value, sh, ls,
+                         sampling_loc, attn_weight, out, S, Lq, nq, nblk);
+    else if (coop)
+      hipLaunchKernelGGL((msda_fwd_m8d32_coop<1, 4>), dim3(nblk), dim3(256), 0, stream, value, sh, ls,
+                         sampling_loc, attn_weight, out, S, Lq, nq, nblk);
+    else if (L == 3)
       hipLaunchKernelGGL((msda_fwd_m8d32<3, 4>), dim3(nblk), dim3(256), 0, stream, value, sh, ls,
                          sampling_loc, attn_weight, out, S, Lq, nq, nblk);
     else if (L == 4)
