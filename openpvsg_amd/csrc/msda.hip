@@ -585,7 +585,7 @@ __device__ __forceinline__ float msda_wave_allreduce(float v) {
   return op(__uint_as_float(b2[0]), __uint_as_float(b2[1]));
 }
 
-template <int L, int P>
+template <int L, int P, bool COOP>
 __global__ __launch_bounds__(MP_THREADS, 4) void msda_proj_ln_kernel(
     const float* __restrict__ value, long long value_stride, const float* __restrict__ oa, long long oa_stride,
     const float* __restrict__ pos_oa, const float* __restrict__ ref, const long long* __restrict__ shapes,
@@ -603,7 +603,8 @@ __global__ __launch_bounds__(MP_THREADS, 4) void msda_proj_ln_kernel(
     const long long gq = q0 + r;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (gq < nq_total)
-      acc = msda_sample_query<L, P>(value, value_stride, oa, oa_stride, pos_oa, ref, shapes, lsi, S, Lq, gq, lane);
+      acc = COOP ? msda_sample_query_coop<L, P>(value, value_stride, oa, oa_stride, pos_oa, ref, shapes, lsi, S, Lq, gq, lane)
+                 : msda_sample_query<L, P>(value, value_stride, oa, oa_stride, pos_oa, ref, shapes, lsi, S, Lq, gq, lane);
     *reinterpret_cast<float4*>(xs + r * MP_LD + lane * 4) = acc;       // lane = (head, quad) -> column 4*lane
   }
   __syncthreads();
@@ -778,11 +779,16 @@ extern "C" int pvsg_msda_proj_ln_forward(const float* value, long long value_row
   const long long nq = (long long)B * Lq;
   const long long nt = (nq + MP_ROWS - 1) / MP_ROWS;
   PVSG_REQUIRE(nt < (1ll << 31), "msda_proj_ln_forward: too many queries");
-  hipLaunchKernelGGL((msda_proj_ln_kernel<3, 4>), dim3((unsigned)nt), dim3(MP_THREADS), 0, stream, value,
-                     value_row_stride, oa, oa_row_stride, pos_oa, ref_points,
-                     reinterpret_cast<const long long*>(spatial_shapes),
-                     reinterpret_cast<const long long*>(level_start_index), wo_packed, wo_bias, identity, gamma, beta,
-                     out, S, Lq, nq, (unsigned)nt, eps);
+  const char* cp = getenv("PVSG_MSDA_COOP");
+  const bool coop = (long long)S * value_row_stride * 4 < (1ll << 31) && !(cp && cp[0] == '0');
+#define PVSG_MPL_LAUNCH(C)                                                                                          \
+  hipLaunchKernelGGL((msda_proj_ln_kernel<3, 4, C>), dim3((unsigned)nt), dim3(MP_THREADS), 0, stream, value,        \
+                     value_row_stride, oa, oa_row_stride, pos_oa, ref_points,                                        \
+                     reinterpret_cast<const long long*>(spatial_shapes),                                             \
+                     reinterpret_cast<const long long*>(level_start_index), wo_packed, wo_bias, identity, gamma, beta, \
+                     out, S, Lq, nq, (unsigned)nt, eps)
+  if (coop) PVSG_MPL_LAUNCH(true); else PVSG_MPL_LAUNCH(false);
+#undef PVSG_MPL_LAUNCH
   PVSG_LAUNCH_CHECK("msda_proj_ln_forward");
   return PVSG_OK;
 }
