@@ -278,10 +278,13 @@ def evaluate(subject_encoder, object_encoder, pair_proposal_model, relation_mode
     final = calculate_final_metrics(rrd, K_values)
     if verbose:
         print(f'Pair Recall@20: {100 * np.array(pair_recall_list).mean():.2f}')
+        rule = '-' * 67                                   # the layout of tools/rel_test.py:96-108: one metric per line
         for K in K_values:
-            print(f"Recall@{K}: {100 * final[K]['recall']:.2f}  Mean Recall@{K}: {100 * final[K]['mean_recall']:.2f}  "
-                  f"Weak Recall@{K}: {100 * final[K]['weak_recall']:.2f}  "
-                  f"Weak Mean Recall@{K}: {100 * final[K]['weak_mean_recall']:.2f}")
+            print(rule)
+            for label, key in (('Recall', 'recall'), ('Mean Recall', 'mean_recall'), ('Weak Recall', 'weak_recall'),
+                               ('Weak Mean Recall', 'weak_mean_recall')):
+                print('%s@%d: %.2f' % (label, K, 100 * final[K][key]))
+            print(rule)
     if csv_file_path is not None:
         import csv
         import os

@@ -145,6 +145,73 @@ def test_tools_rel_test_py_resolves_to_backend(compat_path):
         del sys.modules[k]
 
 
+@needs_ref
+def test_reference_evaluate_function_runs_on_backend_modules(compat_path, tmp_path, monkeypatch, capsys):
+    """tools/rel_test.py's OWN `evaluate` -- the function object of the unmodified file -- EXECUTED against the backend's relation
+    modules, dataset reader, pair selection, result generation, metrics and csv writer, on a synthetic two-video data set, and
+    compared with openpvsg_amd.relation.evaluate (the restatement the GPU tests use) on the same loader.  This container has no
+    GPU and the product has no CPU path, so the one HIP call of the flow (the N x N pair scorer, ops.pair_score) is replaced IN
+    THIS TEST by the oracle's closed form; everything else is product code driven by the reference's caller."""
+    import json
+    import pickle
+    import numpy as np
+    import torch
+    for k in [k for k in sys.modules if k.split('.')[0] in ('models', 'datasets', 'utils')]:
+        del sys.modules[k]
+    sys.path.insert(1, REF)
+    try:
+        spec = importlib.util.spec_from_file_location('ref_rel_test_run', os.path.join(REF, 'tools', 'rel_test.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.path.remove(REF)
+    import openpvsg_amd.relation as prel
+    from openpvsg_amd import ops
+
+    def cpu_pair_score(sub, obj, W1, b1, w2, b2, return_tokens=False, W1T=None):
+        s_tok, o_tok = sub.max(dim=1).values, obj.max(dim=1).values              # oracle/relation.py PairProposalNetwork
+        n = s_tok.shape[0]
+        x = torch.cat([s_tok[:, None].expand(n, n, -1), o_tok[None].expand(n, n, -1)], -1)
+        out = (torch.relu(x @ W1.t() + b1) @ w2.reshape(-1, 1) + b2).reshape(n, n)
+        out[torch.eye(n, dtype=torch.bool)] = 0.0
+        return out
+    monkeypatch.setattr(ops, 'pair_score', cpu_pair_score)
+    monkeypatch.setattr(ops, 'pair_prepare_weights', lambda w: w)
+    rs = np.random.RandomState(3)
+    relations = ['on', 'in', 'next to', 'holding']
+    anno = dict(split=dict(vidor=dict(val=['v1']), epic_kitchen=dict(val=[]), ego4d=dict(val=['v2'])),
+                objects=dict(thing=['a', 'b'], stuff=['c']), relations=relations, data=[dict(video_id='v1'), dict(video_id='v2')])
+    (tmp_path / 'pvsg.json').write_text(json.dumps(anno))
+    T = 6
+    for vid, n in (('v1', 7), ('v2', 5)):
+        os.makedirs(tmp_path / 'wd' / vid)
+        feats = {10 * (i + 1): rs.standard_normal((T, 256)) for i in range(n)}
+        rels = [dict(subject_index=10 * (a + 1), object_index=10 * (b + 1), relation=int(rs.randint(0, 4)),
+                     relation_span=(rs.uniform(size=T) < 0.5).astype(np.float64))
+                for a, b in ((0, 1), (2, 0), (1, 3), (4, 2))]
+        with open(tmp_path / 'wd' / vid / 'relations.pickle', 'wb') as f:
+            pickle.dump(dict(feats=feats, relations=rels), f)
+    ds = mod.PVSGRelationDataset(str(tmp_path / 'pvsg.json'), 'val', str(tmp_path / 'wd'))
+    loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False)
+    torch.manual_seed(5)
+    se, oe = mod.ObjectEncoder(256), mod.ObjectEncoder(256)
+    pp, rm = mod.PairProposalNetwork(256, 1024), mod.TemporalTransformer(512, len(relations))
+    with torch.no_grad():
+        pp.pair_ffn[2].weight.mul_(30.0)                                   # spread the pair scores
+    capsys.readouterr()
+    mod.evaluate(se, oe, pp, rm, loader, 100, ds.relations, 'cpu', str(tmp_path / 'ref.csv'), 'ref')
+    ref_out = capsys.readouterr().out
+    final, recalls = prel.evaluate(se, oe, pp, rm, loader, 100, ds.relations, 'cpu', str(tmp_path / 'own.csv'), 'own')
+    own_out = capsys.readouterr().out
+    pick = lambda text: [ln.strip() for ln in text.splitlines() if 'Recall' in ln]
+    assert pick(ref_out) and pick(ref_out) == pick(own_out)                # Pair Recall@20, Recall / Mean / Weak @20/50/100
+    assert ref_out == own_out                                                # the printed report, character for character
+    assert os.path.exists(tmp_path / 'ref.csv') and os.path.exists(tmp_path / 'own.csv')
+    assert len(recalls) == 2 and set(final) == {20, 50, 100}
+    for k in [k for k in sys.modules if k.split('.')[0] in ('models', 'datasets', 'utils')]:
+        del sys.modules[k]
+
+
 def test_relation_dataset_contract(compat_path, tmp_path):
     """Item layout + DataLoader(batch_size=1) behaviour tools/rel_test.py:33-48 relies on."""
     import json
