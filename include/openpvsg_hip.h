@@ -172,12 +172,16 @@ int pvsg_decoder_rows_pre(const pvsg_decoder_layer* layer, const float* attn_cor
  * workspace: NULL, or pvsg_decoder_rows_post_workspace_bytes(B, Q) bytes ZEROED ONCE by the caller and reused from call to
  *   call (one stream at a time): with it, and at most 32 row tiles (B * ceil(Q/16)), the FFN of a tile is split over eight
  *   workgroups that meet through it (a clip's 100 query rows would otherwise occupy 7 CUs); every launch leaves its
- *   arrival counters at zero.  The byte count is 0 when the split does not apply. */
+ *   arrival counters at zero.  The byte count is 0 when the split does not apply.
+ * emb_pack_f16x2: NULL, or B * pvsg_gemm_f16x2_packed_elems(Q, 256) 16-bit elements, ZEROED ONCE by the caller: the kernel also
+ *   writes the mask embeddings as the packed row operand of pvsg_attn_mask_bits_packed_f16x2 (one exact power-of-two scale per
+ *   query row: the bits are signs), which saves the amax / pack / zero launches of pvsg_attn_mask_bits_f16x2 in every layer.
+ * flags_zero: NULL, or (B, 4) words the kernel sets to 0 -- the flag words the bits kernel ORs into. */
 long long pvsg_decoder_rows_post_workspace_bytes(int B, int Q);
 int pvsg_decoder_rows_post(const pvsg_decoder_layer* layer, const pvsg_decoder_head* head, const float* next_q_w,
                            const float* next_q_b, const float* x1, const float* qkv, const float* query_pos,
                            float* query_out, float* cls_out, float* mask_embed_out, float* next_q_out, void* workspace,
-                           int B, int Q, void* stream);
+                           void* emb_pack_f16x2, uint32_t* flags_zero, int B, int Q, void* stream);
 
 /* ---- a11: pairwise relation proposal scorer -------------------------------------------------
  * Replaces models/relation_head/base.py:49-62 PairProposalNetwork.forward (N^2 Python loop).
@@ -209,6 +213,40 @@ int pvsg_panoptic_fuse(const float* mask_logits, const int* kept_idx, const floa
                        int* counter_ws, int T, int Q, int K, int h, int w, int H, int W, int ih, int iw,
                        int oh, int ow, int num_things, int num_classes, double iou_thr,
                        int filter_low_score, void* stream);
+
+/* ---- a8 + f2 on the device: class decision, fusion and tube bookkeeping without host round trips ----------
+ * pvsg_panoptic_select: the keep decision of mask2former_fusion_head.py:117-124 (`labels.ne(num_classes) & (scores >
+ * object_mask_thr)`) and the compaction `scores[keep] / labels[keep] / mask_pred[keep]` need, written as a device record
+ *   sel[0] = kept count clamped to 127, sel[1] = kept count, sel[2..3] = 0,
+ *   sel[4 + k] = query index, sel[4 + 128 + k] = class, sel[4 + 256 + k] = score bits   of kept query k (query order)
+ * scores (Q) f32 / labels (Q) int64 = F.softmax(mask_cls, -1).max(-1)  (the caller's softmax: bit-identical scores).
+ * pvsg_panoptic_fuse_sel = pvsg_panoptic_fuse with K and the kept tables read from `sel`; seg_id (T, 128) int32, unused = -1.
+ * If sel[1] > 127 the fused kernels cannot hold the kept set: the caller (who reads sel[1] with the tube record) must take
+ * the un-fused path for that input. */
+#define PVSG_SEL_MAXK 128
+#define PVSG_SEL_WORDS (4 + 3 * PVSG_SEL_MAXK)
+int pvsg_panoptic_select(const float* scores, const long long* labels, int Q, int num_classes, float score_thr, int* sel,
+                         void* stream);
+int pvsg_panoptic_fuse_sel(const float* mask_logits, const int* sel, int* panoptic, int* seg_id, unsigned char* owner_ws,
+                           int* counter_ws, int T, int Q, int h, int w, int H, int W, int ih, int iw, int oh, int ow,
+                           int num_things, int num_classes, double iou_thr, int filter_low_score, void* stream);
+
+/* Tube bookkeeping of models/mask2former_vps/utils.py:20-89 (`concat_seq`: tubes keyed by segment id in order of first
+ * appearance; per frame the FIRST query carrying an id supplies the feature; absent frames are zeros,
+ * utils/relation_matching.py:431-444) on the per-frame segment ids pvsg_panoptic_fuse_sel wrote.
+ *   seg_id   frames of 128 ids; frame t lives at row (t / frames_per_block) * rows_per_block + t % frames_per_block
+ *            (a local clip: both = T; an all-gathered frame shard with one trailing row per rank whose first word is that
+ *            rank's f16x2 overflow count: T_local and T_local + 1)
+ *   overflow the local f16x2 overflow counter (or NULL); table_ws: pvsg_tube_index_table_words() ints of scratch
+ *   rec      8 ints: [N tubes, K, K before clamping, overflow count, 0...]  -- the ONE record the host reads per clip
+ *   tube_ids (T * 128) int64, first N valid; rowmap (T, 128) int32: tube row of a frame-first query, else -1
+ * pvsg_tube_scatter: feats (N, T, C) from the query rows (row stride in floats) of the frame-first queries; zeros elsewhere.
+ * Segment ids must be < 128 000 (class < 1000 = [3P] INSTANCE_OFFSET, at most 127 instances). */
+long long pvsg_tube_index_table_words(void);
+int pvsg_tube_index(const int* seg_id, const int* sel, int T, int frames_per_block, int rows_per_block,
+                    const uint32_t* overflow, int* table_ws, int* rec, long long* tube_ids, int* rowmap, void* stream);
+int pvsg_tube_scatter(const float* query, long long query_row_stride, const int* sel, const int* rowmap, float* feats,
+                      int N, int T, int C, void* stream);
 
 /* ---- a8 (instance branch): instance_postprocess without the (Q,H,W) float tensor ----------------
  * Replaces the per-query mask work of MaskFormerFusionHeadCustom.instance_postprocess,
@@ -413,6 +451,10 @@ int pvsg_mask_logits_f16x2(const float* mask_embed, const float* mask_feature, v
                            int Q, int C, long long N, uint32_t* overflow, void* stream);
 int pvsg_attn_mask_bits_f16x2(const float* mask_embed, const float* feature_lowres, void* w_scratch, uint32_t* bits,
                               uint32_t* flags, int B, int T, int Q, int C, long long N, uint32_t* overflow, void* stream);
+/* The same bits from embeddings ALREADY packed by pvsg_decoder_rows_post (emb_pack_f16x2) into flag words ALREADY zero
+ * (flags_zero): one launch for the whole batch.  mask2former_head.py:383-393, :453-454. */
+int pvsg_attn_mask_bits_packed_f16x2(const void* emb_packed, const float* feature_lowres, uint32_t* bits, uint32_t* flags, int B,
+                                     int T, int Q, int C, long long N, uint32_t* overflow, void* stream);
 
 /* [3P] mmdet ResNet stem in one launch: conv1 (7x7 / 2, pad 3, 3 -> 64, no bias) -> frozen BN (scale, shift) -> ReLU ->
  * MaxPool2d(3, 2, 1):  x (N, 3, H, W) -> out (N, 64, Hp, Wp), Hc = (H-1)/2+1, Hp = (Hc-1)/2+1 (same for W).

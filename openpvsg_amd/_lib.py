@@ -52,11 +52,16 @@ SIGNATURES = {
     'pvsg_pack_rows_weight': [_c_f, _c_f, _i, _i, _c_f],
     'pvsg_decoder_rows_pre': [ctypes.POINTER(DecoderLayer), _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _c_f],
     'pvsg_decoder_rows_post_workspace_bytes': [_i, _i],
-    'pvsg_decoder_rows_post': [ctypes.POINTER(DecoderLayer), ctypes.POINTER(DecoderHead)] + [_c_f] * 10 + [_i, _i, _c_f],
+    'pvsg_decoder_rows_post': [ctypes.POINTER(DecoderLayer), ctypes.POINTER(DecoderHead)] + [_c_f] * 12 + [_i, _i, _c_f],
     'pvsg_pair_prepare_weights': [_c_f, _c_f, _i, _i, _c_f],
     'pvsg_pair_score_forward': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _c_f],
     'pvsg_panoptic_fuse': [_c_f] * 8 + [_i] * 13 + [ctypes.c_double, _i, _c_f],
     'pvsg_instance_masks': [_c_f] * 5 + [_i] * 12 + [_c_f],
+    'pvsg_panoptic_select': [_c_f, _c_f, _i, _i, _f, _c_f, _c_f],
+    'pvsg_panoptic_fuse_sel': [_c_f] * 6 + [_i] * 12 + [ctypes.c_double, _i, _c_f],
+    'pvsg_tube_index_table_words': [],
+    'pvsg_tube_index': [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f],
+    'pvsg_tube_scatter': [_c_f, _ll, _c_f, _c_f, _c_f, _i, _i, _i, _c_f],
     'pvsg_msda_fused_forward': [_c_f, _ll, _c_f, _ll, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _i, _i, _c_f],
     'pvsg_msda_proj_ln_forward': [_c_f, _ll, _c_f, _ll] + [_c_f] * 10 + [_i] * 7 + [_f, _c_f],
     'pvsg_add_layernorm': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _ll, _i, _f, _c_f],
@@ -89,6 +94,7 @@ SIGNATURES = {
     'pvsg_conv3x3_f16x2': [_c_f] * 5 + [_i] * 7 + [_c_f, _c_f],
     'pvsg_mask_logits_f16x2': [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _ll, _c_f, _c_f],
     'pvsg_attn_mask_bits_f16x2': [_c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _ll, _c_f, _c_f],
+    'pvsg_attn_mask_bits_packed_f16x2': [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _ll, _c_f, _c_f],
     'pvsg_stem7x7_pack': [_c_f, _c_f, _c_f],
     'pvsg_group_norm_affine': [_c_f] * 6 + [_i, _i, _i, _ll, _f, _c_f],
     'pvsg_stem7x7_bn_relu_pool': [_c_f] * 5 + [_i, _i, _i, _c_f],
@@ -97,7 +103,7 @@ SIGNATURES = {
 # entry points that return a value instead of a status code
 VALUE_RETURNING = ('pvsg_xattn_num_splits', 'pvsg_gemm_bf16x3_packed_elems', 'pvsg_gemm_f16x2_packed_elems',
                    'pvsg_minvis_chain_workspace_bytes', 'pvsg_reconsdot_workspace_bytes', 'pvsg_rle_counts_to_chars',
-                   'pvsg_decoder_rows_post_workspace_bytes')
+                   'pvsg_decoder_rows_post_workspace_bytes', 'pvsg_tube_index_table_words')
 
 _lib = None
 
@@ -127,7 +133,7 @@ def load():
             raise BackendMissingError('symbol %s missing from %s' % (name, LIB_PATH)) from e
         f.restype = _ll if name in ('pvsg_gemm_bf16x3_packed_elems', 'pvsg_gemm_f16x2_packed_elems', 'pvsg_minvis_chain_workspace_bytes',
                                    'pvsg_decoder_rows_post_workspace_bytes', 'pvsg_reconsdot_workspace_bytes',
-                                   'pvsg_rle_counts_to_chars') else _i
+                                   'pvsg_rle_counts_to_chars', 'pvsg_tube_index_table_words') else _i
         f.argtypes = argtypes
     _lib = lib
     try:                                    # loud, once: a second tenant on the GPU without a CU partition (parallel.py)
@@ -148,36 +154,71 @@ def load():
 # (measurements of the effect itself).
 _MFMA16 = ('bf16x3', 'f16x2', 'masked_xattn')
 _MFMA16_NAMES = frozenset(n for n in SIGNATURES if any(k in n for k in _MFMA16))
-_cur = [None, False]        # [stream handle of the previous launch, has that stream run a 16-bit-MFMA kernel since it took over]
+# Per DEVICE: [stream handle of the previous launch there, has that stream run a 16-bit-MFMA kernel since it took over].
+# Kernels on different devices cannot co-reside, so a process that drives two GPUs (or two threads, one GPU each) alternates
+# freely; two threads on ONE device with different streams is exactly the overlap the rule forbids, so the key is not the thread.
+_cur = {}
 _hip = None
+_HIP_ERROR_NOT_READY = 600
+
+try:
+    _cur_dev = torch._C._cuda_getDevice
+except AttributeError:                    # pragma: no cover
+    _cur_dev = torch.cuda.current_device
 
 
 def _stream_busy(handle):
+    """work still pending on `handle` (a stream of the CURRENT device: ops.py enters the tensor's device before it calls).
+    Only hipErrorNotReady means busy: an invalid / destroyed handle (an ExternalStream that is gone) has nothing in flight."""
     global _hip
     if _hip is None:
         _hip = ctypes.CDLL('libamdhip64.so')          # already mapped by torch: same runtime instance
         _hip.hipStreamQuery.argtypes = [ctypes.c_void_p]
         _hip.hipStreamQuery.restype = ctypes.c_int
-    return _hip.hipStreamQuery(ctypes.c_void_p(handle)) != 0        # hipErrorNotReady (or an error: treat as busy)
+        _hip.hipGetLastError.argtypes = []
+        _hip.hipGetLastError.restype = ctypes.c_int
+    rc = _hip.hipStreamQuery(ctypes.c_void_p(handle))
+    if rc not in (0, _HIP_ERROR_NOT_READY):
+        _hip.hipGetLastError()                        # clear the sticky error of a dead handle: it is not this launch's
+    return rc == _HIP_ERROR_NOT_READY
 
 
 class ConcurrentStreamError(RuntimeError):
     pass
 
 
-def _stream_changed(name, stream):
-    """slow path of `call`: the launch goes to another stream than the previous one"""
+def _stream_changed(name, stream, ent):
+    """slow path of `call`: the launch goes to another stream of its device than the previous one"""
     if torch.cuda.is_current_stream_capturing():       # captured launches do not execute; the replay runs on ONE stream
         return
     mfma16 = name in _MFMA16_NAMES
-    prev = _cur[0]
-    if prev is not None and (mfma16 or _cur[1]) and _stream_busy(prev):
+    prev = ent[0]
+    if prev is not None and (mfma16 or ent[1]) and _stream_busy(prev):
         raise ConcurrentStreamError(
-            '%s launched on HIP stream %#x while stream %#x still runs kernels of this backend: 16-bit-MFMA kernels must not '
-            'share the GPU with other kernels (co-residency corruption, DESIGN.md section 3.13).  Keep the backend on one '
-            'stream, or order the streams (wait_stream + synchronize) before switching; PVSG_MULTI_STREAM=allow disables this '
-            'check.' % (name, stream, prev))
-    _cur[0], _cur[1] = stream, mfma16
+            '%s launched on HIP stream %#x while stream %#x of the same device still runs kernels of this backend: '
+            '16-bit-MFMA kernels must not share the GPU with other kernels (co-residency corruption, DESIGN.md section 3).  '
+            'Keep the backend on one stream per device, or order the streams (wait_stream + synchronize) before switching; '
+            'PVSG_MULTI_STREAM=allow disables this check.' % (name, stream, prev))
+    ent[0], ent[1] = stream, mfma16
+
+
+def note_replay(stream=None):
+    """A hipGraph of this backend's launches was replayed on `stream` (default: torch's current one): the replayed kernels
+    are 16-bit-MFMA work on that stream as far as the one-stream rule is concerned (detectors._graphed,
+    pipeline._graphed_forward call this after graph.replay())."""
+    if not _CHECK_STREAMS:
+        return
+    dev = _cur_dev()
+    if stream is None:
+        stream = torch._C._cuda_getCurrentRawStream(dev) if hasattr(torch._C, '_cuda_getCurrentRawStream') \
+            else torch.cuda.current_stream().cuda_stream
+    ent = _cur.get(dev)
+    if ent is None:
+        ent = _cur[dev] = [None, False]
+    if ent[0] is not None and ent[0] != stream and _stream_busy(ent[0]):
+        raise ConcurrentStreamError('hipGraph replayed on HIP stream %#x while stream %#x of the same device still runs '
+                                    'kernels of this backend (one stream per device)' % (stream, ent[0]))
+    ent[0], ent[1] = stream, True
 
 
 _CHECK_STREAMS = os.environ.get('PVSG_MULTI_STREAM', 'deny') != 'allow'
@@ -188,10 +229,13 @@ def call(name, *args):
     lib = load()
     if _CHECK_STREAMS:
         stream = args[-1] or 0
-        if stream != _cur[0]:
-            _stream_changed(name, stream)
-        elif not _cur[1] and name in _MFMA16_NAMES:
-            _cur[1] = True
+        ent = _cur.get(_cur_dev())
+        if ent is None:
+            ent = _cur[_cur_dev()] = [None, False]
+        if stream != ent[0]:
+            _stream_changed(name, stream, ent)
+        elif not ent[1] and name in _MFMA16_NAMES:
+            ent[1] = True
     rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.pvsg_last_error()

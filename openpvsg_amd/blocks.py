@@ -84,6 +84,20 @@ def pin_graph_caches():
     return [list(c.values()) for c in list(_GRAPH_CACHES)]
 
 
+def _packed_weight(owner, slot, key, make):
+    """`make()` = the packed form of a weight for the CURRENT split mode, cached on `owner` per (slot, mode): once a call has
+    fallen back from f16x2 to bf16x3 (ops.rerun_on_bf16x3) both packs stay, so neither direction repacks.  `key` = (address,
+    version, device ...) of the source weight(s): a changed weight rebuilds its entry."""
+    cache = owner.__dict__.get('_pvsg_packed')
+    if not isinstance(cache, dict):
+        cache = owner.__dict__['_pvsg_packed'] = {}
+    k = (slot, ops.split_mode())
+    ent = cache.get(k)
+    if ent is None or ent[0] != key:
+        ent = cache[k] = (key, make())
+    return ent[1]
+
+
 def conv3x3_fast(conv, x, scale=None, shift=None, relu=False, out=None):
     """3x3 / pad 1 convolution without bias on the matrix-core kernels -- stride 1: Winograd F(2x2,3x3)
     (csrc/winograd3x3.hip); stride 2 (needs scale/shift): direct convolution (csrc/conv3x3s2.hip) -- or None when this
@@ -112,12 +126,8 @@ def conv3x3_fast(conv, x, scale=None, shift=None, relu=False, out=None):
         pack, run = ops.conv3x3s2_pack, ops.conv3x3s2_affine          # direct convolution on the f32 MFMA, csrc/conv3x3s2.hip
     else:
         return None
-    key = (w.data_ptr(), w._version, str(w.device), pack.__name__, ops.split_mode())
-    cache = getattr(conv, '_pvsg_packed', None)
-    if cache is None or cache[0] != key:
-        cache = (key, pack(w.detach()))
-        conv._pvsg_packed = cache
-    return run(x, cache[1], w.shape[0], scale, shift, relu=relu, out=out)
+    wp = _packed_weight(conv, pack.__name__, (w.data_ptr(), w._version, str(w.device)), lambda: pack(w.detach()))
+    return run(x, wp, w.shape[0], scale, shift, relu=relu, out=out)
 
 
 def conv1x1_fast(conv, x, scale=None, shift=None, residual=None, relu=False, out=None, always=False, in_norm=None):
@@ -140,12 +150,9 @@ def conv1x1_fast(conv, x, scale=None, shift=None, residual=None, relu=False, out
         return None
     if conv.bias is not None:
         shift = conv.bias if shift is None else shift + conv.bias * (scale if scale is not None else 1.0)
-    key = (w.data_ptr(), w._version, str(w.device), ops.split_mode())
-    cache = getattr(conv, '_pvsg_packed', None)
-    if cache is None or cache[0] != key:
-        cache = (key, ops.gemm_bf16x3_pack(w.detach().reshape(cout, cin).contiguous()))
-        conv._pvsg_packed = cache
-    return ops.conv1x1_bf16x3(x, cache[1], cout, scale, shift, residual, relu=relu, stride=stride, out=out,
+    wp = _packed_weight(conv, 'conv1x1', (w.data_ptr(), w._version, str(w.device)),
+                        lambda: ops.gemm_bf16x3_pack(w.detach().reshape(cout, cin).contiguous()))
+    return ops.conv1x1_bf16x3(x, wp, cout, scale, shift, residual, relu=relu, stride=stride, out=out,
                               in_scale=in_norm[0] if in_norm is not None else None,
                               in_shift=in_norm[1] if in_norm is not None else None)
 
@@ -161,12 +168,12 @@ def linear_fast(owner, tag, weights, x, bias=None, relu=False):
             os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and ops.gemm_bf16x3_supported(n, k)):
         y = F.linear(x, ws[0] if len(ws) == 1 else torch.cat(ws, 0), bias)
         return F.relu(y, inplace=True) if relu else y
-    key = tuple((w.data_ptr(), w._version, str(w.device)) for w in ws) + (ops.split_mode(),)
+    key = tuple((w.data_ptr(), w._version, str(w.device)) for w in ws)
     cache = owner.__dict__.setdefault('_pvsg_gemm', {})
-    ent = cache.get(tag)
+    ent = cache.get((tag, ops.split_mode()))
     if ent is None or ent[0] != key:
         w = ws[0] if len(ws) == 1 else torch.cat(ws, 0)
-        ent = cache[tag] = (key, ops.gemm_bf16x3_pack(w.detach().contiguous()))
+        ent = cache[(tag, ops.split_mode())] = (key, ops.gemm_bf16x3_pack(w.detach().contiguous()))
     y = ops.gemm_bf16x3(x.reshape(-1, k), ent[1], n, bias, relu=relu)
     return y.view(*x.shape[:-1], n)
 
@@ -196,11 +203,11 @@ def linear_add_layernorm_fast(owner, tag, weight, x, bias, identity, norm):
     if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and
             n == 256 and k % 32 == 0 and ops.split_mode() == 'f16x2' and os.environ.get('PVSG_FUSE_LN', 'on') != 'off' and
             isinstance(norm, nn.LayerNorm) and norm.normalized_shape == (256,) and _fused_ln_fills_the_gpu(x, k)):
-        key = ((weight.data_ptr(), weight._version, str(weight.device)), 'f16x2')
+        key = ((weight.data_ptr(), weight._version, str(weight.device)),)
         cache = owner.__dict__.setdefault('_pvsg_gemm', {})
-        ent = cache.get(tag)
+        ent = cache.get((tag, 'f16x2'))
         if ent is None or ent[0] != key:
-            ent = cache[tag] = (key, ops.gemm_bf16x3_pack(weight.detach().contiguous(), mode='f16x2'))
+            ent = cache[(tag, 'f16x2')] = (key, ops.gemm_bf16x3_pack(weight.detach().contiguous(), mode='f16x2'))
         y = ops.gemm_add_layernorm(x.reshape(-1, k), ent[1], bias, identity.reshape(-1, 256), norm)
         return y.view(*x.shape[:-1], 256)
     t = linear_fast(owner, tag, weight, x)
@@ -703,10 +710,23 @@ class MSDeformAttnPixelDecoder(BaseModule):
           output_proj, + identity, LayerNorm         -> GEMM + add_layernorm kernel
           FFN: Linear+ReLU fused epilogue, Linear, + identity, LayerNorm -> 2 GEMMs + add_layernorm"""
         a = layer.attentions[0]
-        w_oa = torch.cat([a.sampling_offsets.weight, a.attention_weights.weight], 0)
-        b_oa = torch.cat([a.sampling_offsets.bias, a.attention_weights.bias], 0)
-        pos_oa = linear_fast(a, 'offsets_weights', (a.sampling_offsets.weight, a.attention_weights.weight), pos, b_oa)  # (S, 288)
-        b_cat = torch.cat([a.value_proj.bias, torch.zeros_like(b_oa)], 0)
+        # constants of (weights, geometry): the position term of the offset / weight projection and the concatenated bias.
+        # Rebuilding them every forward cost 6 launches per layer (two cats, a GEMM over the position table, a fill, ...):
+        # 0.3 ms of a 4-frame step's 14.  Cached per layer on (parameter address / version, position table, split mode).
+        ckey = tuple((t.data_ptr(), t._version) for t in (a.sampling_offsets.weight, a.sampling_offsets.bias,
+                                                           a.attention_weights.weight, a.attention_weights.bias,
+                                                           a.value_proj.bias)) + (pos.data_ptr(), pos._version, tuple(pos.shape),
+                                                                                  str(pos.device), ops.split_mode())
+        cache = a.__dict__.get('_pvsg_consts')
+        if cache is None:
+            cache = a.__dict__['_pvsg_consts'] = _ShapeCache(limit=4)
+        ent = cache.get(ckey)
+        if ent is None:
+            b_oa = torch.cat([a.sampling_offsets.bias, a.attention_weights.bias], 0)
+            pos_oa = linear_fast(a, 'offsets_weights', (a.sampling_offsets.weight, a.attention_weights.weight), pos, b_oa)  # (S, 288)
+            b_cat = torch.cat([a.value_proj.bias, torch.zeros_like(b_oa)], 0)
+            ent = cache[ckey] = (pos_oa, b_cat, pos)          # (pos kept alive: its address is part of the key)
+        pos_oa, b_cat = ent[0], ent[1]
         y = linear_fast(a, 'value_offsets_weights', (a.value_proj.weight, a.sampling_offsets.weight,
                                                      a.attention_weights.weight), x, b_cat)      # (B, S, 544)
         if MSDeformAttnPixelDecoder.fuse_out_proj:
@@ -732,7 +752,20 @@ class MSDeformAttnPixelDecoder(BaseModule):
         shapes = [tuple(feats[self.num_input_levels - 1 - i].shape[-2:]) for i in range(self.num_encoder_levels)]
         pos_l, ref, ss, lsi = self._geometry(shapes, feats[0].device)
         glue = self.fuse_glue and feats[0].is_cuda and not torch.is_grad_enabled()
-        pos = torch.cat([pos_l[i] + self.level_encoding.weight[i][None, :] for i in range(self.num_encoder_levels)], 0)[None]
+        le = self.level_encoding.weight
+        pkey = (le.data_ptr(), le._version, tuple(shapes), str(feats[0].device))
+        pc = self.__dict__.get('_pos_cache')
+        if pc is None:
+            pc = self.__dict__['_pos_cache'] = _ShapeCache(limit=4)
+        pent = pc.get(pkey)
+        if pent is None or torch.is_grad_enabled():
+            # level encoding + sine encoding per token, and the (S, 2) reference points of the fused layers: functions of
+            # (level_encoding, geometry) only -- three adds, a cat and a strided copy per forward otherwise
+            pos = torch.cat([pos_l[i] + le[i][None, :] for i in range(self.num_encoder_levels)], 0)[None]
+            pent = (pos, ref[0, :, 0].contiguous())
+            if not torch.is_grad_enabled():
+                pc[pkey] = (pos.detach(), pent[1])
+        pos, ref2d = pent
         if glue and not any(m.act for m in self.input_convs):
             # GroupNorm apply + NCHW -> token transpose of each level in one pass into its slice of x
             x = feats[0].new_empty((B, sum(h * w for h, w in shapes), self.input_convs[0].conv.out_channels))
@@ -754,7 +787,7 @@ class MSDeformAttnPixelDecoder(BaseModule):
         for layer in self.encoder.layers:
             # BaseTransformerLayer ('self_attn','norm','ffn','norm') on batch-first tensors
             if self._fusable(layer, x):
-                x = self._encoder_layer_fused(layer, x, pos[0], ref[0, :, 0].contiguous(), ss, lsi)
+                x = self._encoder_layer_fused(layer, x, pos[0], ref2d, ss, lsi)
                 continue
             x = layer.attentions[0].forward_bsc(x, pos, ref, ss, lsi)
             x = layer.norms[0](x)

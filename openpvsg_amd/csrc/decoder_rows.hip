@@ -252,7 +252,8 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
     const float* __restrict__ next_q_b, const float* __restrict__ x1, const float* __restrict__ qkv,
     const float* __restrict__ qpos, float* __restrict__ query_out, float* __restrict__ cls_out,
     float* __restrict__ emb_out, float* __restrict__ next_q_out, int Q, int tiles_per_b, float scale, float eps,
-    float* __restrict__ ws_part, int* __restrict__ ws_count, int nspl) {
+    float* __restrict__ ws_part, int* __restrict__ ws_count, int nspl, unsigned short* __restrict__ emb_pack,
+    unsigned* __restrict__ flags_zero) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int s_last;
   float* xa = smem;                       // [16][DR_LD]
@@ -494,9 +495,49 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
-        if (r < valid) emb_out[(row0 + r) * DR_C + col] = acc[i][e] + bv;
+        const float v = acc[i][e] + bv;
+        if (r < valid) emb_out[(row0 + r) * DR_C + col] = v;
+        if (emb_pack) xc[r * DR_LD + col] = r < valid ? v : 0.f;     // xc: last read by the m1 GEMM, free since the barrier above
       }
     }
+  }
+  if (flags_zero && tile == 0 && threadIdx.x < 4) flags_zero[b * 4 + threadIdx.x] = 0u;   // the flag words the bits kernel ORs into
+  if (emb_pack) {
+    // The mask embeddings of these 16 queries as the ROW operand of the attention-mask-bits GEMM (csrc/gemm_bf16x3.hip, f16x2
+    // form: [k-tile 16][w_h | w_l][k-group 2][128 rows][8] f16), packed here instead of by f16x2_amax_kernel +
+    // gemm_f16x2_pack_kernel + two zero_words launches per layer.  The bits only need the SIGN of embedding . feature, so each
+    // query row gets its own exact power-of-two scale 2^e with max|row| 2^e in [2^13, 2^14): both limbs stay normal f16
+    // numbers for any embedding magnitude, and no un-scaling is needed.  Rows Q..127 of the buffer are zero (zeroed once by
+    // the caller; rows of the last tile beyond Q are written as zeros here).
+    __syncthreads();
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const int r = threadIdx.x >> 5, c0 = (threadIdx.x & 31) * 8;
+    const float4 v0 = *reinterpret_cast<const float4*>(xc + r * DR_LD + c0);
+    const float4 v1 = *reinterpret_cast<const float4*>(xc + r * DR_LD + c0 + 4);
+    const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    float am = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) am = fmaxf(am, __builtin_fabsf(vv[i]));
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));     // the 32 lanes of a row are half a wave
+    int ex = 0;
+    if (am > 0.f && am < 3.0e38f) {
+      ex = 13 - ilogbf(am);
+      ex = ex > 126 ? 126 : (ex < -126 ? -126 : ex);
+    }
+    h8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float sv = ldexpf(vv[i], ex);
+      const _Float16 hh = (_Float16)sv;
+      hi[i] = hh;
+      lo[i] = (_Float16)(sv - (float)hh);
+    }
+    constexpr int NPAD = 128, LIMB = 2 * NPAD * 8;                             // f16 elements
+    const int kt = c0 >> 4, kg = (c0 >> 3) & 1;
+    unsigned short* dst = emb_pack + (long long)b * (2LL * NPAD * DR_C + 8) + (long long)kt * 2 * LIMB + ((long long)kg * NPAD + q0 + r) * 8;
+    *reinterpret_cast<h8*>(dst) = hi;
+    *reinterpret_cast<h8*>(dst + LIMB) = lo;
   }
 }
 
@@ -556,8 +597,8 @@ extern "C" int pvsg_decoder_rows_pre(const pvsg_decoder_layer* layer, const floa
 extern "C" int pvsg_decoder_rows_post(const pvsg_decoder_layer* layer, const pvsg_decoder_head* head,
                                       const float* next_q_w, const float* next_q_b, const float* x1,
                                       const float* qkv, const float* query_pos, float* query_out, float* cls_out,
-                                      float* mask_embed_out, float* next_q_out, void* workspace, int B, int Q,
-                                      void* stream_) {
+                                      float* mask_embed_out, float* next_q_out, void* workspace, void* emb_pack_f16x2,
+                                      uint32_t* flags_zero, int B, int Q, void* stream_) {
   using namespace pvsg;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   PVSG_REQUIRE(head && x1 && query_pos && cls_out && mask_embed_out, "decoder_rows_post: null pointer argument");
@@ -565,6 +606,7 @@ extern "C" int pvsg_decoder_rows_post(const pvsg_decoder_layer* layer, const pvs
   PVSG_REQUIRE((next_q_w == nullptr) == (next_q_b == nullptr) && (!next_q_w || next_q_out),
                "decoder_rows_post: next_q_w / next_q_b / next_q_out go together");
   PVSG_REQUIRE(B > 0 && Q > 0, "decoder_rows_post: non-positive dimension");
+  PVSG_REQUIRE(!(reinterpret_cast<uintptr_t>(emb_pack_f16x2) & 15u), "decoder_rows_post: emb_pack_f16x2 must be 16-byte aligned");
   PVSG_REQUIRE(head->pn_g && head->pn_b && head->cls_w && head->cls_b && head->m0_w && head->m0_b && head->m1_w &&
                    head->m1_b && head->m2_w && head->m2_b, "decoder_rows_post: null pointer in pvsg_decoder_head");
   if (Q > DR_MAXQ) return set_err(PVSG_ERR_UNSUPPORTED, "decoder_rows_post: at most %d queries (got %d)", DR_MAXQ, Q);
@@ -588,7 +630,8 @@ extern "C" int pvsg_decoder_rows_post(const pvsg_decoder_layer* layer, const pvs
   int* ws_count = workspace ? reinterpret_cast<int*>(ws_part + (size_t)B * tiles * DR_SPLIT * 16 * DR_C) : nullptr;
   hipLaunchKernelGGL(decoder_rows_post_kernel, dim3(B * tiles * nspl), dim3(DR_THREADS), DR_POST_LDS, stream, L, *head,
                      layer ? 1 : 0, next_q_w, next_q_b, x1, qkv, query_pos, query_out, cls_out, mask_embed_out,
-                     next_q_out, Q, tiles, 0.17677669529663687f, 1e-5f, ws_part, ws_count, nspl);
+                     next_q_out, Q, tiles, 0.17677669529663687f, 1e-5f, ws_part, ws_count, nspl,
+                     static_cast<unsigned short*>(emb_pack_f16x2), flags_zero);
   PVSG_LAUNCH_CHECK("decoder_rows_post");
   return PVSG_OK;
 }

@@ -1133,7 +1133,8 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
                                const float* __restrict__ shift, const float* __restrict__ residual,
                                const float* __restrict__ in_scale, const float* __restrict__ in_shift, float* __restrict__ y,
                                int Cin, int Cout, int Cpad, int HWin, int Win, int HWo, int Wo, int stride, int tiles_c,
-                               int tiles_p, unsigned* __restrict__ flags = nullptr, unsigned* __restrict__ overflow = nullptr) {
+                               int tiles_p, unsigned* __restrict__ flags = nullptr, unsigned* __restrict__ overflow = nullptr,
+                               int imgs_per_w = 0, long long w_batch_stride = 0) {
   constexpr int XL = F16 ? 2 : 3;                                // limbs of the on-the-fly (pixel) operand
   constexpr int WL = F16 ? 2 : 3;                                // arrays of the packed weight
   constexpr int X_AT = WL * K32_LIMB;                            // where the pixel tile starts
@@ -1149,6 +1150,11 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
   logical /= tiles_c;
   const int tp = logical % tiles_p, img = logical / tiles_p;
   const int c0 = tc * GB_M, p0 = tp * GB_N;
+  if (BITS && imgs_per_w > 0) {                                  // one launch for a batch: image img belongs to batch element
+    const int bb = img / imgs_per_w;                             // img / imgs_per_w, which has its own packed embeddings / flags
+    Wp += (long long)bb * w_batch_stride;
+    flags += 4 * bb;
+  }
   // staging: weights -- (k-group tid/128, row tid%128) of both 16-deep sub-steps, 3 limbs; pixels -- (k-group tid/128, pixel
   // tid%128), the 8 channels of that k-group in each sub-step
   const int skg = __builtin_amdgcn_readfirstlane(tid >> 7), srow = tid & 127;
@@ -1991,6 +1997,30 @@ static int attn_mask_bits_split_run(const float* mask_embed, const float* featur
                          rec, C, Q, GB_M, (int)N, (int)N, (int)N, (int)N, 1, 1, tiles_p, flags + (size_t)b * 4);
     PVSG_LAUNCH_CHECK(nm);
   }
+  return PVSG_OK;
+}
+
+// The bits from embeddings that are ALREADY packed (pvsg_decoder_rows_post writes them in its epilogue, one exact power-of-two
+// scale per query row -- the bits are signs) into flag words that are already zero: ONE launch for the whole batch, where the
+// entry above issues zero + amax + pack + GEMM per batch element.
+extern "C" int pvsg_attn_mask_bits_packed_f16x2(const void* emb_packed, const float* feature_lowres, uint32_t* bits,
+                                                uint32_t* flags, int B, int T, int Q, int C, long long N, uint32_t* overflow,
+                                                void* stream) {
+  using namespace pvsg;
+  const char* nm = "attn_mask_bits_packed_f16x2";
+  PVSG_REQUIRE(emb_packed && feature_lowres && bits && flags, "%s: null pointer argument", nm);
+  PVSG_REQUIRE(B > 0 && T > 0 && Q > 0 && C > 0 && N > 0, "%s: bad shape", nm);
+  if (C % 32 || Q > GB_M || (long long)C * N >= (1LL << 29) || (long long)B * T * N >= (1LL << 27) ||
+      ((reinterpret_cast<uintptr_t>(bits) | reinterpret_cast<uintptr_t>(emb_packed)) & 15u))
+    return set_err(PVSG_ERR_UNSUPPORTED, "%s: built for C %% 32 == 0, Q <= 128, C*N < 2^29, B*T*N < 2^27, 16B-aligned buffers "
+                   "(got B=%d T=%d Q=%d C=%d N=%lld)", nm, B, T, Q, C, N);
+  const int tiles_p = (int)((N + GB_N - 1) / GB_N);
+  const float* nul = nullptr;
+  hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<false, false, false, true, 128, 1, true>), dim3((unsigned)(B * T * tiles_p)), dim3(256),
+                     0, static_cast<hipStream_t>(stream), feature_lowres, static_cast<const __bf16*>(emb_packed), nul, nul, nul, nul,
+                     nul, reinterpret_cast<float*>(bits), C, Q, GB_M, (int)N, (int)N, (int)N, (int)N, 1, 1, tiles_p, flags, overflow,
+                     T, pvsg_gemm_f16x2_packed_elems(Q, C));
+  PVSG_LAUNCH_CHECK(nm);
   return PVSG_OK;
 }
 

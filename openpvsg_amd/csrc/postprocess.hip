@@ -32,11 +32,13 @@
 namespace pvsg {
 
 constexpr int MAXK = 128;
+#define PVSG_SEL_MAXK 128       // include/openpvsg_hip.h (not included here: this file declares its streams as hipStream_t); tubes.hip checks the layout
 
 __global__ __launch_bounds__(256) void pan_owner_kernel(
     const float* __restrict__ logits, const int* __restrict__ kept_idx, const float* __restrict__ kept_score,
     unsigned char* __restrict__ owner_out, int* __restrict__ counters, int Q, int K, int h, int w,
-    int H, int W, int ih, int iw) {
+    int H, int W, int ih, int iw, const int* __restrict__ kdev) {
+  if (kdev) K = *kdev;                       // kept count decided on the device (pvsg_panoptic_select)
   __shared__ int s_area[MAXK], s_orig[MAXK], s_region_conf[MAXK];
   __shared__ int s_idx[MAXK];
   __shared__ float s_score[MAXK];
@@ -98,7 +100,8 @@ __global__ __launch_bounds__(256) void pan_owner_kernel(
 // formula specialised to scale 1/4), so the two kernels agree bit for bit.
 __global__ __launch_bounds__(256) void pan_owner_x4_kernel(
     const float* __restrict__ logits, const int* __restrict__ kept_idx, const float* __restrict__ kept_score,
-    unsigned char* __restrict__ owner_out, int* __restrict__ counters, int Q, int K, int h, int w, int ih, int iw) {
+    unsigned char* __restrict__ owner_out, int* __restrict__ counters, int Q, int K, int h, int w, int ih, int iw, const int* __restrict__ kdev) {
+  if (kdev) K = *kdev;                       // kept count decided on the device (pvsg_panoptic_select)
   __shared__ int s_area[MAXK], s_orig[MAXK], s_region_conf[MAXK];
   __shared__ int s_idx[MAXK];
   __shared__ float s_score[MAXK];
@@ -237,7 +240,8 @@ __device__ __forceinline__ float sample2(const float* __restrict__ p, int w, con
 __global__ __launch_bounds__(256) void pan_owner_2stage_kernel(
     const float* __restrict__ logits, const int* __restrict__ kept_idx, const float* __restrict__ kept_score,
     unsigned char* __restrict__ owner_out, int* __restrict__ counters, int Q, int K, int h, int w,
-    int H, int W, int ih, int iw, int oh, int ow) {
+    int H, int W, int ih, int iw, int oh, int ow, const int* __restrict__ kdev) {
+  if (kdev) K = *kdev;                       // kept count decided on the device (pvsg_panoptic_select)
   __shared__ int s_area[MAXK], s_orig[MAXK], s_region_conf[MAXK];
   __shared__ int s_idx[MAXK];
   __shared__ float s_score[MAXK];
@@ -365,9 +369,13 @@ __global__ __launch_bounds__(256) void inst_masks_kernel(
 
 __global__ void pan_decide_kernel(const int* __restrict__ counters, const int* __restrict__ kept_class,
                                   int* __restrict__ seg_id, int K, int num_things, double iou_thr,
-                                  int filter_low) {
+                                  int filter_low, const int* __restrict__ kdev, int seg_stride) {
   const int t = blockIdx.x;
   if (threadIdx.x != 0) return;
+  if (kdev) {                                  // device-side kept count: rows of `seg_stride` ids, unused slots = -1
+    K = *kdev;
+    for (int k = K; k < seg_stride; ++k) seg_id[(long long)t * seg_stride + k] = -1;
+  }
   const int* ct = counters + (long long)t * 3 * MAXK;
   int inst = 0;
   for (int k = 0; k < K; ++k) {
@@ -382,17 +390,19 @@ __global__ void pan_decide_kernel(const int* __restrict__ counters, const int* _
       if (cls < num_things) { ++inst; id = cls + inst * 1000; }
       else id = cls;
     }
-    seg_id[(long long)t * K + k] = id;
+    seg_id[(long long)t * seg_stride + k] = id;
   }
 }
 
 __global__ __launch_bounds__(256) void pan_paint_kernel(const unsigned char* __restrict__ owner,
                                                        const int* __restrict__ seg_id,
                                                        int* __restrict__ panoptic, int K, long long npix,
-                                                       int num_classes, int filter_low) {
+                                                       int num_classes, int filter_low, const int* __restrict__ kdev,
+                                                       int seg_stride) {
   const int t = blockIdx.y;
+  if (kdev) K = *kdev;
   __shared__ int s_id[MAXK];
-  for (int k = threadIdx.x; k < MAXK; k += blockDim.x) s_id[k] = k < K ? seg_id[(long long)t * K + k] : -1;
+  for (int k = threadIdx.x; k < MAXK; k += blockDim.x) s_id[k] = k < K ? seg_id[(long long)t * seg_stride + k] : -1;
   __syncthreads();
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
        i += (long long)gridDim.x * blockDim.x) {
@@ -405,42 +415,65 @@ __global__ __launch_bounds__(256) void pan_paint_kernel(const unsigned char* __r
 
 }  // namespace pvsg
 
-extern "C" int pvsg_panoptic_fuse(const float* mask_logits, const int* kept_idx, const float* kept_score,
-                                  const int* kept_class, int* panoptic, int* seg_id,
-                                  unsigned char* owner_ws, int* counter_ws, int T, int Q, int K, int h,
-                                  int w, int H, int W, int ih, int iw, int oh, int ow, int num_things,
-                                  int num_classes, double iou_thr, int filter_low_score, hipStream_t stream) {
+static int panoptic_fuse_run(const char* nm, const float* mask_logits, const int* kept_idx, const float* kept_score,
+                            const int* kept_class, const int* kdev, int seg_stride, int* panoptic, int* seg_id,
+                            unsigned char* owner_ws, int* counter_ws, int T, int Q, int K, int h, int w, int H, int W, int ih,
+                            int iw, int oh, int ow, int num_things, int num_classes, double iou_thr, int filter_low_score,
+                            hipStream_t stream) {
   using namespace pvsg;
-  PVSG_REQUIRE(mask_logits && panoptic && owner_ws && counter_ws, "panoptic_fuse: null pointer argument");
+  PVSG_REQUIRE(mask_logits && panoptic && owner_ws && counter_ws, "%s: null pointer argument", nm);
   PVSG_REQUIRE(T > 0 && Q > 0 && h > 0 && w > 0 && H > 0 && W > 0 && ih > 0 && iw > 0 && ih <= H && iw <= W &&
                    oh > 0 && ow > 0,
-               "panoptic_fuse: bad geometry (h=%d w=%d H=%d W=%d ih=%d iw=%d oh=%d ow=%d)", h, w, H, W, ih, iw, oh, ow);
-  PVSG_REQUIRE(K >= 0 && K <= MAXK - 1, "panoptic_fuse: at most %d kept queries (got %d)", MAXK - 1, K);
-  PVSG_REQUIRE(K == 0 || (kept_idx && kept_score && kept_class && seg_id), "panoptic_fuse: null kept-query tables");
+               "%s: bad geometry (h=%d w=%d H=%d W=%d ih=%d iw=%d oh=%d ow=%d)", nm, h, w, H, W, ih, iw, oh, ow);
+  PVSG_REQUIRE(K >= 0 && K <= MAXK - 1, "%s: at most %d kept queries (got %d)", nm, MAXK - 1, K);
+  PVSG_REQUIRE(K == 0 || (kept_idx && kept_score && kept_class && seg_id), "%s: null kept-query tables", nm);
   const long long npix = (long long)oh * ow;
   hipError_t e = zero_words_async(counter_ws, (size_t)T * 3 * MAXK * sizeof(int), stream);
-  if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "panoptic_fuse: memset: %s", hipGetErrorString(e));
+  if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "%s: memset: %s", nm, hipGetErrorString(e));
   if (K > 0) {
     if (oh != ih || ow != iw)
       hipLaunchKernelGGL(pan_owner_2stage_kernel, dim3((ow + 63) / 64, (oh + 3) / 4, T), dim3(256), 0, stream,
-                         mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, H, W, ih, iw, oh, ow);
+                         mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, H, W, ih, iw, oh, ow, kdev);
     else if (H == 4 * h && W == 4 * w)
       hipLaunchKernelGGL(pan_owner_x4_kernel, dim3((w + 1 + 31) / 32, (h + 1 + 7) / 8, T), dim3(256), 0, stream,
-                         mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, ih, iw);
+                         mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, ih, iw, kdev);
     else
       hipLaunchKernelGGL(pan_owner_kernel, dim3((iw + 63) / 64, (ih + 3) / 4, T), dim3(256), 0, stream,
-                         mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, H, W, ih, iw);
+                         mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, H, W, ih, iw, kdev);
     PVSG_LAUNCH_CHECK("panoptic_fuse(owner)");
     hipLaunchKernelGGL(pan_decide_kernel, dim3(T), dim3(64), 0, stream, counter_ws, kept_class, seg_id, K,
-                       num_things, iou_thr, filter_low_score);
+                       num_things, iou_thr, filter_low_score, kdev, seg_stride);
     PVSG_LAUNCH_CHECK("panoptic_fuse(decide)");
   }
   long long nb = (npix + 255) / 256;
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(pan_paint_kernel, dim3((unsigned)nb, T), dim3(256), 0, stream, owner_ws, seg_id,
-                     panoptic, K, npix, num_classes, filter_low_score);
+                     panoptic, K, npix, num_classes, filter_low_score, kdev, seg_stride);
   PVSG_LAUNCH_CHECK("panoptic_fuse(paint)");
   return PVSG_OK;
+}
+
+extern "C" int pvsg_panoptic_fuse(const float* mask_logits, const int* kept_idx, const float* kept_score,
+                                  const int* kept_class, int* panoptic, int* seg_id,
+                                  unsigned char* owner_ws, int* counter_ws, int T, int Q, int K, int h,
+                                  int w, int H, int W, int ih, int iw, int oh, int ow, int num_things,
+                                  int num_classes, double iou_thr, int filter_low_score, hipStream_t stream) {
+  return panoptic_fuse_run("panoptic_fuse", mask_logits, kept_idx, kept_score, kept_class, nullptr, K > 0 ? K : 1, panoptic,
+                           seg_id, owner_ws, counter_ws, T, Q, K, h, w, H, W, ih, iw, oh, ow, num_things, num_classes, iou_thr,
+                           filter_low_score, stream);
+}
+
+// The same with the kept set decided on the device: `sel` = the record pvsg_panoptic_select wrote (kept count in sel[0], the
+// kept-query tables behind it); seg_id rows have PVSG_SEL_MAXK entries, unused ones -1.  No host round trip between the
+// class decision and the fusion.
+extern "C" int pvsg_panoptic_fuse_sel(const float* mask_logits, const int* sel, int* panoptic, int* seg_id,
+                                      unsigned char* owner_ws, int* counter_ws, int T, int Q, int h, int w, int H, int W,
+                                      int ih, int iw, int oh, int ow, int num_things, int num_classes, double iou_thr,
+                                      int filter_low_score, hipStream_t stream) {
+  PVSG_REQUIRE(sel && seg_id, "panoptic_fuse_sel: null pointer argument");
+  return panoptic_fuse_run("panoptic_fuse_sel", mask_logits, sel + 4, reinterpret_cast<const float*>(sel + 4 + 2 * PVSG_SEL_MAXK),
+                           sel + 4 + PVSG_SEL_MAXK, sel, PVSG_SEL_MAXK, panoptic, seg_id, owner_ws, counter_ws, T, Q,
+                           pvsg::MAXK - 1, h, w, H, W, ih, iw, oh, ow, num_things, num_classes, iou_thr, filter_low_score, stream);
 }
 
 extern "C" int pvsg_instance_masks(const float* mask_logits, const int* sel_idx, unsigned char* masks,

@@ -17,7 +17,7 @@ import os
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from .blocks import BaseModule, pin_graph_caches
 from .config import _wrap
 from .registry import DETECTORS, build_backbone, build_head, build_neck
@@ -78,25 +78,42 @@ class _Base(BaseModule):
         x = self.backbone(img)
         return self.neck(x) if self.with_neck else x
 
-    def __setattr__(self, name, value):
-        if isinstance(value, torch.nn.Module):                     # a replaced sub-module: the tensor list below is stale
-            self.__dict__.pop('_sig_tensors', None)
-        super().__setattr__(name, value)
-
     def invalidate_graphs(self):
-        """Drop every captured hipGraph and the cached parameter list (call after replacing a NESTED sub-module in place;
-        assignments on the detector itself, load_state_dict, in-place updates and .to() are noticed without it)."""
+        """Drop every captured hipGraph and the cached module walk (never required for correctness: weight changes of any
+        kind -- load_state_dict with or without assign=True, in-place updates, .to(), a replaced parameter object, a swapped
+        or added sub-module at any depth, parametrize / prune -- are noticed by `_weights_signature`)."""
         self._graphs.clear()
         self._graph_seen.clear()
-        self.__dict__.pop('_sig_tensors', None)
+        self.__dict__.pop('_sig_links', None)
+
+    def _sig_modules(self):
+        """the modules of the tree that own parameters or buffers.  The walk is cached as (child table, its (name, module)
+        pairs) links; every check confirms that each table still holds exactly those modules under those names (a swapped /
+        added / removed sub-module at any depth re-walks), the same scheme as heads.DecoderRows._modules."""
+        ent = self.__dict__.get('_sig_links')
+        if ent is not None and all(len(tab) == len(kids) and all(tab.get(n) is m for n, m in kids) for tab, kids in ent[0]):
+            return ent[1]
+        links, mods = [], []
+
+        def walk(m):
+            mods.append(m)
+            kids = tuple((n, c) for n, c in m._modules.items())
+            links.append((m._modules, kids))
+            for _, c in kids:
+                if c is not None:
+                    walk(c)
+
+        walk(self)
+        self.__dict__['_sig_links'] = (links, mods)
+        return mods
 
     def _weights_signature(self):
-        """(address, version) of every parameter and buffer: what a captured graph baked in.  The tensor list is walked once
-        (the module-tree traversal was 3x the cost of reading the 800 address / version pairs on the host-bound small-batch path)."""
-        ts = self.__dict__.get('_sig_tensors')
-        if ts is None:
-            ts = self.__dict__['_sig_tensors'] = list(self.parameters()) + list(self.buffers())
-        return tuple((t.data_ptr(), t._version) for t in ts)
+        """(address, version) of every parameter and buffer: what a captured graph baked in.  The module walk is cached
+        (3x the cost of reading the 800 address / version pairs on the host-bound small-batch path), but the tensors are looked
+        up afresh in each module's `_parameters` / `_buffers` table, so a REPLACED tensor object (load_state_dict(assign=True),
+        `m.weight = nn.Parameter(...)`, parametrize) changes the signature just like an in-place update or a device move."""
+        return tuple((t.data_ptr(), t._version) for m in self._sig_modules()
+                     for tab in (m._parameters, m._buffers) for t in tab.values() if t is not None)
 
     def _graphed(self, tag, fn, x):
         """fn(x) -> tuple of tensors (no host sync inside).  Eager on the first sighting of (tag, shape), then two warm-up
@@ -107,7 +124,7 @@ class _Base(BaseModule):
         if (not self.use_graph or not x.is_cuda or x.shape[0] > self.graph_max_frames or torch.is_grad_enabled() or
                 torch.cuda.is_current_stream_capturing() or self.head_override is not None):
             return fn(x)
-        key = (tag, tuple(x.shape), str(x.device))
+        key = (tag, tuple(x.shape), str(x.device), ops.split_mode())
         sig = self._weights_signature()
         ent = self._graphs.get(key)
         if ent is not None and ent is not False and ent[3] != sig:
@@ -145,15 +162,19 @@ class _Base(BaseModule):
         graph, static_in, static_out = ent[:3]
         static_in.copy_(x)
         graph.replay()
+        _lib.note_replay()
         return static_out
 
     def forward(self, img=None, img_metas=None, return_loss=True, **kwargs):
         if return_loss:
             raise NotImplementedError('training is outside the MI355X inference hot path')
-        with torch.no_grad():
-            out = self.forward_test(img, img_metas, **kwargs)
-        ops.split_overflow_check()      # f16x2 kernels: an operand beyond the f16 range invalidates the results (ops.py)
-        return out
+        def run():
+            with torch.no_grad():
+                return self.forward_test(img, img_metas, **kwargs)
+        # f16x2 kernels: an activation beyond the f16 range invalidates the results -> the call is re-run on the bf16x3
+        # form (ops.rerun_on_bf16x3; the results have just gone to the host, so reading the counter costs no extra sync)
+        p = next(self.parameters(), None)
+        return ops.rerun_on_bf16x3(run, p.device) if p is not None and p.is_cuda else run()
 
     def forward_train(self, *a, **k):
         raise NotImplementedError('training is outside the MI355X inference hot path')

@@ -99,6 +99,19 @@ class MaskFormerFusionHeadCustom(BaseModule):
                                      ori_hw=None if ori_shape is None else ori_shape[:2])
         return pan, seg, keep
 
+    def panoptic_fused_device(self, mask_cls, mask_logits4, batch_input_shape, img_shape, ori_shape=None, extra_rows=0):
+        """panoptic_fused without its host wait: the keep decision and the compaction stay on the device (ops.panoptic_select),
+        the fusion kernels read the kept count from that record.  -> (panoptic (T,oh,ow) int32, seg_id (T+extra_rows, 128) int32
+        with -1 in dropped / unused slots, sel record, (scores, labels)).  sel[1] > 127 (read by the caller together with the
+        tube record) means the kept set does not fit the fused kernels: redo the input through the un-fused path."""
+        scores, labels = F.softmax(mask_cls, dim=-1).max(-1)
+        sel = ops.panoptic_select(scores, labels, self.num_classes, self.test_cfg.get('object_mask_thr', 0.8))
+        pan, seg = ops.panoptic_fuse_sel(mask_logits4, sel, batch_input_shape, img_shape[:2], self.num_things_classes,
+                                         self.num_classes, self.test_cfg.get('iou_thr', 0.8),
+                                         self.test_cfg.get('filter_low_score', False),
+                                         ori_hw=None if ori_shape is None else ori_shape[:2], extra_rows=extra_rows)
+        return pan, seg, sel, (scores, labels)
+
     def fused_capacity_ok(self, mask_cls):
         """The fused kernel keeps its kept-query tables in LDS (<= 127 queries)."""
         return int(self.panoptic_select(mask_cls)[2].sum()) <= ops.PANOPTIC_FUSE_MAX_KEPT

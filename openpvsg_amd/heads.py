@@ -118,7 +118,7 @@ class DecoderRows:
 
         C = 256
         self.layers, self.next_q = [], []
-        self._ws = _ShapeCache(limit=8)              # (B, Q, device) -> workspace of decoder_rows_post's split form
+        self._ws = _ShapeCache(limit=16)             # (B, Q, device) -> workspace of decoder_rows_post's split form
         for layer in head.transformer_decoder.layers:
             xa, sa, ffn = layer.attentions[0].attn, layer.attentions[1].attn, layer.ffns[0]
             f1, f2 = ffn.layers[0][0], ffn.layers[1]
@@ -140,21 +140,29 @@ class DecoderRows:
             m0_w=pk(me[0].weight), m0_b=raw(me[0].bias), m1_w=pk(me[2].weight), m1_b=raw(me[2].bias),
             m2_w=pk(me[4].weight), m2_b=raw(me[4].bias), num_cls_out=self.num_cls_out)
 
-    def start(self, q, q_pos):
-        """forward_head's query side on the initial queries + layer 0's cross-attention query."""
-        _, cls, emb, nq = ops.decoder_rows_post(None, self.head, self.next_q[0] if self.layers else None, q, None,
-                                                q_pos, self.num_cls_out)
-        return cls, emb, nq
+    def pack_buffer(self, B, Q, device):
+        """the buffer decoder_rows_post packs the mask embeddings into (zeroed once per (B, Q, device), like the workspace)"""
+        key = ('pack', B, Q, str(device))
+        buf = self._ws.get(key)
+        if buf is None:
+            buf = self._ws[key] = ops.decoder_rows_pack_buffer(B, Q, device)
+        return buf
 
-    def layer(self, i, attn_core, q, q_pos):
-        """layer i after its cross-attention core -> (new queries, class logits, mask embeddings, next layer's q)."""
+    def start(self, q, q_pos, pack=None):
+        """forward_head's query side on the initial queries + layer 0's cross-attention query [+ flags with `pack`]."""
+        out = ops.decoder_rows_post(None, self.head, self.next_q[0] if self.layers else None, q, None,
+                                    q_pos, self.num_cls_out, pack=pack)
+        return out[1:]
+
+    def layer(self, i, attn_core, q, q_pos, pack=None):
+        """layer i after its cross-attention core -> (new queries, class logits, mask embeddings, next layer's q [, flags])."""
         x1, qkv = ops.decoder_rows_pre(self.layers[i], attn_core, q, q_pos)
         nxt = self.next_q[i + 1] if i + 1 < len(self.layers) else None
         key = (x1.shape[0], x1.shape[1], str(x1.device))
         ws = self._ws.get(key, False)
         if ws is False:                              # zeroed once; the kernel leaves its arrival counters at zero
             ws = self._ws[key] = ops.decoder_rows_post_workspace(x1.shape[0], x1.shape[1], x1.device)
-        return ops.decoder_rows_post(self.layers[i], self.head, nxt, x1, qkv, q_pos, self.num_cls_out, workspace=ws)
+        return ops.decoder_rows_post(self.layers[i], self.head, nxt, x1, qkv, q_pos, self.num_cls_out, workspace=ws, pack=pack)
 
 
 class _Mask2FormerHeadBase(BaseModule):
@@ -328,8 +336,24 @@ class _Mask2FormerHeadBase(BaseModule):
         if rows is not None:
             # query rows through csrc/decoder_rows.hip: two launches per layer (+ mask bits, attention, merge)
             q_pos2 = self.query_embed.weight
-            cls_pred, emb, qproj = rows.start(q, q_pos2)
-            logits, mask = self._mask_step(emb, mf, lows, 0, all_masks or n_layers == 0)
+            # fast mask path on the f16x2 split: the query-row kernel packs the mask embeddings as the bits GEMM's row operand
+            # and zeroes its flag words, so a layer's attention mask is ONE launch (was zero + zero + amax + pack + GEMM, per
+            # batch element)
+            pack = None
+            if (lows is not None and ops.split_mode() == 'f16x2' and os.environ.get('PVSG_MASK_GEMM', 'bf16x3') != 'f32' and
+                    os.environ.get('PVSG_ROWS_PACK', 'on') != 'off' and self.mask_sync is None and
+                    all(lows[i].shape[-1] * lows[i].shape[-2] * 256 < 2 ** 29 for i in lows)):
+                pack = rows.pack_buffer(B, q.shape[1], dev)
+
+            def mask_step(emb, flags, level, want_logits, need_mask=True):
+                if pack is None:
+                    return self._mask_step(emb, mf, lows, level, want_logits, need_mask)
+                logits = ops.mask_logits(emb, mf) if want_logits else None
+                return logits, (ops.attn_mask_bits_packed(pack, lows[level], flags, q.shape[1]) if need_mask else None)
+
+            out = rows.start(q, q_pos2, pack)
+            cls_pred, emb, qproj = out[:3]
+            logits, mask = mask_step(emb, out[3] if pack is not None else None, 0, all_masks or n_layers == 0)
             cls_list.append(cls_pred)
             mask_list.append(logits)
             for i in range(n_layers):
@@ -338,10 +362,11 @@ class _Mask2FormerHeadBase(BaseModule):
                 kp, vp = attn.project_kv(k_in[lvl], v_in[lvl])
                 part = ops.masked_xattn_partial(qproj, kp, vp, mask, self.num_heads)
                 core = ops.xattn_combine(*part) if self.partial_combine is None else self.partial_combine(*part, mask)
-                q, cls_pred, emb, qproj = rows.layer(i, core, q, q_pos2)
                 last = i == n_layers - 1
-                logits, mask = self._mask_step(emb, mf, lows, (i + 1) % L, all_masks or last,
-                                               need_mask=not last or all_masks)
+                out = rows.layer(i, core, q, q_pos2, pack if (not last or all_masks) else None)
+                q, cls_pred, emb, qproj = out[:4]
+                logits, mask = mask_step(emb, out[4] if len(out) > 4 else None, (i + 1) % L, all_masks or last,
+                                         need_mask=not last or all_masks)
                 cls_list.append(cls_pred)
                 mask_list.append(logits)
             return cls_list, mask_list, q.transpose(0, 1)

@@ -336,6 +336,93 @@ def panoptic_fuse(mask_logits, kept_idx, kept_score, kept_class, out_hw, crop_hw
 
 
 MAX_QUERIES = 112              # mask_gemm.hip / masked_xattn.hip: 7 query tiles of 16
+SEL_MAXK = 128                 # include/openpvsg_hip.h PVSG_SEL_MAXK: stride of the device-side kept-query tables / seg_id rows
+SEL_WORDS = 4 + 3 * SEL_MAXK
+
+
+def panoptic_select(scores, labels, num_classes, score_thr):
+    """The keep decision of fusion_head.py:117-124 as a DEVICE record (no torch.nonzero, no host wait):
+    scores (Q,) f32, labels (Q,) int64 = softmax(mask_cls).max(-1) -> sel (SEL_WORDS,) int32
+    [K clamped to 127, K, 0, 0 | kept query index (128) | kept class (128) | kept score bits (128)]."""
+    sc, lb = _chk(scores, 'scores'), _chk(labels, 'labels', torch.int64)
+    Q = sc.shape[0]
+    if sc.dim() != 1 or lb.shape != sc.shape or Q > SEL_MAXK:
+        raise RuntimeError('panoptic_select: scores / labels must be (Q,) with Q <= %d' % SEL_MAXK)
+    sel = torch.empty((SEL_WORDS,), device=sc.device, dtype=torch.int32)
+    with _on(sc.device):
+        _lib.call('pvsg_panoptic_select', sc.data_ptr(), lb.data_ptr(), Q, int(num_classes), float(score_thr), sel.data_ptr(),
+                  _stream_ptr())
+    return sel
+
+
+def panoptic_fuse_sel(mask_logits, sel, out_hw, crop_hw, num_things, num_classes, iou_thr=0.8, filter_low_score=False,
+                      ori_hw=None, extra_rows=0):
+    """panoptic_fuse with the kept set read from the device record `sel` (panoptic_select).
+    -> (panoptic (T,oh,ow) int32, seg_id (T + extra_rows, 128) int32: -1 = dropped / unused slot; the extra rows are left
+    to the caller -- a frame shard puts its overflow count there before the all-gather)."""
+    x = _chk(mask_logits, 'mask_logits')
+    if x.dim() != 4:
+        raise RuntimeError('panoptic_fuse_sel: mask_logits must be (T,Q,h,w)')
+    T, Q, h, w = x.shape
+    H, W = int(out_hw[0]), int(out_hw[1])
+    ih, iw = int(crop_hw[0]), int(crop_hw[1])
+    oh, ow = (ih, iw) if ori_hw is None else (int(ori_hw[0]), int(ori_hw[1]))
+    dev = x.device
+    pan = torch.empty((T, oh, ow), device=dev, dtype=torch.int32)
+    seg = torch.empty((T + extra_rows, SEL_MAXK), device=dev, dtype=torch.int32)
+    owner = torch.empty((T * oh * ow,), device=dev, dtype=torch.uint8)
+    counters = torch.empty((T * 3 * 128,), device=dev, dtype=torch.int32)
+    with _on(dev):
+        _lib.call('pvsg_panoptic_fuse_sel', x.data_ptr(), _chk(sel, 'sel', torch.int32).data_ptr(), pan.data_ptr(), seg.data_ptr(),
+                  owner.data_ptr(), counters.data_ptr(), T, Q, h, w, H, W, ih, iw, oh, ow, int(num_things), int(num_classes),
+                  float(iou_thr), int(bool(filter_low_score)), _stream_ptr())
+    return pan, seg
+
+
+_tube_tables = {}
+
+
+def tube_index(seg, sel, num_frames, frames_per_block=None, rows_per_block=None, with_overflow=True):
+    """First-appearance tube bookkeeping on the device (csrc/tubes.hip): seg = panoptic_fuse_sel's id rows (or the all-gathered
+    rows of a frame shard) -> (rec (8,) int32 [N, K, K unclamped, f16x2 overflow count, ...], tube_ids (T*128,) int64 with the
+    first N valid, rowmap (T,128) int32)."""
+    sg, sl = _chk(seg, 'seg', torch.int32), _chk(sel, 'sel', torch.int32)
+    T = int(num_frames)
+    fpb = T if frames_per_block is None else int(frames_per_block)
+    rpb = fpb if rows_per_block is None else int(rows_per_block)
+    if sg.dim() != 2 or sg.shape[1] != SEL_MAXK or sg.shape[0] < (T // fpb) * rpb:
+        raise RuntimeError('tube_index: seg %s does not hold %d frames in blocks of %d / %d rows' % (tuple(sg.shape), T, fpb, rpb))
+    dev = sg.device
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    table = _tube_tables.get(idx)
+    if table is None:            # scratch of the one-workgroup kernel, reused: calls on a device are ordered by the one-stream rule
+        table = _tube_tables[idx] = torch.empty((int(_lib.load().pvsg_tube_index_table_words()),), device=dev, dtype=torch.int32)
+    rec = torch.empty((8,), device=dev, dtype=torch.int32)
+    ids = torch.empty((T * SEL_MAXK,), device=dev, dtype=torch.int64)
+    rowmap = torch.empty((T, SEL_MAXK), device=dev, dtype=torch.int32)
+    ovf = _overflow.get(idx) if with_overflow else None
+    with _on(dev):
+        _lib.call('pvsg_tube_index', sg.data_ptr(), sl.data_ptr(), T, fpb, rpb, ovf.data_ptr() if ovf is not None else None,
+                  table.data_ptr(), rec.data_ptr(), ids.data_ptr(), rowmap.data_ptr(), _stream_ptr())
+    return rec, ids, rowmap
+
+
+def tube_scatter(query, sel, rowmap, num_tubes):
+    """feats (N,T,C): the query feature (row of `query` (Q,C), any row stride) of each tube's frame-first query, zeros where a
+    tube is absent from a frame."""
+    if not (query.is_cuda and query.dtype == torch.float32 and query.dim() == 2 and query.stride(1) == 1):
+        raise RuntimeError('tube_scatter: query must be a float32 HIP tensor (Q,C) with unit column stride')
+    T = rowmap.shape[0]
+    C = query.shape[1]
+    feats = torch.empty((int(num_tubes), T, C), device=query.device, dtype=torch.float32)
+    if not num_tubes:
+        return feats
+    with _on(query.device):
+        _lib.call('pvsg_tube_scatter', query.data_ptr(), query.stride(0), sel.data_ptr(), rowmap.data_ptr(), feats.data_ptr(),
+                  int(num_tubes), T, C, _stream_ptr())
+    return feats
+
+
 PANOPTIC_FUSE_MAX_KEPT = 127   # kept-query tables of postprocess.hip live in LDS (MAXK - 1)
 
 
@@ -727,27 +814,64 @@ def conv3x3_bf16x3(x, w_packed, cout, scale=None, shift=None, relu=True, out=Non
 #   per-device counter which `split_overflow_check()` turns into an error at the caller's next synchronisation point.
 # 'bf16x3': three bf16 limbs, six limb products, the full f32 exponent range.
 # A packed weight knows its form (two arrays + an 8-element trailer vs three arrays), so the run functions below take either.
+_split_override = None
+
+
 def split_mode():
+    if _split_override is not None:
+        return _split_override
     m = os.environ.get('PVSG_SPLIT', 'f16x2')
     if m not in ('f16x2', 'bf16x3'):
         raise RuntimeError("PVSG_SPLIT must be 'f16x2' or 'bf16x3' (got %r)" % m)
     return m
 
 
+class force_split:
+    """`with ops.force_split('bf16x3'):` -- every split kernel launched inside uses that form regardless of PVSG_SPLIT (the
+    packed weights of both forms are cached side by side, blocks._packed_weight).  Used by the detectors / the pipeline to
+    re-run a call whose activations left the f16 range on the three-limb bf16 form, which covers the whole f32 range."""
+
+    def __init__(self, mode):
+        if mode not in ('f16x2', 'bf16x3'):
+            raise RuntimeError("force_split: mode must be 'f16x2' or 'bf16x3' (got %r)" % (mode,))
+        self.mode = mode
+
+    def __enter__(self):
+        global _split_override
+        self.prev, _split_override = _split_override, self.mode
+        return self
+
+    def __exit__(self, *a):
+        global _split_override
+        _split_override = self.prev
+        return False
+
+
+class SplitOverflowError(RuntimeError):
+    """an f16x2 kernel met |operand| > 65504: the results of the call are invalid"""
+
+
 _overflow = {}
+_overflow_warned = [False]
 
 
 def _overflow_counter(device):
-    t = _overflow.get(device.index)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    t = _overflow.get(idx)
     if t is None:
-        t = _overflow[device.index] = torch.zeros(4, device=device, dtype=torch.int32)
+        t = _overflow[idx] = torch.zeros(4, device=torch.device('cuda', idx), dtype=torch.int32)
     return t
 
 
 def split_overflow_count(device=None, reset=True):
-    """staging threads of f16x2 kernels that met an operand beyond the f16 range since the last reset, on `device` or (None) on
-    every device that ran such a kernel (synchronises with those devices)"""
-    devs = list(_overflow) if device is None else [torch.device(device).index]
+    """staging threads of f16x2 kernels that met an operand beyond the f16 range since the last reset, on `device` (an index-less
+    'cuda' means the current device) or -- None -- on every device that ran such a kernel (synchronises with those devices;
+    pass the device of the call being checked so that another device's count stays with ITS caller)."""
+    if device is None:
+        devs = list(_overflow)
+    else:
+        d = torch.device(device)
+        devs = [d.index if d.index is not None else torch.cuda.current_device()]
     n = 0
     for d in devs:
         t = _overflow.get(d)
@@ -761,12 +885,34 @@ def split_overflow_count(device=None, reset=True):
 
 
 def split_overflow_check(device=None):
-    """Raise if an f16x2 kernel saw |operand| > 65504 since the last check: what it produced is not the product.  Called by the
-    detectors and the pipeline where they synchronise with the device anyway (results going to the host)."""
+    """Raise SplitOverflowError if an f16x2 kernel saw |operand| > 65504 since the last check: what it produced is not the
+    product.  The detectors and the pipeline catch it where they synchronise with the device anyway and re-run the call on the
+    bf16x3 form (`rerun_on_bf16x3`); direct users of `ops` call this themselves."""
     n = split_overflow_count(device)
     if n:
-        raise RuntimeError('f16x2 split kernels met operands beyond the f16 range (|a| > 65504; %d staging threads): the results of '
-                           'this call are invalid. Set PVSG_SPLIT=bf16x3 for inputs of that magnitude.' % n)
+        raise SplitOverflowError('f16x2 split kernels met operands beyond the f16 range (|a| > 65504; %d staging threads): the '
+                                 'results of this call are invalid. Run it under ops.force_split(\'bf16x3\') or set '
+                                 'PVSG_SPLIT=bf16x3 for inputs of that magnitude.' % n)
+
+
+def rerun_on_bf16x3(fn, device=None):
+    """fn() -> result, with the f16x2 range check: if the call's activations left the f16 range (the per-device counter the
+    kernels keep), warn once and run fn() again under force_split('bf16x3').  The caller has synchronised or is about to
+    (results going to the host): reading the counter is one 4-byte copy."""
+    out = fn()
+    if split_mode() != 'f16x2' or not _overflow:
+        return out
+    n = split_overflow_count(device)
+    if not n:
+        return out
+    if not _overflow_warned[0]:
+        _overflow_warned[0] = True
+        import warnings
+        warnings.warn('f16x2 split kernels met activations beyond the f16 range (|a| > 65504; %d staging threads): re-running '
+                      'the call on the three-limb bf16 split (full f32 range, ~1.25x the time).  Set PVSG_SPLIT=bf16x3 if inputs '
+                      'of this magnitude are the norm.' % n)
+    with force_split('bf16x3'):
+        return fn()
 
 
 def _is_f16x2(wp, n, k):
@@ -961,10 +1107,21 @@ def decoder_rows_post_workspace(B, Q, device):
     return torch.zeros(((n + 3) // 4,), device=device, dtype=torch.float32) if n else None
 
 
-def decoder_rows_post(layer_struct, head_struct, next_q, x1, qkv, query_pos, num_cls_out, workspace=None):
+def decoder_rows_pack_buffer(B, Q, device):
+    """Zeroed buffer decoder_rows_post writes the packed mask embeddings into (f16x2 row operand of the attention-mask-bits
+    GEMM, B packs of pvsg_gemm_f16x2_packed_elems(Q, 256) 16-bit elements; rows Q..127 stay zero): allocate once per (B, Q)."""
+    n = int(_lib.load().pvsg_gemm_f16x2_packed_elems(Q, 256))
+    buf = torch.zeros((B, n), device=device, dtype=torch.bfloat16)
+    buf[:, -8:].view(torch.float32)[:, :2] = 1.0          # trailer (max|w|, 2^-e): the rows carry their own scales, nothing to undo
+    return buf
+
+
+def decoder_rows_post(layer_struct, head_struct, next_q, x1, qkv, query_pos, num_cls_out, workspace=None, pack=None):
     """Self-attention + FFN + norms (layer_struct None: skipped, x1 = the queries) and the query side of
     forward_head; next_q = (packed Wq, bq) of the next layer's cross-attention or None.
-    -> query_out (B,Q,256) or None, cls (B,Q,num_cls_out), mask_embed (B,Q,256), next_q (B,Q,256) or None."""
+    pack: None, or a decoder_rows_pack_buffer: the kernel also writes the packed mask embeddings there and zeroes a fresh
+    (B,4) flag tensor, returned as a fifth value (attn_mask_bits_packed consumes both).
+    -> query_out (B,Q,256) or None, cls (B,Q,num_cls_out), mask_embed (B,Q,256), next_q (B,Q,256) or None [, flags]."""
     x1, pos = _chk(x1, 'x1'), _chk(query_pos, 'query_pos')
     B, Q, C = x1.shape
     dev = x1.device
@@ -972,6 +1129,7 @@ def decoder_rows_post(layer_struct, head_struct, next_q, x1, qkv, query_pos, num
     cls = torch.empty((B, Q, num_cls_out), device=dev, dtype=torch.float32)
     emb = torch.empty_like(x1)
     nq = torch.empty_like(x1) if next_q is not None else None
+    flags = torch.empty((B, 4), device=dev, dtype=torch.int32) if pack is not None else None
     with _on(dev):
         _lib.call('pvsg_decoder_rows_post', ctypes.byref(layer_struct) if layer_struct is not None else None,
                   ctypes.byref(head_struct), next_q[0].data_ptr() if next_q is not None else None,
@@ -979,8 +1137,27 @@ def decoder_rows_post(layer_struct, head_struct, next_q, x1, qkv, query_pos, num
                   _chk(qkv, 'qkv').data_ptr() if qkv is not None else None, pos.data_ptr(),
                   q_out.data_ptr() if q_out is not None else None, cls.data_ptr(), emb.data_ptr(),
                   nq.data_ptr() if nq is not None else None,
-                  workspace.data_ptr() if workspace is not None else None, B, Q, _stream_ptr())
-    return q_out, cls, emb, nq
+                  workspace.data_ptr() if workspace is not None else None,
+                  pack.data_ptr() if pack is not None else None, flags.data_ptr() if flags is not None else None,
+                  B, Q, _stream_ptr())
+    return (q_out, cls, emb, nq) if pack is None else (q_out, cls, emb, nq, flags)
+
+
+def attn_mask_bits_packed(pack, feature_lowres, flags, num_queries):
+    """attn_mask_from_lowres_feature with the embeddings already packed and the flag words already zeroed by
+    decoder_rows_post(pack=...): one launch for the whole batch.  feature_lowres (B,C,h,w) or (B,T,C,h,w)."""
+    f = _chk(feature_lowres, 'feature_lowres')
+    B = f.shape[0]
+    T = f.shape[1] if f.dim() == 5 else 1
+    C = f.shape[-3]
+    N = f.shape[-1] * f.shape[-2]
+    if pack.shape[0] != B or tuple(flags.shape) != (B, 4):
+        raise RuntimeError('attn_mask_bits_packed: pack / flags do not match the batch of %d' % B)
+    bits = torch.empty((B, T * N, 4), device=f.device, dtype=torch.int32)
+    with _on(f.device):
+        _lib.call('pvsg_attn_mask_bits_packed_f16x2', pack.data_ptr(), f.data_ptr(), bits.data_ptr(), flags.data_ptr(), B, T,
+                  int(num_queries), C, N, _overflow_counter(f.device).data_ptr(), _stream_ptr())
+    return AttnMask(bits, flags, num_queries)
 
 
 conv3x3s2_bf16x3_pack = conv3x3_bf16x3_pack

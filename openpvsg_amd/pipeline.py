@@ -14,7 +14,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import ops, parallel
+from . import _lib, ops, parallel
 from .blocks import pin_graph_caches
 
 
@@ -117,7 +117,7 @@ class PVSGPipeline(torch.nn.Module):
         ONE hipGraph per input shape: the launches come from torch ops and from the C ABI alike, all on the
         capturing stream.  First call per shape: two eager warm-up runs (MIOpen / hipBLASLt pick their
         kernels), then capture.  Falls back to eager if capture is not possible."""
-        key = (tuple(clip.shape), str(clip.device))
+        key = (tuple(clip.shape), str(clip.device), ops.split_mode())
         entry = self._graphs.get(key)
         det, head = self.detector, self.detector.panoptic_head
         T = clip.shape[0]
@@ -156,6 +156,7 @@ class PVSGPipeline(torch.nn.Module):
         graph, static_in, static_out = entry[:3]
         static_in.copy_(clip)
         graph.replay()
+        _lib.note_replay()
         cls, masks4, q = static_out
         # the graph's output buffers are overwritten by the next replay: hand out copies of the small ones
         # (masks4, 0.75 GB at 32 x 720p, is consumed by the fusion kernels of this same call)
@@ -208,14 +209,14 @@ class PVSGPipeline(torch.nn.Module):
         graph, static_in, static_out = ent
         static_in.copy_(feats)
         graph.replay()
+        _lib.note_replay()
         return {k: v.clone() for k, v in static_out.items()}     # small tensors; the static ones are reused next replay
 
-    @torch.no_grad()
-    def vps_clip(self, clip, batch_input_shape, img_shape=None, total_frames=None, group=None, solo=False):
-        """clip (T_local,3,H,W) normalised frames of ONE video (this rank's shard).
-        Returns per-frame panoptic maps (T_local,H,W) int32, seg ids / kept features per frame."""
+    def _head_outputs(self, clip, total_frames=None, group=None, solo=False):
+        """backbone + pixel decoder + decoder of this rank's frames -> cls (1,Q,C+1), masks4 (1,T,Q,H/4,W/4), q (Q,1,C)
+        (hipGraph replay where `use_graph` says so; frame shards run eagerly: their layers exchange records)."""
         det = self.detector
-        head, fusion = det.panoptic_head, det.panoptic_fusion_head
+        head = det.panoptic_head
         T = clip.shape[0]
         shard = None
         if parallel.is_dist(group) and not solo:
@@ -232,6 +233,30 @@ class PVSGPipeline(torch.nn.Module):
                 shard.release()
         if self.head_override is not None:
             cls, masks4 = self.head_override(cls, masks4)
+        return cls, masks4, q
+
+    @property
+    def _last_keep(self):
+        """(Q,) bool keep mask of the last clip (tests; the segments layout): from the stored class decision"""
+        ent = self.__dict__.get('_last_select')
+        if ent is None:
+            return None
+        if isinstance(ent, torch.Tensor):
+            return ent
+        fusion = self.detector.panoptic_fusion_head
+        return ent[1].ne(fusion.num_classes) & (ent[0] > fusion.test_cfg.get('object_mask_thr', 0.8))
+
+    @_last_keep.setter
+    def _last_keep(self, v):
+        self.__dict__['_last_select'] = v
+
+    @torch.no_grad()
+    def vps_clip(self, clip, batch_input_shape, img_shape=None, total_frames=None, group=None, solo=False, head_out=None):
+        """clip (T_local,3,H,W) normalised frames of ONE video (this rank's shard).
+        Returns per-frame panoptic maps (T_local,H,W) int32, seg ids / kept features per frame."""
+        fusion = self.detector.panoptic_fusion_head
+        T = clip.shape[0]
+        cls, masks4, q = head_out if head_out is not None else self._head_outputs(clip, total_frames, group, solo)
         H, W = batch_input_shape
         ih, iw = (img_shape or batch_input_shape)[:2]
         if self.fused_postprocess:
@@ -252,8 +277,61 @@ class PVSGPipeline(torch.nn.Module):
             seg_ids.append(sid)
         return torch.stack(pans), seg_ids, [k_feats] * T, cls, q
 
-    @torch.no_grad()
+    # ---- the device-resident tail: class decision -> fusion -> tube bookkeeping, ONE host wait (the tube count) ------------
+    def _device_tail_ok(self, q):
+        fusion = self.detector.panoptic_fusion_head
+        return (self.fused_postprocess and os.environ.get('PVSG_DEVICE_TAIL', 'on') != 'off' and q.is_cuda and
+                q.shape[0] <= ops.SEL_MAXK and fusion.num_classes < 1000)
+
+    def _tail_device(self, head_out, batch_input_shape, img_shape, group, dist_on):
+        """-> (pans, tube_ids (N,), feats (N,T,C)) or None when the kept set exceeds the fused kernels' capacity (the caller
+        then runs the host-side tail on the same head outputs).  Raises ops.SplitOverflowError for the f16x2 range check."""
+        cls, masks4, q = head_out
+        fusion = self.detector.panoptic_fusion_head
+        T_local = masks4.shape[1]
+        H, W = batch_input_shape
+        ih, iw = (img_shape or batch_input_shape)[:2]
+        pans, seg, sel, decision = fusion.panoptic_fused_device(cls[0], masks4[0], (H, W), (ih, iw), extra_rows=1 if dist_on else 0)
+        self._last_keep = decision
+        if dist_on:
+            # every rank needs each frame's id row (K and the class decision are identical on all ranks: queries and class
+            # logits are replicated after the per-layer merge); the rank's f16x2 overflow count rides in the extra row so that
+            # all ranks take the same branch on it
+            seg[T_local, :1].copy_(ops._overflow_counter(q.device)[:1])
+            seg = parallel.all_gather_cat(seg, 0, group)
+            T = seg.shape[0] // (T_local + 1) * T_local
+            rec, ids, rowmap = ops.tube_index(seg, sel, T, T_local, T_local + 1, with_overflow=False)
+        else:
+            T = T_local
+            rec, ids, rowmap = ops.tube_index(seg, sel, T)
+        n_tubes, _, k_raw, ovf = rec.tolist()[:4]                      # the one host wait of the step
+        if ovf:
+            ops._overflow_counter(q.device).zero_()
+            raise ops.SplitOverflowError('f16x2 split kernels met operands beyond the f16 range (|a| > 65504; %d staging '
+                                         'threads): the results of this clip are invalid.' % ovf)
+        if k_raw > ops.SEL_MAXK - 1:
+            return None
+        feats = ops.tube_scatter(q[:, 0], sel, rowmap, n_tubes)
+        return pans, ids[:n_tubes], feats
+
     def forward(self, clip, batch_input_shape, img_shape=None, total_frames=None, group=None, shard='frames'):
+        """`_forward` with the f16x2 range fallback: a clip whose activations leave the f16 range (the kernels count them, tube
+        assembly checks the counter at its host sync and raises ops.SplitOverflowError) is re-run on the bf16x3 form.  Under a
+        process group every rank must take the same branch: the overflow count is then agreed on by `_forward` itself."""
+        try:
+            return self._forward(clip, batch_input_shape, img_shape, total_frames, group, shard)
+        except ops.SplitOverflowError as e:
+            if ops.split_mode() != 'f16x2':
+                raise
+            if not ops._overflow_warned[0]:
+                ops._overflow_warned[0] = True
+                import warnings
+                warnings.warn('%s  Re-running the clip on the three-limb bf16 split.' % e)
+            with ops.force_split('bf16x3'):
+                return self._forward(clip, batch_input_shape, img_shape, total_frames, group, shard)
+
+    @torch.no_grad()
+    def _forward(self, clip, batch_input_shape, img_shape=None, total_frames=None, group=None, shard='frames'):
         """clip: this rank's frames.  With a process group:
         shard='frames'   ONE clip split by frame over the ranks (strong scaling): clip-level attention merges
                          partials across ranks every decoder layer; the per-frame segment records are gathered.
@@ -284,8 +362,17 @@ class PVSGPipeline(torch.nn.Module):
                     seg_ids.append(ids[t])
                     k_feats.append(allfeat[r])
         else:
+            head_out = self._head_outputs(clip, total_frames, group, solo=not dist_on)
+            cls, q = head_out[0], head_out[2]
+            done = None
+            if self._device_tail_ok(q):
+                done = self._tail_device(head_out, batch_input_shape, img_shape, group, dist_on)
+            if done is not None:
+                pans, tube_ids, feats = done
+                rel = self._relation(feats) if feats.shape[0] >= 2 else None
+                return dict(pan_results=pans, tube_ids=tube_ids, tube_feats=feats, relation=rel, cls=cls, query=q)
             pans, seg_ids, k_feats, cls, q = self.vps_clip(clip, batch_input_shape, img_shape, total_frames, group,
-                                                           solo=not dist_on)
+                                                           solo=not dist_on, head_out=head_out)
             if dist_on:
                 # tube reassembly: every rank needs each frame's segment-id record (K is identical on all ranks
                 # in this mode because queries and class logits are replicated after the merge)

@@ -163,3 +163,44 @@ def test_unsupported_shapes_report(hip_lib):
     assert rc == 1 and b'null pointer in pvsg_decoder_layer' in hip_lib.pvsg_last_error()
     rc = hip_lib.pvsg_decoder_rows_pre(ctypes.byref(lay), one, one, one, one, one, 1, 200, None)
     assert rc == 2 and b'at most 128 queries' in hip_lib.pvsg_last_error()
+
+
+@pytest.mark.parametrize('B,T,Q,hw,escale', [(1, 4, 100, (23, 40), 1.0), (3, None, 100, (46, 80), 1e-4), (2, 2, 37, (16, 24), 3e3),
+                                             (1, None, 128, (8, 16), 1.0)])
+def test_rows_post_packs_the_mask_embeddings_for_the_bits_kernel(hip_lib, B, T, Q, hw, escale):
+    """decoder_rows_post(pack=...) writes the mask embeddings as the f16x2 row operand (per-row power-of-two scale) and zeroes
+    the flag words; pvsg_attn_mask_bits_packed_f16x2 on them == pvsg_attn_mask_bits_f16x2 on the plain embeddings (amax + pack +
+    zero + GEMM per batch element), bit for bit outside logits that round to 0, for embeddings of any magnitude; the buffer's
+    rows beyond Q stay zero so a second call with other contents is not polluted (mask2former_head.py:383-393, :453-454)."""
+    from openpvsg_amd import ops
+    from openpvsg_amd.heads import DecoderRows
+    head = _head(True, 21, gains={'cls_embed.weight': 12.0, 'mask_embed.4.weight': escale})
+    rows = DecoderRows(head)
+    q_pos = det_input('pos', (Q, 256), 3).to(DEV)
+    feat = det_input('feat', ((B, 256) if T is None else (B, T, 256)) + hw, 6).to(DEV)
+    pack = rows.pack_buffer(B, Q, DEV)
+    for rep in range(2):
+        q = det_input('q', (B, Q, 256), 2 + rep).to(DEV)
+        with torch.no_grad():
+            cls0, emb0, nq0 = rows.start(q, q_pos)
+            cls1, emb1, nq1, flags = rows.start(q, q_pos, pack)
+        assert torch.equal(emb0, emb1) and torch.equal(cls0, cls1) and torch.equal(nq0, nq1)
+        assert int(flags.abs().sum()) == 0
+        got = ops.attn_mask_bits_packed(pack, feat, flags, Q)
+        ref = ops.attn_mask_from_lowres_feature(emb0, feat)
+        gb, rb = got.to_bool(reset_all_blocked=False), ref.to_bool(reset_all_blocked=False)
+        diff = gb != rb
+        f2 = feat.flatten(-2) if T is not None else feat.flatten(-2)[:, None]                # (B,T,C,N)
+        logit = torch.einsum('bqc,btcn->bqtn', emb0.double(), f2.double()).flatten(2)        # keys ordered (t, n)
+        scale = (emb0.double().abs().unsqueeze(2) @ f2.double().abs().flatten(0, 1).amax(0, keepdim=True).amax(-1, keepdim=True)).amax()
+        assert diff.float().mean() < 1e-5
+        if diff.any():
+            assert float(logit[diff].abs().max()) < 1e-6 * float(scale)
+        # the reference decision itself, away from zero
+        far = logit.abs() > 1e-6 * float(scale)
+        assert torch.equal(gb[far], (logit < 0)[far])
+        has = (~gb).any(-1)
+        qq = torch.arange(Q, device=DEV)
+        fl = ((got.flags.to(torch.int64)[:, qq // 32] >> (qq % 32)) & 1).bool()
+        assert torch.equal(fl, has)
+    assert ops.split_overflow_count() == 0

@@ -38,7 +38,7 @@ def test_non_mfma_kernels_may_overlap(hip_lib):
     """two streams of f32 / HBM-bound kernels (the backbone's opt-in two-stream mode with PVSG_GEMM=lib) are not refused"""
     from openpvsg_amd import _lib, ops
     torch.cuda.synchronize()
-    _lib._cur[0], _lib._cur[1] = None, False              # fresh owner: no 16-bit-MFMA history on the current stream
+    _lib._cur.clear()                                     # fresh owner: no 16-bit-MFMA history on the current stream
     x = torch.randn(200000, 256, device='cuda')
     ln = torch.nn.LayerNorm(256).cuda()
     side = torch.cuda.Stream()
@@ -46,4 +46,41 @@ def test_non_mfma_kernels_may_overlap(hip_lib):
         ops.add_layernorm(x, None, None, ln)
     with torch.cuda.stream(side):
         ops.add_layernorm(x, None, None, ln)
+    torch.cuda.synchronize()
+
+
+def test_guard_state_is_per_device_and_dead_handles_are_idle(hip_lib):
+    """the previous-stream record is kept per device (two GPUs / two threads with one GPU each alternate freely),
+    a destroyed stream handle counts as idle, and a graph replay registers its stream."""
+    from openpvsg_amd import _lib, ops
+    torch.cuda.synchronize()
+    _lib._cur.clear()
+    dev = torch.cuda.current_device()
+    # another device's record with a busy-looking foreign stream must not matter for launches here
+    _lib._cur[dev + 1] = [0xdead0000, True]
+    x = torch.randn(1000, 256, device='cuda')
+    ln = torch.nn.LayerNorm(256).cuda()
+    ops.add_layernorm(x, None, None, ln)
+    assert _lib._cur[dev][0] is not None and _lib._cur[dev + 1] == [0xdead0000, True]
+    # a dead handle as this device's previous stream: hipStreamQuery errors -> treated as idle, the launch goes through
+    torch.cuda.synchronize()
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+    dead = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(dead)) == 0 and hip.hipStreamDestroy(dead) == 0
+    s = torch.cuda.Stream()
+    handle = s.cuda_stream
+    _lib._cur[dev] = [dead.value, True]
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(4096, 256, generator=g).cuda()
+    wp = ops.gemm_bf16x3_pack(torch.randn(256, 256, generator=g).cuda())
+    ops.gemm_bf16x3(a, wp, 256)
+    torch.cuda.synchronize()
+    # replay registration
+    _lib._cur.clear()
+    with torch.cuda.stream(s):
+        _lib.note_replay()
+    assert _lib._cur[dev] == [handle, True]
+    s.synchronize()
+    ops.gemm_bf16x3(a, wp, 256)                           # idle hand-over back to the default stream
     torch.cuda.synchronize()
