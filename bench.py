@@ -184,8 +184,9 @@ class KernelTimer:
         import openpvsg_amd.ops as ops
         ops._lib.call = timed
 
+    KEPT_HINT = 32             # kept queries of the synthetic head outputs (--keep): the device-side tail does not tell the host
     SPLIT_F16X2 = ('pvsg_gemm_f16x2', 'pvsg_gemm_f16x2_add_layernorm', 'pvsg_conv1x1_f16x2', 'pvsg_conv3x3_f16x2',
-                   'pvsg_mask_logits_f16x2', 'pvsg_attn_mask_bits_f16x2')
+                   'pvsg_mask_logits_f16x2', 'pvsg_attn_mask_bits_f16x2', 'pvsg_attn_mask_bits_packed_f16x2')
 
     @classmethod
     def work(cls, name, a):
@@ -193,6 +194,9 @@ class KernelTimer:
         if name == 'pvsg_gemm_f16x2_add_layernorm':     # projection + identity + LayerNorm: reads a, residual; writes the normalised rows
             M, N, K = a[8:11]
             return 4.0 * M * (K + 2 * N) + 4.0 * N * K, 6.0 * M * N * K
+        if name == 'pvsg_attn_mask_bits_packed_f16x2':   # embeddings pre-packed by decoder_rows_post: (pack, f, bits, flags, B, T, Q, C, N, ..)
+            B, T, Q, C, N = a[4:9]
+            return 4.0 * B * T * N * C + 16.0 * B * T * N, 6.0 * B * T * Q * C * N
         if name in cls.SPLIT_F16X2:
             # two-limb f16 form: same arguments up to the trailing (overflow, stream); flops = the f16 limb products issued,
             # 3 per f32 multiply-add (the bf16 form issues 6)
@@ -233,6 +237,9 @@ class KernelTimer:
         if name == 'pvsg_panoptic_fuse':
             T, Q, K, h, w, H, W, ih, iw = a[8:17]
             return 4.0 * T * K * h * w + 5.0 * T * ih * iw + 1.0 * T * ih * iw, 0.0
+        if name == 'pvsg_panoptic_fuse_sel':          # kept count decided on the device: priced with the bench's keep count
+            T, Q, h, w, H, W, ih, iw = a[6:14]
+            return 4.0 * T * KernelTimer.KEPT_HINT * h * w + 5.0 * T * ih * iw + 1.0 * T * ih * iw, 0.0
         if name == 'pvsg_center_downsample':
             planes, H, W = a[4:7]
             return 4.0 * planes * H * W * (1 + 21.0 / 64), 0.0
@@ -275,7 +282,7 @@ class KernelTimer:
             B, Q = a[6:8]
             return 4.0 * (256 * 256 + 768 * 256) + 4.0 * B * Q * 256 * 6, 2.0 * B * Q * 256 * (256 + 768)
         if name == 'pvsg_decoder_rows_post':
-            B, Q = a[12:14]
+            B, Q = a[14:16]
             w_head = 128 * 256 + 3 * 256 * 256 + (256 * 256 if a[2] else 0)
             w_layer = (256 * 256 + 2 * 256 * 2048) if a[0] is not None else 0
             att = 4.0 * B * Q * Q * 256 if a[0] is not None else 0.0
@@ -452,9 +459,9 @@ def fastpath_bit_flip_rate(head, feats, T):
     rec = {}
     orig = head._mask_step
 
-    def spy(emb, mf, lows, level, want_logits, need_mask=True):
+    def spy(emb, mf, lows, level, want_logits, need_mask=True, **kw):
         rec['emb'], rec['mf'], rec['lows'] = emb, mf, lows
-        return orig(emb, mf, lows, level, want_logits, need_mask)
+        return orig(emb, mf, lows, level, want_logits, need_mask, **kw)
     head._mask_step = spy
     try:
         with torch.no_grad():
@@ -626,6 +633,7 @@ def main():
         pipe.head_override = make_override(syn, dev)
 
     timer = KernelTimer()
+    KernelTimer.KEPT_HINT = args.keep
     if not args.no_kernel_timing and rank == 0:
         timer.install()
 

@@ -222,12 +222,15 @@ class _Mask2FormerHeadBase(BaseModule):
                 nn.init.xavier_normal_(p)
 
     # ---- one `forward_head` step ----------------------------------------------------------------
-    def _mask_step(self, emb, mask_features, lows, level, want_logits, need_mask=True):
-        """mask embeddings (B,Q,C) -> mask logits or None, ops.AttnMask for `level` or None."""
+    def _mask_step(self, emb, mask_features, lows, level, want_logits, need_mask=True, packed=None):
+        """mask embeddings (B,Q,C) -> mask logits or None, ops.AttnMask for `level` or None.
+        packed = (pack buffer, zeroed flags) when decoder_rows_post has already packed `emb` for the bits kernel."""
         logits = ops.mask_logits(emb, mask_features) if (want_logits or lows is None) else None
         mask = None
         if need_mask:
-            if lows is not None:
+            if packed is not None and lows is not None:
+                mask = ops.attn_mask_bits_packed(packed[0], lows[level], packed[1], emb.shape[1])
+            elif lows is not None:
                 mask = ops.attn_mask_from_lowres_feature(emb, lows[level])
             else:
                 size = self._level_sizes[level]
@@ -346,10 +349,8 @@ class _Mask2FormerHeadBase(BaseModule):
                 pack = rows.pack_buffer(B, q.shape[1], dev)
 
             def mask_step(emb, flags, level, want_logits, need_mask=True):
-                if pack is None:
-                    return self._mask_step(emb, mf, lows, level, want_logits, need_mask)
-                logits = ops.mask_logits(emb, mf) if want_logits else None
-                return logits, (ops.attn_mask_bits_packed(pack, lows[level], flags, q.shape[1]) if need_mask else None)
+                return self._mask_step(emb, mf, lows, level, want_logits, need_mask,
+                                       packed=(pack, flags) if (pack is not None and flags is not None) else None)
 
             out = rows.start(q, q_pos2, pack)
             cls_pred, emb, qproj = out[:3]

@@ -346,7 +346,7 @@ def test_graph_replay_survives_cache_eviction_and_follows_weight_updates(hip_lib
     m.use_graph = True
     run(30)
     run(30)                                                     # capture at 64 x 96
-    ent = m._graphs[('image', (1, 3, 64, 96), DEV)]
+    ent = m._graphs[('image', (1, 3, 64, 96), DEV, 'f16x2')]
     assert ent not in (None, False) and any(len(p) for p in ent[4]), 'the graph entry pins nothing'
     m.use_graph = False                                         # 20 other shapes, eagerly: every bounded cache turns over
     for i in range(20):
@@ -356,7 +356,7 @@ def test_graph_replay_survives_cache_eviction_and_follows_weight_updates(hip_lib
     junk = [torch.full((1 << 20,), float('nan'), device=DEV) for _ in range(64)]      # reuse whatever was freed
     del junk
     m.use_graph = True
-    assert m._graphs.get(('image', (1, 3, 64, 96), DEV)) is ent
+    assert m._graphs.get(('image', (1, 3, 64, 96), DEV, 'f16x2')) is ent
     np.testing.assert_array_equal(np.asarray(run(31)['pan_results']), want)
     # in-place weight update: new capture (two sightings), then replays of the NEW weights
     with torch.no_grad():
@@ -366,7 +366,7 @@ def test_graph_replay_survives_cache_eviction_and_follows_weight_updates(hip_lib
     m.use_graph = True
     for _ in range(3):
         np.testing.assert_array_equal(np.asarray(run(31)['pan_results']), want2)
-    assert m._graphs[('image', (1, 3, 64, 96), DEV)] is not ent
+    assert m._graphs[('image', (1, 3, 64, 96), DEV, 'f16x2')] is not ent
 
 
 def test_vps_detector_instance_on_and_rescale_vs_reference_golden(hip_lib, golden_dir):
@@ -685,8 +685,8 @@ def test_config2_ips_720p_batch_independence(hip_lib):
     rec = []
     orig = h._mask_step
 
-    def spy(emb, mf, lows, level, want_logits, need_mask=True):
-        out = orig(emb, mf, lows, level, want_logits, need_mask)
+    def spy(emb, mf, lows, level, want_logits, need_mask=True, **kw):
+        out = orig(emb, mf, lows, level, want_logits, need_mask, **kw)
         rec[-1].append(None if out[1] is None else out[1].bits.clone())
         return out
     h._mask_step = spy
@@ -795,3 +795,91 @@ def test_config5_full_size_64_frames_1080p_properties(hip_lib):
     assert masks_a.shape == (1, T, 100, 272, 480) and torch.isfinite(masks_a).all()
     assert torch.allclose(cls_a, cls_b, rtol=1e-3, atol=1e-3) and torch.allclose(q_a, q_b, rtol=1e-3, atol=1e-3)
     assert float((masks_a - masks_b).abs().max()) < 2e-3 * float(masks_a.abs().max())
+
+
+def test_graph_follows_replaced_parameter_objects_and_nested_module_swaps(hip_lib):
+    """the weight signature looks parameters up afresh in every module's table, so a REPLACED tensor object
+    (`m.weight = nn.Parameter(...)`, load_state_dict(assign=True)) or a swapped NESTED sub-module changes it and the captured
+    hipGraph is not replayed on stale weights -- without a call to invalidate_graphs()."""
+    m = build_detector(False, 5, {'cls_embed.weight': 40.0})
+    meta = dict(img_shape=(64, 96, 3), ori_shape=(64, 96, 3))
+    x = det_input('img', (1, 3, 64, 96), 31).to(DEV)
+
+    def run():
+        return np.asarray(m.forward([x], [[dict(meta)]], return_loss=False, rescale=True)[0]['pan_results'])
+
+    def eager():
+        m.use_graph = False
+        try:
+            return run()
+        finally:
+            m.use_graph = True
+
+    for _ in range(3):
+        base = run()                                            # sighting, capture, replay
+    sig0 = m._weights_signature()
+    # (1) a parameter OBJECT is replaced (the old tensor stays alive in `old`)
+    head = m.panoptic_head
+    old = head.cls_embed.weight
+    head.cls_embed.weight = torch.nn.Parameter(old.detach().clone() * 0.25)
+    assert m._weights_signature() != sig0
+    want = eager()
+    for _ in range(3):
+        np.testing.assert_array_equal(run(), want)
+    # (2) load_state_dict(assign=True): every tensor object is new
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    sd['panoptic_head.query_feat.weight'] = sd['panoptic_head.query_feat.weight'] * 1.5
+    sig1 = m._weights_signature()
+    m.load_state_dict(sd, assign=True)
+    assert m._weights_signature() != sig1
+    want = eager()
+    for _ in range(3):
+        np.testing.assert_array_equal(run(), want)
+    # (3) a nested sub-module is swapped
+    import copy
+    sig2 = m._weights_signature()
+    new_ffn = copy.deepcopy(head.transformer_decoder.layers[3].ffns[0])
+    with torch.no_grad():
+        for p in new_ffn.parameters():
+            p.mul_(0.5)
+    head.transformer_decoder.layers[3].ffns[0] = new_ffn
+    assert m._weights_signature() != sig2
+    want = eager()
+    for _ in range(3):
+        np.testing.assert_array_equal(run(), want)
+    del old
+
+
+def test_f16x2_overflow_reruns_the_call_on_bf16x3(hip_lib):
+    """an activation beyond the f16 range (|a| > 65504) no longer kills the call.  The detector notices the
+    kernels' overflow count where it hands results to the host, warns once and re-runs the forward on the three-limb bf16 split;
+    the result equals a run forced to that form from the start, and the next in-range call is back on f16x2."""
+    import warnings
+    from openpvsg_amd import ops
+    m = build_detector(False, 5, {'cls_embed.weight': 40.0})
+    m.panoptic_fusion_head.test_cfg = dict(m.panoptic_fusion_head.test_cfg, instance_on=False)
+    meta = dict(img_shape=(64, 96, 3), ori_shape=(64, 96, 3))
+    x = det_input('img', (1, 3, 64, 96), 33).to(DEV)
+    big = x * 3.0e5                                              # pushes the backbone's activations past 65504
+
+    def run(inp):
+        r = m.forward([inp], [[dict(meta)]], return_loss=False, rescale=True)[0]
+        return np.asarray(r['pan_results']), {k: np.stack([np.asarray(f) for f in v]) for k, v in r['query_feats'].items()}
+
+    small = run(x)
+    assert ops.split_overflow_count() == 0
+    ops._overflow_warned[0] = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        got = run(big)
+    assert any('re-running' in str(i.message) for i in w), [str(i.message) for i in w]
+    assert ops.split_overflow_count() == 0                       # consumed by the fallback
+    with ops.force_split('bf16x3'):
+        want = run(big)
+    np.testing.assert_array_equal(got[0], want[0])
+    assert got[1].keys() == want[1].keys()
+    for k in got[1]:
+        np.testing.assert_array_equal(got[1][k], want[1][k])
+    assert ops.split_mode() == 'f16x2'
+    again = run(x)                                               # back on the default form, same answer as before
+    np.testing.assert_array_equal(again[0], small[0])
