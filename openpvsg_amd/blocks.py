@@ -84,6 +84,45 @@ def pin_graph_caches():
     return [list(c.values()) for c in list(_GRAPH_CACHES)]
 
 
+class WeightSignature:
+    """(address, version) of every parameter and buffer under some modules: what a captured hipGraph baked in.
+    The module walk is cached as (child table, its (name, module) pairs) links; every call confirms that each table still holds
+    exactly those modules under those names (a swapped / added / removed sub-module at ANY depth re-walks) and looks the tensors
+    up afresh in each module's `_parameters` / `_buffers` table, so a REPLACED tensor object (load_state_dict(assign=True),
+    `m.weight = nn.Parameter(...)`, parametrize) changes the signature just like an in-place update or a device move.
+    (A full `parameters()` + `buffers()` traversal per call cost 3x as much on the host-bound small-batch paths.)"""
+
+    def __init__(self, *roots):
+        self.roots = roots
+        self._links = None
+
+    def modules(self):
+        ent = self._links
+        if ent is not None and all(len(tab) == len(kids) and all(tab.get(n) is m for n, m in kids) for tab, kids in ent[0]):
+            return ent[1]
+        links, mods = [], []
+
+        def walk(m):
+            mods.append(m)
+            kids = tuple((n, c) for n, c in m._modules.items())
+            links.append((m._modules, kids))
+            for _, c in kids:
+                if c is not None:
+                    walk(c)
+
+        for r in self.roots:
+            walk(r)
+        self._links = (links, mods)
+        return mods
+
+    def invalidate(self):
+        self._links = None
+
+    def __call__(self):
+        return tuple((t.data_ptr(), t._version) for m in self.modules()
+                     for tab in (m._parameters, m._buffers) for t in tab.values() if t is not None)
+
+
 def _packed_weight(owner, slot, key, make):
     """`make()` = the packed form of a weight for the CURRENT split mode, cached on `owner` per (slot, mode): once a call has
     fallen back from f16x2 to bf16x3 (ops.rerun_on_bf16x3) both packs stay, so neither direction repacks.  `key` = (address,

@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, ops, parallel
-from .blocks import pin_graph_caches
+from .blocks import WeightSignature, pin_graph_caches
 
 
 def _first_appearances_numpy(host):
@@ -121,12 +121,25 @@ class PVSGPipeline(torch.nn.Module):
         entry = self._graphs.get(key)
         det, head = self.detector, self.detector.panoptic_head
         T = clip.shape[0]
-        # the graph bakes in parameter addresses and the tensors derived from them (packed limbs, BN affine tables): a weight
-        # change -- load_state_dict, an in-place update, .to() -- is seen through (address, version) and triggers a new capture
-        sig = det._weights_signature()
-        if entry is not None and entry is not False and entry[3] != sig:
+        # The graph bakes in parameter addresses and the tensors derived from them (packed limbs, BN affine tables): a weight
+        # change -- load_state_dict, an in-place update, .to(), a replaced tensor or module -- is seen through the (address,
+        # version) signature and triggers a new capture.  Reading the ~650 (address, version) pairs costs the host ~0.3 ms, which
+        # on a short clip is GPU idle time at the step boundary -- so the replay is launched FIRST and the signature is checked
+        # while it runs; a stale replay (it only read buffers the entry keeps alive) is discarded and redone after a re-capture.
+        if entry is not None and entry is not False:
+            graph, static_in, static_out = entry[:3]
+            static_in.copy_(clip)
+            graph.replay()
+            _lib.note_replay()
+            if entry[3] == det._weights_signature():
+                cls, masks4, q = static_out
+                # the graph's output buffers are overwritten by the next replay: hand out copies of the small ones
+                # (masks4, 0.75 GB at 32 x 720p, is consumed by the fusion kernels of this same call)
+                return cls.clone(), masks4, q.clone()
             entry = None
         if entry is None:
+            sig = det._weights_signature()
+
             def run(x):
                 return head.clip_logits(det.extract_feat(x), 1, T)
             try:
@@ -158,8 +171,6 @@ class PVSGPipeline(torch.nn.Module):
         graph.replay()
         _lib.note_replay()
         cls, masks4, q = static_out
-        # the graph's output buffers are overwritten by the next replay: hand out copies of the small ones
-        # (masks4, 0.75 GB at 32 x 720p, is consumed by the fusion kernels of this same call)
         return cls.clone(), masks4, q.clone()
 
     def _relation(self, feats):
@@ -171,11 +182,22 @@ class PVSGPipeline(torch.nn.Module):
         if not self.relation_graph or not feats.is_cuda or torch.cuda.is_current_stream_capturing():
             return run(feats)
         # the graph bakes in parameter ADDRESSES and derived buffers (the pair scorer's transposed W1): any weight change,
-        # in place or by swapping modules, gets a new graph
-        sig = tuple((p.data_ptr(), p._version) for m in (self.subject_encoder, self.object_encoder, self.pair_model, self.relation_model)
-                    for p in m.parameters())
-        key = (tuple(feats.shape), str(feats.device), sig)
+        # in place or by swapping modules, gets a new graph.  Replay first, check the signature while the device works.
+        roots = (self.subject_encoder, self.object_encoder, self.pair_model, self.relation_model)
+        ws = self.__dict__.get('_rel_sig')
+        if ws is None or any(a is not b for a, b in zip(ws.roots, roots)):          # (a module of the head was reassigned)
+            ws = self.__dict__['_rel_sig'] = WeightSignature(*roots)
+        key = (tuple(feats.shape), str(feats.device))
         ent = self._rel_graphs.get(key)
+        if ent is not None and ent is not False:
+            graph, static_in, static_out, sig = ent
+            static_in.copy_(feats)
+            graph.replay()
+            _lib.note_replay()
+            if sig == ws():
+                return {k: v.clone() for k, v in static_out.items()}     # small tensors; the static ones are reused next replay
+            ent = None
+            self._rel_graphs.pop(key, None)
         if ent is None:
             if len(self._rel_seen) >= 64:                    # bounded like the graphs: forget the oldest sightings
                 self._rel_seen.pop(next(iter(self._rel_seen)))
@@ -184,6 +206,7 @@ class PVSGPipeline(torch.nn.Module):
                 return run(feats)                      # first sighting of this shape: eager (also warms the libraries)
             self._rel_seen.pop(key, None)
             try:
+                sig = ws()
                 static_in = feats.clone()
                 side = torch.cuda.Stream(device=feats.device)
                 torch.cuda.current_stream().synchronize()    # one-stream rule of _lib.call: hand over an idle stream
@@ -196,7 +219,7 @@ class PVSGPipeline(torch.nn.Module):
                 # thread_local: CUDA calls of other threads (RCCL's watchdog polls events) must not invalidate the capture
                 with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                     static_out = run(static_in)
-                ent = (graph, static_in, static_out)
+                ent = (graph, static_in, static_out, sig)
             except Exception as e:
                 import warnings
                 warnings.warn('hipGraph capture of the relation head failed (%r); running eagerly' % (e,))
@@ -206,11 +229,11 @@ class PVSGPipeline(torch.nn.Module):
             self._rel_graphs[key] = ent
         if ent is False:
             return run(feats)
-        graph, static_in, static_out = ent
+        graph, static_in, static_out = ent[:3]
         static_in.copy_(feats)
         graph.replay()
         _lib.note_replay()
-        return {k: v.clone() for k, v in static_out.items()}     # small tensors; the static ones are reused next replay
+        return {k: v.clone() for k, v in static_out.items()}
 
     def _head_outputs(self, clip, total_frames=None, group=None, solo=False):
         """backbone + pixel decoder + decoder of this rank's frames -> cls (1,Q,C+1), masks4 (1,T,Q,H/4,W/4), q (Q,1,C)
