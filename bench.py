@@ -67,6 +67,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--mode', default='vps', choices=['vps', 'ips'],
+                    help='vps: BASELINE config 3/4/5 flow (clip-level VPS + relation head, the headline); ips: BASELINE config 2 '
+                         '(Mask2Former R50 IPS detector on a batch of --frames frames, per-frame decoder, fused panoptic fusion)')
     ap.add_argument('--frames', type=int, default=32)
     ap.add_argument('--height', type=int, default=720)
     ap.add_argument('--width', type=int, default=1280)
@@ -91,6 +94,8 @@ def parse():
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL over xGMI); gloo only for same-device logic tests')
     ap.add_argument('--graph', choices=('auto', 'on', 'off'), nargs='?', const='on', default='auto',
                     help='replay backbone + head as one hipGraph: auto = clips of <= 8 frames (host-bound)')
+    ap.add_argument('--projection', default='on', choices=['on', 'off'],
+                    help='N = 1 only: also time the T/N-frame steps (N = 2, 4, 8) and report the projected strong-scaling efficiency')
     ap.add_argument('--checksum', action='store_true', help='add a result checksum (sharding-invariance check)')
     return ap.parse_args()
 
@@ -157,6 +162,111 @@ def build_models(seed=0):
     for m in rel.values():
         m.eval()
     return det, rel
+
+
+def build_ips_detector(seed=0):
+    """BASELINE config 2: Mask2Former R50 IPS detector (configs/mask2former/..._single_video_test.py), panoptic branch"""
+    from openpvsg_amd import backbone, blocks, detectors, fusion, heads  # noqa: F401
+    from openpvsg_amd.model_zoo import mask2former_r50_model_cfg
+    from openpvsg_amd.registry import build_detector
+    torch.manual_seed(seed)
+    cfg = mask2former_r50_model_cfg(video=False)
+    cfg['test_cfg'] = dict(cfg['test_cfg'], instance_on=False)
+    det = build_detector(cfg).eval()
+    det.panoptic_head.init_weights()
+    with torch.no_grad():
+        det.panoptic_head.cls_embed.weight.mul_(CLS_GAIN)
+        det.panoptic_head.query_feat.weight.mul_(8.0)
+    return det
+
+
+class IPSBatchPipeline(torch.nn.Module):
+    """BASELINE config 2 as one step: the IPS detector on a batch of T frames -- backbone, pixel decoder, the PER-FRAME 9-layer
+    decoder (keys = h*w of one frame; models/mask2former/mask2former_head.py:397-479), last-layer mask logits, fused x4
+    up-sampling + panoptic fusion per frame (mask2former_fusion_head.py:96-171) with the class decision on the device, and the
+    one device->host copy of the frames' segment ids the result dictionaries need.  No tube stage: the IPS flavour's
+    association is a separate program (tools/prepare_query_tube_ips.py; scripts/ips_pipeline_bench.py measures it)."""
+
+    def __init__(self, det):
+        super().__init__()
+        self.detector = det
+        self.head_override = None
+        self.use_graph, self.graph_max_frames, self.relation_graph = False, 0, False
+
+    @torch.no_grad()
+    def forward(self, clip, batch_input_shape, img_shape=None, **kw):
+        det = self.detector
+        head, fusion = det.panoptic_head, det.panoptic_fusion_head
+        T = clip.shape[0]
+        cls_list, mask_list, q = head._decode(det.extract_feat(clip), T, 1, all_masks=False)
+        cls, masks4 = cls_list[-1], mask_list[-1]                    # (T,Q,127), (T,Q,h,w), q (Q,T,C)
+        if self.head_override is not None:
+            c, m = self.head_override(cls[:1], masks4[None])
+            cls, masks4 = c.expand(T, -1, -1), m[0]
+        H, W = batch_input_shape
+        ih, iw = (img_shape or batch_input_shape)[:2]
+        pans, segs = [], []
+        for t in range(T):
+            pan, seg, sel, _ = fusion.panoptic_fused_device(cls[t], masks4[t:t + 1], (H, W), (ih, iw))
+            pans.append(pan[0])
+            segs.append(seg[0])
+        ids = torch.stack(segs).tolist()                             # the host wait of the step: the frames' segment ids
+        self.last_ids = ids
+        pans = torch.stack(pans)
+        return dict(pan_results=pans, tube_ids=torch.zeros(0, dtype=torch.long, device=clip.device),
+                    tube_feats=torch.zeros((0, T, 256), device=clip.device), relation=None, cls=cls, query=q)
+
+
+def cpu_baseline_and_parity_ips(det_gpu, pipe, args, dev, frames, reps):
+    """--mode ips: the oracle's IPS detector (oracle/pipeline.py IPSDetectorOracle, one frame per call as the reference runs it)
+    on `frames` frames of the same batch, 1 warm-up + `reps` timed repetitions, and the product's panoptic maps against it."""
+    import numpy as np
+    import torch.nn.functional as F
+    from oracle import pipeline as opipe
+    T = frames
+    ncpu = host_cores()
+    torch.set_num_threads(ncpu)
+    clip, (Hp, Wp) = make_clip(T, args.height, args.width)
+    o = opipe.IPSDetectorOracle(test_cfg=dict(opipe.DEFAULT_TEST_CFG)).eval()
+    o.load_state_dict({k: v.detach().cpu() for k, v in det_gpu.state_dict().items()})
+    meta = dict(batch_input_shape=(Hp, Wp), img_shape=(args.height, args.width, 3), ori_shape=(args.height, args.width, 3))
+    syn = synthetic_head_outputs(T, Hp // 4, Wp // 4, n_keep=args.keep, T_total=T) if args.head_outputs == 'synthetic' else None
+
+    def run():
+        res = []
+        with torch.no_grad():
+            for t in range(T):
+                if syn is not None:
+                    up = F.interpolate(syn[1][t:t + 1], size=(Hp, Wp), mode='bilinear', align_corners=False)
+                    o.head_override = lambda cls, masks, up=up: (syn[0], masks + up)
+                res.append(o.simple_test(clip[t:t + 1], [meta], rescale=True)[0])
+        return res
+    run()
+    times = []
+    for _ in range(max(1, reps)):
+        t0 = time.perf_counter()
+        res = run()
+        times.append(time.perf_counter() - t0)
+    cpu_s = sum(times) / len(times)
+    base = dict(value=T / cpu_s, unit='frames/s', cores=ncpu, kind='port',
+                sample='%d frames of the batch, IPS detector one frame per call + panoptic fusion (oracle/, torch CPU fp32, %d threads): '
+                       '1 warm-up + %d timed runs, %.1f s each (min %.1f, max %.1f)'
+                       % (T, torch.get_num_threads(), len(times), cpu_s, min(times), max(times)), seconds_per_run=times)
+    saved = pipe.head_override
+    if syn is not None:
+        pipe.head_override = make_override(syn, dev)
+    try:
+        out = pipe(clip.to(dev), (Hp, Wp), (args.height, args.width))
+    finally:
+        pipe.head_override = saved
+    a = out['pan_results'].cpu().numpy()
+    b = np.stack([res[t]['pan_results'].numpy() for t in range(T)])
+    ids = (set(np.unique(a)) | set(np.unique(b))) - {126}
+    inter = sum(((a == i) & (b == i)).sum() for i in ids)
+    union = sum(((a == i) | (b == i)).sum() for i in ids)
+    seg_equal = all(sorted(set(i for i in pipe.last_ids[t] if i >= 0)) == sorted(res[t]['query_feats'].keys()) for t in range(T))
+    return base, dict(frames=T, pixel_mismatch=float((a != b).mean()), mask_iou=float(inter / union) if union else 1.0,
+                      segments=len(ids), segment_ids_equal=bool(seg_equal))
 
 
 class KernelTimer:
@@ -609,11 +719,20 @@ def main():
     from openpvsg_amd import parallel
     from openpvsg_amd.pipeline import PVSGPipeline
 
-    det, rel = build_models(0)
-    det = det.to(dev)
-    rel = {k: m.to(dev) for k, m in rel.items()}
-    pipe = PVSGPipeline(det, rel['subject_encoder'], rel['object_encoder'], rel['pair_model'],
-                        rel['relation_model'], use_graph={'auto': 'auto', 'on': True, 'off': False}[args.graph]).eval()
+    ips = args.mode == 'ips'
+    if ips:
+        if world > 1:
+            raise SystemExit('bench.py --mode ips: single-GPU line (BASELINE config 2 runs on 1 MI355X)')
+        det, rel = build_ips_detector(0).to(dev), {}
+        pipe = IPSBatchPipeline(det).eval()
+    else:
+        det, rel = build_models(0)
+        det = det.to(dev)
+        rel = {k: m.to(dev) for k, m in rel.items()}
+        pipe = PVSGPipeline(det, rel['subject_encoder'], rel['object_encoder'], rel['pair_model'],
+                            rel['relation_model'], use_graph={'auto': 'auto', 'on': True, 'off': False}[args.graph]).eval()
+        pipe.graph_max_frames = 8      # --graph auto: clips above 8 frames run eagerly here so that their kernels carry HIP events
+                                       # (the product default, 64, is measured separately: `product_default_hipgraph`)
 
     T = args.frames
     weak = world > 1 and args.scaling == 'weak'
@@ -666,6 +785,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
+    if dist.is_initialized() and rank == 0:
+        parallel.EXCHANGE_TIMER = []               # HIP events around every exchange of the timed steps (rank 0)
     start = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -675,6 +796,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - start
     timer.enabled = False
+    exchanges, parallel.EXCHANGE_TIMER = parallel.EXCHANGE_TIMER, None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -719,8 +841,8 @@ def main():
             'collectives': {'backend': dist.get_backend() if dist.is_initialized() else None,
                             'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
                             'exchanges_run': bool(parallel.is_dist()), 'forced_at_world_1': bool(force and world == 1)},
-            'dtype_note': (('every tensor, accumulation and result f32; the 3x3 convolutions run on the f32 MFMA, the large '
-                            'GEMMs / 1x1 convolutions / mask projections split their f32 operands into ' +
+            'dtype_note': (('every tensor, accumulation and result f32; the token GEMMs, the 1x1 and 3x3 convolutions and the mask '
+                            'projections split their f32 operands into ' +
                             ('two f16 limbs (3 limb products per multiply on the f16 MFMA, operands within the f16 range, '
                              'low limbs kept normal by exact power-of-two factors; PVSG_SPLIT=bf16x3 selects the other form)'
                              if ops_split_mode() == 'f16x2' else
@@ -748,6 +870,70 @@ def main():
                        'parallelism': ('%d x 32-frame segments, all-gather of tube records' % world) if weak
                        else ('frame-shard x%d, attention partials merged per layer' % world)},
         }
+        if exchanges:
+            by_size = {}
+            for nbytes, s_ev, e_ev in exchanges:
+                by_size.setdefault(nbytes, []).append(s_ev.elapsed_time(e_ev) * 1e3)
+            line['collectives']['per_exchange'] = [dict(bytes_per_rank=k, count_per_step=len(v) / args.steps, avg_us=sum(v) / len(v),
+                                                        min_us=min(v), max_us=max(v)) for k, v in sorted(by_size.items())]
+            line['collectives']['exchange_us_per_step'] = sum(sum(v) for v in by_size.values()) / args.steps
+        if ips:
+            line['metric'] = 'frames/sec for the 720p IPS detector forward on a batch of frames (BASELINE config 2)'
+            line['config']['workload'] = ('Mask2Former R50 IPS detector, batch of %d frames %dx%d (padded %dx%d): backbone, MSDeformAttn '
+                                          'pixel decoder, per-frame 9-layer decoder (100 queries, keys = h*w of one frame), last-layer '
+                                          'mask logits, fused x4 up-sampling + panoptic fusion per frame, segment ids to the host'
+                                          % (T, args.height, args.width, Hp, Wp))
+            line['config']['test_cfg'] = 'instance_on=False (the shipped config sets instance_on=True; scripts/shipped_config_bench.py)'
+            line['config']['parallelism'] = 'one GPU'
+            line['config'].pop('tubes', None)
+        if world == 1 and not ips and args.projection == 'on' and T >= 8:
+            # What N GPUs would run on this clip sharded by frame: the step of T/N frames measured here on one GPU (no exchanges) ->
+            # the strong-scaling efficiency the frame-independent part of a step allows, before any RCCL latency.  The driver's
+            # SCALE record measures the real thing when it has an 8-GPU node.
+            proj = {}
+            saved_ov, saved_gmf, pipe.graph_max_frames = pipe.head_override, pipe.graph_max_frames, 64   # (the product default)
+            timer.enabled = False
+            for n in (2, 4, 8):
+                if T % n:
+                    continue
+                tl = T // n
+                c = clip[:tl].to(dev)
+                if args.head_outputs == 'synthetic':
+                    pipe.head_override = make_override(synthetic_head_outputs(tl, Hp // 4, Wp // 4, n_keep=args.keep, T_total=T), dev)
+                for _ in range(3):
+                    pipe(c, (Hp, Wp), (args.height, args.width), total_frames=T, shard='none')
+                torch.cuda.synchronize()
+                t0p = time.perf_counter()
+                for _ in range(10):
+                    pipe(c, (Hp, Wp), (args.height, args.width), total_frames=T, shard='none')
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0p) / 10 * 1e3
+                proj[str(n)] = dict(frames_per_gpu=tl, ms_per_step_one_gpu=ms, projected_frames_per_s=T / ms * 1e3,
+                                    efficiency_before_collectives=ms_per_step / n / ms)
+            pipe.head_override, pipe.graph_max_frames = saved_ov, saved_gmf
+            line['projected_strong_scaling'] = dict(
+                note='T/N-frame step measured on this GPU (hipGraph replay where the product uses it) vs the %d-frame step / N; '
+                     'excludes the 9 + 1 exchanges per step' % T, by_n_gpus=proj)
+        if world == 1 and not ips and args.graph == 'auto' and not (pipe.use_graph == 'auto' and T <= pipe.graph_max_frames):
+            # the timed region above runs eagerly so that its kernels carry HIP events (`roofline`); the PRODUCT default replays
+            # backbone + head as one hipGraph at every clip length: the same step that way, 5 timed steps
+            try:
+                saved_graph, pipe.use_graph = pipe.use_graph, True
+                timer.enabled = False
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                t0p = time.perf_counter()
+                for _ in range(5):
+                    step()
+                torch.cuda.synchronize()
+                gms = (time.perf_counter() - t0p) / 5 * 1e3
+                line['product_default_hipgraph'] = dict(ms_per_step=gms, frames_per_s=frames_per_step / gms * 1e3,
+                                                        note='PVSGPipeline(use_graph=True): backbone + head as one hipGraph; no per-kernel events')
+            except Exception as e:
+                line['product_default_hipgraph'] = dict(failed=repr(e))
+            finally:
+                pipe.use_graph = saved_graph
         if args.checksum:
             pans = out['pan_results']
             line['checksum'] = dict(pan_local_sum=int(pans.to(torch.int64).sum().item()),
@@ -882,7 +1068,7 @@ def main():
                 else:
                     named.append(dict(kernel=k, bound='launch-latency', avg_launch_us=per_ms * 1e3))
             line['roofline_named_kernels'] = named
-        if world == 1 and args.sub_benchmarks == 'on':
+        if world == 1 and args.sub_benchmarks == 'on' and not ips:
             try:
                 line['sub_benchmarks'] = sub_benchmarks(det, rel, pipe, args, dev)
                 line['sub_benchmarks']['head_only'] = head_only_benchmark(det, pipe, clip_local, step)
@@ -891,7 +1077,14 @@ def main():
                 del feats
             except Exception as e:
                 line['sub_benchmarks'] = dict(failed=repr(e))
-        if args.cpu_baseline != 'off' and world == 1:
+        if args.cpu_baseline != 'off' and world == 1 and ips:
+            try:
+                base, parity = cpu_baseline_and_parity_ips(det, pipe, args, dev, args.cpu_frames, args.cpu_reps)
+                line['cpu_baseline'], line['parity_on_cpu_sample'] = base, parity
+                line['speedup_vs_cpu_baseline'] = fps / base['value']
+            except Exception as e:  # the bench line must still be printed
+                line['cpu_baseline'] = dict(value=None, unit='frames/s', cores=host_cores(), kind='port', sample='failed: %r' % (e,))
+        elif args.cpu_baseline != 'off' and world == 1:
             try:
                 base, parity = cpu_baseline_and_parity(det, rel, pipe, args, dev, args.cpu_frames, args.cpu_reps)
                 line['cpu_baseline'] = base

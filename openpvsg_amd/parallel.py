@@ -112,6 +112,9 @@ def shard_frames(num_frames, rank, world):
     return rank * per, per
 
 
+EXCHANGE_TIMER = None      # measurements only (bench.py): a list that collects (bytes per rank, start event, end event) per exchange
+
+
 def all_gather_cat(t, dim=0, group=None):
     """all_gather of equally-shaped tensors, concatenated along `dim` (rank order).  RCCL: one
     `all_gather_into_tensor` straight into the result (no per-rank staging tensors, no torch.cat launch)."""
@@ -121,7 +124,14 @@ def all_gather_cat(t, dim=0, group=None):
     t = t.contiguous()
     if dist.get_backend(group) == 'nccl':
         out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t, group=group)
+        if EXCHANGE_TIMER is not None and t.is_cuda:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            dist.all_gather_into_tensor(out, t, group=group)
+            e.record()
+            EXCHANGE_TIMER.append((t.numel() * t.element_size(), s, e))
+        else:
+            dist.all_gather_into_tensor(out, t, group=group)
         if dim == 0:
             return out.flatten(0, 1)
         return torch.cat(list(out.unbind(0)), dim=dim)

@@ -95,10 +95,13 @@ class PVSGPipeline(torch.nn.Module):
                  num_top_pairs=100, fused_postprocess=True, use_graph='auto'):
         super().__init__()
         self.fused_postprocess = fused_postprocess
-        # True / False / 'auto': short clips (<= graph_max_frames) are limited by the host's launch rate, so backbone + head
-        # are replayed as one hipGraph; long clips are GPU-bound and the capture would only pin their buffers
+        # True / False / 'auto' (clips of <= graph_max_frames frames): backbone + head are replayed as one hipGraph.  Short
+        # clips are limited by the host's launch rate (16.7 vs 18.1 ms at 4 frames); at 32 frames the replay still saves ~1 ms of
+        # a 77 ms step (profiles/r04_graph_T32.txt), so the default covers every clip the hot path names (64 x 1080p included);
+        # a captured shape pins its activation pool, the four newest shapes are kept.  bench.py lowers the limit to 8 for its
+        # timed region because graphed launches cannot carry the per-kernel HIP events `roofline` is measured with.
         self.use_graph = use_graph
-        self.graph_max_frames = 8
+        self.graph_max_frames = 64
         self._graphs = {}
         self.detector = detector
         self.subject_encoder, self.object_encoder = subject_encoder, object_encoder
