@@ -221,18 +221,21 @@ _CU_COUNT = {}
 
 
 def _fused_ln_fills_the_gpu(x, k):
-    """The fused projection + LayerNorm kernel owns whole rows: 256-row tiles, one workgroup per CU.  With few rows the last
-    round of workgroups leaves most CUs idle (4 frames of 720p = 302 tiles on 256 CUs: 0.165 ms where 128 x 128 tiles + the
-    separate LayerNorm take 0.10); then the two-launch form is used.  PVSG_FUSE_LN=force keeps the fused kernel regardless."""
+    """The fused projection + LayerNorm kernel owns whole rows: 128-row tiles, two workgroups per CU (PVSG_LN_TILE=256: the
+    round-4 form, 256-row tiles, one per CU).  With few rows the last round of workgroups leaves most CUs idle (4 frames of 720p
+    = 604 tiles on 512 slots); then the two-launch form (128 x 128 tiles + the add-LayerNorm kernel) is used.
+    PVSG_FUSE_LN=force keeps the fused kernel regardless."""
     if os.environ.get('PVSG_FUSE_LN', 'on') == 'force':
         return True
     dev = x.device.index or 0
     cus = _CU_COUNT.get(dev)
     if cus is None:
         cus = _CU_COUNT[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
-    tiles = (x.numel() // k + 255) // 256
-    rounds = (tiles + cus - 1) // cus
-    return tiles >= float(os.environ.get('PVSG_FUSE_LN_MINEFF', '0.85')) * rounds * cus
+    big = os.environ.get('PVSG_LN_TILE', '128')[:1] == '2'
+    tile, slots = (256, cus) if big else (128, 2 * cus)
+    tiles = (x.numel() // k + tile - 1) // tile
+    rounds = (tiles + slots - 1) // slots
+    return tiles >= float(os.environ.get('PVSG_FUSE_LN_MINEFF', '0.85')) * rounds * slots
 
 
 def linear_add_layernorm_fast(owner, tag, weight, x, bias, identity, norm):

@@ -905,6 +905,206 @@ void gemm_f16x2_t256_kernel(const float* __restrict__ A, const __bf16* __restric
 constexpr int T256_LDS_BYTES = 2 * (2 * 4 * (256 + 2) * 8 + 2 * 4 * 256 * 8) * 2;
 
 // ------------------------------------------------------------------------------------------------------------------
+// LayerNorm-fused projection on 128-ROW tiles, two workgroups per CU (round 5).  The 256 x 256 form above owns a CU alone: its
+// epilogue -- read 256 KB of residual, two row passes, write 256 KB -- runs with the matrix pipe idle, and its main loop with the
+// memory pipe half idle; on the second FFN layer (K = 1024) that serialisation cost what the fusion saved (1.3 ms against
+// 1.01 + 0.33 for GEMM + add-LayerNorm launches).  Here a workgroup owns 128 whole rows (tile 128 x 256, four waves of 64 rows x
+// 128 columns: the same 128 accumulator registers per lane), keeps A in ONE 16 KB stage (the two-barrier step of
+// gemm_f16x2_dma_kernel) and W in two 32 KB LDS-DMA buffers: 80 KB, so TWO workgroups share a CU and one's epilogue runs under
+// the other's MFMAs.  Row statistics exactly as above (two passes; lane groups by shuffles, the two column halves of a row
+// through 1 KB of LDS).  No row padding in the A stage (80 KB x 2 = the CU's 160 KB to the byte).
+__global__ __launch_bounds__(256, 2)
+void gemm_f16x2_ln128_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
+                             float* __restrict__ out, int M, int K, unsigned* __restrict__ overflow,
+                             const float* __restrict__ residual, const float* __restrict__ gamma,
+                             const float* __restrict__ beta, float eps) {
+  constexpr int TM = 128, TN = 256, Npad = 256;
+  constexpr int A_KG = TM * 8, A_LIMB = 4 * A_KG;                // f16 elements
+  constexpr int W_AT = 2 * A_LIMB, W_LIMB = 4 * TN * 8, W_BUF = 2 * W_LIMB;
+  extern __shared__ __attribute__((aligned(16))) __bf16 ldsln[];
+  __bf16* lds = ldsln;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int m0 = (int)logical * TM;
+  const int ar = tid >> 2, akg = tid & 3;                        // rows ar and ar + 64, k-group akg
+  unsigned a_voff[2];
+#pragma unroll
+  for (int p2 = 0; p2 < 2; ++p2)                                 // rows beyond M read as 0
+    a_voff[p2] = m0 + ar + 64 * p2 < M ? (unsigned)(((ar + 64 * p2) * K + 8 * akg) * 4) : 0x80000000u;
+  const auto asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A) + (size_t)m0 * K * 4), 0,
+                                                      (unsigned)((size_t)TM * K * 4), 0x00020000);
+  f32x4 a_regs[4];
+  auto loadA = [&](int kt) {
+    const unsigned so = (unsigned)kt * (32 * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      a_regs[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc, a_voff[q >> 1] + 16 * (q & 1), so, 0));
+  };
+  // weight slabs of a step: (array l, k-group kg of 4, column quarter) = 32 x 1 KB; wave w brings slabs 8 w .. 8 w + 7
+  const size_t w_kg_stride = (size_t)Npad * 8;
+  auto dmaW = [&](int kt, int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int sl = wave * 8 + i, l = sl >> 4, kg = (sl >> 2) & 3, qt = sl & 3;
+      const __bf16* src = Wp + ((((size_t)(2 * kt + (kg >> 1)) * 2 + l) * 2 + (kg & 1)) * w_kg_stride) + (size_t)(qt * 64 + lane) * 8;
+      __bf16* dst = lds + W_AT + buf * W_BUF + l * W_LIMB + (kg * TN + qt * 64) * 8;
+      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  u32x4 limbs[2][2];
+  float amax = 0.f;
+  auto split = [&]() {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      unsigned hh[4], mm[4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 v = a_regs[2 * gq + q];
+        split2h(v[0], v[1], hh[2 * q], mm[2 * q], amax);
+        split2h(v[2], v[3], hh[2 * q + 1], mm[2 * q + 1], amax);
+      }
+      limbs[gq][0] = u32x4{hh[0], hh[1], hh[2], hh[3]};
+      limbs[gq][1] = u32x4{mm[0], mm[1], mm[2], mm[3]};
+    }
+    asm volatile("" : "+v"(amax));                                // (see gemm_f16x2_dma_kernel: keeps the A registers reusable)
+  };
+  auto writeA = [&]() {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      __bf16* pa = lds + akg * A_KG + (ar + 64 * gq) * 8;
+#pragma unroll
+      for (int l = 0; l < 2; ++l) *reinterpret_cast<u32x4*>(pa + l * A_LIMB) = limbs[gq][l];
+    }
+  };
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i >> 3][i & 7] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int l15 = lane & 15, kg4 = lane >> 4;
+  const __bf16* afr = lds + kg4 * A_KG + (wr * 64 + l15) * 8;                  // + limb * A_LIMB + row block * 128
+  const __bf16* wfr0 = lds + W_AT + (kg4 * TN + wc * 128 + l15) * 8;           // + buffer * W_BUF + array * W_LIMB + column block * 128
+  auto frag = [](const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); };
+  auto mf = [](u32x4 a, u32x4 b, f32x4 c) { return mfma_k32<true>(a, b, c); };
+  const int KT = K / 32;
+  dmaW(0, 0);
+  loadA(0);
+  split();
+  writeA();
+  loadA(KT > 1 ? 1 : 0);
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                 // W(kt), A(kt) complete; buffer (kt+1)&1 is no longer read
+    split();                                                     // A of step kt+1
+    __builtin_amdgcn_sched_barrier(0);
+    dmaW(kt + 1 < KT ? kt + 1 : KT - 1, (kt + 1) & 1);
+    loadA(kt + 2 < KT ? kt + 2 : KT - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const __bf16* wfr = wfr0 + (kt & 1) * W_BUF;
+    u32x4 ahf[4], alf[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      ahf[rb] = frag(afr + rb * 128);
+      alf[rb] = frag(afr + A_LIMB + rb * 128);
+    }
+    u32x4 wh = frag(wfr), wl = frag(wfr + W_LIMB);
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {                             // small terms first: (l', 2^-11 h) (h, l) (h, h)
+      u32x4 whn = wh, wln = wl;
+      if (cb < 7) {
+        whn = frag(wfr + (cb + 1) * 128);
+        wln = frag(wfr + W_LIMB + (cb + 1) * 128);
+      }
+      const u32x4 wh2 = f16x2_lo_scale(wh);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wh2, alf[rb], acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wl, ahf[rb], acc[rb][cb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wh, ahf[rb], acc[rb][cb]);
+      __builtin_amdgcn_sched_barrier(0);
+      wh = whn;
+      wl = wln;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                // everyone is done reading A of step kt
+    writeA();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the repeated last slabs / rows: nothing may land after the end)
+  // register r of block (rb, cb) = row rb*16 + (lane&15), column cb*16 + 4*(lane>>4) + r of the wave's 64 x 128 tile
+  const float unscale = f16x2_unscale(Wp, Npad, K);
+  const int rows = M - m0 < TM ? M - m0 : TM;
+  const unsigned tile_bytes = (unsigned)((size_t)rows * 256 * 4);
+  const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)m0 * 256, 0, tile_bytes, 0x00020000);
+  const auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual) + (size_t)m0 * 256, 0, tile_bytes, 0x00020000);
+  const auto brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, bias ? 1024u : 0u, 0x00020000);
+  const unsigned vrow = (unsigned)(wr * 64 + l15) * 1024u + (unsigned)(wc * 128 + 4 * kg4) * 4u;     // + rb * 16 KiB + cb * 64 B
+  float rsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb) {
+    const int col = wc * 128 + cb * 16 + 4 * kg4;
+    const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, (unsigned)col * 4u, 0, 0));   // no bias: reads 0
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const f32x4 res = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, vrow, rb * 16384 + cb * 64, 0));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = __builtin_fmaf(acc[rb][cb][r], unscale, bv[r]) + res[r];
+        acc[rb][cb][r] = v;
+        rsum[rb] += v;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                            // (one column block's residual loads in flight at a time: registers)
+  }
+  __builtin_amdgcn_s_barrier();                                   // everybody is done with the stages: LDS is free
+  float* red = reinterpret_cast<float*>(lds);                     // red[pass][wave][64 rows]
+  auto row_reduce = [&](float (&part)[4], int pass) {
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      part[rb] += __shfl_xor(part[rb], 16);
+      part[rb] += __shfl_xor(part[rb], 32);
+    }
+    if (kg4 == 0)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) red[(pass * 4 + wave) * 64 + rb * 16 + l15] = part[rb];
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) part[rb] += red[(pass * 4 + (wave ^ 1)) * 64 + rb * 16 + l15];
+  };
+  row_reduce(rsum, 0);
+  float mean[4], rstd[4], sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb) mean[rb] = rsum[rb] * (1.f / 256.f);
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = acc[rb][cb][r] - mean[rb];
+        acc[rb][cb][r] = d;
+        sq[rb] = __builtin_fmaf(d, d, sq[rb]);
+      }
+  row_reduce(sq, 1);
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb) rstd[rb] = rsqrtf(sq[rb] * (1.f / 256.f) + eps);
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb) {
+    const int col = wc * 128 + cb * 16 + 4 * kg4;
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + col), be = *reinterpret_cast<const f32x4*>(beta + col);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = __builtin_fmaf(acc[rb][cb][r] * rstd[rb], gv[r], be[r]);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, vrow, rb * 16384 + cb * 64, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  f16x2_count_overflow(amax, overflow);
+}
+constexpr int LN128_LDS_BYTES = (2 * 4 * 128 * 8 + 2 * 2 * 4 * 256 * 8) * 2;      // 80 KB
+
+// ------------------------------------------------------------------------------------------------------------------
 // 1x1 convolution in NCHW on the same arithmetic:  y[b, co, p] = act( (sum_ci w[co, ci] x[b, ci, pin(p)]) * scale[co]
 // + shift[co] (+ residual[b, co, p]) ), pin(p) = p (stride 1) or the stride-2 sub-sampled pixel.  Per image a GEMM with
 // rows = output channels (the packed weight, same pack as above), columns = pixels, K = input channels.  The pixel
@@ -1766,6 +1966,18 @@ extern "C" int pvsg_gemm_f16x2_add_layernorm(const float* a, const void* w_packe
   PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(bias) |
                   reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
                   reinterpret_cast<uintptr_t>(out)) & 15u), "gemm_f16x2_add_layernorm: pointers must be 16-byte aligned");
+  // PVSG_LN_TILE=256: the round-4 kernel (256-row tiles, one workgroup per CU); default: 128-row tiles, two workgroups per CU
+  const char* tsel = getenv("PVSG_LN_TILE");
+  if (!(tsel && tsel[0] == '2')) {
+    static std::atomic<unsigned long long> done128{0};
+    const hipError_t e1 = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f16x2_ln128_kernel), LN128_LDS_BYTES, done128);
+    if (e1 != hipSuccess) return set_err(PVSG_ERR_HIP, "gemm_f16x2_add_layernorm: dynamic LDS: %s", hipGetErrorString(e1));
+    hipLaunchKernelGGL(gemm_f16x2_ln128_kernel, dim3((unsigned)((M + 127) / 128)), dim3(256), LN128_LDS_BYTES,
+                       static_cast<hipStream_t>(stream), a, static_cast<const __bf16*>(w_packed), bias, out, (int)M, K, overflow,
+                       residual, gamma, beta, eps);
+    PVSG_LAUNCH_CHECK("gemm_f16x2_add_layernorm");
+    return PVSG_OK;
+  }
   static std::atomic<unsigned long long> done{0};
   const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f16x2_t256_kernel<false, true>), T256_LDS_BYTES, done);
   if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "gemm_f16x2_add_layernorm: dynamic LDS: %s", hipGetErrorString(e));

@@ -129,11 +129,14 @@ def test_f16x2_matches_bf16x3_at_encoder_size(hip_lib, N, K, relu):
     assert torch.equal(y, y2)                           # bitwise run to run
 
 
-@pytest.mark.parametrize('M,K', [(1000, 256), (257, 1024), (77280, 256), (64, 32)])
-def test_gemm_add_layernorm_matches_the_two_step_form(hip_lib, M, K):
-    """LayerNorm(identity + x W^T + b) in one launch (256-tile f16x2 kernel with the statistics in its epilogue) against the
-    float64 definition, next to the unfused pair (split GEMM, then pvsg_add_layernorm) -- ragged row tiles included."""
+@pytest.mark.parametrize('tile', ['128', '256'])
+@pytest.mark.parametrize('M,K', [(1000, 256), (257, 1024), (77280, 256), (64, 32), (127, 64), (129, 2048)])
+def test_gemm_add_layernorm_matches_the_two_step_form(hip_lib, monkeypatch, M, K, tile):
+    """LayerNorm(identity + x W^T + b) in one launch (f16x2 kernel with the statistics in its epilogue: 128-row tiles, two
+    workgroups per CU -- round 5 -- and the 256-row form behind PVSG_LN_TILE=256) against the float64 definition, next to the
+    unfused pair (split GEMM, then pvsg_add_layernorm) -- ragged row tiles included."""
     from openpvsg_amd import ops
+    monkeypatch.setenv('PVSG_LN_TILE', tile)
     g = torch.Generator().manual_seed(M + K)
     x = torch.randn(M, K, generator=g).cuda()
     w = (torch.randn(256, K, generator=g) / K ** 0.5).cuda()
@@ -151,4 +154,10 @@ def test_gemm_add_layernorm_matches_the_two_step_form(hip_lib, M, K):
     e1, e2 = (y.double().cpu() - ref).abs().max().item(), (two.double().cpu() - ref).abs().max().item()
     assert e1 < 2e-5 and e1 < 3 * e2 + 2e-6, (e1, e2)
     assert torch.equal(y, ops.gemm_add_layernorm(x, wp, b, idn, ln))
+    y0 = ops.gemm_add_layernorm(x, wp, None, idn, ln)                # no bias: the descriptor reads zeros
+    ref0 = F.layer_norm((idn.double() + x.double() @ w.double().t()).cpu(), (256,), ln.weight.double().cpu(), ln.bias.double().cpu(), ln.eps)
+    assert (y0.double().cpu() - ref0).abs().max().item() < 2e-5
+    guard = torch.full((M + 300, 256), 7.0, device='cuda')          # nothing written past row M
+    ops.gemm_add_layernorm(x, wp, b, idn, ln, out=guard[:M])
+    assert torch.equal(guard[:M], y) and bool((guard[M:] == 7.0).all())
     assert ops.split_overflow_count() == 0
