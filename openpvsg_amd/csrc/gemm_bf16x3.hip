@@ -913,12 +913,16 @@ constexpr int T256_LDS_BYTES = 2 * (2 * 4 * (256 + 2) * 8 + 2 * 4 * 256 * 8) * 2
 // gemm_f16x2_dma_kernel) and W in two 32 KB LDS-DMA buffers: 80 KB, so TWO workgroups share a CU and one's epilogue runs under
 // the other's MFMAs.  Row statistics exactly as above (two passes; lane groups by shuffles, the two column halves of a row
 // through 1 KB of LDS).  No row padding in the A stage (80 KB x 2 = the CU's 160 KB to the byte).
+// LN = false: the same tile and pipeline as a plain GEMM (bias / ReLU epilogue) for N > 256: `tiles_n` 256-column tiles per row
+// block, consecutive workgroups share the row block (A from L2).  Opt-in (PVSG_F16X2_TILE=w256), measured in
+// scripts/lab/gemm_tile_ab.py.
+template <bool LN, bool RELU>
 __global__ __launch_bounds__(256, 2)
 void gemm_f16x2_ln128_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
                              float* __restrict__ out, int M, int K, unsigned* __restrict__ overflow,
                              const float* __restrict__ residual, const float* __restrict__ gamma,
-                             const float* __restrict__ beta, float eps) {
-  constexpr int TM = 128, TN = 256, Npad = 256;
+                             const float* __restrict__ beta, float eps, int N = 256, int Npad = 256, int tiles_n = 1) {
+  constexpr int TM = 128, TN = 256;
   constexpr int A_KG = TM * 8, A_LIMB = 4 * A_KG;                // f16 elements
   constexpr int W_AT = 2 * A_LIMB, W_LIMB = 4 * TN * 8, W_BUF = 2 * W_LIMB;
   extern __shared__ __attribute__((aligned(16))) __bf16 ldsln[];
@@ -926,7 +930,8 @@ void gemm_f16x2_ln128_kernel(const float* __restrict__ A, const __bf16* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
-  const int m0 = (int)logical * TM;
+  const int tn = LN ? 0 : (int)(logical % (unsigned)tiles_n), n0 = tn * TN;
+  const int m0 = (int)(LN ? logical : logical / (unsigned)tiles_n) * TM;
   const int ar = tid >> 2, akg = tid & 3;                        // rows ar and ar + 64, k-group akg
   unsigned a_voff[2];
 #pragma unroll
@@ -947,7 +952,8 @@ void gemm_f16x2_ln128_kernel(const float* __restrict__ A, const __bf16* __restri
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int sl = wave * 8 + i, l = sl >> 4, kg = (sl >> 2) & 3, qt = sl & 3;
-      const __bf16* src = Wp + ((((size_t)(2 * kt + (kg >> 1)) * 2 + l) * 2 + (kg & 1)) * w_kg_stride) + (size_t)(qt * 64 + lane) * 8;
+      const int c0 = n0 + qt * 64 < Npad ? n0 + qt * 64 : Npad - 64;         // (a quarter beyond the packed columns: never stored)
+      const __bf16* src = Wp + ((((size_t)(2 * kt + (kg >> 1)) * 2 + l) * 2 + (kg & 1)) * w_kg_stride) + (size_t)(c0 + lane) * 8;
       __bf16* dst = lds + W_AT + buf * W_BUF + l * W_LIMB + (kg * TN + qt * 64) * 8;
       __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
@@ -1033,6 +1039,29 @@ void gemm_f16x2_ln128_kernel(const float* __restrict__ A, const __bf16* __restri
   // register r of block (rb, cb) = row rb*16 + (lane&15), column cb*16 + 4*(lane>>4) + r of the wave's 64 x 128 tile
   const float unscale = f16x2_unscale(Wp, Npad, K);
   const int rows = M - m0 < TM ? M - m0 : TM;
+  if constexpr (!LN) {
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)m0 * N, 0, (unsigned)((size_t)rows * N * 4), 0x00020000);
+    const auto brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, bias ? (unsigned)N * 4u : 0u, 0x00020000);
+    const unsigned rowpitch = (unsigned)N * 4u;
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      const int col = n0 + wc * 128 + cb * 16 + 4 * kg4;         // N % 4 == 0 (checked by the host): a float4 is all in or all out
+      const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (unsigned)col * 4u, 0, 0));
+      const unsigned vbase = (unsigned)(wr * 64 + l15) * rowpitch + (unsigned)col * 4u;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] = __builtin_fmaf(acc[rb][cb][r], unscale, bv[r]);
+          if (RELU) o[r] = fmaxf(o[r], 0.f);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, col < N ? vbase + (unsigned)(rb * 16) * rowpitch : 0x80000000u, 0, 0);
+      }
+    }
+    f16x2_count_overflow(amax, overflow);
+    return;
+  }
   const unsigned tile_bytes = (unsigned)((size_t)rows * 256 * 4);
   const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)m0 * 256, 0, tile_bytes, 0x00020000);
   const auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual) + (size_t)m0 * 256, 0, tile_bytes, 0x00020000);
@@ -1908,6 +1937,27 @@ static int gemm_split_run(const float* a, const void* w_packed, const float* bia
     // (23.4 vs 23.2 ms over the 48 launches), so the default stays on the 128 x 128 kernels.
     const char* tsel = getenv("PVSG_F16X2_TILE");
     const bool big = tsel && atoi(tsel) == 256;
+    // 128-row x 256-column tiles, two workgroups per CU (the LayerNorm-fused kernel's pipeline): default for wide layers
+    // (N >= 512, N % 256 == 0: the encoder's first FFN layer 1.39 -> 1.24 ms at 32 x 720p, scripts/lab/gemm_tile_ab.py; narrower
+    // or ragged N stays on 128 x 128: 544 columns would pad to 768).  PVSG_F16X2_TILE=w256 forces it, =128 switches it off.
+    const bool wide = tsel ? tsel[0] == 'w' : (N >= 512 && N % 256 == 0);
+    if (wide && N % 4 == 0 && (long long)128 * N * 4 < (1LL << 31)) {
+      static std::atomic<unsigned long long> dw_r{0}, dw_n{0};
+      const int tnw = (N + 255) / 256;
+      const dim3 gw((unsigned)(((M + 127) / 128) * tnw)), b256(256);
+      hipError_t e = relu ? ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f16x2_ln128_kernel<false, true>), LN128_LDS_BYTES, dw_r)
+                          : ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f16x2_ln128_kernel<false, false>), LN128_LDS_BYTES, dw_n);
+      if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "%s: dynamic LDS: %s", nm, hipGetErrorString(e));
+      const float* nulf = nullptr;
+      if (relu)
+        hipLaunchKernelGGL((gemm_f16x2_ln128_kernel<false, true>), gw, b256, LN128_LDS_BYTES, st, a, wp, bias, out, (int)M, K, overflow,
+                           nulf, nulf, nulf, 0.f, N, Npad, tnw);
+      else
+        hipLaunchKernelGGL((gemm_f16x2_ln128_kernel<false, false>), gw, b256, LN128_LDS_BYTES, st, a, wp, bias, out, (int)M, K, overflow,
+                           nulf, nulf, nulf, 0.f, N, Npad, tnw);
+      PVSG_LAUNCH_CHECK(nm);
+      return PVSG_OK;
+    }
     if (big && (long long)256 * N * 4 < (1LL << 31) && (long long)256 * K * 4 < (1LL << 31)) {
       static std::atomic<unsigned long long> done_r{0}, done_n{0};
       const int tn256 = (N + 255) / 256;
@@ -1970,9 +2020,9 @@ extern "C" int pvsg_gemm_f16x2_add_layernorm(const float* a, const void* w_packe
   const char* tsel = getenv("PVSG_LN_TILE");
   if (!(tsel && tsel[0] == '2')) {
     static std::atomic<unsigned long long> done128{0};
-    const hipError_t e1 = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f16x2_ln128_kernel), LN128_LDS_BYTES, done128);
+    const hipError_t e1 = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f16x2_ln128_kernel<true, false>), LN128_LDS_BYTES, done128);
     if (e1 != hipSuccess) return set_err(PVSG_ERR_HIP, "gemm_f16x2_add_layernorm: dynamic LDS: %s", hipGetErrorString(e1));
-    hipLaunchKernelGGL(gemm_f16x2_ln128_kernel, dim3((unsigned)((M + 127) / 128)), dim3(256), LN128_LDS_BYTES,
+    hipLaunchKernelGGL((gemm_f16x2_ln128_kernel<true, false>), dim3((unsigned)((M + 127) / 128)), dim3(256), LN128_LDS_BYTES,
                        static_cast<hipStream_t>(stream), a, static_cast<const __bf16*>(w_packed), bias, out, (int)M, K, overflow,
                        residual, gamma, beta, eps);
     PVSG_LAUNCH_CHECK("gemm_f16x2_add_layernorm");
