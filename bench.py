@@ -1011,6 +1011,15 @@ def main():
                                         frac=ach / HBM_PEAK_GBS, traffic=traffic, avg_launch_ms=per,
                                         launches_per_step=d['calls'] / args.steps,
                                         algorithmic_bytes_per_launch=d['bytes'] / d['calls'], scope=scope)
+            if dom.startswith('pvsg_conv1x1_f16x2'):
+                # measured on this kernel itself (round 5): socket power / shader clock while one layer loops, and the timing
+                # ablations (no MFMAs / no stores) of the two heaviest shapes
+                line['roofline']['limited_by'] = (
+                    'mixed over its 41 launches: the HBM-heavy layers (256->64, 64->256 at 184x320) stream 4.7-5.3 TB/s of algorithmic '
+                    'bytes (0.58-0.66 of 8 TB/s; 0.74-0.83 of the ~6.3 TB/s a pure streaming kernel reaches here) at 1290-1385 W with '
+                    'the shader clock un-throttled (2.35-2.38 GHz) and run no faster with the MFMAs removed; the deep layers '
+                    '(512->128, 256->1024) sit at the 1400 W socket limit with the clock down to 1.87-2.05 GHz')
+                line['roofline']['limited_by_source'] = 'profiles/r05_power_probe_conv1x1.txt (scripts/lab/r05_power_conv.sh)'
             # the four kernels the north-star names, each against its own roof (same HIP-event data)
             named = []
             for key, bound in (('pvsg_gemm_f16x2', 'mfma'), ('pvsg_gemm_bf16x3', 'mfma'), ('pvsg_conv3x3_f16x2', 'mfma'),
@@ -1018,7 +1027,8 @@ def main():
                                ('pvsg_mask_logits_forward', 'mfma'), ('pvsg_mask_logits_bf16x3', 'mfma'),
                                ('pvsg_mask_logits_f16x2', 'mfma'),
                                ('pvsg_attn_mask_bits_forward', 'mfma'), ('pvsg_attn_mask_bits_bf16x3', 'mfma'),
-                               ('pvsg_attn_mask_bits_f16x2', 'mfma'),
+                               ('pvsg_attn_mask_bits_f16x2', 'mfma'), ('pvsg_attn_mask_bits_packed_f16x2', 'mfma'),
+                               ('pvsg_gemm_f16x2_add_layernorm', 'mfma'),
                                ('pvsg_masked_xattn_partial', 'mfma'), ('pvsg_pair_score_forward', 'latency')):
                 ks = [k for k in agg if k.startswith(key)]
                 if not ks:
@@ -1059,7 +1069,7 @@ def main():
                     if k.split('[')[0] in KernelTimer.SPLIT_F16X2 or 'bf16x3' in k:
                         # measured with rocm-smi while one layer loops (scripts/lab/power_probe.py, profiles/r04_power_probe.txt):
                         # the split kernels run at the socket's 1400 W limit with the shader clock throttled to 1.6-2.2 GHz
-                        ent['limited_by'] = 'socket power (1400 W), profiles/r04_power_probe.txt'
+                        ent['limited_by'] = 'socket power (1400 W), profiles/r04_power_probe.txt, profiles/r05_power_probe_conv1x1.txt'
                     if pk != F32_MFMA_PEAK_TF:      # split kernels: also the model's f32 arithmetic against the f32 matrix roof
                         limb_products = 3.0 if k.split('[')[0] in KernelTimer.SPLIT_F16X2 else 6.0
                         ent['f32_equivalent_TFLOPs'] = a_ / limb_products

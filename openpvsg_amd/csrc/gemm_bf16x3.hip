@@ -65,11 +65,29 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float F16X2_LO = 2048.f;                    // 2^11
 
+// PVSG_SPLIT_ISA (lab builds, scripts/lab/split_isa_lab.sh; profiles/r05_split_lab.txt): 0 = the form below as hipcc compiles it
+// (v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_mul_f32, v_pk_fma_f32, v_cvt_pk_f16_f32: packed f32 VALU beside the MFMAs);
+// 1 = the mixed-precision FMAs read the f16 halves directly: r = a - h by v_fma_mix_f32 (exact), l = f16(2^11 r) by
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 -- five VALU instructions per pair, none packed, same bits.
+#ifndef PVSG_SPLIT_ISA
+#define PVSG_SPLIT_ISA 0
+#endif
 __device__ __forceinline__ void split2h(float a0, float a1, unsigned& h, unsigned& l, float& amax) {
   const f16x2 hh = __builtin_convertvector(f32x2{a0, a1}, f16x2);
   h = __builtin_bit_cast(unsigned, hh);
+#if PVSG_SPLIT_ISA == 1
+  float r0, r1;
+  unsigned lo = 0u;
+  const float k = F16X2_LO;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(a0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(a1));
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(lo) : "v"(r0), "v"(k));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(lo) : "v"(r1), "v"(k));
+  l = lo;
+#else
   const float r0 = __builtin_fmaf((float)hh[0], -F16X2_LO, a0 * F16X2_LO), r1 = __builtin_fmaf((float)hh[1], -F16X2_LO, a1 * F16X2_LO);
   l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, f16x2));
+#endif
   amax = fmaxf(fmaxf(amax, __builtin_fabsf(a0)), __builtin_fabsf(a1));
 }
 
@@ -1610,6 +1628,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
           float v = fmaf(acc[rb][cb][r], sc4[r], sh4[r]);
           if (RESIDUAL) v += res[cb][r];
           if (RELU) v = fmaxf(v, 0.f);
+          if (PVSG_ABL == 11 && v != 1.2345e33f) continue;        // lab build: no epilogue stores (timing only)
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, pvoff[cb] + (unsigned)(chb + r) * chpitch, 0, 0);
         }
     }
