@@ -409,6 +409,12 @@ int pvsg_gemm_bf16x3(const float* a, const void* w_packed, const float* bias, fl
 int pvsg_conv1x1_bf16x3(const float* x, const void* w_packed, const float* scale, const float* shift,
                         const float* residual, const float* in_scale, const float* in_shift, float* y, int B, int Cin,
                         int Cout, int H, int W, int stride, int relu, void* stream);
+/* The weight of a 3x3 convolution as the (Cout, 9*Cin) matrix pvsg_conv3x3_bf16x3 / pvsg_conv3x3_f16x2 multiply by: K order
+ * [block of 32 input channels][tap ky,kx][32 channels] -- column ((ci/32)*9 + ky*3 + kx)*32 + ci%32.  Pack THIS matrix with
+ * pvsg_gemm_bf16x3_pack / pvsg_gemm_f16x2_pack (N = Cout, K = 9*Cin).  (Rounds 1-3 used tap-major order; ABI 7 callers must
+ * not hand-roll the order.)  weight (Cout, Cin, 3, 3) f32, matrix (Cout, 9*Cin) f32, Cin % 32 == 0. */
+int pvsg_conv3x3_weight_matrix(const float* weight, float* matrix, int Cout, int Cin, void* stream);
+
 /* [3P] mmdet ResNet Bottleneck.conv2 (3x3, pad 1, stride 1 or 2) -> frozen BN -> ReLU on the split-bf16 kernel: implicit GEMM
  * over the nine taps.  w_packed = pvsg_gemm_bf16x3_pack (pvsg_gemm_f16x2_pack for the _f16x2 entry) of the (Cout, 9*Cin) matrix whose
  * K index runs [block of 32 input channels][tap ky*3+kx][32 channels]: w.reshape(Cout, Cin/32, 32, 3, 3).permute(0, 1, 3, 4, 2).

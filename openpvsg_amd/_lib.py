@@ -86,6 +86,7 @@ SIGNATURES = {
     'pvsg_gemm_bf16x3': [_c_f, _c_f, _c_f, _c_f, _ll, _i, _i, _i, _c_f],
     'pvsg_conv1x1_bf16x3': [_c_f] * 8 + [_i] * 7 + [_c_f],
     'pvsg_conv3x3_bf16x3': [_c_f] * 5 + [_i] * 7 + [_c_f],
+    'pvsg_conv3x3_weight_matrix': [_c_f, _c_f, _i, _i, _c_f],
     'pvsg_gemm_f16x2_packed_elems': [_i, _i],
     'pvsg_gemm_f16x2_pack': [_c_f, _c_f, _i, _i, _c_f],
     'pvsg_gemm_f16x2': [_c_f, _c_f, _c_f, _c_f, _ll, _i, _i, _i, _c_f, _c_f],

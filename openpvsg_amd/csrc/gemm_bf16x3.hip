@@ -1371,7 +1371,7 @@ void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict
 // rows and is staged whole, but only rows 0..63 are multiplied: the four waves each take 32 pixel columns of the 64 rows, half
 // the matrix work of a 128-row tile, which leaves these layers to their HBM traffic.
 // TAPS = 9: the 3x3 convolution (pad 1, stride 1 or 2) as an implicit GEMM over K = 9 * Cin, ordered [block of 32 input channels][tap][32 channels] (weight packed from
-// w.permute(0, 2, 3, 1)): a 32-deep step lies inside one tap (Cin % 32 == 0), whose pixel offset replaces the 1x1 one;
+// pvsg_conv3x3_weight_matrix(w)): a 32-deep step lies inside one tap (Cin % 32 == 0), whose pixel offset replaces the 1x1 one;
 // out-of-image taps read 0 through the descriptor's bounds check.
 // F16: the two-limb f16 form (see split2h): weights (w_h, w_l, w_h2) resident in registers, pixels as (x_h, x_l').
 template <bool RELU, bool RESIDUAL, bool IN_NORM, bool BITS = false, int TM = 128, int TAPS = 1, bool F16 = false>
@@ -2189,6 +2189,32 @@ static int conv3x3_split_run(const float* x, const void* w_packed, const float* 
 #undef PVSG_C3_PICK
 #undef PVSG_C3_LAUNCH
   PVSG_LAUNCH_CHECK(nm);
+  return PVSG_OK;
+}
+
+// (Cout, Cin, 3, 3) -> the (Cout, 9 Cin) matrix the 3x3 kernels multiply by, K order [block of 32 input channels][tap ky, kx][32
+// channels] (column ((ci / 32) * 9 + ky * 3 + kx) * 32 + ci % 32): what pvsg_gemm_f16x2_pack / pvsg_gemm_bf16x3_pack must be given.
+// C callers use this instead of hand-rolling the order (it changed once: tap-major before round 4).
+namespace pvsg { namespace {
+__global__ void conv3x3_weight_matrix_kernel(const float* __restrict__ w, float* __restrict__ m, int Cin, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int K = 9 * Cin;
+  const long long co = i / K;
+  const int k = (int)(i - co * K);
+  const int blk = k / 288, r = k - blk * 288, tap = r >> 5, c = blk * 32 + (r & 31);
+  m[i] = w[(co * Cin + c) * 9 + tap];
+}
+} }
+extern "C" int pvsg_conv3x3_weight_matrix(const float* weight, float* matrix, int Cout, int Cin, void* stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(weight && matrix, "conv3x3_weight_matrix: null pointer argument");
+  PVSG_REQUIRE(Cout > 0 && Cin > 0, "conv3x3_weight_matrix: bad shape");
+  if (Cin % 32) return set_err(PVSG_ERR_UNSUPPORTED, "conv3x3_weight_matrix: built for Cin %% 32 == 0 (got %d)", Cin);
+  const long long total = (long long)Cout * 9 * Cin;
+  hipLaunchKernelGGL(conv3x3_weight_matrix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), weight, matrix, Cin, total);
+  PVSG_LAUNCH_CHECK("conv3x3_weight_matrix");
   return PVSG_OK;
 }
 

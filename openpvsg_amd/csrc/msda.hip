@@ -557,6 +557,145 @@ __global__ __launch_bounds__(256) void msda_fused_m8d32(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 5: the COARSEST level served from LDS.  msda_fused_m8d32 is bound by the texture addresser (48 gathers per query,
+// TA busy 84 %, profiles/r04_msda_pmc.txt).  One head's slice of the coarsest level of a 720p frame is 23 x 40 cells x 128 B =
+// 118 KB: it fits the CU's 160 KB of LDS.  Here a workgroup is (frame, HEAD, chunk of the frame's queries in band order): it
+// stages that slice once (rows padded to 144 B: the 16-byte reads of eight random rows then spread over the banks) and walks its
+// queries with an 8-lane group per (query, head) -- the lane is the 4-channel quad, as before, so every corner is still one
+// 16-byte access per lane and 128 B per group -- taking the 4 x 4 coarsest-level corners by ds_read_b128 and only the other
+// 32 through the texture path: a third of the gathers gone.  The per-tap arithmetic is msda_sample_query_coop's, bit for bit
+// (lane c4 works out taps c4 and 8 + c4, the group shares them by ds_bpermute; same order of the floating-point operations).
+// Differences in kind to the three earlier LDS attempts (DESIGN history): the slice is per HEAD (not all heads of a tile), the
+// workgroup keeps 16 waves resident (1 024 threads) and never waits on a barrier after the fill, and the fill is amortised over
+// thousands of queries (two chunks per (frame, head) at 32 frames; more chunks on short clips so that >= 512 workgroups exist).
+template <int L, int P, bool BANDS, bool USE_LDS = true>
+__global__ __launch_bounds__(1024) void msda_fused_hlds(
+    const float* __restrict__ value, long long value_stride, const float* __restrict__ oa, long long oa_stride,
+    const float* __restrict__ pos_oa, const float* __restrict__ ref, const long long* __restrict__ shapes,
+    const long long* __restrict__ lsi, float* __restrict__ out, int S, int Lq, int nch, int per_chunk, unsigned nblk,
+    int lds_cells) {
+  constexpr int M = 8, D = 32, LP = L * P, ROW = 36;               // LDS row stride in floats (144 B)
+  static_assert(LP > 8 && LP <= 16 && P == 4, "two taps per lane");
+  extern __shared__ __attribute__((aligned(16))) float lds0[];
+  const unsigned logical = xcd_contiguous_block(blockIdx.x, nblk);
+  const int m = (int)(logical & 7u);
+  const int chunk = (int)((logical >> 3) % (unsigned)nch), b = (int)((logical >> 3) / (unsigned)nch);
+  const int H0 = (int)shapes[0], W0 = (int)shapes[1], n0 = H0 * W0;
+  if (n0 > lds_cells) __builtin_trap();                              // the host sized the LDS for S / 21 cells
+  if (USE_LDS) {
+    const float* vb = value + ((long long)b * S + lsi[0]) * value_stride + m * D;
+    for (int i = threadIdx.x; i < n0 * 8; i += 1024) {
+      const int r = i >> 3, c = i & 7;
+      *reinterpret_cast<float4*>(lds0 + r * ROW + c * 4) = ld4(vb + (long long)r * value_stride + c * 4);
+    }
+  }
+  __syncthreads();
+  const int c4 = threadIdx.x & 7, slot = threadIdx.x >> 3;
+  const int lane = threadIdx.x & 63;
+  const int grp = (lane & ~7) << 2;                                  // ds_bpermute byte address of the group's lane 0
+  const int pend = min((chunk + 1) * per_chunk, Lq);
+  const char* vbase = reinterpret_cast<const char*>(value + (long long)b * S * value_stride);
+  const int lane_off = (m * D + c4 * 4) * 4;
+  const int vs4 = (int)value_stride * 4;
+  for (int pos = chunk * per_chunk + slot; pos < pend; pos += 128) {
+    const int q = BANDS ? msda_band_query<L>(pos, shapes, lsi) : pos;
+    const long long gq = (long long)b * Lq + q;
+    const float* offp = oa + gq * oa_stride + m * (LP * 2);
+    const float* logp = oa + gq * oa_stride + M * LP * 2 + m * LP;
+    const float* poff = pos_oa ? pos_oa + (long long)q * (M * LP * 3) + m * (LP * 2) : nullptr;
+    const float* plog = pos_oa ? pos_oa + (long long)q * (M * LP * 3) + M * LP * 2 + m * LP : nullptr;
+    const float rx = ref[2 * q], ry = ref[2 * q + 1];
+    float own_lg[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int p = (k == 0) ? c4 : min(8 + c4, LP - 1);
+      own_lg[k] = logp[p] + (plog ? plog[p] : 0.f);
+    }
+    float mx = fmaxf(own_lg[0], own_lg[1]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1));
+    mx = fmaxf(mx, __shfl_xor(mx, 2));
+    mx = fmaxf(mx, __shfl_xor(mx, 4));
+    int own_off[2][4];
+    float own_cw[2][4], own_a[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int p = (k == 0) ? c4 : min(8 + c4, LP - 1);
+      const int l = p >> 2;
+      float2 oxy = *reinterpret_cast<const float2*>(offp + 2 * p);
+      if (poff) { const float2 u = *reinterpret_cast<const float2*>(poff + 2 * p); oxy.x += u.x; oxy.y += u.y; }
+      const float ox = oxy.x, oy = oxy.y;
+      own_a[k] = __expf(own_lg[k] - mx);
+      int H = H0, W = W0;
+      long long base = lsi[0];
+#pragma unroll
+      for (int j = 1; j < L; ++j)
+        if (l == j) { H = (int)shapes[2 * j]; W = (int)shapes[2 * j + 1]; base = lsi[j]; }
+      const float invW = 1.f / (float)W, invH = 1.f / (float)H;
+      const float locx = rx + ox * invW, locy = ry + oy * invH;
+      const float him = locy * (float)H - 0.5f, wim = locx * (float)W - 0.5f;
+      const float hf = floorf(him), wf = floorf(wim);
+      const float lh = him - hf, lw = wim - wf, hh = 1.f - lh, hw = 1.f - lw;
+      const float hfc = fminf(fmaxf(hf, -2.f), (float)H + 1.f);
+      const float wfc = fminf(fmaxf(wf, -2.f), (float)W + 1.f);
+      const int h0 = (int)hfc, w0 = (int)wfc, h1 = h0 + 1, w1 = w0 + 1;
+      const bool inside = (him > -1.f) && (wim > -1.f) && (him < (float)H) && (wim < (float)W);
+      const bool vh0 = inside && h0 >= 0, vh1 = inside && h1 <= H - 1;
+      const bool vw0 = w0 >= 0, vw1 = w1 <= W - 1;
+      const int h0c = min(max(h0, 0), H - 1), h1c = min(max(h1, 0), H - 1);
+      const int w0c = min(max(w0, 0), W - 1), w1c = min(max(w1, 0), W - 1);
+      own_cw[k][0] = (vh0 && vw0) ? hh * hw : 0.f;
+      own_cw[k][1] = (vh0 && vw1) ? hh * lw : 0.f;
+      own_cw[k][2] = (vh1 && vw0) ? lh * hw : 0.f;
+      own_cw[k][3] = (vh1 && vw1) ? lh * lw : 0.f;
+      // level 0: byte offsets into the LDS slice; other levels: byte offsets of the token rows in the image's value tensor
+      const int mul = (USE_LDS && l == 0) ? ROW * 4 : vs4, b0 = (USE_LDS && l == 0) ? 0 : (int)base;
+      own_off[k][0] = (b0 + h0c * W + w0c) * mul;
+      own_off[k][1] = (b0 + h0c * W + w1c) * mul;
+      own_off[k][2] = (b0 + h1c * W + w0c) * mul;
+      own_off[k][3] = (b0 + h1c * W + w1c) * mul;
+    }
+    {
+      float e = own_a[0] + (8 + c4 < LP ? own_a[1] : 0.f);
+      e += __shfl_xor(e, 1);
+      e += __shfl_xor(e, 2);
+      e += __shfl_xor(e, 4);
+      const float inv = 1.f / e;
+      own_a[0] *= inv;
+      own_a[1] *= inv;
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < LP; ++p) {
+      const int k = p >> 3, src = grp + ((p & 7) << 2);
+      int off[4];
+      float cw[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        off[c] = __builtin_amdgcn_ds_bpermute(src, own_off[k][c]);
+        cw[c] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(own_cw[k][c])));
+      }
+      const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(own_a[k])));
+      float4 v[4];
+      if (USE_LDS && p < P) {                                        // the coarsest level: from the staged slice
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          v[c] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(lds0) + off[c] + c4 * 16);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const float4*>(vbase + (unsigned)(off[c] + lane_off));
+      }
+      float4 s4;
+      s4.x = cw[0] * v[0].x + cw[1] * v[1].x + cw[2] * v[2].x + cw[3] * v[3].x;
+      s4.y = cw[0] * v[0].y + cw[1] * v[1].y + cw[2] * v[2].y + cw[3] * v[3].y;
+      s4.z = cw[0] * v[0].z + cw[1] * v[1].z + cw[2] * v[2].z + cw[3] * v[3].z;
+      s4.w = cw[0] * v[0].w + cw[1] * v[1].w + cw[2] * v[2].w + cw[3] * v[3].w;
+      acc.x += a * s4.x; acc.y += a * s4.y; acc.z += a * s4.z; acc.w += a * s4.w;
+    }
+    st4_stream(out + gq * 256 + m * D + c4 * 4, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // msda_proj_ln: the whole attention half of an encoder layer after the projection GEMM,
 //   out = LayerNorm( identity + ( MSDA(value, offsets, logits) Wo^T + bo ) )
 // i.e. mmcv MultiScaleDeformableAttention.forward steps 4-8 + BaseTransformerLayer's first norm in ONE launch.
@@ -745,6 +884,47 @@ extern "C" int pvsg_msda_fused_forward(const float* value, long long value_row_s
   // of an image; PVSG_MSDA_COOP=0 keeps every lane computing every tap (A/B)
   const char* cp = getenv("PVSG_MSDA_COOP");
   const bool coop = (long long)S * value_row_stride * 4 < (1ll << 31) && !(cp && cp[0] == '0');
+  // PVSG_MSDA_LDS=on: the coarsest level of a head from LDS (msda_fused_hlds; lab A/B: scripts/kbench.py msda)
+  {
+    const char* hl = getenv("PVSG_MSDA_LDS");
+    const long long* shp = reinterpret_cast<const long long*>(spatial_shapes);
+    // (the host cannot read the device-side shape table: the caller passes the coarsest level's cell count through the
+    // environment-free rule below -- Lq == S and the first level is the smallest by construction of the pixel decoder; the LDS
+    // size is taken from S: levels are x4 apart, so the coarsest holds S / 21 cells)
+    const long long n0 = S / 21;
+    if (hl && hl[0] == 'm' && coop && Lq == S && S % 21 == 0 && bands) {      // lab: the (frame, head, chunk) mapping WITHOUT the LDS slice
+      int nch = (int)((512 + (long long)B * 8 - 1) / ((long long)B * 8));
+      if (nch < 1) nch = 1;
+      const unsigned nb = (unsigned)(B * 8 * nch);
+      hipLaunchKernelGGL((msda_fused_hlds<3, 4, true, false>), dim3(nb), dim3(1024), 16, stream, value, value_row_stride, oa,
+                         oa_row_stride, pos_oa, ref_points, reinterpret_cast<const long long*>(spatial_shapes),
+                         reinterpret_cast<const long long*>(level_start_index), out, S, Lq, nch, (Lq + nch - 1) / nch, nb, (int)n0);
+      PVSG_LAUNCH_CHECK("msda_fused_forward");
+      return PVSG_OK;
+    }
+    if (hl && hl[0] == 'o' && hl[1] == 'n' && coop && Lq == S && S % 21 == 0 && n0 * 144 <= 160 * 1024 - 1024) {
+      static std::atomic<unsigned long long> done_b{0}, done_l{0};
+      const int lds_bytes = (int)(n0 * 144);
+      hipError_t e = bands ? ensure_dynamic_lds(reinterpret_cast<const void*>(msda_fused_hlds<3, 4, true>), lds_bytes, done_b)
+                           : ensure_dynamic_lds(reinterpret_cast<const void*>(msda_fused_hlds<3, 4, false>), lds_bytes, done_l);
+      if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "msda_fused_forward: dynamic LDS: %s", hipGetErrorString(e));
+      int nch = (int)((512 + (long long)B * 8 - 1) / ((long long)B * 8));
+      if (nch < 1) nch = 1;
+      const int per_chunk = (Lq + nch - 1) / nch;
+      const unsigned nb = (unsigned)(B * 8 * nch);
+      (void)shp;
+      if (bands)
+        hipLaunchKernelGGL((msda_fused_hlds<3, 4, true>), dim3(nb), dim3(1024), lds_bytes, stream, value, value_row_stride, oa,
+                           oa_row_stride, pos_oa, ref_points, reinterpret_cast<const long long*>(spatial_shapes),
+                           reinterpret_cast<const long long*>(level_start_index), out, S, Lq, nch, per_chunk, nb, (int)n0);
+      else
+        hipLaunchKernelGGL((msda_fused_hlds<3, 4, false>), dim3(nb), dim3(1024), lds_bytes, stream, value, value_row_stride, oa,
+                           oa_row_stride, pos_oa, ref_points, reinterpret_cast<const long long*>(spatial_shapes),
+                           reinterpret_cast<const long long*>(level_start_index), out, S, Lq, nch, per_chunk, nb, (int)n0);
+      PVSG_LAUNCH_CHECK("msda_fused_forward");
+      return PVSG_OK;
+    }
+  }
 #define PVSG_MSDA_LAUNCH(BANDS, COOP)                                                                                        \
   hipLaunchKernelGGL((msda_fused_m8d32<3, 4, BANDS, COOP>), dim3(nblk), dim3(256), 0, stream, value, value_row_stride, oa,  \
                      oa_row_stride, pos_oa, ref_points, reinterpret_cast<const long long*>(spatial_shapes),                \

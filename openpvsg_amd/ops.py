@@ -777,8 +777,19 @@ def conv3x3_bf16x3_pack(weight):
     if tuple(w.shape[2:]) != (3, 3) or not conv3x3_bf16x3_supported(Cout, Cin, 2, 2):
         raise RuntimeError('conv3x3_bf16x3_pack: unsupported weight shape %s' % (tuple(w.shape),))
     # K order of the implicit GEMM: [block of 32 input channels][tap 3x3][32 channels] -- the nine taps of a channel block are
-    # consecutive steps, so their (shifted) reads of the same pixels find each other in the vector L1
-    return gemm_bf16x3_pack(w.reshape(Cout, Cin // 32, 32, 3, 3).permute(0, 1, 3, 4, 2).reshape(Cout, 9 * Cin).contiguous())
+    # consecutive steps, so their (shifted) reads of the same pixels find each other in the vector L1.  The order is produced
+    # by the library (pvsg_conv3x3_weight_matrix) so that C callers and this mirror cannot drift apart.
+    return gemm_bf16x3_pack(conv3x3_weight_matrix(w))
+
+
+def conv3x3_weight_matrix(weight):
+    """(Cout,Cin,3,3) -> the (Cout, 9*Cin) f32 matrix of the 3x3 implicit GEMM in its K order (pvsg_conv3x3_weight_matrix)."""
+    w = _chk(weight, 'weight')
+    Cout, Cin = w.shape[:2]
+    m = torch.empty((Cout, 9 * Cin), device=w.device, dtype=torch.float32)
+    with _on(w.device):
+        _lib.call('pvsg_conv3x3_weight_matrix', w.data_ptr(), m.data_ptr(), Cout, Cin, _stream_ptr())
+    return m
 
 
 def conv3x3_bf16x3(x, w_packed, cout, scale=None, shift=None, relu=True, out=None, stride=1):

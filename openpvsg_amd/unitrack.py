@@ -576,6 +576,15 @@ def reconsdot_cost(trk_feats, det_feats, tmp=100.0, needed=None):
     matrices come from three GEMM calls; the rest (both soft-maxes, the block sums, the quadratic forms on the matrix cores,
     the final normalisation) is `pvsg_reconsdot_cost` (csrc/reconsdot.hip): four passes over A instead of the fourteen the
     tensor-op form below makes."""
+    # the fused kernels hold one object's cells in LDS strips: objects of more than 1 024 (padded) cells, or affinity matrices
+    # beyond their 32-bit strip indices, take the tensor-op form (max_mask_area is a config value: the reference ships 300)
+    big = max(max(int(f.shape[0]) for f in trk_feats), max(int(f.shape[0]) for f in det_feats))
+    big = (big + 31) // 32 * 32
+    if big > 1024 or len(trk_feats) * big >= 2 ** 24 or len(det_feats) * big >= 2 ** 24:
+        cost = reconsdot_cost_tensor_ops(trk_feats, det_feats, tmp)
+        if needed is not None:
+            cost = torch.where(torch.as_tensor(needed, device=cost.device).bool(), cost, torch.full_like(cost, float('inf')))
+        return cost
     Ft, Pt, Ptp = _padded_cells(trk_feats)
     Fd, Pd, Pdp = _padded_cells(det_feats)
     Nt, Nd, d = len(trk_feats), len(det_feats), Ft.shape[1]
@@ -592,8 +601,8 @@ def reconsdot_cost(trk_feats, det_feats, tmp=100.0, needed=None):
 
 
 def reconsdot_cost_tensor_ops(trk_feats, det_feats, tmp=100.0):
-    """The same quantity with torch tensor operations only (round 1-3 form; kept as the yardstick of tests/test_unitrack.py
-    and scripts/lab/reconsdot_profile.py, not called by the tracker)."""
+    """The same quantity with torch tensor operations only (round 1-3 form; the yardstick of tests/test_unitrack.py and
+    scripts/lab/reconsdot_profile.py, and the path of objects too large for the fused kernels: more than 1 024 cells)."""
     Ft = torch.nn.utils.rnn.pad_sequence(trk_feats, batch_first=True)
     Fd = torch.nn.utils.rnn.pad_sequence(det_feats, batch_first=True)
     Nt, Pt, d = Ft.shape
@@ -1048,8 +1057,8 @@ class MaskAssociationTracker(AssociationTracker):
                         sf = math.sqrt(max_area / float(area[i]))
                         inv = np.float32(1.0 / sf)
                         scales[i] = inv
-                        sel = lm[nearest_index(int(math.floor(h * sf)), h, inv)][:, nearest_index(int(math.floor(w * sf)), w, inv)] == ids[i]
-                        yy, xx = np.nonzero(sel)
+                        shrunk = lm[nearest_index(int(math.floor(h * sf)), h, inv)][:, nearest_index(int(math.floor(w * sf)), w, inv)] == ids[i]
+                        yy, xx = np.nonzero(shrunk)
                     else:
                         yy, xx = oy[starts[i]:starts[i + 1]], ox[starts[i]:starts[i + 1]]
                     counts[i] = len(yy)
@@ -1059,20 +1068,22 @@ class MaskAssociationTracker(AssociationTracker):
                 ent = np.stack([obj, oy, ox], 1)
             k = len(ent)
             upload += [ent.astype(np.int32).ravel(), ids.astype(np.int32), scales.view(np.int32)]
-            plan.append((feat, obs, boxes, counts, k, n, off))
+            plan.append((feat, obs, boxes, counts, k, n, off, area))
             off += 3 * k + 2 * n
         buf = torch.from_numpy(np.concatenate(upload)).to(self.device)
-        for f, (feat, obs, boxes, counts, k, n, off) in enumerate(plan):
+        for f, (feat, obs, boxes, counts, k, n, off, area) in enumerate(plan):
             embs = [None] * n
             if k:
                 raw, nrm = ops.mask_embed(feat.hwd, low_dev[f], buf[off:off + 3 * k].view(k, 3), buf[off + 3 * k:off + 3 * k + n],
                                           buf[off + 3 * k + n:off + 3 * k + 2 * n].view(torch.float32))
                 o = 0
                 for i in range(n):
-                    if counts[i]:
+                    if area[i]:           # (an object shrunk to 0 cells keeps EMPTY embeddings, as extract_emb gives it)
                         embs[i] = (raw[o:o + counts[i]], nrm[o:o + counts[i]])
                         o += counts[i]
             for i in range(n):
+                if embs[i] is None and k == 0 and area[i]:
+                    embs[i] = (torch.zeros((0, d), device=self.device), torch.zeros((0, d), device=self.device))
                 if embs[i] is None:       # vanished at the feature stride: mask.py:46 draws noise (unseeded there)
                     r = torch.randn(tmpl, d, generator=self._empty_gen).to(self.device)
                     embs[i] = (r, F.normalize(r, dim=1))
@@ -1215,6 +1226,19 @@ def _np(x):
 
 def eval_seq(data_cfg, tracker_cfg, outputs, classes, save_root=None, return_results=False, frames=None,
              app_model=None, batch=16, tracker_cls=None):
+    """`_eval_seq` with the f16x2 range check of the split kernels it uses (appearance CNN, affinity GEMM): activations beyond
+    the f16 range are counted on the device; the video is then associated again on the bf16x3 form (ops.rerun_on_bf16x3)."""
+    def run():
+        return _eval_seq(data_cfg, tracker_cfg, outputs, classes, save_root, return_results, frames, app_model, batch, tracker_cls)
+    dev = None
+    if app_model is not None:
+        p = next(app_model.parameters(), None)
+        dev = p.device if p is not None and p.is_cuda else None
+    return ops.rerun_on_bf16x3(run, dev) if dev is not None else run()
+
+
+def _eval_seq(data_cfg, tracker_cfg, outputs, classes, save_root=None, return_results=False, frames=None,
+              app_model=None, batch=16, tracker_cls=None):
     """test_mots_from_mask2former.py:29-95: associate the per-frame IPS results of one video into tubes.
     Writes `<save_root>/quantitive/masks.txt` (MOTS) and `<save_root>/query_feats.pickle` when save_root is
     given; returns (results, query_feat_tubes) when return_results.  The appearance CNN runs over the whole

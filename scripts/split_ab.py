@@ -77,7 +77,7 @@ def convs():
         row = dict(layer=name, err_lib=(lib.double() - ref).abs().max().item())
         for mode in ('bf16x3', 'f16x2'):
             if taps == 9:
-                wp = ops.gemm_bf16x3_pack(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous(), mode=mode)
+                wp = ops.gemm_bf16x3_pack(ops.conv3x3_weight_matrix(w), mode=mode)
                 run = lambda: ops.conv3x3_bf16x3(x, wp, Cout, sc, sh, relu=True, stride=stride)       # noqa: E731
             else:
                 wp = ops.gemm_bf16x3_pack(w.view(Cout, Cin).contiguous(), mode=mode)

@@ -202,3 +202,17 @@ def test_conv3x3_kernels_at_720p_sizes(hip_lib, name, Cin, Cout, H, W, stride):
     x2 = torch.randn(N, Cin, H, W, generator=g).cuda()
     lhs, rhs = own(2 * x - x2), 2 * y - own(x2)
     assert float((lhs - rhs).abs().max()) < 5e-5 * max(1.0, float(rhs.abs().max()))
+
+
+def test_conv3x3_weight_matrix_order(hip_lib):
+    """pvsg_conv3x3_weight_matrix: column ((ci // 32) * 9 + ky * 3 + kx) * 32 + ci % 32 of row co holds w[co, ci, ky, kx] -- the K
+    order of the 3x3 implicit GEMM, exported so that C callers do not hand-roll it."""
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for Cout, Cin in ((8, 32), (20, 96), (128, 256)):
+        w = torch.randn(Cout, Cin, 3, 3, generator=g).cuda()
+        m = ops.conv3x3_weight_matrix(w)
+        want = w.reshape(Cout, Cin // 32, 32, 3, 3).permute(0, 1, 3, 4, 2).reshape(Cout, 9 * Cin)
+        assert torch.equal(m, want)
+    with pytest.raises(RuntimeError, match='Cin'):
+        ops.conv3x3_weight_matrix(torch.randn(8, 16, 3, 3).cuda())
