@@ -182,7 +182,12 @@ def test_bench_line_reports_rccl_ranks(hip_lib):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
-    assert line['collectives'] == dict(backend='nccl', rccl_ranks=1, exchanges_run=True, forced_at_world_1=True)
+    col = line['collectives']
+    assert {k: col[k] for k in ('backend', 'rccl_ranks', 'exchanges_run', 'forced_at_world_1')} == \
+        dict(backend='nccl', rccl_ranks=1, exchanges_run=True, forced_at_world_1=True)
+    # per-exchange timing (HIP events around every all-gather of the timed step): 9 merged-attention records + 1 id-row gather
+    assert sum(e['count_per_step'] for e in col['per_exchange']) == 10 and col['exchange_us_per_step'] > 0
+    assert any(e['bytes_per_rank'] == 108816 and e['count_per_step'] == 9 for e in col['per_exchange'])
     assert line['n_gpus'] == 1
 
 
