@@ -448,6 +448,20 @@ int pvsg_gemm_f16x2(const float* a, const void* w_packed, const float* bias, flo
 int pvsg_gemm_f16x2_add_layernorm(const float* a, const void* w_packed, const float* bias, const float* residual,
                                   const float* gamma, const float* beta, float eps, float* out, long long M, int N, int K,
                                   uint32_t* overflow, void* stream);
+
+/* Key AND value projections of one decoder level in one launch, straight from the encoder's token tensor: per decoder layer
+ * `k = (memory + level_embed + pos) Wk^T + bk`, `v = (memory + level_embed) Wv^T + bv` ([3P] nn.MultiheadAttention in_proj on the
+ * key / value inputs that models/mask2former/mask2former_head.py:421-436 builds and :457-468 passes).  level_embed and the
+ * positional encoding are linear terms of the input, so they enter through the epilogue as two small tables; the (K, 256) key /
+ * value INPUT tensors are never written.
+ *   tokens (frames, S, 256) encoder memory; the level's tokens are rows start .. start + hw of every frame
+ *   w_packed = pvsg_gemm_f16x2_pack of [Wk ; Wv] (512, 256)
+ *   tab_cell (hw, 256) = (pe_yx + level_embed) Wk^T + bk;  tab_frame (zrows, 256) = pe_z Wk^T, frame f uses row f % zrows
+ *   (image head: zrows = 1, zeros);  bias_v (256) = level_embed Wv^T + bv;  k_out, v_out (frames * hw, 256)
+ * The token tensor must stay below 4 GB (else PVSG_ERR_UNSUPPORTED: use pvsg_decoder_kv_inputs + two pvsg_gemm_f16x2). */
+int pvsg_decoder_kv_project_f16x2(const float* tokens, int frames, int S, int start, int hw, const void* w_packed,
+                                  const float* tab_cell, const float* tab_frame, int zrows, const float* bias_v, float* k_out,
+                                  float* v_out, uint32_t* overflow, void* stream);
 int pvsg_conv1x1_f16x2(const float* x, const void* w_packed, const float* scale, const float* shift,
                        const float* residual, const float* in_scale, const float* in_shift, float* y, int B, int Cin,
                        int Cout, int H, int W, int stride, int relu, uint32_t* overflow, void* stream);

@@ -91,6 +91,7 @@ SIGNATURES = {
     'pvsg_gemm_f16x2_pack': [_c_f, _c_f, _i, _i, _c_f],
     'pvsg_gemm_f16x2': [_c_f, _c_f, _c_f, _c_f, _ll, _i, _i, _i, _c_f, _c_f],
     'pvsg_gemm_f16x2_add_layernorm': [_c_f] * 6 + [_f, _c_f, _ll, _i, _i, _c_f, _c_f],
+    'pvsg_decoder_kv_project_f16x2': [_c_f, _i, _i, _i, _i, _c_f, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f],
     'pvsg_conv1x1_f16x2': [_c_f] * 8 + [_i] * 7 + [_c_f, _c_f],
     'pvsg_conv3x3_f16x2': [_c_f] * 5 + [_i] * 7 + [_c_f, _c_f],
     'pvsg_mask_logits_f16x2': [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _ll, _c_f, _c_f],

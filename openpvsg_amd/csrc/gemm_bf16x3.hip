@@ -934,12 +934,20 @@ constexpr int T256_LDS_BYTES = 2 * (2 * 4 * (256 + 2) * 8 + 2 * 4 * 256 * 8) * 2
 // LN = false: the same tile and pipeline as a plain GEMM (bias / ReLU epilogue) for N > 256: `tiles_n` 256-column tiles per row
 // block, consecutive workgroups share the row block (A from L2).  Opt-in (PVSG_F16X2_TILE=w256), measured in
 // scripts/lab/gemm_tile_ab.py.
-template <bool LN, bool RELU>
+// KV = true (round 5): the decoder's key AND value projections of one level in one launch, straight from the encoder's token
+// tensor.  Rows = the level's tokens of every frame (row r -> frame r / hw, token start + r % hw of `A` = (frames, S, 256));
+// W = [Wk ; Wv] (N = 512): column tile 0 writes keys to `out`, tile 1 values to `residual` (reused as the second output).
+// The reference adds level_embed and the positional encoding to the INPUT of the key projection (mask2former_head.py:421-436);
+// both are linear terms, so they come in through the epilogue: keys += gamma[r % hw] + beta[(r / hw) % zrows] (two small tables:
+// ((pe_yx + level_embed) Wk^T + bk) per cell and (pe_z Wk^T) per frame), values += bias (level_embed Wv^T + bv).  The key / value
+// INPUT tensors (4 KB per key written + read by pvsg_decoder_kv_inputs and the two projections) never exist.
+template <bool LN, bool RELU, bool KV = false>
 __global__ __launch_bounds__(256, 2)
 void gemm_f16x2_ln128_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
                              float* __restrict__ out, int M, int K, unsigned* __restrict__ overflow,
                              const float* __restrict__ residual, const float* __restrict__ gamma,
-                             const float* __restrict__ beta, float eps, int N = 256, int Npad = 256, int tiles_n = 1) {
+                             const float* __restrict__ beta, float eps, int N = 256, int Npad = 256, int tiles_n = 1,
+                             int kv_S = 0, int kv_start = 0, int kv_hw = 1, int kv_zrows = 1) {
   constexpr int TM = 128, TN = 256;
   constexpr int A_KG = TM * 8, A_LIMB = 4 * A_KG;                // f16 elements
   constexpr int W_AT = 2 * A_LIMB, W_LIMB = 4 * TN * 8, W_BUF = 2 * W_LIMB;
@@ -953,10 +961,18 @@ void gemm_f16x2_ln128_kernel(const float* __restrict__ A, const __bf16* __restri
   const int ar = tid >> 2, akg = tid & 3;                        // rows ar and ar + 64, k-group akg
   unsigned a_voff[2];
 #pragma unroll
-  for (int p2 = 0; p2 < 2; ++p2)                                 // rows beyond M read as 0
-    a_voff[p2] = m0 + ar + 64 * p2 < M ? (unsigned)(((ar + 64 * p2) * K + 8 * akg) * 4) : 0x80000000u;
-  const auto asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A) + (size_t)m0 * K * 4), 0,
-                                                      (unsigned)((size_t)TM * K * 4), 0x00020000);
+  for (int p2 = 0; p2 < 2; ++p2) {                               // rows beyond M read as 0
+    const int r = m0 + ar + 64 * p2;
+    if constexpr (KV) {                                          // token row of frame r / hw (the whole tensor is below 4 GB: host check)
+      const int f = r / kv_hw, c = r - f * kv_hw;
+      a_voff[p2] = r < M ? (unsigned)(((size_t)f * kv_S + kv_start + c) * K + 8 * akg) * 4u : 0xffffffe0u;   // (+16 must not wrap)
+    } else {
+      a_voff[p2] = r < M ? (unsigned)(((ar + 64 * p2) * K + 8 * akg) * 4) : 0x80000000u;
+    }
+  }
+  const auto asrc = KV ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (unsigned)((size_t)(M / kv_hw) * kv_S * K * 4), 0x00020000)
+                       : __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A) + (size_t)m0 * K * 4), 0,
+                                                           (unsigned)((size_t)TM * K * 4), 0x00020000);
   f32x4 a_regs[4];
   auto loadA = [&](int kt) {
     const unsigned so = (unsigned)kt * (32 * 4);
@@ -1057,6 +1073,36 @@ void gemm_f16x2_ln128_kernel(const float* __restrict__ A, const __bf16* __restri
   // register r of block (rb, cb) = row rb*16 + (lane&15), column cb*16 + 4*(lane>>4) + r of the wave's 64 x 128 tile
   const float unscale = f16x2_unscale(Wp, Npad, K);
   const int rows = M - m0 < TM ? M - m0 : TM;
+  if constexpr (KV) {
+    float* dst = tn == 0 ? out : const_cast<float*>(residual);
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(dst + (size_t)m0 * 256, 0, (unsigned)((size_t)rows * 1024), 0x00020000);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const int rl = wr * 64 + rb * 16 + l15, r = m0 + rl;
+      const int f = r / kv_hw, cell = r - f * kv_hw, z = f % kv_zrows;
+      const float* ty = gamma + (size_t)cell * 256 + wc * 128 + 4 * kg4;
+      const float* tz = beta + (size_t)z * 256 + wc * 128 + 4 * kg4;
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb) {
+        f32x4 add;
+        if (tn == 0) {
+          if (r < M) {
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(ty + cb * 16), a2 = *reinterpret_cast<const f32x4*>(tz + cb * 16);
+            add = a1 + a2;
+          } else add = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+          add = *reinterpret_cast<const f32x4*>(bias + wc * 128 + cb * 16 + 4 * kg4);
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(acc[rb][cb][e], unscale, add[e]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc,
+                                               (unsigned)rl * 1024u + (unsigned)(wc * 128 + cb * 16 + 4 * kg4) * 4u, 0, 0);
+      }
+    }
+    f16x2_count_overflow(amax, overflow);
+    return;
+  }
   if constexpr (!LN) {
     const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)m0 * N, 0, (unsigned)((size_t)rows * N * 4), 0x00020000);
     const auto brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, bias ? (unsigned)N * 4u : 0u, 0x00020000);
@@ -2054,6 +2100,34 @@ extern "C" int pvsg_gemm_f16x2_add_layernorm(const float* a, const void* w_packe
                      static_cast<hipStream_t>(stream), a, static_cast<const __bf16*>(w_packed), bias, out, (int)M, 256, K, 256, 1,
                      overflow, residual, gamma, beta, eps);
   PVSG_LAUNCH_CHECK("gemm_f16x2_add_layernorm");
+  return PVSG_OK;
+}
+
+// Key and value projections of one decoder level in ONE launch from the encoder's token tensor (see gemm_f16x2_ln128_kernel,
+// KV form).  Replaces, per decoder layer, `k = (memory + level_embed + pos) Wk^T + bk`, `v = (memory + level_embed) Wv^T + bv`
+// ([3P] nn.MultiheadAttention in_proj on the key / value inputs models/mask2former/mask2former_head.py:421-436,457-468 builds).
+//   tokens (frames, S, 256): level rows start .. start + hw of every frame;  w_packed = pvsg_gemm_f16x2_pack([Wk ; Wv]) (512 x 256)
+//   tab_cell (hw, 256) = (pe_yx + level_embed) Wk^T + bk;  tab_frame (zrows, 256) = pe_z Wk^T (frame f uses row f % zrows; zrows = 1
+//   and zeros for the image head);  bias_v (256) = level_embed Wv^T + bv;  k_out / v_out (frames * hw, 256)
+extern "C" int pvsg_decoder_kv_project_f16x2(const float* tokens, int frames, int S, int start, int hw, const void* w_packed,
+                                             const float* tab_cell, const float* tab_frame, int zrows, const float* bias_v,
+                                             float* k_out, float* v_out, uint32_t* overflow, void* stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(tokens && w_packed && tab_cell && tab_frame && bias_v && k_out && v_out, "decoder_kv_project_f16x2: null pointer argument");
+  PVSG_REQUIRE(frames > 0 && S > 0 && hw > 0 && start >= 0 && start + hw <= S && zrows > 0, "decoder_kv_project_f16x2: bad shape");
+  const long long M = (long long)frames * hw;
+  if ((long long)frames * S * 1024 >= 0xffffffe0LL || M >= (1LL << 31))
+    return set_err(PVSG_ERR_UNSUPPORTED, "decoder_kv_project_f16x2: the token tensor must stay below 4 GB (frames=%d S=%d)", frames, S);
+  PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(tokens) | reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(tab_cell) |
+                  reinterpret_cast<uintptr_t>(tab_frame) | reinterpret_cast<uintptr_t>(bias_v) | reinterpret_cast<uintptr_t>(k_out) |
+                  reinterpret_cast<uintptr_t>(v_out)) & 15u), "decoder_kv_project_f16x2: pointers must be 16-byte aligned");
+  static std::atomic<unsigned long long> done{0};
+  const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f16x2_ln128_kernel<false, false, true>), LN128_LDS_BYTES, done);
+  if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "decoder_kv_project_f16x2: dynamic LDS: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL((gemm_f16x2_ln128_kernel<false, false, true>), dim3((unsigned)(((M + 127) / 128) * 2)), dim3(256), LN128_LDS_BYTES,
+                     static_cast<hipStream_t>(stream), tokens, static_cast<const __bf16*>(w_packed), bias_v, k_out, (int)M, 256, overflow,
+                     v_out, tab_cell, tab_frame, 0.f, 512, 512, 2, S, start, hw, zrows);
+  PVSG_LAUNCH_CHECK("decoder_kv_project_f16x2");
   return PVSG_OK;
 }
 

@@ -282,6 +282,43 @@ class _Mask2FormerHeadBase(BaseModule):
                 st = self._rows_state = DecoderRows(self)
         return st
 
+    def _kv_project(self, mha, level, src, B, T):
+        """Projected keys / values (B, T*h*w, 256) of `level` for the nn.MultiheadAttention `mha` in one launch from the encoder
+        memory (ops.decoder_kv_project).  k = (mem + level_embed + pe) Wk^T + bk: level_embed and pe are linear terms of the
+        input, so they enter as epilogue tables -- per cell ((pe_yx + level_embed) Wk^T + bk) and per frame (pe_z Wk^T; the 3-D
+        encoding of position_encoding.py:74-98 is a sum of a (y, x) and a (t) part) -- built once per (weights, geometry)."""
+        tok, start, hw, pe = src
+        C = 256
+        W, b, le = mha.in_proj_weight, mha.in_proj_bias, self.level_embed.weight
+        key = (W.data_ptr(), W._version, b.data_ptr(), b._version, le.data_ptr(), le._version, level, pe.data_ptr(), tuple(pe.shape), T)
+        cache = mha.__dict__.get('_pvsg_kv_tables')
+        if cache is None:
+            cache = mha.__dict__['_pvsg_kv_tables'] = _ShapeCache(limit=4)
+        ent = cache.get(key)
+        if ent is None:
+            with torch.no_grad():
+                Wk, Wv, bk, bv = W[C:2 * C].double(), W[2 * C:].double(), b[C:2 * C].double(), b[2 * C:].double()
+                lev = le[level].double()
+                if self.video and T > 1:
+                    pe3 = pe.view(T, hw, C).double()
+                    cell, frame = pe3[0], pe3[:, 0] - pe3[0, 0]
+                    if float((pe3 - (cell[None] + frame[:, None])).abs().max()) > 1e-5:
+                        cell = None                                  # not a (cell) + (frame) sum: keep the two-GEMM path
+                else:
+                    cell, frame = pe.view(-1, C)[:hw].double(), torch.zeros((1, C), dtype=torch.float64, device=pe.device)
+                if cell is None:
+                    ent = cache[key] = False
+                else:
+                    ent = cache[key] = (((cell + lev) @ Wk.t() + bk).float().contiguous(), (frame @ Wk.t()).float().contiguous(),
+                                        (lev @ Wv.t() + bv).float().contiguous(),
+                                        ops.gemm_bf16x3_pack(W[C:].detach().contiguous(), mode='f16x2'), pe)
+        if ent is False:
+            v, k = ops.decoder_kv_inputs(tok, start, hw, le[level].detach(), pe)
+            return (ops.gemm_bf16x3(k, ops.gemm_bf16x3_pack(W[C:2 * C].detach().contiguous()), C, b[C:2 * C]).view(B, T * hw, C),
+                    ops.gemm_bf16x3(v, ops.gemm_bf16x3_pack(W[2 * C:].detach().contiguous()), C, b[2 * C:]).view(B, T * hw, C))
+        k, v = ops.decoder_kv_project(tok, start, hw, ent[3], ent[0], ent[1], ent[2])
+        return k.view(B, T * hw, C), v.view(B, T * hw, C)
+
     def forward_head(self, decoder_out, mask_feature, attn_mask_target_size):
         """Reference signature (head.py:355): decoder_out (Q,B,C) -> cls_pred, mask_pred and the
         (B*heads, Q, K) bool attention mask (materialised here only for API parity / tests)."""
@@ -304,13 +341,30 @@ class _Mask2FormerHeadBase(BaseModule):
         dev = mask_features.device
         k_in, v_in, sizes = [], [], {}
         tokens = getattr(self.pixel_decoder, 'last_tokens', None)
+        rows = self._rows()
+        # PVSG_KV_FUSE=on (measured, not the default): key AND value projections of a layer in one launch from the encoder's token
+        # tensor (ops.decoder_kv_project), the key / value input tensors never built.  9 launches 2.75 ms against 18 + 3 launches
+        # 2.59 ms at 32 x 720p, 13.25 vs 13.24 ms per 4-frame step: the per-element epilogue tables cost what the saved pass over
+        # the keys bought (profiles/r05_kv_fuse_ab.txt).
+        kv_fused = (rows is not None and tokens is not None and mask_features.is_cuda and C == 256 and
+                    ops.split_mode() == 'f16x2' and os.environ.get('PVSG_KV_FUSE', 'off') == 'on' and
+                    os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and tokens[0].shape[0] == B * T and
+                    tokens[0].numel() * 4 < 0xffffffe0 and
+                    all(isinstance(p, nn.Identity) for p in self.decoder_input_projs))
+        kv_src = {}
         for i in range(L):
             h, w = memories[i].shape[-2:]
             sizes[i] = (h, w)
             pe = self._pe_tokens(T, h, w, dev)                       # (T*h*w, C) video / (h*w, C) image, key order (t, y, x)
-            if (tokens is not None and mask_features.is_cuda and isinstance(self.decoder_input_projs[i], nn.Identity) and
-                    C == 256 and tokens[0].shape[0] == B * T and tokens[2][i] == (h, w) and
-                    memories[i].data_ptr() == tokens[0].data_ptr() + 4 * tokens[1][i] * C):
+            from_tokens = (tokens is not None and mask_features.is_cuda and isinstance(self.decoder_input_projs[i], nn.Identity) and
+                           C == 256 and tokens[0].shape[0] == B * T and tokens[2][i] == (h, w) and
+                           memories[i].data_ptr() == tokens[0].data_ptr() + 4 * tokens[1][i] * C)
+            if kv_fused and from_tokens:
+                kv_src[i] = (tokens[0], tokens[1][i], h * w, pe)
+                k_in.append(None)
+                v_in.append(None)
+                continue
+            if from_tokens:
                 # one pass from the encoder's token tensor: value = tokens + level_embed, key = value + pe
                 v, k = ops.decoder_kv_inputs(tokens[0], tokens[1][i], h * w, self.level_embed.weight[i].detach(), pe)
                 v_in.append(v.view(B, T * h * w, C))
@@ -335,7 +389,6 @@ class _Mask2FormerHeadBase(BaseModule):
         q = self.query_feat.weight[None].expand(B, -1, -1).contiguous()
         cls_list, mask_list = [], []
         n_layers = self.num_transformer_decoder_layers
-        rows = self._rows()
         if rows is not None:
             # query rows through csrc/decoder_rows.hip: two launches per layer (+ mask bits, attention, merge)
             q_pos2 = self.query_embed.weight
@@ -360,7 +413,10 @@ class _Mask2FormerHeadBase(BaseModule):
             for i in range(n_layers):
                 lvl = i % L
                 attn = self.transformer_decoder.layers[i].attentions[0]
-                kp, vp = attn.project_kv(k_in[lvl], v_in[lvl])
+                if lvl in kv_src:
+                    kp, vp = self._kv_project(attn.attn, lvl, kv_src[lvl], B, T)
+                else:
+                    kp, vp = attn.project_kv(k_in[lvl], v_in[lvl])
                 part = ops.masked_xattn_partial(qproj, kp, vp, mask, self.num_heads)
                 core = ops.xattn_combine(*part) if self.partial_combine is None else self.partial_combine(*part, mask)
                 last = i == n_layers - 1

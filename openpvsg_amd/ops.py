@@ -1089,6 +1089,25 @@ def decoder_kv_inputs(tokens, start, hw, level_embed, pos_enc):
     return v, k
 
 
+def decoder_kv_project(tokens, start, hw, w_packed, tab_cell, tab_frame, bias_v):
+    """Key and value projections of one decoder level in one launch from the encoder memory `tokens` (F,S,256) (level rows
+    start..start+hw): k = tokens Wk^T + tab_cell[cell] + tab_frame[frame % zrows], v = tokens Wv^T + bias_v; w_packed =
+    gemm_bf16x3_pack(cat(Wk, Wv), mode='f16x2').  -> (k (F*hw,256), v (F*hw,256)).  csrc/gemm_bf16x3.hip, KV form."""
+    x = _chk(tokens, 'tokens')
+    Fr, S, C = x.shape
+    tc, tf, bv = _chk(tab_cell, 'tab_cell'), _chk(tab_frame, 'tab_frame'), _chk(bias_v, 'bias_v')
+    wp = _chk(w_packed, 'w_packed', torch.bfloat16)
+    if C != 256 or tuple(tc.shape) != (hw, 256) or tf.dim() != 2 or tf.shape[1] != 256 or bv.numel() != 256 or \
+            not _is_f16x2(wp, 512, 256) or start + hw > S:
+        raise RuntimeError('decoder_kv_project: inconsistent shapes')
+    k = torch.empty((Fr * hw, 256), device=x.device, dtype=torch.float32)
+    v = torch.empty_like(k)
+    with _on(x.device):
+        _lib.call('pvsg_decoder_kv_project_f16x2', x.data_ptr(), Fr, S, int(start), int(hw), wp.data_ptr(), tc.data_ptr(), tf.data_ptr(),
+                  int(tf.shape[0]), bv.data_ptr(), k.data_ptr(), v.data_ptr(), _overflow_counter(x.device).data_ptr(), _stream_ptr())
+    return k, v
+
+
 # ---- decoder query rows (decoder_rows.hip) ---------------------------------------------------------
 def pack_rows_weight(W):
     """(N,K) Linear weight -> MFMA-fragment order (roundup16(N)*K,), once per checkpoint."""

@@ -204,3 +204,39 @@ def test_rows_post_packs_the_mask_embeddings_for_the_bits_kernel(hip_lib, B, T, 
         fl = ((got.flags.to(torch.int64)[:, qq // 32] >> (qq % 32)) & 1).bool()
         assert torch.equal(fl, has)
     assert ops.split_overflow_count() == 0
+
+
+@pytest.mark.parametrize('video,B,T,hw', [(True, 1, 4, (23, 40)), (True, 2, 3, (8, 12)), (False, 3, 1, (46, 80)), (True, 1, 1, (16, 24))])
+def test_fused_kv_projection_equals_inputs_plus_two_gemms(hip_lib, video, B, T, hw):
+    """ops.decoder_kv_project (keys and values of a decoder level in one launch from the encoder memory, level_embed and the
+    positional encoding as epilogue tables) against the reference order: value input = memory + level_embed, key input = value
+    input + pos (mask2former_head.py:421-436), then the two in-projections of [3P] nn.MultiheadAttention -- in float64."""
+    from openpvsg_amd import ops
+    head = _head(video, 17)
+    h, w = hw
+    S = h * w + 37                                                    # the level sits inside a longer token tensor
+    start = 21
+    tok = det_input('tok', (B * T, S, 256), 4).to(DEV)
+    pe = head._pe_tokens(T, h, w, torch.device(DEV))
+    level = 1
+    mha = head.transformer_decoder.layers[4].attentions[0].attn
+    with torch.no_grad():
+        kp, vp = head._kv_project(mha, level, (tok, start, h * w, pe), B, T)
+        assert head.__dict__ is not None and mha.__dict__['_pvsg_kv_tables']       # the fused form ran (tables cached)
+        assert next(iter(mha.__dict__['_pvsg_kv_tables'].values())) is not False
+        W, b, le = mha.in_proj_weight.double(), mha.in_proj_bias.double(), head.level_embed.weight[level].double()
+        mem = tok[:, start:start + h * w].double().reshape(B, T * h * w, 256)
+        v_in = mem + le
+        k_in = v_in + (pe.double()[None] if video else pe.double().repeat(T, 1)[None])
+        k_ref = k_in @ W[256:512].t() + b[256:512]
+        v_ref = v_in @ W[512:].t() + b[512:]
+    assert kp.shape == (B, T * h * w, 256) and vp.shape == kp.shape
+    for got, ref in ((kp, k_ref), (vp, v_ref)):
+        err = float((got.double() - ref).abs().max())
+        assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
+    # and against the product's own two-GEMM path at the bar of a re-association
+    with torch.no_grad():
+        v2, k2 = ops.decoder_kv_inputs(tok, start, h * w, head.level_embed.weight[level].detach(), pe)
+        k_old, v_old = head.transformer_decoder.layers[4].attentions[0].project_kv(k2.view(B, -1, 256), v2.view(B, -1, 256))
+    assert float((kp - k_old).abs().max()) < 1e-4 and float((vp - v_old).abs().max()) < 1e-4
+    assert ops.split_overflow_count() == 0
