@@ -490,6 +490,18 @@ int pvsg_stem7x7_bn_relu_pool(const float* x, const float* w_packed, const float
 int pvsg_group_norm_affine(const float* x, const float* weight, const float* bias, double* workspace, float* scale,
                            float* shift, int B, int C, int G, long long HW, float eps, void* stream);
 
+/* The same scale / shift from partial sums produced by a convolution's epilogue (no pass over its output):
+ * pvsg_conv1x1_f16x2_stats = pvsg_conv1x1_f16x2 (no input normalisation) that also writes, per (image, group of 8 output channels,
+ * chunk), the sum and sum of squares of what it stores into gn_partials (B * Cout/8 * pvsg_conv1x1_stats_chunks(H, W, stride)
+ * pairs of doubles); pvsg_group_norm_finish turns them into scale / shift as pvsg_group_norm_affine would.
+ * [3P] mmcv ConvModule(norm_cfg=GN) of the pixel decoder's input / lateral convolutions. */
+int pvsg_conv1x1_stats_chunks(int H, int W, int stride);
+int pvsg_conv1x1_f16x2_stats(const float* x, const void* w_packed, const float* scale, const float* shift, const float* residual,
+                             float* y, double* gn_partials, int B, int Cin, int Cout, int H, int W, int stride, int relu,
+                             uint32_t* overflow, void* stream);
+int pvsg_group_norm_finish(const double* partials, int nchunks, const float* weight, const float* bias, float* scale, float* shift,
+                           int B, int C, int G, long long HW, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -196,6 +196,24 @@ def conv1x1_fast(conv, x, scale=None, shift=None, residual=None, relu=False, out
                               in_shift=in_norm[1] if in_norm is not None else None)
 
 
+def conv1x1_gn_fast(conv, gn, x):
+    """[3P] mmcv ConvModule(1x1 conv -> GroupNorm) as (raw conv output, scale, shift) with GN(raw) == raw * scale[b,c] + shift[b,c]:
+    the statistics come out of the convolution's epilogue (ops.conv1x1_f16x2_gn) instead of a second pass over its output.
+    None where that form does not apply (the caller then runs conv1x1_fast + ops.group_norm_affine)."""
+    w = conv.weight
+    cout, cin = w.shape[:2]
+    if not (isinstance(gn, nn.GroupNorm) and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and
+            conv.groups == 1 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and
+            not torch.is_grad_enabled() and os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and ops.split_mode() == 'f16x2' and
+            cin % 32 == 0):
+        return None
+    wp = _packed_weight(conv, 'conv1x1', (w.data_ptr(), w._version, str(w.device)),
+                        lambda: ops.gemm_bf16x3_pack(w.detach().reshape(cout, cin).contiguous()))
+    if not ops.conv1x1_gn_supported(wp, cout, cin, x.shape[2], x.shape[3], gn):
+        return None
+    return ops.conv1x1_f16x2_gn(x, wp, cout, gn, bias=conv.bias)
+
+
 def linear_fast(owner, tag, weights, x, bias=None, relu=False):
     """act(F.linear(x, cat(weights), bias)) for a token-major f32 tensor.  On the HIP device this runs on the bf16 matrix
     cores from an exact three-limb split of both operands (csrc/gemm_bf16x3.hip: f32-class accuracy, 1.3-1.45x the
@@ -814,10 +832,14 @@ class MSDeformAttnPixelDecoder(BaseModule):
             start = 0
             for i, (h, w) in enumerate(shapes):
                 m = self.input_convs[i]
-                raw = conv1x1_fast(m.conv, feats[self.num_input_levels - 1 - i], always=True)
-                if raw is None:
-                    raw = m.conv(feats[self.num_input_levels - 1 - i])
-                sc, sh = ops.group_norm_affine(raw, m.gn) if m.gn is not None else (None, None)
+                fused = conv1x1_gn_fast(m.conv, m.gn, feats[self.num_input_levels - 1 - i]) if m.gn is not None else None
+                if fused is not None:
+                    raw, sc, sh = fused                                  # GroupNorm statistics from the convolution's epilogue
+                else:
+                    raw = conv1x1_fast(m.conv, feats[self.num_input_levels - 1 - i], always=True)
+                    if raw is None:
+                        raw = m.conv(feats[self.num_input_levels - 1 - i])
+                    sc, sh = ops.group_norm_affine(raw, m.gn) if m.gn is not None else (None, None)
                 ops.nchw_to_tokens(raw, x, start, sc, sh)
                 start += h * w
         else:
@@ -858,10 +880,15 @@ class MSDeformAttnPixelDecoder(BaseModule):
             if (glue and lm.gn is not None and not lm.act and om.gn is not None and om.act and
                     (hl, wl) == (2 * top.shape[-2], 2 * top.shape[-1]) and top.shape[-1] % 2 == 0):
                 # GN(lateral) + x2 bilinear(top) in one pass; GN + ReLU after the 3x3 conv in one in-place pass
-                raw = conv1x1_fast(lm.conv, feats[i], always=True)
-                if raw is None:
-                    raw = lm.conv(feats[i])
-                y = ops.fpn_merge_up2x(raw, *ops.group_norm_affine(raw, lm.gn), top.contiguous())
+                fused = conv1x1_gn_fast(lm.conv, lm.gn, feats[i])
+                if fused is not None:
+                    raw, lsc, lsh = fused
+                else:
+                    raw = conv1x1_fast(lm.conv, feats[i], always=True)
+                    if raw is None:
+                        raw = lm.conv(feats[i])
+                    lsc, lsh = ops.group_norm_affine(raw, lm.gn)
+                y = ops.fpn_merge_up2x(raw, lsc, lsh, top.contiguous())
                 o = conv3x3_fast(om.conv, y)
                 if o is None:
                     o = om.conv(y)

@@ -560,6 +560,8 @@ void gemm_f16x2_dma_kernel(const float* __restrict__ A, const __bf16* __restrict
   auto frag = [](const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); };
   auto mf = [](u32x4 a, u32x4 b, f32x4 c) { return mfma_k32<true>(a, b, c); };
   const int KT = K / 32;
+  // 16-column blocks of this wave's 64 columns that hold real outputs (wave-uniform): 4 except in a ragged last column tile
+  const int ncb = __builtin_amdgcn_readfirstlane(min(4, max(0, (N - (n0 + wc * 64) + 15) >> 4)));
   dmaW(0, 0);
   loadA(0);
   split();
@@ -590,6 +592,7 @@ void gemm_f16x2_dma_kernel(const float* __restrict__ A, const __bf16* __restrict
     }
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {                             // small terms first: (l', 2^-11 h) (h, l) (h, h)
+      if (cb >= ncb) continue;                                   // column blocks past N (ragged last tile, e.g. N = 544): no MFMAs
       const u32x4 wh = frag(wfr + cb * 128), wl = frag(wfr + K32_LIMB + cb * 128), wh2 = f16x2_lo_scale(wh);
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wh2, alf[rb], acc[rb][cb]);
@@ -1427,7 +1430,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
                                const float* __restrict__ in_scale, const float* __restrict__ in_shift, float* __restrict__ y,
                                int Cin, int Cout, int Cpad, int HWin, int Win, int HWo, int Wo, int stride, int tiles_c,
                                int tiles_p, unsigned* __restrict__ flags = nullptr, unsigned* __restrict__ overflow = nullptr,
-                               int imgs_per_w = 0, long long w_batch_stride = 0) {
+                               int imgs_per_w = 0, long long w_batch_stride = 0, double* __restrict__ gn_part = nullptr) {
   constexpr int XL = F16 ? 2 : 3;                                // limbs of the on-the-fly (pixel) operand
   constexpr int WL = F16 ? 2 : 3;                                // arrays of the packed weight
   constexpr int X_AT = WL * K32_LIMB;                            // where the pixel tile starts
@@ -1667,6 +1670,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
           for (int r = 0; r < 4; ++r)
             res[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, pvoff[cb] + (unsigned)(chb + r) * chpitch, 0, 0));
       }
+      float gs = 0.f, gq = 0.f;                                     // GroupNorm statistics of what is stored (gn_part != nullptr)
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -1674,9 +1678,26 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
           float v = fmaf(acc[rb][cb][r], sc4[r], sh4[r]);
           if (RESIDUAL) v += res[cb][r];
           if (RELU) v = fmaxf(v, 0.f);
+          if (pvoff[cb] != 0x80000000u) { gs += v; gq = fmaf(v, v, gq); }
           if (PVSG_ABL == 11 && v != 1.2345e33f) continue;        // lab build: no epilogue stores (timing only)
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, pvoff[cb] + (unsigned)(chb + r) * chpitch, 0, 0);
         }
+      if constexpr (TM == 128) {
+        if (gn_part) {
+          // groups of 8 channels: lanes (l15 = 0..15, kg4 in {0,1} | {2,3}) x this row block hold one group's values of the wave's
+          // 64 pixels.  Fixed-order reduction (bit-reproducible); one (sum, sum of squares) pair per (image, group, pixel tile,
+          // wave column) into `gn_part`, summed in f64 by gn_finish_kernel: the statistics pass over the 1.9 GB the convolution
+          // has just written never runs.
+#pragma unroll
+          for (int off = 1; off <= 16; off <<= 1) { gs += __shfl_xor(gs, off); gq += __shfl_xor(gq, off); }
+          if (l15 == 0 && (kg4 & 1) == 0 && chb < Cout) {
+            const int g = (chb >> 3), G = Cout >> 3;
+            double* dst = gn_part + ((((size_t)img * G + g) * tiles_p + tp) * 2 + wc) * 2;
+            dst[0] = (double)gs;
+            dst[1] = (double)gq;
+          }
+        }
+      }
     }
   }
 }
@@ -2133,7 +2154,8 @@ extern "C" int pvsg_decoder_kv_project_f16x2(const float* tokens, int frames, in
 
 static int conv1x1_split_run(const float* x, const void* w_packed, const float* scale, const float* shift,
                              const float* residual, const float* in_scale, const float* in_shift, float* y, int B, int Cin,
-                             int Cout, int H, int W, int stride, int relu, bool f16, uint32_t* overflow, void* stream) {
+                             int Cout, int H, int W, int stride, int relu, bool f16, uint32_t* overflow, void* stream,
+                             double* gn_part = nullptr) {
   using namespace pvsg;
   const char* nm = f16 ? "conv1x1_f16x2" : "conv1x1_bf16x3";
   PVSG_REQUIRE(x && w_packed && y, "%s: null pointer argument", nm);
@@ -2161,10 +2183,12 @@ static int conv1x1_split_run(const float* x, const void* w_packed, const float* 
   const char* sel = getenv("PVSG_GEMM_K32");
   const bool k32 = f16 || (Cin % 32 == 0 && !(sel && sel[0] == '0') && ((sel && sel[0] == '1') || stride == 2 || Ho * Wo >= 2048));
   const bool tm64 = k32 && Cout <= 64;
+  if (gn_part && (!f16 || tm64 || Cout % 8))
+    return set_err(PVSG_ERR_UNSUPPORTED, "%s: GroupNorm statistics come with the f16x2 form, Cout > 64, groups of 8 channels", nm);
 #define PVSG_C1_K32(R, S, NORM, TMV, F)                                                                                  \
   hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<R, S, NORM, false, TMV, 1, F>), grid, block, 0, st, x, wp, scale, shift,  \
                      residual, in_scale, in_shift, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p, \
-                     noflags, overflow)
+                     noflags, overflow, 0, 0LL, gn_part)
 #define PVSG_C1_LAUNCH(R, S)                                                                                            \
   do {                                                                                                                  \
     if (f16) { if (tm64) PVSG_C1_K32(R, S, false, 64, true); else PVSG_C1_K32(R, S, false, 128, true); }                 \
@@ -2205,6 +2229,21 @@ extern "C" int pvsg_conv1x1_f16x2(const float* x, const void* w_packed, const fl
                                   int Cin, int Cout, int H, int W, int stride, int relu, uint32_t* overflow, void* stream) {
   return conv1x1_split_run(x, w_packed, scale, shift, residual, in_scale, in_shift, y, B, Cin, Cout, H, W, stride, relu, true,
                            overflow, stream);
+}
+
+// pvsg_conv1x1_f16x2 that also leaves the GroupNorm statistics of its OUTPUT behind ([3P] mmcv ConvModule(norm_cfg=GN): conv -> GN;
+// groups of 8 channels): gn_partials receives B * (Cout / 8) * pvsg_conv1x1_stats_chunks(H, W, stride) pairs of doubles (sum, sum of
+// squares), to be turned into per-(image, channel) scale / shift by pvsg_group_norm_finish.
+extern "C" int pvsg_conv1x1_stats_chunks(int H, int W, int stride) {
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  return 2 * ((Ho * Wo + pvsg::GB_N - 1) / pvsg::GB_N);
+}
+extern "C" int pvsg_conv1x1_f16x2_stats(const float* x, const void* w_packed, const float* scale, const float* shift,
+                                        const float* residual, float* y, double* gn_partials, int B, int Cin, int Cout, int H, int W,
+                                        int stride, int relu, uint32_t* overflow, void* stream) {
+  PVSG_REQUIRE(gn_partials, "conv1x1_f16x2_stats: null pointer argument");
+  return conv1x1_split_run(x, w_packed, scale, shift, residual, nullptr, nullptr, y, B, Cin, Cout, H, W, stride, relu, true, overflow,
+                           stream, gn_partials);
 }
 
 // [3P] mmdet ResNet Bottleneck.conv2 (3x3, pad 1, stride 1 or 2) + frozen BN + ReLU on the split kernel: implicit GEMM over the

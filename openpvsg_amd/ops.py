@@ -1045,6 +1045,38 @@ def conv1x1_bf16x3(x, w_packed, cout, scale=None, shift=None, residual=None, rel
     return out
 
 
+def conv1x1_f16x2_gn(x, w_packed, cout, gn, bias=None, out=None):
+    """conv1x1(x, w) (+ bias) with the GroupNorm statistics of the OUTPUT produced by the convolution's epilogue ([3P] mmcv
+    ConvModule(norm_cfg=GN)): -> (raw output, scale (B*C), shift (B*C)) with GroupNorm(raw) == raw * scale[b,c] + shift[b,c],
+    i.e. what conv1x1_bf16x3 + group_norm_affine return, without the statistics pass over the output.  f16x2 form, groups of 8."""
+    x = _chk(x, 'x')
+    B, Cin, H, W = x.shape
+    wp = _chk(w_packed, 'w_packed', torch.bfloat16)
+    G = gn.num_groups
+    if not conv1x1_gn_supported(wp, cout, Cin, H, W, gn):
+        raise RuntimeError('conv1x1_f16x2_gn: unsupported shape Cout=%d Cin=%d groups=%d' % (cout, Cin, G))
+    if out is None:
+        out = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    nch = int(lib.pvsg_conv1x1_stats_chunks(H, W, 1))
+    part = torch.empty((B * G * nch * 2,), device=x.device, dtype=torch.float64)
+    scale = torch.empty(B * cout, device=x.device, dtype=torch.float32)
+    shift = torch.empty(B * cout, device=x.device, dtype=torch.float32)
+    with _on(x.device):
+        _lib.call('pvsg_conv1x1_f16x2_stats', x.data_ptr(), wp.data_ptr(), None, _chk(bias, 'bias').data_ptr() if bias is not None else None,
+                  None, out.data_ptr(), part.data_ptr(), B, Cin, cout, H, W, 1, 0, _overflow_counter(x.device).data_ptr(), _stream_ptr())
+        _lib.call('pvsg_group_norm_finish', part.data_ptr(), nch, gn.weight.data_ptr() if gn.weight is not None else None,
+                  gn.bias.data_ptr() if gn.bias is not None else None, scale.data_ptr(), shift.data_ptr(), B, cout, G, H * W,
+                  float(gn.eps), _stream_ptr())
+    return out, scale, shift
+
+
+def conv1x1_gn_supported(w_packed, cout, cin, h, w, gn):
+    return (cout % gn.num_groups == 0 and cout // gn.num_groups == 8 and cout > 64 and cin % 32 == 0 and
+            conv1x1_bf16x3_supported(cout, cin, h, w) and _is_f16x2(w_packed, cout, cin) and
+            os.environ.get('PVSG_GN_EPILOGUE', 'on') != 'off')
+
+
 def stem7x7_pack(weight):
     """(64,3,7,7) stem weight -> the operand order of csrc/stem7x7.hip (once per weight)."""
     w = _chk(weight, 'weight')
