@@ -296,7 +296,8 @@ class KernelTimer:
 
     KEPT_HINT = 32             # kept queries of the synthetic head outputs (--keep): the device-side tail does not tell the host
     SPLIT_F16X2 = ('pvsg_gemm_f16x2', 'pvsg_gemm_f16x2_add_layernorm', 'pvsg_conv1x1_f16x2', 'pvsg_conv3x3_f16x2',
-                   'pvsg_mask_logits_f16x2', 'pvsg_attn_mask_bits_f16x2', 'pvsg_attn_mask_bits_packed_f16x2')
+                   'pvsg_mask_logits_f16x2', 'pvsg_attn_mask_bits_f16x2', 'pvsg_attn_mask_bits_packed_f16x2',
+                   'pvsg_conv1x1_f16x2_stats', 'pvsg_conv3x3_f16x2_stats')
 
     @classmethod
     def work(cls, name, a):
@@ -307,6 +308,13 @@ class KernelTimer:
         if name == 'pvsg_attn_mask_bits_packed_f16x2':   # embeddings pre-packed by decoder_rows_post: (pack, f, bits, flags, B, T, Q, C, N, ..)
             B, T, Q, C, N = a[4:9]
             return 4.0 * B * T * N * C + 16.0 * B * T * N, 6.0 * B * T * Q * C * N
+        if name == 'pvsg_conv1x1_f16x2_stats':          # pvsg_conv1x1_f16x2 + GroupNorm partial sums (x, wp, scale, shift, residual, y, part, B, ..)
+            B, Cin, Cout, H, W, st = a[7:13]
+            hw = ((H - 1) // st + 1) * ((W - 1) // st + 1)
+            return 4.0 * B * hw * (Cin + Cout * (2 if a[4] else 1)) + 6.0 * Cin * Cout, 6.0 * B * Cin * Cout * hw
+        if name == 'pvsg_conv3x3_f16x2_stats':          # (x, wp, scale, shift, y, part, B, Cin, Cout, H, W, relu, ..), stride 1
+            N, Cin, Cout, H, W = a[6:11]
+            return 4.0 * N * H * W * (Cin + Cout) + 54.0 * Cin * Cout, 3 * 18.0 * N * Cin * Cout * H * W
         if name in cls.SPLIT_F16X2:
             # two-limb f16 form: same arguments up to the trailing (overflow, stream); flops = the f16 limb products issued,
             # 3 per f32 multiply-add (the bf16 form issues 6)

@@ -499,6 +499,11 @@ int pvsg_conv1x1_stats_chunks(int H, int W, int stride);
 int pvsg_conv1x1_f16x2_stats(const float* x, const void* w_packed, const float* scale, const float* shift, const float* residual,
                              float* y, double* gn_partials, int B, int Cin, int Cout, int H, int W, int stride, int relu,
                              uint32_t* overflow, void* stream);
+/* The 3x3 form (stride 1, pad 1, Cout > 64 in groups of 8): the FPN output convolution -> GN -> ReLU of
+ * [3P] mmdet MSDeformAttnPixelDecoder.output_convs; chunks = pvsg_conv3x3_stats_chunks(H, W). */
+int pvsg_conv3x3_stats_chunks(int H, int W);
+int pvsg_conv3x3_f16x2_stats(const float* x, const void* w_packed, const float* scale, const float* shift, float* y,
+                             double* gn_partials, int B, int Cin, int Cout, int H, int W, int relu, uint32_t* overflow, void* stream);
 int pvsg_group_norm_finish(const double* partials, int nchunks, const float* weight, const float* bias, float* scale, float* shift,
                            int B, int C, int G, long long HW, float eps, void* stream);
 

@@ -101,6 +101,8 @@ SIGNATURES = {
     'pvsg_group_norm_affine': [_c_f] * 6 + [_i, _i, _i, _ll, _f, _c_f],
     'pvsg_conv1x1_stats_chunks': [_i, _i, _i],
     'pvsg_conv1x1_f16x2_stats': [_c_f] * 7 + [_i] * 7 + [_c_f, _c_f],
+    'pvsg_conv3x3_stats_chunks': [_i, _i],
+    'pvsg_conv3x3_f16x2_stats': [_c_f] * 6 + [_i] * 6 + [_c_f, _c_f],
     'pvsg_group_norm_finish': [_c_f, _i, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _ll, _f, _c_f],
     'pvsg_stem7x7_bn_relu_pool': [_c_f] * 5 + [_i, _i, _i, _c_f],
     'pvsg_conv3x3s2_affine': [_c_f] * 5 + [_i] * 6 + [_c_f],
@@ -108,7 +110,8 @@ SIGNATURES = {
 # entry points that return a value instead of a status code
 VALUE_RETURNING = ('pvsg_xattn_num_splits', 'pvsg_gemm_bf16x3_packed_elems', 'pvsg_gemm_f16x2_packed_elems',
                    'pvsg_minvis_chain_workspace_bytes', 'pvsg_reconsdot_workspace_bytes', 'pvsg_rle_counts_to_chars',
-                   'pvsg_decoder_rows_post_workspace_bytes', 'pvsg_tube_index_table_words', 'pvsg_conv1x1_stats_chunks')
+                   'pvsg_decoder_rows_post_workspace_bytes', 'pvsg_tube_index_table_words', 'pvsg_conv1x1_stats_chunks',
+                   'pvsg_conv3x3_stats_chunks')
 
 _lib = None
 

@@ -214,6 +214,24 @@ def conv1x1_gn_fast(conv, gn, x):
     return ops.conv1x1_f16x2_gn(x, wp, cout, gn, bias=conv.bias)
 
 
+def conv3x3_gn_fast(conv, gn, x):
+    """[3P] mmcv ConvModule(3x3 conv -> GroupNorm [-> ReLU]) as (raw conv output, scale, shift), the statistics out of the
+    convolution's epilogue (ops.conv3x3_f16x2_gn); None where that form does not apply."""
+    w = conv.weight
+    if not (isinstance(gn, nn.GroupNorm) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and
+            conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and x.is_cuda and x.dtype == torch.float32 and
+            x.dim() == 4 and x.is_contiguous() and not torch.is_grad_enabled() and os.environ.get('PVSG_WINOGRAD', 'on') != 'off' and
+            os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and os.environ.get('PVSG_CONV3X3', 'bf16x3') != 'f32' and
+            ops.split_mode() == 'f16x2' and w.shape[1] >= 64 and
+            ops.conv3x3_bf16x3_supported(w.shape[0], w.shape[1], x.shape[2], x.shape[3])):
+        return None
+    pack = ops.conv3x3_bf16x3_pack
+    wp = _packed_weight(conv, pack.__name__, (w.data_ptr(), w._version, str(w.device)), lambda: pack(w.detach()))
+    if not ops.conv3x3_gn_supported(wp, w.shape[0], w.shape[1], x.shape[2], x.shape[3], gn):
+        return None
+    return ops.conv3x3_f16x2_gn(x, wp, w.shape[0], gn)
+
+
 def linear_fast(owner, tag, weights, x, bias=None, relu=False):
     """act(F.linear(x, cat(weights), bias)) for a token-major f32 tensor.  On the HIP device this runs on the bf16 matrix
     cores from an exact three-limb split of both operands (csrc/gemm_bf16x3.hip: f32-class accuracy, 1.3-1.45x the
@@ -889,10 +907,14 @@ class MSDeformAttnPixelDecoder(BaseModule):
                         raw = lm.conv(feats[i])
                     lsc, lsh = ops.group_norm_affine(raw, lm.gn)
                 y = ops.fpn_merge_up2x(raw, lsc, lsh, top.contiguous())
-                o = conv3x3_fast(om.conv, y)
-                if o is None:
-                    o = om.conv(y)
-                sc, sh = ops.group_norm_affine(o, om.gn)
+                fused = conv3x3_gn_fast(om.conv, om.gn, y)
+                if fused is not None:
+                    o, sc, sh = fused
+                else:
+                    o = conv3x3_fast(om.conv, y)
+                    if o is None:
+                        o = om.conv(y)
+                    sc, sh = ops.group_norm_affine(o, om.gn)
                 if i == 0 and isinstance(self.mask_feature, nn.Conv2d):
                     # last FPN level: its only consumer is the mask-feature 1x1 convolution, which applies the GroupNorm
                     # + ReLU while it stages its input -- the 1.9 GB normalise pass never runs

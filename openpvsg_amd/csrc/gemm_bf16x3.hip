@@ -1717,7 +1717,8 @@ template <bool RELU, int CT>
 __global__ __launch_bounds__(256, 2)
 void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ scale,
                                const float* __restrict__ shift, float* __restrict__ y, int Cin, int Cout, int Cpad, int H, int W,
-                               int tiles_c, int tiles_x, int tiles_y, unsigned* __restrict__ overflow) {
+                               int tiles_c, int tiles_x, int tiles_y, unsigned* __restrict__ overflow,
+                               double* __restrict__ gn_part = nullptr) {
   constexpr int PR = CT == 128 ? 8 : 16;                         // pixel rows of the tile
   constexpr int PH = PR + 2, PW = 18, PP = PH * PW;              // patch
   constexpr int P_KG = PP * 8, P_LIMB = 4 * P_KG;                // elements
@@ -1866,14 +1867,30 @@ void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __rest
                         : f32x4{1.f, 1.f, 1.f, 1.f};
       sc4 *= unscale;
       const f32x4 sh4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, (unsigned)chb * 4u, 0, 0));
+      float gs = 0.f, gq = 0.f;                                     // GroupNorm statistics of what is stored (gn_part != nullptr)
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = fmaf(acc[rb][cb][r], sc4[r], sh4[r]);
           if (RELU) v = fmaxf(v, 0.f);
+          if (pvoff[cb] != 0x80000000u) { gs += v; gq = fmaf(v, v, gq); }
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, pvoff[cb] + (unsigned)(chb + r) * chpitch, 0, 0);
         }
+      if constexpr (CT == 128) {
+        if (gn_part) {
+          // as in conv1x1_bf16x3_k32_kernel: groups of 8 channels = lanes (l15, kg4 in {0,1} | {2,3}) of this row block, the wave's
+          // 4 x 16 pixels; one (sum, sum of squares) pair per (image, group, pixel tile, wave pixel half), fixed order
+#pragma unroll
+          for (int off = 1; off <= 16; off <<= 1) { gs += __shfl_xor(gs, off); gq += __shfl_xor(gq, off); }
+          if (l15 == 0 && (kg4 & 1) == 0 && chb < Cout) {
+            const int g = (chb >> 3), G = Cout >> 3;
+            double* dst = gn_part + ((((size_t)img * G + g) * (tiles_y * tiles_x) + (ty * tiles_x + tx)) * 2 + wc) * 2;
+            dst[0] = (double)gs;
+            dst[1] = (double)gq;
+          }
+        }
+      }
     }
   }
   f16x2_count_overflow(amax, overflow);
@@ -2251,7 +2268,8 @@ extern "C" int pvsg_conv1x1_f16x2_stats(const float* x, const void* w_packed, co
 // channel-minor).  Direct-form arithmetic (18 Cin Cout flop per output pixel): it wins where the f32 kernels are weakest -- the
 // stride-2 layers (pvsg_conv3x3s2_affine) and, against Winograd (pvsg_conv3x3_winograd), the 64- and 512-channel layers.
 static int conv3x3_split_run(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B,
-                             int Cin, int Cout, int H, int W, int stride, int relu, bool f16, uint32_t* overflow, void* stream) {
+                             int Cin, int Cout, int H, int W, int stride, int relu, bool f16, uint32_t* overflow, void* stream,
+                             double* gn_part = nullptr) {
   using namespace pvsg;
   const char* nm = f16 ? "conv3x3_f16x2" : "conv3x3_bf16x3";
   PVSG_REQUIRE(x && w_packed && y, "%s: null pointer argument", nm);
@@ -2282,7 +2300,9 @@ static int conv3x3_split_run(const float* x, const void* w_packed, const float* 
       PVSG_REQUIRE(hb < (1LL << 31), "%s: too many blocks", nm);
 #define PVSG_HALO_LAUNCH(R, C)                                                                                                     \
   hipLaunchKernelGGL((conv3x3_f16x2_halo_kernel<R, C>), dim3((unsigned)hb), block, 0, st, x, wp, scale, shift, y, Cin, Cout, Cpad, \
-                     H, W, tc, tiles_x, tiles_y, overflow)
+                     H, W, tc, tiles_x, tiles_y, overflow, gn_part)
+      if (gn_part && (!wide || Cout % 8))
+        return set_err(PVSG_ERR_UNSUPPORTED, "%s: the GroupNorm-statistics epilogue needs Cout > 64 in groups of 8 channels", nm);
       if (wide) { if (relu) PVSG_HALO_LAUNCH(true, 128); else PVSG_HALO_LAUNCH(false, 128); }
       else { if (relu) PVSG_HALO_LAUNCH(true, 64); else PVSG_HALO_LAUNCH(false, 64); }
 #undef PVSG_HALO_LAUNCH
@@ -2290,6 +2310,7 @@ static int conv3x3_split_run(const float* x, const void* w_packed, const float* 
       return PVSG_OK;
     }
   }
+  if (gn_part) return set_err(PVSG_ERR_UNSUPPORTED, "%s: the GroupNorm-statistics epilogue is built into the stride-1 f16x2 form", nm);
 #define PVSG_C3_LAUNCH(R, TMV, F)                                                                                               \
   hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<R, false, false, false, TMV, 9, F>), grid, block, 0, st, x, wp, scale, shift, nul, \
                      nul, nul, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p, noflags, overflow)
@@ -2339,6 +2360,17 @@ extern "C" int pvsg_conv3x3_bf16x3(const float* x, const void* w_packed, const f
 extern "C" int pvsg_conv3x3_f16x2(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B,
                                   int Cin, int Cout, int H, int W, int stride, int relu, uint32_t* overflow, void* stream) {
   return conv3x3_split_run(x, w_packed, scale, shift, y, B, Cin, Cout, H, W, stride, relu, true, overflow, stream);
+}
+
+// pvsg_conv3x3_f16x2 (stride 1) that also leaves the GroupNorm statistics of its OUTPUT behind ([3P] mmcv ConvModule(3x3 conv ->
+// GN -> ReLU), the FPN output convolution of MSDeformAttnPixelDecoder): gn_partials receives B * (Cout / 8) *
+// pvsg_conv3x3_stats_chunks(H, W) pairs of doubles (sum, sum of squares) for pvsg_group_norm_finish.
+extern "C" int pvsg_conv3x3_stats_chunks(int H, int W) { return 2 * ((W + 15) / 16) * ((H + 7) / 8); }
+extern "C" int pvsg_conv3x3_f16x2_stats(const float* x, const void* w_packed, const float* scale, const float* shift, float* y,
+                                        double* gn_partials, int B, int Cin, int Cout, int H, int W, int relu, uint32_t* overflow,
+                                        void* stream) {
+  PVSG_REQUIRE(gn_partials, "conv3x3_f16x2_stats: null pointer argument");
+  return conv3x3_split_run(x, w_packed, scale, shift, y, B, Cin, Cout, H, W, 1, relu, true, overflow, stream, gn_partials);
 }
 
 // einsum('bqc,b[t]chw->b[t]qhw') (mask2former_head.py:382, mask2former_video_head.py:344) on the split kernels: per batch

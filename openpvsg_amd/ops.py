@@ -1071,6 +1071,37 @@ def conv1x1_f16x2_gn(x, w_packed, cout, gn, bias=None, out=None):
     return out, scale, shift
 
 
+def conv3x3_f16x2_gn(x, w_packed, cout, gn, out=None):
+    """conv3x3(x, w) (stride 1, pad 1, no bias) with the GroupNorm statistics of the OUTPUT from the convolution's epilogue:
+    -> (raw output, scale (B*C), shift (B*C)) as conv1x1_f16x2_gn ([3P] MSDeformAttnPixelDecoder.output_convs: conv -> GN -> ReLU)."""
+    x = _chk(x, 'x')
+    B, Cin, H, W = x.shape
+    wp = _chk(w_packed, 'w_packed', torch.bfloat16)
+    G = gn.num_groups
+    if not conv3x3_gn_supported(wp, cout, Cin, H, W, gn):
+        raise RuntimeError('conv3x3_f16x2_gn: unsupported shape Cout=%d Cin=%d groups=%d' % (cout, Cin, G))
+    if out is None:
+        out = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    nch = int(lib.pvsg_conv3x3_stats_chunks(H, W))
+    part = torch.empty((B * G * nch * 2,), device=x.device, dtype=torch.float64)
+    scale = torch.empty(B * cout, device=x.device, dtype=torch.float32)
+    shift = torch.empty(B * cout, device=x.device, dtype=torch.float32)
+    with _on(x.device):
+        _lib.call('pvsg_conv3x3_f16x2_stats', x.data_ptr(), wp.data_ptr(), None, None, out.data_ptr(), part.data_ptr(), B, Cin, cout,
+                  H, W, 0, _overflow_counter(x.device).data_ptr(), _stream_ptr())
+        _lib.call('pvsg_group_norm_finish', part.data_ptr(), nch, gn.weight.data_ptr() if gn.weight is not None else None,
+                  gn.bias.data_ptr() if gn.bias is not None else None, scale.data_ptr(), shift.data_ptr(), B, cout, G, H * W,
+                  float(gn.eps), _stream_ptr())
+    return out, scale, shift
+
+
+def conv3x3_gn_supported(w_packed, cout, cin, h, w, gn):
+    return (cout % gn.num_groups == 0 and cout // gn.num_groups == 8 and cout > 64 and cin % 32 == 0 and
+            conv3x3_bf16x3_supported(cout, cin, h, w) and _is_f16x2(w_packed, cout, 9 * cin) and
+            os.environ.get('PVSG_GN_EPILOGUE', 'on') != 'off' and os.environ.get('PVSG_CONV3X3_HALO', '1') != '0')
+
+
 def conv1x1_gn_supported(w_packed, cout, cin, h, w, gn):
     return (cout % gn.num_groups == 0 and cout // gn.num_groups == 8 and cout > 64 and cin % 32 == 0 and
             conv1x1_bf16x3_supported(cout, cin, h, w) and _is_f16x2(w_packed, cout, cin) and

@@ -149,6 +149,7 @@ def test_group_norm_affine_equals_torch_group_norm(hip_lib, B, C, G, H, W):
     assert torch.equal(sc, sc2) and torch.equal(sh, sh2)
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize('B,Cin,Cout,H,W', [(2, 256, 256, 23, 40), (3, 2048, 256, 8, 12), (1, 512, 256, 46, 80), (2, 64, 128, 17, 9)])
 def test_conv1x1_with_groupnorm_statistics_from_its_epilogue(hip_lib, B, Cin, Cout, H, W):
     """ops.conv1x1_f16x2_gn: the 1x1 convolution's epilogue leaves per-(image, group, chunk) partial sums of what it stores, and
@@ -175,4 +176,33 @@ def test_conv1x1_with_groupnorm_statistics_from_its_epilogue(hip_lib, B, Cin, Co
     assert torch.allclose(sc, sc2, rtol=1e-5, atol=1e-7) and torch.allclose(sh, sh2, rtol=1e-5, atol=1e-6)
     r3, s3, h3 = ops.conv1x1_f16x2_gn(x, wp, Cout, gn)
     assert torch.equal(sc, s3) and torch.equal(sh, h3)           # fixed-order reduction: bitwise run to run
+    assert ops.split_overflow_count() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,Cin,Cout,H,W', [(2, 256, 256, 23, 40), (1, 64, 128, 17, 35), (3, 128, 256, 8, 16)])
+def test_conv3x3_with_groupnorm_statistics_from_its_epilogue(hip_lib, B, Cin, Cout, H, W):
+    """ops.conv3x3_f16x2_gn: the same for the FPN output convolution ([3P] MSDeformAttnPixelDecoder.output_convs: 3x3 conv -> GN ->
+    ReLU) -- partial sums per (image, group, 8 x 16 pixel tile, wave half), ragged tiles included."""
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(B + Cin + H)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda() * 1.3 - 0.2
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).cuda()
+    gn = torch.nn.GroupNorm(Cout // 8, Cout).cuda()
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+        gn.bias.copy_(torch.randn(Cout, generator=g))
+    wp = ops.conv3x3_bf16x3_pack(w)
+    assert ops.conv3x3_gn_supported(wp, Cout, Cin, H, W, gn)
+    raw, sc, sh = ops.conv3x3_f16x2_gn(x, wp, Cout, gn)
+    raw2 = ops.conv3x3_bf16x3(x, wp, Cout, relu=False)
+    assert torch.equal(raw, raw2)
+    sc2, sh2 = ops.group_norm_affine(raw2, gn)
+    y = raw * sc.view(B, Cout, 1, 1) + sh.view(B, Cout, 1, 1)
+    ref = F.group_norm(F.conv2d(x.double().cpu(), w.double().cpu(), padding=1), Cout // 8, gn.weight.double().cpu(),
+                       gn.bias.double().cpu(), gn.eps)
+    assert float((y.double().cpu() - ref).abs().max()) < 2e-5
+    assert torch.allclose(sc, sc2, rtol=1e-5, atol=1e-7) and torch.allclose(sh, sh2, rtol=1e-5, atol=1e-6)
+    r3, s3, h3 = ops.conv3x3_f16x2_gn(x, wp, Cout, gn)
+    assert torch.equal(sc, s3) and torch.equal(sh, h3)
     assert ops.split_overflow_count() == 0
