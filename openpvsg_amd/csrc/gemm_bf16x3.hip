@@ -20,6 +20,15 @@
 // per element pair, hidden beside the bf16 MFMAs); W is split once by pvsg_gemm_bf16x3_pack into the staging order.
 // LDS tiles are [limb][k-group of 8][row][8 bf16]: consecutive lanes read consecutive 16-byte groups.
 #include "common.h"
+
+// lab switches (scripts/lab/r05_nt_lab.sh): cache-policy bits of the 1x1 convolution's streaming accesses (gfx940+: 1 = sc0, 2 = nt,
+// 16 = sc1); the product build uses 0 everywhere
+#ifndef PVSG_NT_ST
+#define PVSG_NT_ST 0
+#endif
+#ifndef PVSG_NT_LD
+#define PVSG_NT_LD 0
+#endif
 #include <stdlib.h>
 
 #include <type_traits>
@@ -1483,7 +1492,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
 #if defined(PVSG_ABL) && (PVSG_ABL == 8 || PVSG_ABL == 9)
         x_regs[gq][j] = 0.5f + (float)(so + j);        // lab build: no pixel loads (timing only)
 #else
-        x_regs[gq][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff, so + j * plane, 0));
+        x_regs[gq][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff, so + j * plane, PVSG_NT_LD));
 #endif
       }
       const __bf16* wk = wsrc + (size_t)(2 * kt + gq) * WL * w_limb_stride;
@@ -1668,7 +1677,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            res[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, pvoff[cb] + (unsigned)(chb + r) * chpitch, 0, 0));
+            res[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, pvoff[cb] + (unsigned)(chb + r) * chpitch, 0, PVSG_NT_LD));
       }
       float gs = 0.f, gq = 0.f;                                     // GroupNorm statistics of what is stored (gn_part != nullptr)
 #pragma unroll
@@ -1680,7 +1689,7 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
           if (RELU) v = fmaxf(v, 0.f);
           if (pvoff[cb] != 0x80000000u) { gs += v; gq = fmaf(v, v, gq); }
           if (PVSG_ABL == 11 && v != 1.2345e33f) continue;        // lab build: no epilogue stores (timing only)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, pvoff[cb] + (unsigned)(chb + r) * chpitch, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, pvoff[cb] + (unsigned)(chb + r) * chpitch, 0, PVSG_NT_ST);
         }
       if constexpr (TM == 128) {
         if (gn_part) {
