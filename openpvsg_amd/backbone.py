@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .blocks import BaseModule, conv1x1_fast, conv3x3_fast
+from .blocks import BaseModule, _packed_weight, conv1x1_fast, conv3x3_fast
 from .registry import BACKBONES
 
 
@@ -65,18 +65,63 @@ class _Bottleneck(nn.Module):
         out = self.bn3(self.conv3(out))
         return F.relu(out + identity, inplace=True)
 
-    def forward_fused(self, x, aff, out=None, gemm=True):
+    def forward_fused(self, x, aff, out=None, gemm=True, mid=None, nxt=None, nxt_aff=None):
         """Frozen BN as per-channel affine: BN+ReLU and BN+residual+ReLU are one HIP pass each
         (csrc/elementwise.hip) behind MIOpen's convolutions.  `out`: where the block's result goes (a batch
-        slice of a stage-output tensor) instead of over conv3's own output."""
-        if self.downsample is None:
+        slice of a stage-output tensor) instead of over conv3's own output.
+        `mid`: this block's conv1 -> bn1 -> relu output when the previous block's tail already produced it; `nxt` / `nxt_aff`: the
+        next block of the stage -- on the 64-plane stage its conv1 runs inside this block's conv3 pass (ops.bottleneck_tail: the
+        256-channel map is not read again).  -> (block output, the next block's `mid` or None)."""
+        head = self._head_fused(x, aff) if mid is None and self.downsample is not None else None
+        if head is not None:
+            identity, mid = head
+        elif self.downsample is None:
             identity = x
         else:
             identity = _conv_bn(self.downsample[0], x, aff['ds'], None, False, None, gemm)
-        y = _conv_bn(self.conv1, x, aff['bn1'], None, True, None, gemm)
+        y = mid if mid is not None else _conv_bn(self.conv1, x, aff['bn1'], None, True, None, gemm)
         y2 = conv3x3_fast(self.conv2, y, aff['bn2'][0], aff['bn2'][1], relu=True)     # BN + ReLU in the epilogue
         y = y2 if y2 is not None else ops.affine_act_nchw_(self.conv2(y), *aff['bn2'])
-        return _conv_bn(self.conv3, y, aff['bn3'], identity, True, out, gemm)
+        fused = self._tail_fused(y, aff, identity, out, nxt, nxt_aff)
+        if fused is not None:
+            return fused
+        return _conv_bn(self.conv3, y, aff['bn3'], identity, True, out, gemm), None
+
+    def _head_fused(self, x, aff):
+        """downsample(x) and relu(bn1(conv1(x))) from one read of x (ops.bottleneck_head) on the 64-plane stage, else None."""
+        ds, c1 = self.downsample[0], self.conv1
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and not torch.is_grad_enabled() and
+                os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and ds.kernel_size == (1, 1) and ds.stride == (1, 1) and ds.bias is None and
+                c1.kernel_size == (1, 1) and c1.stride == (1, 1) and c1.bias is None and c1.out_channels == 64 and
+                ops.bottleneck_tail_supported(ds.in_channels, ds.out_channels, 64, x.shape[2], x.shape[3])):
+            return None
+        packs = []
+        for c in (ds, c1):
+            w = c.weight
+            packs.append(_packed_weight(c, 'conv1x1', (w.data_ptr(), w._version, str(w.device)),
+                                        lambda w=w: ops.gemm_bf16x3_pack(w.detach().reshape(w.shape[0], w.shape[1]).contiguous())))
+        return ops.bottleneck_head(x, packs[0], aff['ds'][0], aff['ds'][1], packs[1], aff['bn1'][0], aff['bn1'][1])
+
+    def _tail_fused(self, y, aff, identity, out, nxt, nxt_aff):
+        c3 = self.conv3
+        if not (y.is_cuda and y.dtype == torch.float32 and y.is_contiguous() and identity.is_contiguous() and
+                not torch.is_grad_enabled() and os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib' and c3.bias is None and
+                (out is None or out.is_contiguous())):
+            return None
+        n1 = nxt.conv1 if nxt is not None else None
+        if n1 is not None and not (n1.kernel_size == (1, 1) and n1.stride == (1, 1) and n1.bias is None and n1.out_channels == 64 and
+                                   nxt.downsample is None):
+            n1 = None
+        if not ops.bottleneck_tail_supported(c3.in_channels, c3.out_channels, 64 if n1 is not None else None, y.shape[2], y.shape[3]):
+            return None
+        w3 = c3.weight
+        w3p = _packed_weight(c3, 'conv1x1', (w3.data_ptr(), w3._version, str(w3.device)),
+                             lambda: ops.gemm_bf16x3_pack(w3.detach().reshape(w3.shape[0], w3.shape[1]).contiguous()))
+        if n1 is None:
+            return ops.bottleneck_tail(y, w3p, aff['bn3'][0], aff['bn3'][1], identity, out=out)
+        w1 = n1.weight
+        w1p = _packed_weight(n1, 'bneck_next', (w1.data_ptr(), w1._version, str(w1.device)), lambda: ops.bottleneck_next_pack(w1.detach()))
+        return ops.bottleneck_tail(y, w3p, aff['bn3'][0], aff['bn3'][1], identity, w1p, nxt_aff['bn1'][0], nxt_aff['bn1'][1], out=out)
 
 
 @BACKBONES.register_module()
@@ -174,8 +219,11 @@ class ResNet(BaseModule):
         x = self._stem(x, aff)
         for li in range(1, 5):
             blocks = getattr(self, 'layer%d' % li)
+            mid = None
             for bi, blk in enumerate(blocks):
-                x = blk.forward_fused(x, aff[(li, bi)], out=outs[li - 1] if bi == len(blocks) - 1 else None, gemm=gemm)
+                last = bi == len(blocks) - 1
+                x, mid = blk.forward_fused(x, aff[(li, bi)], out=outs[li - 1] if last else None, gemm=gemm, mid=mid,
+                                           nxt=None if last else blocks[bi + 1], nxt_aff=None if last else aff[(li, bi + 1)])
 
     def forward(self, x):
         # Measured on MI355X (32x736x1280 fp32): MIOpen's fused conv+bias+ReLU plans (aten::miopen_convolution_relu

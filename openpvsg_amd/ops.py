@@ -1071,6 +1071,64 @@ def conv1x1_f16x2_gn(x, w_packed, cout, gn, bias=None, out=None):
     return out, scale, shift
 
 
+def bottleneck_next_pack(weight):
+    """(64, 256[,1,1]) conv1 weight of the NEXT bottleneck -> f16x2 limbs in the K order bottleneck_tail multiplies in."""
+    w = _chk(weight.reshape(weight.shape[0], -1), 'weight')
+    m = torch.empty_like(w)
+    with _on(w.device):
+        _lib.call('pvsg_bottleneck_next_weight_matrix', w.data_ptr(), m.data_ptr(), w.shape[0], w.shape[1], _stream_ptr())
+    return gemm_bf16x3_pack(m, mode='f16x2')
+
+
+def bottleneck_tail_supported(cmid, cout, cnext, h, w):
+    return (cmid == 64 and cout == 256 and cnext in (None, 64) and (h * w) % 2 == 0 and 256 * h * w * 4 < 2 ** 32 and
+            split_mode() == 'f16x2' and os.environ.get('PVSG_BNECK_FUSE', 'on') != 'off')
+
+
+def bottleneck_tail(mid, w3_packed, scale3, shift3, identity, w1n_packed=None, scale1n=None, shift1n=None, out=None):
+    """[3P] mmdet ResNet Bottleneck (64 planes): y = relu(conv3(mid) * scale3 + shift3 + identity) and, with w1n_packed
+    (bottleneck_next_pack of the next block's conv1), mid_next = relu(conv1_next(y) * scale1n + shift1n) in the same pass over the
+    pixels (csrc/gemm_bf16x3.hip bottleneck_tail64_kernel).  -> (y, mid_next or None)."""
+    mid, identity = _chk(mid, 'mid'), _chk(identity, 'identity')
+    B, Cmid, H, W = mid.shape
+    Cout = identity.shape[1]
+    nxt = w1n_packed is not None
+    if not bottleneck_tail_supported(Cmid, Cout, 64 if nxt else None, H, W) or tuple(identity.shape) != (B, Cout, H, W):
+        raise RuntimeError('bottleneck_tail: unsupported shape mid %s identity %s' % (tuple(mid.shape), tuple(identity.shape)))
+    if not (_is_f16x2(w3_packed, Cout, Cmid) and (not nxt or _is_f16x2(w1n_packed, 64, Cout))):
+        raise RuntimeError('bottleneck_tail: weights must be f16x2 packs of (256, 64) and (64, 256)')
+    if out is None:
+        out = torch.empty((B, Cout, H, W), device=mid.device, dtype=torch.float32)
+    elif not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (B, Cout, H, W)):
+        raise RuntimeError('bottleneck_tail: out must be a contiguous float32 HIP tensor (B,256,H,W)')
+    mid_next = torch.empty((B, 64, H, W), device=mid.device, dtype=torch.float32) if nxt else None
+    with _on(mid.device):
+        _lib.call('pvsg_bottleneck_tail_f16x2', mid.data_ptr(), w3_packed.data_ptr(), _chk(scale3, 'scale3').data_ptr(),
+                  _chk(shift3, 'shift3').data_ptr(), identity.data_ptr(), out.data_ptr(),
+                  w1n_packed.data_ptr() if nxt else None, _chk(scale1n, 'scale1n').data_ptr() if nxt else None,
+                  _chk(shift1n, 'shift1n').data_ptr() if nxt else None, mid_next.data_ptr() if nxt else None,
+                  B, Cmid, Cout, 64 if nxt else 0, H, W, _overflow_counter(mid.device).data_ptr(), _stream_ptr())
+    return out, mid_next
+
+
+def bottleneck_head(x, wds_packed, scale_ds, shift_ds, w1_packed, scale1, shift1):
+    """First block of the 64-plane stage from ONE read of its input x (B,64,H,W): identity = downsample_conv(x) * scale_ds +
+    shift_ds (256 channels, no ReLU) and mid = relu(conv1(x) * scale1 + shift1) (64 channels); both weights plain f16x2 packs.
+    -> (identity, mid)   ([3P] mmdet Bottleneck.forward: `identity = self.downsample(x)`, `out = relu(bn1(conv1(x)))`)."""
+    x = _chk(x, 'x')
+    B, C, H, W = x.shape
+    if not bottleneck_tail_supported(C, 256, 64, H, W) or not (_is_f16x2(wds_packed, 256, 64) and _is_f16x2(w1_packed, 64, 64)):
+        raise RuntimeError('bottleneck_head: unsupported shape %s' % (tuple(x.shape),))
+    idn = torch.empty((B, 256, H, W), device=x.device, dtype=torch.float32)
+    mid = torch.empty((B, 64, H, W), device=x.device, dtype=torch.float32)
+    with _on(x.device):
+        _lib.call('pvsg_bottleneck_tail_f16x2', x.data_ptr(), wds_packed.data_ptr(), _chk(scale_ds, 'scale_ds').data_ptr(),
+                  _chk(shift_ds, 'shift_ds').data_ptr(), None, idn.data_ptr(), w1_packed.data_ptr(), _chk(scale1, 'scale1').data_ptr(),
+                  _chk(shift1, 'shift1').data_ptr(), mid.data_ptr(), B, 64, 256, 64, H, W, _overflow_counter(x.device).data_ptr(),
+                  _stream_ptr())
+    return idn, mid
+
+
 def conv3x3_f16x2_gn(x, w_packed, cout, gn, out=None):
     """conv3x3(x, w) (stride 1, pad 1, no bias) with the GroupNorm statistics of the OUTPUT from the convolution's epilogue:
     -> (raw output, scale (B*C), shift (B*C)) as conv1x1_f16x2_gn ([3P] MSDeformAttnPixelDecoder.output_convs: conv -> GN -> ReLU)."""

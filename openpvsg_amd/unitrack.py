@@ -77,7 +77,7 @@ class _AppearanceResNet(ResNet):
             x = self._stem(x.contiguous(), aff)
             for li in (1, 2, 3):
                 for bi, blk in enumerate(getattr(self, 'layer%d' % li)):
-                    x = blk.forward_fused(x, aff[(li, bi)])
+                    x = blk.forward_fused(x, aff[(li, bi)])[0]
             return x
         x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, stride=2, padding=1)
         return self.layer3(self.layer2(self.layer1(x)))

@@ -1,0 +1,93 @@
+"""ops.bottleneck_tail (csrc/gemm_bf16x3.hip bottleneck_tail64_kernel): conv3 -> bn3 -> + identity -> ReLU of a 64-plane ResNet
+bottleneck and conv1 -> bn1 -> ReLU of the next block in one pass ([3P] mmdet ResNet Bottleneck.forward), against float64 and
+against the two separate split-kernel launches; the backbone with and without the fusion."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _case(B, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    mid = torch.relu(torch.randn(B, 64, H, W, generator=g)) * 1.5
+    idn = torch.relu(torch.randn(B, 256, H, W, generator=g)) * 2.0
+    w3 = torch.randn(256, 64, generator=g) / 8
+    w1 = torch.randn(64, 256, generator=g) / 16
+    s3, h3 = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.3
+    s1, h1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    return [t.to(DEV) for t in (mid, idn, w3, w1, s3, h3, s1, h1)]
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 23, 40), (1, 7, 10), (3, 16, 16), (1, 1, 2), (2, 184, 320)])
+def test_bottleneck_tail_matches_float64_and_the_separate_launches(hip_lib, B, H, W):
+    from openpvsg_amd import ops
+    mid, idn, w3, w1, s3, h3, s1, h1 = _case(B, H, W, B * 1000 + H)
+    w3p = ops.gemm_bf16x3_pack(w3, mode='f16x2')
+    w1np = ops.bottleneck_next_pack(w1.view(64, 256, 1, 1))
+    y, nxt = ops.bottleneck_tail(mid, w3p, s3, h3, idn, w1np, s1, h1)
+    d = lambda t: t.double().cpu()                                                          # noqa: E731
+    yr = torch.relu(torch.einsum('oc,bchw->bohw', d(w3), d(mid)) * d(s3).view(1, -1, 1, 1) + d(h3).view(1, -1, 1, 1) + d(idn))
+    nr = torch.relu(torch.einsum('oc,bchw->bohw', d(w1), yr) * d(s1).view(1, -1, 1, 1) + d(h1).view(1, -1, 1, 1))
+    assert float((d(y) - yr).abs().max()) < 2e-5 * max(1.0, float(yr.abs().max()))
+    assert float((d(nxt) - nr).abs().max()) < 2e-5 * max(1.0, float(nr.abs().max()))
+    # the two launches it replaces (same split arithmetic, another summation order for the second)
+    y2 = ops.conv1x1_bf16x3(mid, w3p, 256, s3, h3, idn, relu=True)
+    n2 = ops.conv1x1_bf16x3(y2, ops.gemm_bf16x3_pack(w1, mode='f16x2'), 64, s1, h1, None, relu=True)
+    assert torch.allclose(y, y2, rtol=1e-6, atol=1e-6) and torch.allclose(nxt, n2, rtol=1e-5, atol=1e-5)
+    # last block of the stage: conv3 only, into a caller's tensor
+    out = torch.full_like(y, float('nan'))
+    y3, none = ops.bottleneck_tail(mid, w3p, s3, h3, idn, out=out)
+    assert none is None and y3 is out and torch.equal(y3, y)
+    assert ops.split_overflow_count() == 0
+
+
+def test_bottleneck_tail_counts_out_of_range_operands(hip_lib):
+    from openpvsg_amd import ops
+    mid, idn, w3, w1, s3, h3, s1, h1 = _case(1, 4, 8, 5)
+    ops.split_overflow_count(reset=True)
+    idn[0, 3, 1, 1] = 1.0e5                                  # y > 65504: conv1_next's operand cannot be split into f16 limbs
+    ops.bottleneck_tail(mid, ops.gemm_bf16x3_pack(w3, mode='f16x2'), s3, h3, idn, ops.bottleneck_next_pack(w1), s1, h1)
+    assert ops.split_overflow_count(reset=True) > 0
+
+
+def test_backbone_layer1_with_and_without_the_fused_tails(hip_lib, monkeypatch):
+    from openpvsg_amd.backbone import ResNet
+    torch.manual_seed(3)
+    net = ResNet(depth=50, out_indices=(0, 1, 2, 3)).to(DEV).eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+        x = torch.randn(2, 3, 96, 160, device=DEV)
+        monkeypatch.setenv('PVSG_BNECK_FUSE', 'on')
+        a = net(x)
+        monkeypatch.setenv('PVSG_BNECK_FUSE', 'off')
+        b = net(x)
+    for ya, yb in zip(a, b):
+        assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4 * float(yb.abs().max()))
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 23, 40), (1, 5, 6)])
+def test_bottleneck_head_downsample_and_conv1_from_one_read(hip_lib, B, H, W):
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(B + H)
+    x = (torch.relu(torch.randn(B, 64, H, W, generator=g)) * 1.5).to(DEV)
+    wds, w1 = (torch.randn(256, 64, generator=g) / 8).to(DEV), (torch.randn(64, 64, generator=g) / 8).to(DEV)
+    sd, hd = (torch.rand(256, generator=g) + 0.5).to(DEV), (torch.randn(256, generator=g) * 0.3).to(DEV)
+    s1, h1 = (torch.rand(64, generator=g) + 0.5).to(DEV), (torch.randn(64, generator=g) * 0.3).to(DEV)
+    wdsp, w1p = ops.gemm_bf16x3_pack(wds, mode='f16x2'), ops.gemm_bf16x3_pack(w1, mode='f16x2')
+    idn, mid = ops.bottleneck_head(x, wdsp, sd, hd, w1p, s1, h1)
+    i2 = ops.conv1x1_bf16x3(x, wdsp, 256, sd, hd, None, relu=False)
+    m2 = ops.conv1x1_bf16x3(x, w1p, 64, s1, h1, None, relu=True)
+    assert torch.allclose(idn, i2, rtol=1e-6, atol=1e-6) and torch.allclose(mid, m2, rtol=1e-6, atol=1e-6)
+    d = lambda t: t.double().cpu()                                                          # noqa: E731
+    ir = torch.einsum('oc,bchw->bohw', d(wds), d(x)) * d(sd).view(1, -1, 1, 1) + d(hd).view(1, -1, 1, 1)
+    assert float((d(idn) - ir).abs().max()) < 2e-5 * max(1.0, float(ir.abs().max()))
+    assert ops.split_overflow_count() == 0
