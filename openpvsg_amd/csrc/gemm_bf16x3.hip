@@ -1722,6 +1722,14 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
 //   per channel block and thread: 24 dword loads + 12 split pairs (the tap-by-tap form: 144 + 72)
 // CT = 128: 128 output channels x 8 x 16 pixels (wave = 64 channels x 4 pixel rows); CT = 64 (the 64-channel layers): 64 output
 // channels x 16 x 16 pixels (wave = all 64 channels x 4 pixel rows), patch 18 x 18.
+// NBUF weight buffers: tap t's slabs are asked for NBUF - 1 taps ahead (PVSG_HALO_NBUF, lab: scripts/lab/r05_halo_nbuf.sh)
+#ifndef PVSG_HALO_NBUF
+#define PVSG_HALO_NBUF 2
+#endif
+template <int CT>
+constexpr int halo_lds_bytes() {
+  return (2 * 4 * ((CT == 128 ? 10 : 18) * 18) * 8 + PVSG_HALO_NBUF * 2 * 4 * CT * 8) * 2;
+}
 template <bool RELU, int CT>
 __global__ __launch_bounds__(256, 2)
 void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ scale,
@@ -1734,7 +1742,9 @@ void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __rest
   constexpr int W_ARR = 4 * CT * 8;                              // one limb array of a tap: [k-group 4][CT][8]
   constexpr int W_AT = 2 * P_LIMB, W_BUF = 2 * W_ARR;
   constexpr int NR = (4 * PP + 255) / 256;                       // staging rounds
-  __shared__ __attribute__((aligned(16))) __bf16 lds[W_AT + 2 * W_BUF];
+  constexpr int NBUF = PVSG_HALO_NBUF;
+  static_assert(halo_lds_bytes<CT>() == (W_AT + NBUF * W_BUF) * 2, "halo LDS size");
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -1812,16 +1822,30 @@ void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __rest
   const int NCB = Cin / 32, NSTEP = NCB * 9;
   loadX(0);
   dmaW(0, 0);
+  if (NBUF == 3) dmaW(NSTEP > 1 ? 1 : 0, 1);
   stashX();
-  int step = 0;
+  int step = 0, buf = 0;                                          // buf = step % NBUF
+  constexpr int DMA_OPS = 8 * (CT / 64) / 4, LOAD_OPS = 8 * NR;   // vector-memory operations of one dmaW / loadX per wave
   for (int cib = 0; cib < NCB; ++cib) {
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap, ++step) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own slabs of this tap (and, at tap 0, own patch rows) are in LDS
-      __builtin_amdgcn_s_barrier();                               // ... everybody's are; the other weight buffer is free
-      dmaW(step + 1 < NSTEP ? step + 1 : step, (step + 1) & 1);
+      // own slabs of this tap (and, at tap 0, own patch rows: stashX waited for them) are in LDS.  NBUF == 3: the slabs of the NEXT
+      // tap (asked for one tap ago) and, right behind tap 0, the next channel block's patch loads may still be in flight -- loads
+      // retire in order, so the count of younger operations is what may remain outstanding
+      if (NBUF == 3) {
+        if (tap == 1 || tap == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMA_OPS + LOAD_OPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMA_OPS) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                               // ... everybody's are; the buffer of the previous tap is free
+      {
+        const int ahead = NBUF - 1, nb = buf + ahead >= NBUF ? buf + ahead - NBUF : buf + ahead;
+        dmaW(step + ahead < NSTEP ? step + ahead : NSTEP - 1, nb);
+      }
       if (tap == 0) loadX(cib + 1 < NCB ? cib + 1 : cib);         // next channel block's patch: lands under the nine taps
-      const __bf16* wfr = wfr0 + (step & 1) * W_BUF;
+      const __bf16* wfr = wfr0 + buf * W_BUF;
+      buf = buf + 1 == NBUF ? 0 : buf + 1;
       const int dy = tap / 3, dx = tap - 3 * dy;
       const __bf16* xfr = xfr0 + (dy * PW + dx) * 8;
       u32x4 whf[4], wlf[4], w2f[4];
@@ -2518,8 +2542,13 @@ static int conv3x3_split_run(const float* x, const void* w_packed, const float* 
       const long long hb = (long long)B * tc * tiles_x * tiles_y;
       PVSG_REQUIRE(hb < (1LL << 31), "%s: too many blocks", nm);
 #define PVSG_HALO_LAUNCH(R, C)                                                                                                     \
-  hipLaunchKernelGGL((conv3x3_f16x2_halo_kernel<R, C>), dim3((unsigned)hb), block, 0, st, x, wp, scale, shift, y, Cin, Cout, Cpad, \
-                     H, W, tc, tiles_x, tiles_y, overflow, gn_part)
+  do {                                                                                                                             \
+    static std::atomic<unsigned long long> done{0};                                                                               \
+    const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_f16x2_halo_kernel<R, C>), halo_lds_bytes<C>(), done); \
+    if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "%s: dynamic LDS: %s", nm, hipGetErrorString(e));                           \
+    hipLaunchKernelGGL((conv3x3_f16x2_halo_kernel<R, C>), dim3((unsigned)hb), block, halo_lds_bytes<C>(), st, x, wp, scale, shift, y, \
+                       Cin, Cout, Cpad, H, W, tc, tiles_x, tiles_y, overflow, gn_part);                                            \
+  } while (0)
       if (gn_part && (!wide || Cout % 8))
         return set_err(PVSG_ERR_UNSUPPORTED, "%s: the GroupNorm-statistics epilogue needs Cout > 64 in groups of 8 channels", nm);
       if (wide) { if (relu) PVSG_HALO_LAUNCH(true, 128); else PVSG_HALO_LAUNCH(false, 128); }
