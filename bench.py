@@ -308,9 +308,10 @@ class KernelTimer:
         if name == 'pvsg_attn_mask_bits_packed_f16x2':   # embeddings pre-packed by decoder_rows_post: (pack, f, bits, flags, B, T, Q, C, N, ..)
             B, T, Q, C, N = a[4:9]
             return 4.0 * B * T * N * C + 16.0 * B * T * N, 6.0 * B * T * Q * C * N
-        if name == 'pvsg_bottleneck_tail_f16x2':        # (mid, w3, sc3, sh3, identity, y, w1n, sc1n, sh1n, mid_next, B, Cmid, Cout, Cnext, H, W, ..)
-            B, Cmid, Cout, Cnext, H, W = a[10:16]
-            return 4.0 * B * H * W * (Cmid + 2 * Cout + Cnext), 6.0 * B * H * W * (Cmid * Cout + Cout * Cnext)
+        if name == 'pvsg_bottleneck_tail_f16x2':        # (mid, w3, sc3, sh3, identity, y, y_s2, w1n, sc1n, sh1n, mid_next, B, Cmid, Cout, Cnext, H, W, ..)
+            B, Cmid, Cout, Cnext, H, W = a[11:17]
+            by = 4.0 * B * H * W * (Cmid + Cout * (2 if a[4] else 1) + Cnext) + (1.0 * B * H * W * Cout if a[6] else 0.0)
+            return by, 6.0 * B * H * W * (Cmid * Cout + (Cout if a[4] else Cmid) * Cnext)
         if name == 'pvsg_conv1x1_f16x2_stats':          # pvsg_conv1x1_f16x2 + GroupNorm partial sums (x, wp, scale, shift, residual, y, part, B, ..)
             B, Cin, Cout, H, W, st = a[7:13]
             hw = ((H - 1) // st + 1) * ((W - 1) // st + 1)

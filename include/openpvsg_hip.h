@@ -509,19 +509,22 @@ int pvsg_group_norm_finish(const double* partials, int nchunks, const float* wei
 
 /* [3P] mmdet ResNet Bottleneck.forward (64 planes, stride 1 = ResNet-50 layer1), the tail of one block and the head of the next in
  * one pass over the pixels:  y = relu(conv3(mid) * scale3 + shift3 + identity)  (64 -> 256 channels) and, from y while it is in
- * registers,  mid_next = relu(conv1_next(y) * scale1n + shift1n)  (256 -> 64) -- the next block's conv1 never re-reads y.
- * mid (B,64,H,W) = the block's conv2 -> bn2 -> relu output; identity, y (B,256,H,W); mid_next (B,64,H,W).
+ * registers,  mid_next = relu(conv1_next(y) * scale1n + shift1n)  (256 -> Cnext) -- the next block's conv1 never re-reads y.
+ * mid (B,64,H,W) = the block's conv2 -> bn2 -> relu output; identity, y (B,256,H,W); mid_next (B,Cnext,H,W), Cnext = 64 (next block
+ * of the stage) or 128 (first block of the NEXT stage, whose conv1 runs at this resolution: style='pytorch').
+ * y_stride2 (B,256,ceil(H/2),W/2) or NULL: y's even rows / columns once more, compact -- what the next stage's stride-2 downsample
+ * convolution reads (pvsg_conv1x1_f16x2 with stride 1 on it); needs even W.
  * w3_packed = pvsg_gemm_f16x2_pack of conv3's (256, 64) matrix; w1n_packed = pvsg_gemm_f16x2_pack of
- * pvsg_bottleneck_next_weight_matrix(next conv1's (64, 256) matrix) (the K order the kernel multiplies in).  w1n_packed, scale1n,
- * shift1n, mid_next all NULL: the first line only (last block of the stage).
+ * pvsg_bottleneck_next_weight_matrix(next conv1's (Cnext, 256) matrix) (the K order the kernel multiplies in).  w1n_packed, scale1n,
+ * shift1n, mid_next all NULL: the first line only.
  * identity == NULL: the head of the stage's FIRST block from one read of its input x (given as `mid`, 64 channels):
  * y = downsample_conv(x) * scale3 + shift3 (w3_packed = the downsample's (256, 64) pack; no ReLU) and mid_next = relu(conv1(x) *
- * scale1n + shift1n) with w1n_packed = the plain pvsg_gemm_f16x2_pack of conv1's (64, 64) matrix.
+ * scale1n + shift1n) with w1n_packed = the plain pvsg_gemm_f16x2_pack of conv1's (64, 64) matrix (Cnext = 64).
  * Exactly these channel counts, even H*W. */
 int pvsg_bottleneck_next_weight_matrix(const float* weight, float* matrix, int Cn, int K, void* stream);
 int pvsg_bottleneck_tail_f16x2(const float* mid, const void* w3_packed, const float* scale3, const float* shift3, const float* identity,
-                               float* y, const void* w1n_packed, const float* scale1n, const float* shift1n, float* mid_next, int B,
-                               int Cmid, int Cout, int Cnext, int H, int W, uint32_t* overflow, void* stream);
+                               float* y, float* y_stride2, const void* w1n_packed, const float* scale1n, const float* shift1n,
+                               float* mid_next, int B, int Cmid, int Cout, int Cnext, int H, int W, uint32_t* overflow, void* stream);
 
 #ifdef __cplusplus
 }

@@ -103,7 +103,7 @@ SIGNATURES = {
     'pvsg_conv1x1_f16x2_stats': [_c_f] * 7 + [_i] * 7 + [_c_f, _c_f],
     'pvsg_conv3x3_stats_chunks': [_i, _i],
     'pvsg_bottleneck_next_weight_matrix': [_c_f, _c_f, _i, _i, _c_f],
-    'pvsg_bottleneck_tail_f16x2': [_c_f] * 10 + [_i] * 6 + [_c_f, _c_f],
+    'pvsg_bottleneck_tail_f16x2': [_c_f] * 11 + [_i] * 6 + [_c_f, _c_f],
     'pvsg_conv3x3_f16x2_stats': [_c_f] * 6 + [_i] * 6 + [_c_f, _c_f],
     'pvsg_group_norm_finish': [_c_f, _i, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _ll, _f, _c_f],
     'pvsg_stem7x7_bn_relu_pool': [_c_f] * 5 + [_i, _i, _i, _c_f],

@@ -65,27 +65,42 @@ class _Bottleneck(nn.Module):
         out = self.bn3(self.conv3(out))
         return F.relu(out + identity, inplace=True)
 
-    def forward_fused(self, x, aff, out=None, gemm=True, mid=None, nxt=None, nxt_aff=None):
+    def forward_fused(self, x, aff, out=None, gemm=True, mid=None, nxt=None, nxt_aff=None, x_s2=None):
         """Frozen BN as per-channel affine: BN+ReLU and BN+residual+ReLU are one HIP pass each
         (csrc/elementwise.hip) behind MIOpen's convolutions.  `out`: where the block's result goes (a batch
         slice of a stage-output tensor) instead of over conv3's own output.
-        `mid`: this block's conv1 -> bn1 -> relu output when the previous block's tail already produced it; `nxt` / `nxt_aff`: the
-        next block of the stage -- on the 64-plane stage its conv1 runs inside this block's conv3 pass (ops.bottleneck_tail: the
-        256-channel map is not read again).  -> (block output, the next block's `mid` or None)."""
+        `mid`: this block's conv1 -> bn1 -> relu output when the previous block's tail already produced it; `x_s2`: x[:, :, ::2, ::2]
+        when that tail also left it (the stride-2 downsample convolution then reads the compact tensor); `nxt` / `nxt_aff`: the
+        next block (of this stage or the first of the next) -- behind the 64-plane stage its conv1 runs inside this block's conv3
+        pass (ops.bottleneck_tail: the 256-channel map is not read again).
+        -> (block output, the next block's `mid` or None, the next block's `x_s2` or None)."""
         head = self._head_fused(x, aff) if mid is None and self.downsample is not None else None
         if head is not None:
             identity, mid = head
         elif self.downsample is None:
             identity = x
         else:
-            identity = _conv_bn(self.downsample[0], x, aff['ds'], None, False, None, gemm)
+            identity = self._downsample_s2(x_s2, aff) if x_s2 is not None else None
+            if identity is None:
+                identity = _conv_bn(self.downsample[0], x, aff['ds'], None, False, None, gemm)
         y = mid if mid is not None else _conv_bn(self.conv1, x, aff['bn1'], None, True, None, gemm)
         y2 = conv3x3_fast(self.conv2, y, aff['bn2'][0], aff['bn2'][1], relu=True)     # BN + ReLU in the epilogue
         y = y2 if y2 is not None else ops.affine_act_nchw_(self.conv2(y), *aff['bn2'])
         fused = self._tail_fused(y, aff, identity, out, nxt, nxt_aff)
         if fused is not None:
             return fused
-        return _conv_bn(self.conv3, y, aff['bn3'], identity, True, out, gemm), None
+        return _conv_bn(self.conv3, y, aff['bn3'], identity, True, out, gemm), None, None
+
+    def _downsample_s2(self, x_s2, aff):
+        """The stride-2 1x1 downsample convolution as a stride-1 convolution on the compact even-row / even-column copy of x."""
+        ds = self.downsample[0]
+        if not (ds.kernel_size == (1, 1) and ds.stride == (2, 2) and ds.bias is None and x_s2.is_contiguous() and
+                ops.conv1x1_bf16x3_supported(ds.out_channels, ds.in_channels, x_s2.shape[2], x_s2.shape[3])):
+            return None
+        w = ds.weight
+        wp = _packed_weight(ds, 'conv1x1', (w.data_ptr(), w._version, str(w.device)),
+                            lambda: ops.gemm_bf16x3_pack(w.detach().reshape(w.shape[0], w.shape[1]).contiguous()))
+        return ops.conv1x1_bf16x3(x_s2, wp, ds.out_channels, aff['ds'][0], aff['ds'][1], None, relu=False, stride=1)
 
     def _head_fused(self, x, aff):
         """downsample(x) and relu(bn1(conv1(x))) from one read of x (ops.bottleneck_head) on the 64-plane stage, else None."""
@@ -109,19 +124,31 @@ class _Bottleneck(nn.Module):
                 (out is None or out.is_contiguous())):
             return None
         n1 = nxt.conv1 if nxt is not None else None
-        if n1 is not None and not (n1.kernel_size == (1, 1) and n1.stride == (1, 1) and n1.bias is None and n1.out_channels == 64 and
-                                   nxt.downsample is None):
-            n1 = None
-        if not ops.bottleneck_tail_supported(c3.in_channels, c3.out_channels, 64 if n1 is not None else None, y.shape[2], y.shape[3]):
+        s2 = False
+        if n1 is not None:
+            same_stage = nxt.downsample is None and n1.out_channels == 64
+            # first block of the next stage (style 'pytorch': its conv1 has stride 1, conv2 and the downsample stride 2)
+            next_stage = (nxt.downsample is not None and n1.out_channels == 128 and nxt.conv2.stride == (2, 2) and
+                          os.environ.get('PVSG_BNECK_FUSE_NEXT_STAGE', 'on') != 'off')
+            if not (n1.kernel_size == (1, 1) and n1.stride == (1, 1) and n1.bias is None and n1.in_channels == c3.out_channels and
+                    (same_stage or next_stage)):
+                n1 = None
+            elif next_stage:
+                ds = nxt.downsample[0]
+                s2 = ds.kernel_size == (1, 1) and ds.stride == (2, 2) and y.shape[3] % 2 == 0
+        cn = n1.out_channels if n1 is not None else None
+        if not ops.bottleneck_tail_supported(c3.in_channels, c3.out_channels, cn, y.shape[2], y.shape[3]):
             return None
         w3 = c3.weight
         w3p = _packed_weight(c3, 'conv1x1', (w3.data_ptr(), w3._version, str(w3.device)),
                              lambda: ops.gemm_bf16x3_pack(w3.detach().reshape(w3.shape[0], w3.shape[1]).contiguous()))
         if n1 is None:
-            return ops.bottleneck_tail(y, w3p, aff['bn3'][0], aff['bn3'][1], identity, out=out)
+            return ops.bottleneck_tail(y, w3p, aff['bn3'][0], aff['bn3'][1], identity, out=out) + (None,)
         w1 = n1.weight
         w1p = _packed_weight(n1, 'bneck_next', (w1.data_ptr(), w1._version, str(w1.device)), lambda: ops.bottleneck_next_pack(w1.detach()))
-        return ops.bottleneck_tail(y, w3p, aff['bn3'][0], aff['bn3'][1], identity, w1p, nxt_aff['bn1'][0], nxt_aff['bn1'][1], out=out)
+        r = ops.bottleneck_tail(y, w3p, aff['bn3'][0], aff['bn3'][1], identity, w1p, nxt_aff['bn1'][0], nxt_aff['bn1'][1], out=out,
+                                cnext=cn, stride2_copy=s2)
+        return r if s2 else r + (None,)
 
 
 @BACKBONES.register_module()
@@ -217,13 +244,16 @@ class ResNet(BaseModule):
     def _forward_fused(self, x, aff, outs, gemm=True):
         """x: a batch slice; outs[li-1]: the matching slice of the stage-output tensors (written in place)."""
         x = self._stem(x, aff)
+        mid = x_s2 = None
         for li in range(1, 5):
             blocks = getattr(self, 'layer%d' % li)
-            mid = None
             for bi, blk in enumerate(blocks):
                 last = bi == len(blocks) - 1
-                x, mid = blk.forward_fused(x, aff[(li, bi)], out=outs[li - 1] if last else None, gemm=gemm, mid=mid,
-                                           nxt=None if last else blocks[bi + 1], nxt_aff=None if last else aff[(li, bi + 1)])
+                nxt, nxt_aff = (blocks[bi + 1], aff[(li, bi + 1)]) if not last else (None, None)
+                if last and li < 4:                      # the next stage's first block: its conv1 reads this block's output
+                    nxt, nxt_aff = getattr(self, 'layer%d' % (li + 1))[0], aff[(li + 1, 0)]
+                x, mid, x_s2 = blk.forward_fused(x, aff[(li, bi)], out=outs[li - 1] if last else None, gemm=gemm, mid=mid, nxt=nxt,
+                                                 nxt_aff=nxt_aff, x_s2=x_s2)
 
     def forward(self, x):
         # Measured on MI355X (32x736x1280 fp32): MIOpen's fused conv+bias+ReLU plans (aten::miopen_convolution_relu

@@ -1072,7 +1072,7 @@ def conv1x1_f16x2_gn(x, w_packed, cout, gn, bias=None, out=None):
 
 
 def bottleneck_next_pack(weight):
-    """(64, 256[,1,1]) conv1 weight of the NEXT bottleneck -> f16x2 limbs in the K order bottleneck_tail multiplies in."""
+    """(64 | 128, 256[,1,1]) conv1 weight of the NEXT bottleneck -> f16x2 limbs in the K order bottleneck_tail multiplies in."""
     w = _chk(weight.reshape(weight.shape[0], -1), 'weight')
     m = torch.empty_like(w)
     with _on(w.device):
@@ -1081,34 +1081,39 @@ def bottleneck_next_pack(weight):
 
 
 def bottleneck_tail_supported(cmid, cout, cnext, h, w):
-    return (cmid == 64 and cout == 256 and cnext in (None, 64) and (h * w) % 2 == 0 and 256 * h * w * 4 < 2 ** 32 and
+    return (cmid == 64 and cout == 256 and cnext in (None, 64, 128) and (h * w) % 2 == 0 and 256 * h * w * 4 < 2 ** 32 and
             split_mode() == 'f16x2' and os.environ.get('PVSG_BNECK_FUSE', 'on') != 'off')
 
 
-def bottleneck_tail(mid, w3_packed, scale3, shift3, identity, w1n_packed=None, scale1n=None, shift1n=None, out=None):
+def bottleneck_tail(mid, w3_packed, scale3, shift3, identity, w1n_packed=None, scale1n=None, shift1n=None, out=None, cnext=64,
+                    stride2_copy=False):
     """[3P] mmdet ResNet Bottleneck (64 planes): y = relu(conv3(mid) * scale3 + shift3 + identity) and, with w1n_packed
-    (bottleneck_next_pack of the next block's conv1), mid_next = relu(conv1_next(y) * scale1n + shift1n) in the same pass over the
-    pixels (csrc/gemm_bf16x3.hip bottleneck_tail64_kernel).  -> (y, mid_next or None)."""
+    (bottleneck_next_pack of the next block's conv1, `cnext` = 64 or 128 output channels), mid_next = relu(conv1_next(y) * scale1n +
+    shift1n) in the same pass over the pixels (csrc/gemm_bf16x3.hip bottleneck_tail64_kernel).  stride2_copy: also y[:, :, ::2, ::2]
+    as a compact tensor (the next stage's stride-2 downsample convolution then runs as a stride-1 convolution on it).
+    -> (y, mid_next or None[, y_stride2])."""
     mid, identity = _chk(mid, 'mid'), _chk(identity, 'identity')
     B, Cmid, H, W = mid.shape
     Cout = identity.shape[1]
     nxt = w1n_packed is not None
-    if not bottleneck_tail_supported(Cmid, Cout, 64 if nxt else None, H, W) or tuple(identity.shape) != (B, Cout, H, W):
+    if (not bottleneck_tail_supported(Cmid, Cout, cnext if nxt else None, H, W) or tuple(identity.shape) != (B, Cout, H, W) or
+            (stride2_copy and W % 2)):
         raise RuntimeError('bottleneck_tail: unsupported shape mid %s identity %s' % (tuple(mid.shape), tuple(identity.shape)))
-    if not (_is_f16x2(w3_packed, Cout, Cmid) and (not nxt or _is_f16x2(w1n_packed, 64, Cout))):
-        raise RuntimeError('bottleneck_tail: weights must be f16x2 packs of (256, 64) and (64, 256)')
+    if not (_is_f16x2(w3_packed, Cout, Cmid) and (not nxt or _is_f16x2(w1n_packed, cnext, Cout))):
+        raise RuntimeError('bottleneck_tail: weights must be f16x2 packs of (256, 64) and (%d, 256)' % cnext)
     if out is None:
         out = torch.empty((B, Cout, H, W), device=mid.device, dtype=torch.float32)
     elif not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (B, Cout, H, W)):
         raise RuntimeError('bottleneck_tail: out must be a contiguous float32 HIP tensor (B,256,H,W)')
-    mid_next = torch.empty((B, 64, H, W), device=mid.device, dtype=torch.float32) if nxt else None
+    mid_next = torch.empty((B, cnext, H, W), device=mid.device, dtype=torch.float32) if nxt else None
+    y2 = torch.empty((B, Cout, (H + 1) // 2, W // 2), device=mid.device, dtype=torch.float32) if stride2_copy else None
     with _on(mid.device):
         _lib.call('pvsg_bottleneck_tail_f16x2', mid.data_ptr(), w3_packed.data_ptr(), _chk(scale3, 'scale3').data_ptr(),
-                  _chk(shift3, 'shift3').data_ptr(), identity.data_ptr(), out.data_ptr(),
+                  _chk(shift3, 'shift3').data_ptr(), identity.data_ptr(), out.data_ptr(), y2.data_ptr() if stride2_copy else None,
                   w1n_packed.data_ptr() if nxt else None, _chk(scale1n, 'scale1n').data_ptr() if nxt else None,
                   _chk(shift1n, 'shift1n').data_ptr() if nxt else None, mid_next.data_ptr() if nxt else None,
-                  B, Cmid, Cout, 64 if nxt else 0, H, W, _overflow_counter(mid.device).data_ptr(), _stream_ptr())
-    return out, mid_next
+                  B, Cmid, Cout, cnext if nxt else 0, H, W, _overflow_counter(mid.device).data_ptr(), _stream_ptr())
+    return (out, mid_next, y2) if stride2_copy else (out, mid_next)
 
 
 def bottleneck_head(x, wds_packed, scale_ds, shift_ds, w1_packed, scale1, shift1):
@@ -1123,7 +1128,7 @@ def bottleneck_head(x, wds_packed, scale_ds, shift_ds, w1_packed, scale1, shift1
     mid = torch.empty((B, 64, H, W), device=x.device, dtype=torch.float32)
     with _on(x.device):
         _lib.call('pvsg_bottleneck_tail_f16x2', x.data_ptr(), wds_packed.data_ptr(), _chk(scale_ds, 'scale_ds').data_ptr(),
-                  _chk(shift_ds, 'shift_ds').data_ptr(), None, idn.data_ptr(), w1_packed.data_ptr(), _chk(scale1, 'scale1').data_ptr(),
+                  _chk(shift_ds, 'shift_ds').data_ptr(), None, idn.data_ptr(), None, w1_packed.data_ptr(), _chk(scale1, 'scale1').data_ptr(),
                   _chk(shift1, 'shift1').data_ptr(), mid.data_ptr(), B, 64, 256, 64, H, W, _overflow_counter(x.device).data_ptr(),
                   _stream_ptr())
     return idn, mid

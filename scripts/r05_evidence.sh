@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round 5: everything profiles/r05_* is copied from, in one pass on the MI355X box:
+#   scripts/round_profiles.sh r05  (bench lines, kernel trace, PMC traffic, MFMA utilisation, sub-benchmarks)
+#   + the IPS-batch and 1080p lines (BASELINE configs 2 and 5), the T = 4 fixed-cost trace, the forced-collectives line.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+bash scripts/round_profiles.sh r05 > /dev/null 2>&1
+O=$R/gpurun_out/r05_final
+B="python $R/bench.py"
+$B --mode ips --frames 8 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_line_ips_T8.json
+$B --frames 8 --height 1080 --width 1920 --graph off --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/bench_line_1080p_T8.json
+PVSG_FORCE_COLLECTIVES=1 $B --frames 4 --steps 20 --warmup 5 --cpu-baseline off --sub-benchmarks off 2>/dev/null | tail -1 > $O/bench_line_T4_forced_collectives.json
+bash scripts/r05_fixed_cost.sh r05_final/fixed > /dev/null 2>&1
+ls -la $O $O/fixed
+python - <<PY
+import json, glob
+for f in sorted(glob.glob('$O/bench_line*.json')):
+    try:
+        d = json.load(open(f)); print(f.split('/')[-1], d['ms_per_step'], d['value'], d.get('roofline', {}).get('frac'))
+    except Exception as e: print(f, 'ERR', e)
+PY

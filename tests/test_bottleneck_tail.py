@@ -91,3 +91,27 @@ def test_bottleneck_head_downsample_and_conv1_from_one_read(hip_lib, B, H, W):
     ir = torch.einsum('oc,bchw->bohw', d(wds), d(x)) * d(sd).view(1, -1, 1, 1) + d(hd).view(1, -1, 1, 1)
     assert float((d(idn) - ir).abs().max()) < 2e-5 * max(1.0, float(ir.abs().max()))
     assert ops.split_overflow_count() == 0
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 23, 40), (1, 6, 10), (2, 184, 320)])
+def test_bottleneck_tail_into_the_next_stage(hip_lib, B, H, W):
+    """Last block of the 64-plane stage: the NEXT stage's conv1 (256 -> 128, stride 1 in style 'pytorch') from y in registers and
+    the compact y[:, :, ::2, ::2] its stride-2 downsample convolution reads."""
+    from openpvsg_amd import ops
+    mid, idn, w3, _, s3, h3, _, _ = _case(B, H, W, B * 77 + H)
+    g = torch.Generator().manual_seed(H)
+    w1 = (torch.randn(128, 256, generator=g) / 16).to(DEV)
+    s1, h1 = (torch.rand(128, generator=g) + 0.5).to(DEV), (torch.randn(128, generator=g) * 0.3).to(DEV)
+    w3p = ops.gemm_bf16x3_pack(w3, mode='f16x2')
+    y, nxt, y2 = ops.bottleneck_tail(mid, w3p, s3, h3, idn, ops.bottleneck_next_pack(w1), s1, h1, cnext=128, stride2_copy=True)
+    yr = ops.conv1x1_bf16x3(mid, w3p, 256, s3, h3, idn, relu=True)
+    nr = ops.conv1x1_bf16x3(yr, ops.gemm_bf16x3_pack(w1, mode='f16x2'), 128, s1, h1, None, relu=True)
+    assert torch.allclose(y, yr, rtol=1e-6, atol=1e-6) and torch.allclose(nxt, nr, rtol=1e-5, atol=1e-5)
+    assert torch.equal(y2, y[:, :, ::2, ::2])
+    d = lambda t: t.double().cpu()                                                          # noqa: E731
+    n64 = torch.relu(torch.einsum('oc,bchw->bohw', d(w1), d(y)) * d(s1).view(1, -1, 1, 1) + d(h1).view(1, -1, 1, 1))
+    assert float((d(nxt) - n64).abs().max()) < 2e-5 * max(1.0, float(n64.abs().max()))
+    for _ in range(5):                                       # bit-exact run to run (the MFMA operand hazard this kernel met once)
+        y_b, n_b, y2_b = ops.bottleneck_tail(mid, w3p, s3, h3, idn, ops.bottleneck_next_pack(w1), s1, h1, cnext=128, stride2_copy=True)
+        assert torch.equal(y_b, y) and torch.equal(n_b, nxt) and torch.equal(y2_b, y2)
+    assert ops.split_overflow_count() == 0
