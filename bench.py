@@ -775,13 +775,20 @@ def main():
     # Per-kernel table: HIP events around EVERY C-ABI launch cost 1.7 ms per 32-frame step (370 pairs).  They are taken during
     # the LAST WARM-UP step; the timed region carries events only around the entry that step found dominant -- which is what
     # `roofline` reports (measured live inside the timed region).  --timing all (or --warmup 0) keeps every pair in the timed region.
-    table_records, table_steps = None, args.steps
+    table_records, table_steps, table_from_eager_step = None, args.steps, False
     for w in range(args.warmup):
         last = w == args.warmup - 1 and args.timing == 'dominant' and not args.no_kernel_timing and rank == 0
+        eager_table = (last and world == 1 and getattr(pipe, 'use_graph', False) in (True, 'auto') and
+                       (pipe.use_graph is True or t_local <= getattr(pipe, 'graph_max_frames', 0)))
         if last:
             torch.cuda.synchronize()
             timer.enabled = True
+        if eager_table:                       # the timed region replays a hipGraph (no per-launch events): table from ONE eager step
+            saved_use_graph, pipe.use_graph = pipe.use_graph, False
         out = step()
+        if eager_table:
+            pipe.use_graph = saved_use_graph
+            table_from_eager_step = True
         if last:
             torch.cuda.synchronize()
             timer.enabled = False
@@ -955,8 +962,8 @@ def main():
                                     query_sum=float(out['query'].double().sum().item()),
                                     pair_sum=float(out['relation']['pred_matrix'].double().sum().item())
                                     if out['relation'] is not None else None)
-        if timer.records:
-            live = timer.summary()                            # the timed region: the dominant entry (or everything: --timing all)
+        if timer.records or (table_from_eager_step and table_records):
+            live = timer.summary() if timer.records else {}   # the timed region: the dominant entry (or everything: --timing all)
             if table_records is None:
                 table_records = timer.records
             agg = timer.summary(table_records)                # every C-ABI entry: last warm-up step, or the timed region
@@ -989,8 +996,10 @@ def main():
                 # 3 (f16x2) or 6 (bf16x3) limb products on the 16-bit pipe; this is the honest utilisation figure.
                 pipe_ms = sum(d['flops'] / table_steps / (KernelTimer.mfma_peak(k.split('[')[0])[0] * 1e12) * 1e3 for k, d in agg.items())
                 line['roofline_step'].update(ideal_ms_on_pipes_used=pipe_ms, frac_of_pipe_used=pipe_ms / ms_per_step)
-            dom = max((k for k in live if live[k]['bytes'] > 0), key=lambda k: live[k]['ms'])
-            d = live[dom]
+            # graph replay in the timed region: the dominant entry and its figures come from the eager warm-up step's events
+            pool, pool_steps = (agg, table_steps) if table_from_eager_step else (live, args.steps)
+            dom = max((k for k in pool if pool[k]['bytes'] > 0), key=lambda k: pool[k]['ms'])
+            d = pool[dom]
             per = d['ms'] / d['calls']
             # the roof that binds = the larger ideal time (bytes / HBM peak vs flops / f32 matrix peak) over its launches
             peak_tf, peak_note = KernelTimer.mfma_peak(dom)
@@ -1004,7 +1013,9 @@ def main():
                 ent = json.load(open(tpath)).get(dom.split('[')[0], {})
                 if ent.get('frames') == t_local:
                     traffic = ent.get('hbm_bytes_per_launch')
-            scope = ('dominant HAND-WRITTEN kernel by time, its launches timed with HIP-event pairs INSIDE the timed region.  ' +
+            scope = (('dominant HAND-WRITTEN kernel by time; the timed region replays the step as a hipGraph (no per-launch events), so '
+                      'its launches were timed with HIP-event pairs in ONE EAGER warm-up step of the same clip.  ' if table_from_eager_step else
+                      'dominant HAND-WRITTEN kernel by time, its launches timed with HIP-event pairs INSIDE the timed region.  ') +
                      ('The other entries of `kernels` were timed the same way during the last warm-up step (events around all '
                       '370 launches cost 1.7 ms per step; --timing all puts them into the timed region).  '
                       if table_steps == 1 else 'HIP-event pairs sit around EVERY C-ABI launch inside the timed region '
@@ -1015,13 +1026,13 @@ def main():
                 ach = d['flops'] / d['calls'] / per / 1e9
                 line['roofline'] = dict(kernel=dom, bound='mfma', achieved=ach, peak=peak_tf, flops_counted=peak_note,
                                         unit='TFLOP/s', frac=ach / peak_tf, traffic=traffic,
-                                        avg_launch_ms=per, launches_per_step=d['calls'] / args.steps,
+                                        avg_launch_ms=per, launches_per_step=d['calls'] / pool_steps,
                                         algorithmic_bytes_per_launch=d['bytes'] / d['calls'], scope=scope)
             else:
                 ach = d['bytes'] / d['calls'] / per / 1e6
                 line['roofline'] = dict(kernel=dom, bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
                                         frac=ach / HBM_PEAK_GBS, traffic=traffic, avg_launch_ms=per,
-                                        launches_per_step=d['calls'] / args.steps,
+                                        launches_per_step=d['calls'] / pool_steps,
                                         algorithmic_bytes_per_launch=d['bytes'] / d['calls'], scope=scope)
             if dom.startswith('pvsg_conv1x1_f16x2'):
                 # measured on this kernel itself (round 5): socket power / shader clock while one layer loops, and the timing
@@ -1032,6 +1043,16 @@ def main():
                     'the shader clock un-throttled (2.35-2.38 GHz) and run no faster with the MFMAs removed; the deep layers '
                     '(512->128, 256->1024) sit at the 1400 W socket limit with the clock down to 1.87-2.05 GHz')
                 line['roofline']['limited_by_source'] = 'profiles/r05_power_probe_conv1x1.txt (scripts/lab/r05_power_conv.sh)'
+            elif dom.startswith('pvsg_gemm_f16x2'):
+                # the token GEMM leads once the layer1 bottleneck tails have left the 1x1-convolution entry (round 5): its time is the
+                # encoder's FFN1 (6 x 1.24 ms) and 544-wide projection (6 x 0.76 ms) -- probed in a loop with rocm-smi
+                line['roofline']['limited_by'] = (
+                    'socket power: in a loop FFN1 (618 240 x 256 -> 1024) draws 1375-1381 W at 2.21 GHz and the 544-wide projection 1392 W '
+                    'at 2.11 GHz of the 1400 W limit (2.4 GHz nominal) while issuing 0.26-0.31 of the dense f16 MFMA peak in limb products '
+                    '(3 per f32 multiply-add); the aggregate entry is priced against HBM because the 18 small decoder K/V projections '
+                    'dominate its launch count, not its time')
+                line['roofline']['limited_by_source'] = ('profiles/r05_power_probe_gemm.txt (scripts/lab/power_probe.py ffn1 | proj544), '
+                                                         'profiles/r04_power_probe.txt')
             # the four kernels the north-star names, each against its own roof (same HIP-event data)
             named = []
             for key, bound in (('pvsg_gemm_f16x2', 'mfma'), ('pvsg_gemm_bf16x3', 'mfma'), ('pvsg_conv3x3_f16x2', 'mfma'),

@@ -1,5 +1,6 @@
 """Is a kernel power-limited?  Loops one GEMM shape for a few seconds and samples rocm-smi (socket power, sclk, mclk) meanwhile.
-usage: python scripts/lab/power_probe.py [ffn1|ffn2|oproj] [f16x2|bf16x3] [seconds]"""
+usage: python scripts/lab/power_probe.py [ffn1|ffn2|oproj|proj544] [f16x2|bf16x3] [seconds]
+(ffn1 / proj544 = pvsg_gemm_f16x2 on the encoder's two wide shapes at 32 x 720p; round 5 prints one compact line with watts @ sclk)"""
 import os
 import subprocess
 import sys
@@ -11,7 +12,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from openpvsg_amd import ops  # noqa: E402
 
-shape = {'ffn1': (618240, 1024, 256, True), 'ffn2': (618240, 256, 1024, False), 'oproj': (618240, 256, 256, False)}[sys.argv[1] if len(sys.argv) > 1 else 'ffn1']
+shape = {'ffn1': (618240, 1024, 256, True), 'ffn2': (618240, 256, 1024, False), 'oproj': (618240, 256, 256, False),
+         'proj544': (618240, 544, 256, False)}[sys.argv[1] if len(sys.argv) > 1 else 'ffn1']
 mode = sys.argv[2] if len(sys.argv) > 2 else 'f16x2'
 secs = float(sys.argv[3]) if len(sys.argv) > 3 else 4.0
 M, N, K, relu = shape
@@ -51,5 +53,9 @@ torch.cuda.synchronize()
 stop = True
 th.join()
 print('%s %s: %.3f ms per launch over %d launches' % (sys.argv[1] if len(sys.argv) > 1 else 'ffn1', mode, s.elapsed_time(e) / n, n))
-for smp in samples[1:6]:
-    print('   ', ' | '.join(smp)[:400])
+pw = [[l.split(':')[-1].strip() for l in smp if 'Power (W)' in l] for smp in samples[1:7]]
+sc = [[l.split('(')[-1].split(')')[0] for l in smp if 'sclk' in l] for smp in samples[1:7]]
+ms = s.elapsed_time(e) / n
+print('    %.0f TF/s of f16 limb products (x3) = %.0f TF/s f32-equivalent, %.2f TB/s algorithmic; power / sclk samples: %s'
+      % (6.0 * M * N * K / ms / 1e9, 2.0 * M * N * K / ms / 1e9, 4.0 * M * (N + K) / ms / 1e9,
+         ' '.join('%sW@%s' % (p[0] if p else '?', c[0] if c else '?') for p, c in zip(pw, sc))))

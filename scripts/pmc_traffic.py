@@ -25,7 +25,9 @@ ENTRY = [('msda_fused', 'pvsg_msda_fused_forward'), ('msda_fwd', 'pvsg_ms_deform
          ('gemm_bf16x3_kernel', 'pvsg_gemm_bf16x3'), ('gemm_bf16x3_k32_kernel', 'pvsg_gemm_bf16x3'), ('affine_act_nchw', 'pvsg_affine_act_nchw'),
          ('add_layernorm', 'pvsg_add_layernorm'), ('center_downsample', 'pvsg_center_downsample'),
          ('decoder_rows_post', 'pvsg_decoder_rows_post'), ('decoder_rows_pre', 'pvsg_decoder_rows_pre'),
-         ('pan_owner', 'pvsg_panoptic_fuse'), ('fpn_merge_up2x', 'pvsg_fpn_merge_up2x'),
+         ('pan_owner', 'pvsg_panoptic_fuse_sel'), ('pan_decide', 'pvsg_panoptic_fuse_sel'), ('pan_paint', 'pvsg_panoptic_fuse_sel'),
+         ('gn_partial', 'pvsg_group_norm_affine'), ('gn_finish', 'pvsg_group_norm_finish'), ('tube_index', 'pvsg_tube_index'),
+         ('tube_scatter', 'pvsg_tube_scatter'), ('panoptic_select', 'pvsg_panoptic_select'), ('fpn_merge_up2x', 'pvsg_fpn_merge_up2x'),
          ('stem_bn_relu_pool', 'pvsg_stem_bn_relu_pool'), ('nchw_to_tokens', 'pvsg_nchw_to_tokens'),
          ('tokens_to_nchw', 'pvsg_tokens_to_nchw'), ('decoder_kv_inputs', 'pvsg_decoder_kv_inputs'), ('pair_', 'pvsg_pair_score_forward')]
 
@@ -34,7 +36,7 @@ def run_pass(counter, frames, workdir):
     out = os.path.join(workdir, counter)
     cmd = ['rocprofv3', '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', out, '--',
            sys.executable, os.path.join(ROOT, 'bench.py'), '--frames', str(frames), '--steps', '1', '--warmup', '1',
-           '--cpu-baseline', 'off', '--sub-benchmarks', 'off', '--no-kernel-timing', '--no-flop-count']
+           '--cpu-baseline', 'off', '--sub-benchmarks', 'off', '--no-kernel-timing', '--no-flop-count', '--graph', 'off', '--projection', 'off']
     env = dict(os.environ, TMPDIR='/tmp')
     subprocess.run(cmd, cwd='/tmp', env=env, check=True, stdout=subprocess.DEVNULL)
     files = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
@@ -50,13 +52,19 @@ def split_entry(fn):
     if m:
         name, targs = m.group(1), [t.strip() for t in m.group(2).split(',')]
     else:                                            # rocprofv3 leaves the long instantiations mangled: ...kernelILb1ELb0E...Li128E...E
-        m = re.search(r'(gemm_f16x2_t256_kernel|gemm_f16x2_dma_kernel|gemm_bf16x3_k32_kernel|conv1x1_bf16x3_k32_kernel|conv3x3_f16x2_halo_kernel)I((?:L[bi]\d+E)+)E', fn)
+        m = re.search(r'(gemm_f16x2_t256_kernel|gemm_f16x2_ln128_kernel|gemm_f16x2_dma_kernel|gemm_bf16x3_k32_kernel|conv1x1_bf16x3_k32_kernel|'
+                      r'conv3x3_f16x2_halo_kernel|bottleneck_tail64_kernel)I((?:L[bi]\d+E)+)E', fn)
         if not m:
             return None
         name = m.group(1)
         targs = [('true' if v == '1' else 'false') if t == 'b' else v for t, v in re.findall(r'L([bi])(\d+)E', m.group(2))]
     if name == 'gemm_f16x2_t256_kernel':
         return 'pvsg_gemm_f16x2_add_layernorm' if len(targs) > 1 and targs[1] == 'true' else 'pvsg_gemm_f16x2'
+    if name == 'gemm_f16x2_ln128_kernel':            # <LN, RELU, KV>: round 5's 128 x 256 tile
+        targs += ['false'] * (3 - len(targs))
+        return 'pvsg_gemm_f16x2_add_layernorm' if targs[0] == 'true' else ('pvsg_decoder_kv_project_f16x2' if targs[2] == 'true' else 'pvsg_gemm_f16x2')
+    if name == 'bottleneck_tail64_kernel':
+        return 'pvsg_bottleneck_tail_f16x2'
     if name in ('gemm_f16x2_dma_kernel',):
         return 'pvsg_gemm_f16x2'
     if name == 'conv3x3_f16x2_halo_kernel':
@@ -67,7 +75,7 @@ def split_entry(fn):
         targs += ['false', '128', '1', 'false'][len(targs) - 3:] if len(targs) < 7 else []
         sfx = '_f16x2' if targs[6] == 'true' else '_bf16x3'
         if targs[3] == 'true':
-            return 'pvsg_attn_mask_bits' + sfx
+            return 'pvsg_attn_mask_bits_packed_f16x2' if sfx == '_f16x2' else 'pvsg_attn_mask_bits' + sfx
         return ('pvsg_conv3x3' if targs[5] == '9' else 'pvsg_conv1x1') + sfx
     return None
 
@@ -109,7 +117,7 @@ def main():
                           hbm_bytes_per_launch=fk * 1024 * 2 + wk * 1024)
     out['_source'] = dict(commands=[cmd_f, cmd_w], note='mean over every launch of the kernel in a 1 warm-up + 1 timed '
                           'step run; kernels with several shapes per step (conv1x1, affine, xattn) are '
-                          'per-launch means over those shapes')
+                          'per-launch means over those shapes; pvsg_conv1x1_f16x2 / pvsg_conv3x3_f16x2 include their *_stats launches (same kernel function)')
     json.dump(out, open(a.out, 'w'), indent=1)
     if a.keep_csv:
         for tag, agg in (('FETCH_SIZE', fetch), ('WRITE_SIZE', write)):

@@ -9,7 +9,7 @@ O=$R/gpurun_out/r05_final
 B="python $R/bench.py"
 $B --mode ips --frames 8 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_line_ips_T8.json
 $B --frames 8 --height 1080 --width 1920 --graph off --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/bench_line_1080p_T8.json
-PVSG_FORCE_COLLECTIVES=1 $B --frames 4 --steps 20 --warmup 5 --cpu-baseline off --sub-benchmarks off 2>/dev/null | tail -1 > $O/bench_line_T4_forced_collectives.json
+PVSG_FORCE_COLLECTIVES=1 $B --frames 4 --steps 20 --warmup 5 --cpu-baseline off --sub-benchmarks off 2>/dev/null | grep "^{" | tail -1 > $O/bench_line_T4_forced_collectives.json
 bash scripts/r05_fixed_cost.sh r05_final/fixed > /dev/null 2>&1
 ls -la $O $O/fixed
 python - <<PY

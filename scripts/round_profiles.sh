@@ -12,7 +12,7 @@ B="python $R/bench.py"
 $B > $O/bench_line.json 2> $O/bench_line.err
 for T in 4 8 16; do $B --frames $T --steps 20 --warmup 5 --cpu-baseline off --sub-benchmarks off 2>/dev/null | tail -1 > $O/bench_line_T$T.json; done
 rm -rf /tmp/rp_bench
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_bench -- $B --steps 3 --warmup 2 --cpu-baseline off --sub-benchmarks off --no-flop-count > $O/bench_line_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_bench -- $B --steps 3 --warmup 2 --cpu-baseline off --sub-benchmarks off --no-flop-count --projection off > $O/bench_line_under_rocprof.json 2>/dev/null
 KT=$(find /tmp/rp_bench -name "*kernel_trace.csv" | head -1)
 KS=$(find /tmp/rp_bench -name "*kernel_stats.csv" | head -1)
 python $R/scripts/steady_stats.py $KT --steps 3 > $O/steady_kernel_stats.csv
