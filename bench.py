@@ -297,7 +297,8 @@ class KernelTimer:
     KEPT_HINT = 32             # kept queries of the synthetic head outputs (--keep): the device-side tail does not tell the host
     SPLIT_F16X2 = ('pvsg_gemm_f16x2', 'pvsg_gemm_f16x2_add_layernorm', 'pvsg_conv1x1_f16x2', 'pvsg_conv3x3_f16x2',
                    'pvsg_mask_logits_f16x2', 'pvsg_attn_mask_bits_f16x2', 'pvsg_attn_mask_bits_packed_f16x2',
-                   'pvsg_conv1x1_f16x2_stats', 'pvsg_conv3x3_f16x2_stats', 'pvsg_bottleneck_tail_f16x2')
+                   'pvsg_conv1x1_f16x2_stats', 'pvsg_conv3x3_f16x2_stats', 'pvsg_bottleneck_tail_f16x2',
+                   'pvsg_stem7x7_f16x2_bn_relu_pool')
 
     @classmethod
     def work(cls, name, a):
@@ -312,6 +313,10 @@ class KernelTimer:
             B, Cmid, Cout, Cnext, H, W = a[11:17]
             by = 4.0 * B * H * W * (Cmid + Cout * (2 if a[4] else 1) + Cnext) + (1.0 * B * H * W * Cout if a[6] else 0.0)
             return by, 6.0 * B * H * W * (Cmid * Cout + (Cout if a[4] else Cmid) * Cnext)
+        if name == 'pvsg_stem7x7_f16x2_bn_relu_pool':    # (x, wp, scale, shift, out, N, H, W, ..): flops = the 147 real taps as limb products
+            N, H, W = a[5:8]
+            hc, wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            return 4.0 * N * (3 * H * W + 64 * ((hc - 1) // 2 + 1) * ((wc - 1) // 2 + 1)), 6.0 * 147 * 64 * N * hc * wc
         if name == 'pvsg_conv1x1_f16x2_stats':          # pvsg_conv1x1_f16x2 + GroupNorm partial sums (x, wp, scale, shift, residual, y, part, B, ..)
             B, Cin, Cout, H, W, st = a[7:13]
             hw = ((H - 1) // st + 1) * ((W - 1) // st + 1)

@@ -482,6 +482,12 @@ int pvsg_attn_mask_bits_packed_f16x2(const void* emb_packed, const float* featur
 int pvsg_stem7x7_pack(const float* weight, float* w_packed, void* stream);
 int pvsg_stem7x7_bn_relu_pool(const float* x, const float* w_packed, const float* scale, const float* shift, float* out,
                               int N, int H, int W, void* stream);
+/* The same on the f16 matrix pipe (two-limb split; default for PVSG_SPLIT=f16x2): w_packed = pvsg_gemm_f16x2_pack(N = 64, K = 192) of
+ * the (64, 192) matrix pvsg_stem7x7_f16x2_matrix writes (column 8 g + e = weight[ch][g / 7][g % 7][e]; the 8th tap of a row and
+ * groups 21..23 are zero).  Inputs beyond +-65504 are counted into `overflow` (then use the f32 entry above). */
+int pvsg_stem7x7_f16x2_matrix(const float* weight, float* matrix, void* stream);
+int pvsg_stem7x7_f16x2_bn_relu_pool(const float* x, const void* w_packed, const float* scale, const float* shift, float* out, int N,
+                                    int H, int W, uint32_t* overflow, void* stream);
 
 /* [3P] torch.nn.GroupNorm (mmdet ConvModule norm_cfg=GN) as per-(image, channel) scale / shift:
  * GroupNorm(x)[b, c] == x[b, c] * scale[b*C + c] + shift[b*C + c]  (biased variance over the group's channels x pixels),

@@ -107,6 +107,8 @@ SIGNATURES = {
     'pvsg_conv3x3_f16x2_stats': [_c_f] * 6 + [_i] * 6 + [_c_f, _c_f],
     'pvsg_group_norm_finish': [_c_f, _i, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _ll, _f, _c_f],
     'pvsg_stem7x7_bn_relu_pool': [_c_f] * 5 + [_i, _i, _i, _c_f],
+    'pvsg_stem7x7_f16x2_matrix': [_c_f, _c_f, _c_f],
+    'pvsg_stem7x7_f16x2_bn_relu_pool': [_c_f] * 5 + [_i, _i, _i, _c_f, _c_f],
     'pvsg_conv3x3s2_affine': [_c_f] * 5 + [_i] * 6 + [_c_f],
 }
 # entry points that return a value instead of a status code

@@ -234,10 +234,15 @@ class ResNet(BaseModule):
                 x.is_contiguous() and x.dtype == torch.float32 and os.environ.get('PVSG_WINOGRAD', 'on') != 'off' and
                 3 * x.shape[2] * x.shape[3] < 2 ** 29):
             key = (w.data_ptr(), w._version, str(w.device))
-            cache = getattr(c, '_pvsg_packed', None)
+            if ops.split_mode() == 'f16x2' and os.environ.get('PVSG_STEM', 'f16x2') != 'f32' and os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib':
+                # the f16 matrix pipe (two-limb split, 0.9 vs 2.0 ms at 32 x 720p); the f32-MFMA kernel below stays for the
+                # bf16x3 re-run after an out-of-range input and behind PVSG_STEM=f32
+                wp = _packed_weight(c, 'stem_f16x2', key, lambda: ops.stem7x7_f16x2_pack(w.detach()))
+                return ops.stem7x7_f16x2_bn_relu_pool(x, wp, *aff['stem'])
+            cache = getattr(c, '_pvsg_stem_f32', None)
             if cache is None or cache[0] != key:
                 cache = (key, ops.stem7x7_pack(w.detach()))
-                c._pvsg_packed = cache
+                c._pvsg_stem_f32 = cache
             return ops.stem7x7_bn_relu_pool(x, cache[1], *aff['stem'])
         return ops.stem_bn_relu_pool(c(x), *aff['stem'])            # BN + ReLU + 3x3/2 max-pool in one pass
 

@@ -1182,6 +1182,32 @@ def stem7x7_pack(weight):
     return wp
 
 
+def stem7x7_f16x2_pack(weight):
+    """(64,3,7,7) stem weight -> f16x2 limbs of the (64, 192) matrix csrc/stem7x7.hip's f16 kernel multiplies by (once per weight)."""
+    w = _chk(weight, 'weight')
+    if tuple(w.shape) != (64, 3, 7, 7):
+        raise RuntimeError('stem7x7_f16x2_pack: unsupported weight shape %s' % (tuple(w.shape),))
+    m = torch.empty((64, 192), device=w.device, dtype=torch.float32)
+    with _on(w.device):
+        _lib.call('pvsg_stem7x7_f16x2_matrix', w.data_ptr(), m.data_ptr(), _stream_ptr())
+    return gemm_bf16x3_pack(m, mode='f16x2')
+
+
+def stem7x7_f16x2_bn_relu_pool(x, w_packed, scale, shift):
+    """maxpool3x3/2(relu(conv7x7/2(x) * scale[c] + shift[c])) in one launch on the f16 matrix pipe (two-limb split of x and w:
+    f32-class result; csrc/stem7x7.hip stem7x7_f16x2_kernel).  x (N,3,H,W), |x| <= 65504 (counted otherwise)."""
+    x = _chk(x, 'x')
+    N, C, H, W = x.shape
+    if C != 3 or not _is_f16x2(w_packed, 64, 192):
+        raise RuntimeError('stem7x7_f16x2_bn_relu_pool: unsupported input shape %s / weight pack' % (tuple(x.shape),))
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, 64, (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1), device=x.device, dtype=torch.float32)
+    with _on(x.device):
+        _lib.call('pvsg_stem7x7_f16x2_bn_relu_pool', x.data_ptr(), w_packed.data_ptr(), _chk(scale, 'scale').data_ptr(),
+                  _chk(shift, 'shift').data_ptr(), out.data_ptr(), N, H, W, _overflow_counter(x.device).data_ptr(), _stream_ptr())
+    return out
+
+
 def stem7x7_bn_relu_pool(x, w_packed, scale, shift):
     """maxpool3x3/2(relu(conv7x7/2(x) * scale[c] + shift[c])) in one launch (csrc/stem7x7.hip).  x (N,3,H,W)."""
     x = _chk(x, 'x')

@@ -177,6 +177,13 @@ def test_stem7x7_bn_relu_pool_matches_the_module_chain(hip_lib, N, H, W):
     err = (y.double().cpu() - ref).abs().max().item()
     assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
     assert torch.equal(y, ops.stem7x7_bn_relu_pool(x, ops.stem7x7_pack(w), sc, sh))
+    # the f16 matrix-pipe form (two-limb split): same bar, bitwise run to run, nothing counted out of range
+    y16 = ops.stem7x7_f16x2_bn_relu_pool(x, ops.stem7x7_f16x2_pack(w), sc, sh)
+    err16 = (y16.double().cpu() - ref).abs().max().item()
+    assert err16 < 1e-5 * max(1.0, ref.abs().max().item()), err16
+    for _ in range(3):
+        assert torch.equal(y16, ops.stem7x7_f16x2_bn_relu_pool(x, ops.stem7x7_f16x2_pack(w), sc, sh))
+    assert ops.split_overflow_count() == 0
 
 
 # ---- BASELINE sizes (720p, stride-4 / 8 maps): against the library convolution on the GPU + a size-independent property ----
