@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ENTRY = [('msda_fused', 'pvsg_msda_fused_forward'), ('msda_fwd', 'pvsg_ms_deform_attn_forward'),
          ('mask_gemm_kernel<0', 'pvsg_mask_logits_forward'), ('mask_gemm_kernel<1', 'pvsg_attn_mask_bits_forward'),
          ('xattn_partial', 'pvsg_masked_xattn_partial'), ('xattn_combine', 'pvsg_xattn_combine'),
-         ('conv1x1_affine', 'pvsg_conv1x1_affine'), ('winograd_f2x3', 'pvsg_conv3x3_winograd'), ('conv3x3s2_kernel', 'pvsg_conv3x3s2_affine'), ('stem7x7_kernel', 'pvsg_stem7x7_bn_relu_pool'), ('conv1x1_bf16x3_kernel', 'pvsg_conv1x1_bf16x3'), ('conv1x1_bf16x3_k32_kernel', 'pvsg_conv1x1_bf16x3'),
+         ('conv1x1_affine', 'pvsg_conv1x1_affine'), ('winograd_f2x3', 'pvsg_conv3x3_winograd'), ('conv3x3s2_kernel', 'pvsg_conv3x3s2_affine'), ('stem7x7_f16x2_kernel', 'pvsg_stem7x7_f16x2_bn_relu_pool'), ('stem7x7_kernel', 'pvsg_stem7x7_bn_relu_pool'), ('conv1x1_bf16x3_kernel', 'pvsg_conv1x1_bf16x3'), ('conv1x1_bf16x3_k32_kernel', 'pvsg_conv1x1_bf16x3'),
          ('gemm_bf16x3_kernel', 'pvsg_gemm_bf16x3'), ('gemm_bf16x3_k32_kernel', 'pvsg_gemm_bf16x3'), ('affine_act_nchw', 'pvsg_affine_act_nchw'),
          ('add_layernorm', 'pvsg_add_layernorm'), ('center_downsample', 'pvsg_center_downsample'),
          ('decoder_rows_post', 'pvsg_decoder_rows_post'), ('decoder_rows_pre', 'pvsg_decoder_rows_pre'),
