@@ -1038,6 +1038,12 @@ void gemm_f16x2_ln128_kernel(const float* __restrict__ A, const __bf16* __restri
   auto frag = [](const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); };
   auto mf = [](u32x4 a, u32x4 b, f32x4 c) { return mfma_k32<true>(a, b, c); };
   const int KT = K / 32;
+  // 16-column blocks of this wave's 128 columns that exist (plain GEMM with N % 256 != 0: the encoder's 544-wide projection)
+  int ncb = 8;
+  if constexpr (!LN && !KV) {
+    const int left = N - n0 - wc * 128;
+    ncb = __builtin_amdgcn_readfirstlane(left >= 128 ? 8 : (left <= 0 ? 0 : (left + 15) >> 4));
+  }
   dmaW(0, 0);
   loadA(0);
   split();
@@ -1066,13 +1072,15 @@ void gemm_f16x2_ln128_kernel(const float* __restrict__ A, const __bf16* __restri
         whn = frag(wfr + (cb + 1) * 128);
         wln = frag(wfr + W_LIMB + (cb + 1) * 128);
       }
-      const u32x4 wh2 = f16x2_lo_scale(wh);
+      if (cb < ncb) {                                            // (ragged N: column blocks beyond it are never stored)
+        const u32x4 wh2 = f16x2_lo_scale(wh);
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wh2, alf[rb], acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wh2, alf[rb], acc[rb][cb]);
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wl, ahf[rb], acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wl, ahf[rb], acc[rb][cb]);
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wh, ahf[rb], acc[rb][cb]);
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(wh, ahf[rb], acc[rb][cb]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       wh = whn;
       wl = wln;
@@ -2313,9 +2321,12 @@ static int gemm_split_run(const float* a, const void* w_packed, const float* bia
     const char* tsel = getenv("PVSG_F16X2_TILE");
     const bool big = tsel && atoi(tsel) == 256;
     // 128-row x 256-column tiles, two workgroups per CU (the LayerNorm-fused kernel's pipeline): default for wide layers
-    // (N >= 512, N % 256 == 0: the encoder's first FFN layer 1.39 -> 1.24 ms at 32 x 720p, scripts/lab/gemm_tile_ab.py; narrower
-    // or ragged N stays on 128 x 128: 544 columns would pad to 768).  PVSG_F16X2_TILE=w256 forces it, =128 switches it off.
-    const bool wide = tsel ? tsel[0] == 'w' : (N >= 512 && N % 256 == 0);
+    // (N >= 512, N % 256 == 0: the encoder's first FFN layer 1.39 -> 1.24 ms at 32 x 720p, scripts/lab/gemm_tile_ab.py; ragged N: the
+    // wave skips the 16-column blocks beyond N -- the 544-wide projection 0.78 -> 0.76 ms; narrower N stays on 128 x 128).  PVSG_F16X2_TILE=w256 forces it, =128 switches it off.
+    // PVSG_W256_RAGGED=1: ragged N >= 512 (the 544-wide projection) on these tiles too, waves skipping the 16-column blocks beyond
+    // N: 0.78 -> 0.76 ms in a loop, +0.3 ms inside the step (profiles/r05_w256_ragged.txt) -- opt-in
+    const char* rag = getenv("PVSG_W256_RAGGED");
+    const bool wide = tsel ? tsel[0] == 'w' : (N >= 512 && (N % 256 == 0 || (rag && rag[0] == '1')));
     if (wide && N % 4 == 0 && (long long)128 * N * 4 < (1LL << 31)) {
       static std::atomic<unsigned long long> dw_r{0}, dw_n{0};
       const int tnw = (N + 255) / 256;
