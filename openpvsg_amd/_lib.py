@@ -158,7 +158,7 @@ def load():
 
 # ---- one stream at a time ------------------------------------------------------------------------------------------------
 # Waves of the 16-bit-MFMA kernels (split GEMM / convolution / attention) that share a CU with waves of ANOTHER kernel were
-# observed to corrupt that kernel's registers (DESIGN.md section 3.13, scripts/coresidency_repro.hip) -- from another process
+# observed to corrupt that kernel's registers (DESIGN.md section 3.7, scripts/coresidency_repro.hip) -- from another process
 # (parallel.warn_if_gpu_shared / isolate_shared_gpu) and just as well from a second stream of this process.  Inside one stream
 # kernels run back to back and nothing co-resides.  So launches of this backend may move from one stream to another (graph
 # capture warm-ups do), but never run on two at once: a launch on stream S while the stream that carried the previous launches

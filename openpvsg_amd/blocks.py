@@ -122,6 +122,13 @@ class WeightSignature:
         return tuple((t.data_ptr(), t._version) for m in self.modules()
                      for tab in (m._parameters, m._buffers) for t in tab.values() if t is not None)
 
+    def tensors(self):
+        """The parameter / buffer tensors themselves.  A graph entry holds them: graphs are replayed BEFORE the signature is
+        compared, so the addresses a graph baked in must stay mapped for as long as the entry lives -- after `.to()`,
+        `load_state_dict(assign=True)` or a module swap the module no longer references them, and a trimmed allocator would
+        turn the (discarded) stale replay into a memory access fault."""
+        return tuple(t for m in self.modules() for tab in (m._parameters, m._buffers) for t in tab.values() if t is not None)
+
 
 def _packed_weight(owner, slot, key, make):
     """`make()` = the packed form of a weight for the CURRENT split mode, cached on `owner` per (slot, mode): once a call has

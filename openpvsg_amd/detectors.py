@@ -136,7 +136,7 @@ class _Base(BaseModule):
                     static_out = fn(static_in)
                 # the graph references the cached positional encodings / geometry tables / kernel workspaces by address:
                 # it keeps them alive itself (their bounded caches may evict them long before this entry goes)
-                ent = (graph, static_in, static_out, sig, pin_graph_caches())
+                ent = (graph, static_in, static_out, sig, pin_graph_caches(), self.__dict__['_sig_links'].tensors())
             except Exception as e:      # an op that cannot be captured: stay eager for this key, say so once
                 import warnings
                 warnings.warn('hipGraph capture of the detector forward failed (%r); running eagerly' % (e,))

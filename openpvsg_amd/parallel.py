@@ -99,7 +99,7 @@ def warn_if_gpu_shared():
         import warnings
         warnings.warn('openpvsg_amd: %d other process(es) hold compute queues on this node\'s GPU(s) (pids %s) and HSA_CU_MASK is '
                       'not set.  Waves of the bf16-MFMA kernels co-resident on a CU with another process\'s waves were observed to '
-                      'corrupt that process\'s results (DESIGN.md section 3.13): run one process per GPU, or give the processes '
+                      'corrupt that process\'s results (DESIGN.md section 3.7): run one process per GPU, or give the processes '
                       'disjoint CU ranges with openpvsg_amd.parallel.isolate_shared_gpu() before HIP starts '
                       '(PVSG_SHARED_GPU_WARNING=off silences this).' % (len(others), others[:8]), RuntimeWarning, stacklevel=3)
 
@@ -150,6 +150,16 @@ def or_flags(flags, group=None):
     for r in range(1, world):
         out = out | allf[r]
     return out
+
+
+def agree_max(count, group=None):
+    """MAX over the ranks of a small integer tensor (the f16x2 overflow count before a branch that re-runs the clip: every
+    rank must take the same branch, or the re-run's per-layer exchanges pair with another clip's on the peers).  -> int."""
+    if not is_dist(group):
+        return int(count.reshape(-1)[0].item())
+    c = count.reshape(-1)[:1].clone()
+    dist.all_reduce(c, op=dist.ReduceOp.MAX, group=group)
+    return int(c.item())
 
 
 def merge_partials_reference(part_o, part_ml):

@@ -158,7 +158,8 @@ class PVSGPipeline(torch.nn.Module):
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                     static_out = run(static_in)
-                entry = (graph, static_in, static_out, sig, pin_graph_caches())   # (pins: see detectors._graphed)
+                entry = (graph, static_in, static_out, sig, pin_graph_caches(),   # (pins: see detectors._graphed)
+                         det.__dict__['_sig_links'].tensors())
             except Exception as e:   # capture unsupported for some op: stay eager, say so once
                 import warnings
                 warnings.warn('hipGraph capture of the VPS forward failed (%r); running eagerly' % (e,))
@@ -193,7 +194,7 @@ class PVSGPipeline(torch.nn.Module):
         key = (tuple(feats.shape), str(feats.device))
         ent = self._rel_graphs.get(key)
         if ent is not None and ent is not False:
-            graph, static_in, static_out, sig = ent
+            graph, static_in, static_out, sig = ent[:4]
             static_in.copy_(feats)
             graph.replay()
             _lib.note_replay()
@@ -222,7 +223,7 @@ class PVSGPipeline(torch.nn.Module):
                 # thread_local: CUDA calls of other threads (RCCL's watchdog polls events) must not invalidate the capture
                 with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                     static_out = run(static_in)
-                ent = (graph, static_in, static_out, sig)
+                ent = (graph, static_in, static_out, sig, ws.tensors())     # weights stay mapped while the entry lives
             except Exception as e:
                 import warnings
                 warnings.warn('hipGraph capture of the relation head failed (%r); running eagerly' % (e,))
@@ -406,6 +407,14 @@ class PVSGPipeline(torch.nn.Module):
                 seg_ids = list(sid.unbind(0))
                 k_feats = [k_feats[0]] * len(seg_ids)
         T = len(seg_ids)
+        if dist_on and clip.is_cuda and ops.split_mode() == 'f16x2':
+            # host-side tail under a process group (segments layout, PVSG_DEVICE_TAIL=off, un-fused post-processing, kept
+            # set > 127): assemble_tubes would look at THIS rank's overflow counter only, and a rank that re-runs the clip
+            # alone re-issues its per-layer exchanges against peers that have moved on.  Agree on the count first.
+            if parallel.agree_max(ops._overflow_counter(clip.device), group):
+                ops._overflow_counter(clip.device).zero_()
+                raise ops.SplitOverflowError('f16x2 split kernels met operands beyond the f16 range (|a| > 65504) on a rank of '
+                                             'the group: the results of this clip are invalid.')
         tube_ids, feats = assemble_tubes(seg_ids, k_feats, T)
         rel = None
         if feats.shape[0] >= 2:

@@ -408,6 +408,29 @@ def test_vps_detector_instance_on_and_rescale_vs_reference_golden(hip_lib, golde
     assert (masks != ref).mean() < 1e-3
 
 
+def test_sine_positional_encoding_3d_vs_reference_golden(hip_lib, golden_dir):
+    """The PRODUCT's SinePositionalEncoding3D (blocks.py, computed on the device, cached per shape) against the reference
+    class's own output (models/mask2former_vps/position_encoding.py:55-99 -> tests/golden/pe3d.npz), and its frame-shard form
+    `grid(T_local, h, w, dev, t0, t_total)` = the matching frames of the whole clip's encoding."""
+    from openpvsg_amd import blocks
+    g = np.load(os.path.join(golden_dir, 'pe3d.npz'))
+    pa = blocks.SinePositionalEncoding3D(128, normalize=True)
+    pb = blocks.SinePositionalEncoding3D(8, normalize=False, temperature=20)
+    a = pa(torch.zeros(1, 3, 4, 6, dtype=torch.bool, device=DEV))
+    b = pb(torch.zeros(2, 2, 3, 5, dtype=torch.bool, device=DEV))
+    assert a.is_cuda and a.shape == g['a'].shape and b.shape == g['b'].shape
+    np.testing.assert_allclose(a.cpu().numpy(), g['a'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(b.cpu().numpy(), g['b'], rtol=1e-5, atol=2e-6)
+    for t0, tl in ((0, 1), (1, 2), (2, 1)):                      # frame shards of the 3-frame clip (normalised by t_total = 3)
+        s = pa.grid(tl, 4, 6, torch.device(DEV), t0, 3)
+        np.testing.assert_allclose(s.cpu().numpy(), g['a'][0, t0:t0 + tl], rtol=1e-5, atol=2e-6)
+    for t0 in (0, 1):
+        s = pb.grid(1, 3, 5, torch.device(DEV), t0, 2)
+        np.testing.assert_allclose(s.cpu().numpy(), g['b'][0, t0:t0 + 1], rtol=1e-5, atol=2e-6)
+    with pytest.raises(RuntimeError):
+        pa(torch.ones(1, 3, 4, 6, dtype=torch.bool, device=DEV))
+
+
 REL_CASES = [('rel_s1_N4_T8.npz', ('transformer', 'vanilla')), ('rel_s2_N8_T16.npz', ('transformer', 'filter', 'conv')),
              ('rel_s3_N17_T33.npz', ('transformer',)), ('rel_s4_N2_T5.npz', ('vanilla',)),
              ('rel_s5_N12_T9.npz', ('transformer',))]

@@ -37,7 +37,7 @@ def _worker(rank, world, port, tmp):
     from openpvsg_amd import parallel
     from openpvsg_amd.pipeline import assemble_tubes
     torch.manual_seed(0)   # same "clip" on every rank
-    B, M, Q, D, T, hw = 1, 8, 20, 32, 4, 6
+    B, M, Q, D, T, hw = 1, 8, 20, 32, (4 if world == 2 else 8), 6       # world 8: ONE frame per rank (config 4's layout)
     K = T * hw
     q = torch.randn(B, M, Q, D) * 0.3
     k, v = torch.randn(B, M, K, D), torch.randn(B, M, K, D)
@@ -82,7 +82,7 @@ def _worker(rank, world, port, tmp):
     if rank == 0:
         assert not local_honor[0, 5] and lml[0, 0, 0, 5, 1] > 0
     # ---- tube records: every rank rebuilds the same tubes -----------------------------------------
-    ids_all = torch.tensor([[1005, 120, -1], [1005, -1, 2007], [-1, 120, 2007], [1005, 120, 2007]])
+    ids_all = torch.tensor([[1005, 120, -1], [1005, -1, 2007], [-1, 120, 2007], [1005, 120, 2007]] * (T // 4))
     feats = torch.arange(3 * 8, dtype=torch.float32).view(3, 8)
     local = ids_all[t0:t0 + tl]
     gathered = parallel.all_gather_cat(local, 0)
@@ -90,16 +90,28 @@ def _worker(rank, world, port, tmp):
     tube_ids, tubes = assemble_tubes(list(gathered.unbind(0)), [feats] * T, T)
     assert tube_ids.tolist() == [1005, 120, 2007]
     assert tubes.shape == (3, T, 8) and torch.equal(tubes[0, 2], torch.zeros(8)) and torch.equal(tubes[2, 1], feats[2])
+    # the device tail's layout (pipeline._tail_device): every rank's id rows + ONE extra row carrying its f16x2 overflow
+    # count; after the gather every rank reads the same rows and the same per-rank counts (here: only rank world-1 overflowed)
+    rows = torch.full((tl + 1, 128), -1, dtype=torch.int32)
+    rows[:tl, :3] = local.to(torch.int32)
+    rows[tl, 0] = 7 if rank == world - 1 else 0
+    allrows = parallel.all_gather_cat(rows, 0).view(world, tl + 1, 128)
+    assert torch.equal(allrows[:, :tl, :3].reshape(T, 3).long(), ids_all)
+    assert allrows[:, tl, 0].tolist() == [0] * (world - 1) + [7]
+    # the host tail's agreement on the same count (pipeline._forward -> parallel.agree_max): every rank sees the maximum
+    assert parallel.agree_max(torch.tensor([3 * rank, 0, 0, 0], dtype=torch.int32)) == 3 * (world - 1)
     torch.save(dict(ok=True, merged=merged), os.path.join(tmp, 'r%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_exchange(tmp_path):
-    world = 2
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_two_rank_exchange(tmp_path, world):
+    """world 2, 4 and 8 (tools/test.py:186-190's launcher sizes): frame ranges, R-record merge, id rows with one overflow row
+    per rank, overflow agreement."""
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    a, b = (torch.load(os.path.join(str(tmp_path), 'r%d.pt' % r)) for r in range(world))
-    assert a['ok'] and b['ok'] and torch.equal(a['merged'], b['merged'])
+    parts = [torch.load(os.path.join(str(tmp_path), 'r%d.pt' % r)) for r in range(world)]
+    assert all(p['ok'] for p in parts) and all(torch.equal(parts[0]['merged'], p['merged']) for p in parts[1:])
 
 
 def test_single_process_helpers_are_identity():

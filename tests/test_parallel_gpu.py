@@ -52,19 +52,21 @@ def _worker(rank, world, port, tmp):
     # atomics make the two ranks' backbones differ in the last bits (and a thresholded decoder amplifies that)
     torch.backends.cudnn.deterministic = True
     pipe = _build()
-    T = 4
+    T = 4 if world == 2 else 8
     clip = det_input('clip', (T, 3, 64, 96), 6)
     t0, tl = parallel.shard_frames(T, rank, world)
     out = pipe(clip[t0:t0 + tl].cuda(), (64, 96), total_frames=T, group=None)
     torch.cuda.synchronize()
-    # weak-scaling mode: every rank owns a whole segment (here: the same 4-frame clip) of a longer video
+    # weak-scaling mode: every rank owns a whole segment (here: the same clip) of a longer video
     seg = pipe(clip.cuda(), (64, 96), group=None, shard='segments')
     solo = pipe(clip.cuda(), (64, 96), shard='none')
     ids = solo['tube_ids'].tolist()
-    assert seg['tube_ids'].tolist() == ids + [i + 1000000 for i in ids]
-    assert seg['tube_feats'].shape == (2 * len(ids), 2 * T, 256)
+    assert seg['tube_ids'].tolist() == [i + r * 1000000 for r in range(world) for i in ids]
+    assert seg['tube_feats'].shape == (world * len(ids), world * T, 256)
     assert torch.allclose(seg['tube_feats'][:len(ids), :T], solo['tube_feats'], atol=1e-5)
     assert float(seg['tube_feats'][:len(ids), T:].abs().max()) == 0.0      # absent outside its own segment
+    last = seg['tube_feats'][(world - 1) * len(ids):]
+    assert torch.allclose(last[:, (world - 1) * T:], solo['tube_feats'], atol=1e-5) and float(last[:, :(world - 1) * T].abs().max()) == 0.0
     torch.save(dict(pan=out['pan_results'].cpu(), query=out['query'].cpu(), cls=out['cls'].cpu(),
                     tube_ids=out['tube_ids'].cpu(), tube_feats=out['tube_feats'].cpu(),
                     pm=None if out['relation'] is None else out['relation']['pred_matrix'].cpu(), t0=t0),
@@ -73,9 +75,12 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-def test_two_rank_clip_equals_single_process(hip_lib, tmp_path):
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_two_rank_clip_equals_single_process(hip_lib, tmp_path, world):
+    """world 2 (2 frames per rank), 4 (2 per rank) and 8 (ONE frame per rank = config 4's rank count): per-layer record
+    merge over R = world records, id rows with one overflow row per rank, both sharding layouts."""
     from oracle.detweights import det_input
-    world, T = 2, 4
+    T = 4 if world == 2 else 8
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     pipe = _build()
     clip = det_input('clip', (T, 3, 64, 96), 6)
@@ -116,6 +121,33 @@ def test_bench_gpus_2_runs_two_ranks_on_the_frame_sharded_clip(hip_lib):
     assert two['checksum']['tube_ids'] == one['checksum']['tube_ids'] and len(one['checksum']['tube_ids']) >= 2
     assert abs(two['checksum']['query_sum'] - one['checksum']['query_sum']) < 1e-2 * max(1.0, abs(one['checksum']['query_sum']))
     assert abs(two['checksum']['tube_feat_sum'] - one['checksum']['tube_feat_sum']) < 1e-2 * max(1.0, abs(one['checksum']['tube_feat_sum']))
+
+
+def test_bench_gpus_8_ranks_of_4_frames_at_720p_equals_single_process(hip_lib):
+    """BASELINE.json configs[3] at its full rank count: `bench.py --gpus 8` on the 32-frame 720p clip = 8 ranks x 4 frames
+    (PVSG_ONE_DEVICE=1: all on cuda:0 with 32 CUs each, gloo carries the 9 + 1 exchanges per step), against the single-process
+    run of the same clip: tube ids equal, query / tube-feature sums within 1e-3 relative (tools/test.py:186-190 is the
+    multi-GPU entry this extends)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ['--frames', '32', '--height', '720', '--width', '1280', '--steps', '1', '--warmup', '1', '--cpu-baseline', 'off',
+              '--sub-benchmarks', 'off', '--checksum']
+    env = dict(os.environ, PVSG_ONE_DEVICE='1', PVSG_GEMM_TABLE='off', MASTER_PORT=str(_free_port()))
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + extra + common, env=env, capture_output=True,
+                           text=True, timeout=580)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    eight = run(['--gpus', '8', '--backend', 'gloo'])
+    one = run([])
+    assert eight['n_gpus'] == 8 and eight['scaling'] == 'strong' and eight['config']['frames_per_gpu'] == 4
+    assert one['n_gpus'] == 1 and one['config']['frames_per_gpu'] == 32
+    assert eight['checksum']['tube_ids'] == one['checksum']['tube_ids'] and len(one['checksum']['tube_ids']) >= 30
+    for k in ('query_sum', 'tube_feat_sum'):
+        assert abs(eight['checksum'][k] - one['checksum'][k]) < 1e-3 * max(1.0, abs(one['checksum'][k])), k
 
 
 def _rccl_solo_worker(rank, tmp):

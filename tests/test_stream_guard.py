@@ -1,5 +1,5 @@
 """The backend runs on ONE HIP stream at a time (openpvsg_amd/_lib.py: 16-bit-MFMA kernels must not share the GPU with other
-kernels -- DESIGN.md section 3.13, scripts/coresidency_repro.hip shows the corruption from a second stream of the same
+kernels -- DESIGN.md section 3.7, scripts/coresidency_repro.hip shows the corruption from a second stream of the same
 process).  Moving from one stream to another is fine once the first is idle; launching on a second stream while the first
 still runs kernels of the backend is an error, not a warning."""
 import pytest

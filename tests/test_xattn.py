@@ -112,7 +112,7 @@ def test_large_key_count_rows_sum_to_one(hip_lib):
     assert torch.allclose(out, torch.ones_like(out), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize('R', [2, 3])
+@pytest.mark.parametrize('R', [2, 3, 4, 8])
 def test_one_message_per_layer_exchange_equals_single_device(hip_lib, R):
     """Frame-sharded clip, R emulated ranks: every rank attends on its LOCAL mask flags (no flag exchange), merges
     its key ranges into one packed record (pvsg_xattn_merge_local) and the gathered records are merged with the
@@ -120,7 +120,7 @@ def test_one_message_per_layer_exchange_equals_single_device(hip_lib, R):
     queries blocked on some ranks only, on every rank (reset), and with no mask; and the torch statements of the two
     kernels (parallel.pack_record_reference / merge_records_reference) must agree with them."""
     from openpvsg_amd import ops, parallel
-    B, Q, T, hw = 2, 100, 6, (5, 8)
+    B, Q, T, hw = 2, 100, (6 if R < 4 else 8), (5, 8)        # R = 4 / 8: two / one frame per rank (config 4's 8-rank merge)
     K = T * hw[0] * hw[1]
     q, k, v = (det_input(n, s, 17).to(DEV) for n, s in (('q', (B, Q, 256)), ('k', (B, K, 256)), ('v', (B, K, 256))))
     low = det_input('low', (B, T, Q, hw[0], hw[1]), 18)
