@@ -183,6 +183,56 @@ int pvsg_decoder_rows_post(const pvsg_decoder_layer* layer, const pvsg_decoder_h
                            float* query_out, float* cls_out, float* mask_embed_out, float* next_q_out, void* workspace,
                            void* emb_pack_f16x2, uint32_t* flags_zero, int B, int Q, void* stream);
 
+/* ---- a10 + a13: the relation head's encoders and temporal models as fused row kernels (csrc/relation_rows.hip) ----------
+ * Replace the nn.TransformerEncoder / nn.Linear / F.conv1d library calls of
+ *   models/relation_head/base.py:26-40        ObjectEncoder (2 x TransformerEncoderLayer(256, nhead 8, ff 512), attention across
+ *                                              the N objects of a frame: feats (N, T, 256), batch_first=False)
+ *   models/relation_head/transformer.py:7-56  TemporalTransformer (+ pe, TransformerEncoderLayer(512, nhead 4, ff 512) over the T
+ *                                              frames of a pair, LayerNorm, fc1 / fc2 / span_head / pred_head, max over frames)
+ *   models/relation_head/convolution.py:6-75  HandcraftedFilter, Learnable1DConv;  base.py:6-23 VanillaModel
+ * torch.nn.TransformerEncoderLayer semantics: post-norm, ReLU, eval mode (dropout off).  Weights in MFMA-fragment order
+ * (pvsg_pack_rows_weight); built for (d_model 256, 8 heads) and (d_model 512, 4 heads), dim_feedforward 512, any sequence
+ * length (PVSG_ERR_UNSUPPORTED otherwise).  Rows of a (S sequences x L positions) token set live at
+ * row = s * seq_stride + pos * pos_stride of (rows, d_model) tensors: ObjectEncoder on feats (N, T, 256): S = T, L = N,
+ * seq_stride 1, pos_stride T;  TemporalTransformer on (P, T, 512): S = P, L = T, seq_stride T, pos_stride 1. */
+typedef struct pvsg_encoder_layer {
+  const float *in_w, *in_b;         /* self_attn.in_proj_weight packed (3D, D), in_proj_bias (3D) */
+  const float *out_w, *out_b;       /* self_attn.out_proj       packed (D, D), bias */
+  const float *n1_g, *n1_b;         /* norm1 */
+  const float *f1_w, *f1_b;         /* linear1                  packed (F, D), bias (F) */
+  const float *f2_w, *f2_b;         /* linear2                  packed (D, F), bias (D) */
+  const float *n2_g, *n2_b;         /* norm2 */
+  int d_model, num_heads, ffn_dim;
+  float eps1, eps2;
+} pvsg_encoder_layer;
+typedef struct pvsg_relation_tail {
+  const float *ln_g, *ln_b;         /* NULL, or TemporalTransformer.layer_norm applied to the input rows */
+  const float *fc1_w, *fc1_b;       /* fc1 packed (256, 512), bias */
+  const float *fc2_w, *fc2_b;       /* fc2 packed (128, 256), bias */
+  const float *head_w, *head_b;     /* packed (128, 128): rows 0..R-1 span_head, rows 64..64+R-1 pred_head, the rest zero; bias (128) */
+  const float *filter;              /* NULL, or the 5 taps of HandcraftedFilter (F.conv1d along T, padding 2, per channel) */
+  int dim, num_relations;           /* 512, R <= 64 */
+  float eps;
+} pvsg_relation_tail;
+/* in_proj of the FIRST layer of E (1 or 2) encoders that share their input: qkv (E, rows, 3D), q columns scaled by 1/sqrt(D/heads).
+ *   x (rows, D), or NULL with the gather form: row (p, t) = [gather_sub[pairs[p][0], t, :] | gather_obj[pairs[p][1], t, :]]
+ *   (concatenate_sub_obj, train_utils.py:67-81; sources (N, L, D/2), pairs (rows / L, 2) int64);
+ *   pe: NULL or (>= L, D), added to the row at position `row % L` (PositionalEncoding, transformer.py:59-81);
+ *   x0_out: NULL or (rows, D): the rows after gather / + pe = the first layer's residual input. */
+int pvsg_rel_qkv(const pvsg_encoder_layer* layers, int E, const float* x, const float* gather_sub, const float* gather_obj,
+                 const long long* gather_pairs, const float* pe, float* x0_out, float* qkv, long long rows, int L, void* stream);
+/* one encoder layer of E encoders: y (E, S*L rows, D) = norm2(x1 + FFN(x1)), x1 = norm1(x + out_proj(softmax(q k^T) v));
+ *   x: residual input, encoder e at x + e * x_encoder_stride floats (0: both encoders read the same rows);
+ *   qkv (E, rows, 3D) from pvsg_rel_qkv / the previous layer; qkv_next (E, rows, 3D) != qkv: in_proj of next_layers on y, or both NULL. */
+int pvsg_rel_encoder_layer(const pvsg_encoder_layer* layers, const pvsg_encoder_layer* next_layers, int E, const float* x,
+                           long long x_encoder_stride, const float* qkv, float* y, float* qkv_next, int S, int L,
+                           long long seq_stride, long long pos_stride, void* stream);
+/* Learnable1DConv layer: y (P, T, C) = relu(Conv1d(C, C, 5, padding 2)(x along T));  w_packed = 5 x pvsg_pack_rows_weight(W[:, :, k]) */
+int pvsg_rel_conv5(const float* w_packed, const float* bias, const float* x, float* y, int P, int T, int C, void* stream);
+/* tail of every relation model on x (P, T, 512): span_pred (P, T, R), relation_pred (P, R) = max over T of pred_head */
+int pvsg_rel_tail(const pvsg_relation_tail* tail, const float* x, float* span_pred, float* relation_pred, int P, int T,
+                  void* stream);
+
 /* ---- a11: pairwise relation proposal scorer -------------------------------------------------
  * Replaces models/relation_head/base.py:49-62 PairProposalNetwork.forward (N^2 Python loop).
  *   sub_feats, obj_feats (N, T, 256)  encoder outputs; tokens = max over T (base.py:50-51)
@@ -194,6 +244,12 @@ int pvsg_pair_score_forward(const float* sub_feats, const float* obj_feats, cons
                             const float* b1, const float* w2, const float* b2, float* work_uv,
                             float* tokens_out, float* pair_matrix, int N, int T, int C, int Hd,
                             void* stream);
+
+/* a12: pick_top_pairs_eval (models/relation_head/test_utils.py:4-22): the P = min(N^2 - N, num_total_pairs) best
+ * off-diagonal entries of pair_matrix (N, N), best first, as pairs (P, 2) int64 [subject, object]; ties to the lower flat
+ * index.  One launch instead of clone + fill_diagonal_ + topk + div + remainder + stack.  P <= 1024, N <= 128
+ * (the keys of a video live in the registers of one workgroup; PVSG_ERR_UNSUPPORTED beyond). */
+int pvsg_top_pairs(const float* pair_matrix, long long* pairs, int N, int P, void* stream);
 
 /* ---- a7 + a8: fused x4 up-sampling + panoptic fusion ---------------
  * Replaces F.interpolate(mask_pred, batch_input_shape) models/mask2former/mask2former_head.py:675-679

@@ -34,6 +34,20 @@ class DecoderHead(ctypes.Structure):
         'pn_g', 'pn_b', 'cls_w', 'cls_b', 'm0_w', 'm0_b', 'm1_w', 'm1_b', 'm2_w', 'm2_b')] + [('num_cls_out', _i)]
 
 
+class EncoderLayer(ctypes.Structure):
+    """pvsg_encoder_layer (include/openpvsg_hip.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        'in_w', 'in_b', 'out_w', 'out_b', 'n1_g', 'n1_b', 'f1_w', 'f1_b', 'f2_w', 'f2_b', 'n2_g', 'n2_b')] + [
+        ('d_model', _i), ('num_heads', _i), ('ffn_dim', _i), ('eps1', _f), ('eps2', _f)]
+
+
+class RelationTail(ctypes.Structure):
+    """pvsg_relation_tail (include/openpvsg_hip.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        'ln_g', 'ln_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'head_w', 'head_b', 'filter')] + [
+        ('dim', _i), ('num_relations', _i), ('eps', _f)]
+
+
 # name -> argtypes; must list every function include/openpvsg_hip.h declares
 # (tests/test_capi.py cross-checks this table against the header).
 SIGNATURES = {
@@ -53,6 +67,12 @@ SIGNATURES = {
     'pvsg_decoder_rows_pre': [ctypes.POINTER(DecoderLayer), _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _c_f],
     'pvsg_decoder_rows_post_workspace_bytes': [_i, _i],
     'pvsg_decoder_rows_post': [ctypes.POINTER(DecoderLayer), ctypes.POINTER(DecoderHead)] + [_c_f] * 12 + [_i, _i, _c_f],
+    'pvsg_rel_qkv': [ctypes.POINTER(EncoderLayer), _i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _ll, _i, _c_f],
+    'pvsg_rel_encoder_layer': [ctypes.POINTER(EncoderLayer), ctypes.POINTER(EncoderLayer), _i, _c_f, _ll, _c_f, _c_f, _c_f, _i, _i,
+                               _ll, _ll, _c_f],
+    'pvsg_rel_conv5': [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _c_f],
+    'pvsg_rel_tail': [ctypes.POINTER(RelationTail), _c_f, _c_f, _c_f, _i, _i, _c_f],
+    'pvsg_top_pairs': [_c_f, _c_f, _i, _i, _c_f],
     'pvsg_pair_prepare_weights': [_c_f, _c_f, _i, _i, _c_f],
     'pvsg_pair_score_forward': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _c_f],
     'pvsg_panoptic_fuse': [_c_f] * 8 + [_i] * 13 + [ctypes.c_double, _i, _c_f],

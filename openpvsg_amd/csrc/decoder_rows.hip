@@ -19,13 +19,13 @@
 //   decoder_rows_pre   out_proj + LN, self-attention in_proj (q scaled, k, v)            -> x1, qkv
 //   decoder_rows_post  self-attention, out_proj + LN, FFN + LN, post_norm, cls / mask embeddings, next q
 // `decoder_rows_post` with no layer runs the head part only (the forward_head call on the initial queries).
-#include "common.h"
+#include "rows_common.h"
 
 #include "../../include/openpvsg_hip.h"
 
 namespace pvsg {
 
-constexpr int DR_THREADS = 512;           // 8 waves: 8 heads in the attention step, 8 column groups in the GEMMs
+constexpr int DR_THREADS = ROWS_THREADS;  // 8 waves: 8 heads in the attention step, 8 column groups in the GEMMs (rows_common.h)
 constexpr int DR_C = 256;                 // embed dims (8 heads x 32)
 constexpr int DR_LD = DR_C + 4;           // LDS row stride: rows 16 B apart mod 256 B -> conflict-free b128 reads
 constexpr int DR_FC = 512;                // FFN hidden chunk held in LDS
@@ -44,67 +44,6 @@ __global__ void pack_rows_weight_kernel(const float* __restrict__ W, float* __re
   const int kc = (int)(rest % nkc), tile = (int)(rest / nkc);
   const int n = tile * 16 + (lane & 15), k = kc * 16 + 4 * (lane >> 4) + j;
   P[i] = n < N ? W[(long long)n * K + k] : 0.f;
-}
-
-// acc[i] += X[16 x (16*nkc)] . W^T for column tiles t0 + i (packed weights, k chunks kc0 .. kc0+nkc-1 of a
-// weight with `wkc` chunks per tile).  A fragment: lane (r = lane&15, g = lane>>4) holds X[r][16kc + 4g + j],
-// B fragment: W[16t + r][16kc + 4g + j] -- the k index of MFMA step j is 4g + j on both sides.
-template <int NT, int NKC, int DEPTH>
-__device__ __forceinline__ void rows_gemm(const float* __restrict__ xl, int ld, const float* __restrict__ wp,
-                                          int wkc, int kc0, int t0, f32x4 (&acc)[NT], int lane) {
-  // The weights come from L2 / Infinity Cache (0.5 - 2 us away) while one k chunk is only NT x 128 matrix cycles:
-  // DEPTH chunks of B fragments are kept in flight in a register ring (fully unrolled: static ring indices).
-  const float* xa = xl + (lane & 15) * ld + 4 * (lane >> 4);
-  const float* wb = wp + ((long long)t0 * wkc + kc0) * 256 + lane * 4;
-  const long long tstride = (long long)wkc * 256;
-  float4 ring[DEPTH][NT];
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d)
-#pragma unroll
-    for (int i = 0; i < NT; ++i) ring[d][i] = ld4(wb + i * tstride + d * 256);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int kc = 0; kc < NKC; ++kc) {
-    const float4 a = *reinterpret_cast<const float4*>(xa + kc * 16);
-    float4 cur[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) cur[i] = ring[kc % DEPTH][i];
-    if (kc + DEPTH < NKC) {
-#pragma unroll
-      for (int i = 0; i < NT; ++i) ring[kc % DEPTH][i] = ld4(wb + i * tstride + (kc + DEPTH) * 256);
-    }
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, cur[i].x, acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, cur[i].y, acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, cur[i].z, acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, cur[i].w, acc[i], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);     // keep the ring as written: loads of chunk kc+DEPTH stay behind chunk kc's
-  }
-}
-
-// all-reduce over the 64 lanes in the VALU: DPP quad / row permutations for the first four steps,
-// v_permlane16_swap / v_permlane32_swap for the last two (no LDS crossbar round trips).
-template <bool MAX>
-__device__ __forceinline__ float wave_allreduce(float v) {
-  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
-  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
-  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
-  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xf, 0xf, false)));  // row_half_mirror
-  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x140, 0xf, 0xf, false)));  // row_mirror
-  unsigned u = __float_as_uint(v);
-  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  v = op(__uint_as_float(a[0]), __uint_as_float(a[1]));
-  u = __float_as_uint(v);
-  auto b2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return op(__uint_as_float(b2[0]), __uint_as_float(b2[1]));
-}
-
-template <int NT>
-__device__ __forceinline__ void zero_acc(f32x4 (&acc)[NT]) {
-#pragma unroll
-  for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // LayerNorm over the 256 columns of the 16 LDS rows of `x` (two-pass statistics like ATen), 32 threads per row.

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void pair_token_proj_kernel(
     if (i < N) {
       const float* p = src + (long long)i * T * CF + threadIdx.x;
       m = -INFINITY;
-      for (int t = 0; t < T; ++t) m = fmaxf(m, p[(long long)t * CF]);
+#pragma unroll 8
+      for (int t = 0; t < T; ++t) m = fmaxf(m, p[(long long)t * CF]);      // 8 independent loads in flight
       if (tok_out && blockIdx.x == 0) tok_out[((long long)which * N + i) * CF + threadIdx.x] = m;
     }
     tok[ob][threadIdx.x] = m;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void pair_token_proj_kernel(
   __syncthreads();
   const float* wp = W1T + (long long)which * CF * HDN + k;
   float acc[OB] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
+#pragma unroll 32
   for (int c = 0; c < CF; ++c) {
     const float w = wp[(long long)c * HDN];
 #pragma unroll
@@ -97,7 +98,131 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pick_top_pairs_eval (models/relation_head/test_utils.py:4-22): the P best off-diagonal entries of the pair matrix, best first,
+// as (subject, object) index pairs.  One workgroup: radix select of the P-th largest key (4 passes over 8 bits), unordered
+// collection of the larger entries, index-ordered collection of the entries equal to the threshold, rank sort of the P
+// candidates.  Replaces clone + fill_diagonal_ + topk (radix sort + merge) + div + remainder + stack (12 launches, 70 us).
+// Ties go to the lower flat index (torch.topk leaves their order unspecified).
+// ------------------------------------------------------------------------------------------------
+constexpr int TP_THREADS = 1024;
+constexpr int TP_MAXP = 1024;
+constexpr int TP_SLOTS = 16;                                // keys per thread, held in registers: N^2 <= 16 384
+
+__device__ __forceinline__ unsigned tp_key(float v) {      // order-preserving: larger float <-> larger unsigned; NaN on top
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// count over the block of a per-thread number (every thread gets the total); two barriers
+__device__ __forceinline__ int tp_block_sum(int v, int* wave_tot, int lane, int w) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  if (lane == 0) wave_tot[w] = v;
+  __syncthreads();
+  int tot = 0;
+#pragma unroll
+  for (int ww = 0; ww < TP_THREADS / 64; ++ww) tot += wave_tot[ww];
+  __syncthreads();
+  return tot;
+}
+
+__global__ __launch_bounds__(TP_THREADS) void top_pairs_kernel(const float* __restrict__ m, long long* __restrict__ pairs, int N,
+                                                               int P) {
+  __shared__ unsigned cand_key[TP_MAXP];
+  __shared__ int cand_idx[TP_MAXP];
+  __shared__ int s_ngt;
+  __shared__ int wave_tot[TP_THREADS / 64];
+  const int n = N * N, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // slot s of thread t = flat element s * 1024 + t (consecutive threads = consecutive elements); key 0 = not a candidate
+  unsigned key[TP_SLOTS];
+#pragma unroll
+  for (int s = 0; s < TP_SLOTS; ++s) {
+    const int i = s * TP_THREADS + tid;
+    unsigned k = 0u;
+    if (i < n) {
+      const int r = i / N;
+      if (i - r * N != r) k = tp_key(m[i]);                // the diagonal sorts below everything
+    }
+    key[s] = k;
+  }
+  if (tid == 0) s_ngt = 0;
+  // the P-th largest key, bit by bit from the top: the candidate prefix with the next bit set is kept if at least `need` keys
+  // carry it (a histogram over float keys would pile its LDS atomics onto the two or three exponent bins the values live in)
+  unsigned prefix = 0u;
+  int need = P;
+#pragma unroll 1
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned cand = prefix | (1u << bit), himask = 0xFFFFFFFFu << bit;
+    int c = 0;
+#pragma unroll
+    for (int s = 0; s < TP_SLOTS; ++s) c += (key[s] & himask) == cand ? 1 : 0;
+    const int tot = tp_block_sum(c, wave_tot, lane, w);
+    if (tot >= need) prefix = cand;                        // the P-th largest has this bit set
+    else need -= tot;                                      // all `tot` keys with the bit set are larger than it
+  }
+  // prefix = key of the P-th best entry; `need` entries equal to it are taken (lowest index first), everything above it is
+#pragma unroll
+  for (int s = 0; s < TP_SLOTS; ++s) {
+    if (key[s] > prefix) {
+      const int pos = atomicAdd(&s_ngt, 1);
+      cand_key[pos] = key[s];
+      cand_idx[pos] = s * TP_THREADS + tid;
+    }
+  }
+  __syncthreads();
+  const int ngt = s_ngt;                                   // == P - need
+  int taken = 0;
+#pragma unroll
+  for (int s = 0; s < TP_SLOTS; ++s) {
+    if (taken < need && s * TP_THREADS < n) {              // uniform
+      const bool flag = key[s] == prefix && prefix != 0u;
+      const unsigned long long bal = __ballot(flag);
+      const int wpre = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_tot[w] = __popcll(bal);
+      __syncthreads();
+      int off = 0, tot = 0;
+#pragma unroll
+      for (int ww = 0; ww < TP_THREADS / 64; ++ww) {
+        const int c = wave_tot[ww];
+        off += ww < w ? c : 0;
+        tot += c;
+      }
+      const int pos = taken + off + wpre;
+      if (flag && pos < need) {
+        cand_key[ngt + pos] = prefix;
+        cand_idx[ngt + pos] = s * TP_THREADS + tid;
+      }
+      taken += tot;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  if (tid < P) {
+    const unsigned k = cand_key[tid];
+    const int ix = cand_idx[tid];
+    int rank = 0;
+    for (int j = 0; j < P; ++j) {
+      const unsigned kj = cand_key[j];
+      rank += (kj > k || (kj == k && cand_idx[j] < ix)) ? 1 : 0;
+    }
+    pairs[2 * rank] = ix / N;
+    pairs[2 * rank + 1] = ix % N;
+  }
+}
+
 }  // namespace pvsg
+
+extern "C" int pvsg_top_pairs(const float* pair_matrix, long long* pairs, int N, int P, hipStream_t stream) {
+  using namespace pvsg;
+  PVSG_REQUIRE(pair_matrix && pairs, "top_pairs: null pointer argument");
+  PVSG_REQUIRE(N > 1 && P > 0 && (long long)P <= (long long)N * N - N, "top_pairs: need 1 <= P <= N^2 - N (N=%d P=%d)", N, P);
+  if (P > TP_MAXP || N > 128)
+    return set_err(PVSG_ERR_UNSUPPORTED, "top_pairs: at most %d pairs of at most 128 objects (got %d / %d)", TP_MAXP, P, N);
+  hipLaunchKernelGGL(top_pairs_kernel, dim3(1), dim3(TP_THREADS), 0, stream, pair_matrix, pairs, N, P);
+  PVSG_LAUNCH_CHECK("top_pairs");
+  return PVSG_OK;
+}
 
 extern "C" int pvsg_pair_prepare_weights(const float* W1, float* W1T, int C, int Hd, hipStream_t stream) {
   using namespace pvsg;

@@ -1,0 +1,138 @@
+// Building blocks of the "row" kernels (decoder_rows.hip, relation_rows.hip): a workgroup of 8 waves owns 16 activation rows in
+// LDS and walks a chain of small dense layers over them.  Every GEMM is  X[16 x K] . W^T  on v_mfma_f32_16x16x4_f32 (exact
+// f32 products, f32 accumulation), the weights streamed from L2 in MFMA-fragment order (pvsg_pack_rows_weight: one contiguous
+// 1 KiB per wave load) through a register ring.
+#pragma once
+#include "common.h"
+
+namespace pvsg {
+
+constexpr int ROWS_THREADS = 512;         // 8 waves: 8 column groups in the GEMMs
+
+// acc[i] += X[16 x (16*nkc)] . W^T for column tiles t0 + i (packed weights, k chunks kc0 .. kc0+nkc-1 of a
+// weight with `wkc` chunks per tile).  A fragment: lane (r = lane&15, g = lane>>4) holds X[r][16kc + 4g + j],
+// B fragment: W[16t + r][16kc + 4g + j] -- the k index of MFMA step j is 4g + j on both sides.
+template <int NT, int NKC, int DEPTH>
+__device__ __forceinline__ void rows_gemm(const float* __restrict__ xl, int ld, const float* __restrict__ wp,
+                                          int wkc, int kc0, int t0, f32x4 (&acc)[NT], int lane) {
+  // The weights come from L2 / Infinity Cache (0.5 - 2 us away) while one k chunk is only NT x 128 matrix cycles:
+  // DEPTH chunks of B fragments are kept in flight in a register ring (fully unrolled: static ring indices).
+  const float* xa = xl + (lane & 15) * ld + 4 * (lane >> 4);
+  const float* wb = wp + ((long long)t0 * wkc + kc0) * 256 + lane * 4;
+  const long long tstride = (long long)wkc * 256;
+  float4 ring[DEPTH][NT];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) ring[d][i] = ld4(wb + i * tstride + d * 256);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc) {
+    const float4 a = *reinterpret_cast<const float4*>(xa + kc * 16);
+    float4 cur[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) cur[i] = ring[kc % DEPTH][i];
+    if (kc + DEPTH < NKC) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) ring[kc % DEPTH][i] = ld4(wb + i * tstride + (kc + DEPTH) * 256);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, cur[i].x, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, cur[i].y, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, cur[i].z, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, cur[i].w, acc[i], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);     // keep the ring as written: loads of chunk kc+DEPTH stay behind chunk kc's
+  }
+}
+
+// all-reduce over the 64 lanes in the VALU: DPP quad / row permutations for the first four steps,
+// v_permlane16_swap / v_permlane32_swap for the last two (no LDS crossbar round trips).
+template <bool MAX>
+__device__ __forceinline__ float wave_allreduce(float v) {
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
+  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
+  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xf, 0xf, false)));  // row_half_mirror
+  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x140, 0xf, 0xf, false)));  // row_mirror
+  unsigned u = __float_as_uint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = op(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  u = __float_as_uint(v);
+  auto b2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return op(__uint_as_float(b2[0]), __uint_as_float(b2[1]));
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[NT]) {
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// One dense layer over the 16 LDS rows: out columns [0, NOUT) split over the 8 waves (NOUT / 128 column tiles each, in passes
+// of at most four), epi(tile, acc) receives each finished 16 x 16 tile: acc[e] = row 4 * (lane >> 4) + e, column 16 * tile +
+// (lane & 15).
+template <int KDIM, int NOUT, typename Epi>
+__device__ __forceinline__ void rows_linear(const float* __restrict__ xl, int ld, const float* __restrict__ wp, int w,
+                                            int lane, Epi epi) {
+  static_assert(KDIM % 16 == 0 && NOUT % 128 == 0, "rows_linear: K a multiple of 16, N a multiple of 128");
+  constexpr int TPW = NOUT / 128;                                    // column tiles per wave
+  constexpr int NT = TPW % 4 == 0 ? 4 : (TPW % 2 == 0 ? 2 : 1);
+  constexpr int NKC = KDIM / 16;
+  constexpr int DEPTH = NT == 4 ? 4 : 8;
+#pragma unroll 1
+  for (int pass = 0; pass < TPW / NT; ++pass) {
+    const int t0 = w * TPW + pass * NT;
+    f32x4 acc[NT];
+    zero_acc(acc);
+    // opaque to the optimiser: inside a caller's loop the ~100 fragment addresses of a layer are loop invariants, and hoisting
+    // them (as 64-bit VGPR pairs) is what made the first build of relation_rows.hip spill 1 200 registers
+    const float* wpl = wp;
+    asm volatile("" : "+s"(wpl));
+    rows_gemm<NT, NKC, (DEPTH < NKC ? DEPTH : NKC)>(xl, ld, wpl, NKC, 0, t0, acc, lane);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) epi(t0 + i, acc[i]);
+  }
+}
+
+// LayerNorm over the D columns of the 16 LDS rows of `x` (row stride D + 4; two-pass statistics like ATen), 32 threads per
+// row, thread (r, cl) owns the float4 groups at columns 4 * (32 i + cl).  out: LDS destination or null; g_out: global row
+// pointer of row 0 or null, rows `g_stride` floats apart, rows >= valid_rows not written.
+template <int D>
+__device__ __forceinline__ void rows_layernorm_t(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float eps, float* out,
+                                                 float* __restrict__ g_out, long long g_stride, int valid_rows) {
+  constexpr int LD = D + 4, NG = D / 128;
+  const int r = threadIdx.x >> 5, cl = threadIdx.x & 31;
+  float4 v[NG];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    v[i] = *reinterpret_cast<const float4*>(x + r * LD + 4 * (32 * i + cl));
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s * (1.f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q * (1.f / D) + eps);
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const int c = 4 * (32 * i + cl);
+    const float4 g = ld4(gamma + c), b = ld4(beta + c);
+    const float4 y = make_float4(v[i].x * rstd * g.x + b.x, v[i].y * rstd * g.y + b.y, v[i].z * rstd * g.z + b.z,
+                                 v[i].w * rstd * g.w + b.w);
+    if (out) *reinterpret_cast<float4*>(out + r * LD + c) = y;
+    if (g_out && r < valid_rows) st4(g_out + (long long)r * g_stride + c, y);
+  }
+}
+
+}  // namespace pvsg

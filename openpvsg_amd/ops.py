@@ -300,6 +300,90 @@ def pair_score(sub_feats, obj_feats, W1, b1, w2, b2, return_tokens=False, W1T=No
     return (out, tok) if return_tokens else out
 
 
+def top_pairs(pair_matrix, P):
+    """(P, 2) int64 [subject, object] of the P best off-diagonal entries of pair_matrix (N, N), best first (ties: lower flat
+    index) -- pick_top_pairs_eval, models/relation_head/test_utils.py:4-22."""
+    m = _chk(pair_matrix, 'pair_matrix')
+    if m.dim() != 2 or m.shape[0] != m.shape[1]:
+        raise RuntimeError('top_pairs: pair_matrix must be (N, N)')
+    out = torch.empty((P, 2), device=m.device, dtype=torch.int64)
+    with _on(m.device):
+        _lib.call('pvsg_top_pairs', m.data_ptr(), out.data_ptr(), int(m.shape[0]), int(P), _stream_ptr())
+    return out
+
+
+# ---- relation head rows (relation_rows.hip): ObjectEncoder / TemporalTransformer / convolution models -----------------------
+def rel_qkv(layers, E, D, rows, L, x=None, gather=None, pe=None, want_x0=False):
+    """in_proj of the first layer of E encoders sharing their input rows -> qkv (E, rows, 3D) [, x0 (rows, D)].
+    layers: ctypes array of E _lib.EncoderLayer; x (rows, D) or gather = (sub (N,L,D/2), obj (N,L,D/2), pairs (rows/L, 2) int64);
+    pe (>= L, D) or None is added at position row % L."""
+    if gather is not None:
+        gs, go = _chk(gather[0], 'gather sub'), _chk(gather[1], 'gather obj')
+        gp = _chk(gather[2], 'gather pairs', torch.int64)
+        if gs.shape != go.shape or gs.dim() != 3 or gs.shape[1] != L or gs.shape[2] * 2 != D or gp.numel() * L != 2 * rows:
+            raise RuntimeError('rel_qkv: gather sources must be (N, L, D/2) and pairs (rows / L, 2)')
+        dev = gs.device
+    else:
+        x = _chk(x, 'x')
+        if x.numel() != rows * D:
+            raise RuntimeError('rel_qkv: x must hold rows x D values')
+        dev = x.device
+    if pe is not None:
+        pe = _chk(pe, 'pe')
+        if pe.numel() < L * D:
+            raise RuntimeError('rel_qkv: positional table shorter than the sequence (%d < %d rows)' % (pe.numel() // D, L))
+    qkv = torch.empty((E, rows, 3 * D), device=dev, dtype=torch.float32)
+    x0 = torch.empty((rows, D), device=dev, dtype=torch.float32) if want_x0 else None
+    with _on(dev):
+        _lib.call('pvsg_rel_qkv', layers, E, x.data_ptr() if gather is None else None,
+                  gs.data_ptr() if gather is not None else None, go.data_ptr() if gather is not None else None,
+                  gp.data_ptr() if gather is not None else None, pe.data_ptr() if pe is not None else None,
+                  x0.data_ptr() if x0 is not None else None, qkv.data_ptr(), rows, L, _stream_ptr())
+    return (qkv, x0) if want_x0 else qkv
+
+
+def rel_encoder_layer(layers, next_layers, E, D, x, x_encoder_stride, qkv, S, L, seq_stride, pos_stride):
+    """One post-norm TransformerEncoderLayer of E encoders over S sequences of L positions (row = s * seq_stride + pos *
+    pos_stride) -> y (E, S*L, D), qkv_next (E, S*L, 3D) or None (next_layers None = last layer)."""
+    x, qkv = _chk(x, 'x'), _chk(qkv, 'qkv')
+    rows = S * L
+    if tuple(qkv.shape) != (E, rows, 3 * D) or x.numel() < rows * D + (E - 1) * x_encoder_stride:
+        raise RuntimeError('rel_encoder_layer: inconsistent shapes')
+    y = torch.empty((E, rows, D), device=x.device, dtype=torch.float32)
+    nxt = torch.empty_like(qkv) if next_layers is not None else None
+    with _on(x.device):
+        _lib.call('pvsg_rel_encoder_layer', layers, next_layers, E, x.data_ptr(), int(x_encoder_stride), qkv.data_ptr(),
+                  y.data_ptr(), nxt.data_ptr() if nxt is not None else None, S, L, int(seq_stride), int(pos_stride), _stream_ptr())
+    return y, nxt
+
+
+def rel_conv5(w_packed, bias, x):
+    """relu(Conv1d(C, C, 5, padding 2)) along T of x (P, T, C); w_packed = the 5 taps, each pack_rows_weight(W[:, :, k])."""
+    x, w_packed, bias = _chk(x, 'x'), _chk(w_packed, 'w_packed'), _chk(bias, 'bias')
+    P, T, C = x.shape
+    y = torch.empty_like(x)
+    if P * T == 0:
+        return y
+    with _on(x.device):
+        _lib.call('pvsg_rel_conv5', w_packed.data_ptr(), bias.data_ptr(), x.data_ptr(), y.data_ptr(), P, T, C, _stream_ptr())
+    return y
+
+
+def rel_tail(tail_struct, x, num_relations):
+    """[filter] [LayerNorm] fc1 relu fc2 relu -> span_pred (P, T, R), relation_pred (P, R) = max over T of pred_head."""
+    x = _chk(x, 'x')
+    if x.dim() == 2:
+        raise RuntimeError('rel_tail: x must be (P, T, C)')
+    P, T, _ = x.shape
+    span = torch.empty((P, T, num_relations), device=x.device, dtype=torch.float32)
+    pred = torch.empty((P, num_relations), device=x.device, dtype=torch.float32)
+    if P * T == 0:
+        return span, pred
+    with _on(x.device):
+        _lib.call('pvsg_rel_tail', ctypes.byref(tail_struct), x.data_ptr(), span.data_ptr(), pred.data_ptr(), P, T, _stream_ptr())
+    return span, pred
+
+
 def panoptic_fuse(mask_logits, kept_idx, kept_score, kept_class, out_hw, crop_hw, num_things,
                   num_classes, iou_thr=0.8, filter_low_score=False, ori_hw=None):
     """Fused up-sampling (+ crop + optional second resize to `ori_hw`) + panoptic fusion for T frames

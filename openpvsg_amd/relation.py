@@ -10,18 +10,129 @@ Module/parameter names equal the reference's, so `epoch_*.pth` checkpoints load 
 relation_model).
 
 Changes underneath: the N^2 pair scorer is the HIP kernel (pair_score.hip) and returns a DEVICE
-matrix; top-k, the (subject, object) gather and result ranking are batched tensor ops (one host
-transfer per video instead of thousands of `.item()` / `.cpu()` calls).  The encoders and the
-temporal models are small dense GEMM stacks and stay PyTorch-ROCm library calls.
+matrix; top-k and result ranking are batched tensor ops (one host transfer per video instead of
+thousands of `.item()` / `.cpu()` calls).  The encoders and the temporal models run on the fused row
+kernels of csrc/relation_rows.hip (`_EncoderRows`, `_TailRows`): both ObjectEncoders in three launches
+(in_proj, layer 0 + layer 1's in_proj, layer 1), the TemporalTransformer in three (gather of the
+selected (subject, object) rows + positional table + in_proj, the encoder layer, LayerNorm + the
+fc1 / fc2 / span / pred tail with the max over frames).  On CPU tensors, in training mode, or for
+module sizes the kernels are not built for (d_model / heads other than 256 / 8 and 512 / 4,
+dim_feedforward != 512, more than 64 relations) the torch statements below run instead.
 """
+import ctypes
 import math
+import os
 
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import _lib, ops
+
+
+def _rows_enabled(x, *modules):
+    """the HIP row kernels apply: device tensor, f32, inference (dropout is the identity), not switched off"""
+    return (x.is_cuda and x.dtype == torch.float32 and not any(m.training for m in modules) and
+            os.environ.get('PVSG_RELATION_ROWS', 'on') != 'off')
+
+
+def _signature(*modules):
+    return tuple((t.data_ptr(), t._version) for m in modules for mm in m.modules()
+                 for tab in (mm._parameters, mm._buffers) for t in tab.values() if t is not None)
+
+
+def _cached(owner, slot, modules, make):
+    """`make()` once per weight state of `modules` ((address, version) of every parameter / buffer), kept on `owner`."""
+    sig = _signature(*modules)
+    ent = owner.__dict__.get(slot)
+    if ent is None or ent[0] != sig:
+        ent = owner.__dict__[slot] = (sig, make())
+    return ent[1]
+
+
+class _EncoderRows:
+    """Packed weights (MFMA-fragment order, ops.pack_rows_weight) + C structs of the layers of an nn.TransformerEncoder for
+    csrc/relation_rows.hip."""
+
+    SHAPES = ((256, 8), (512, 4))
+
+    @staticmethod
+    def supported(enc):
+        if not isinstance(enc, nn.TransformerEncoder) or enc.norm is not None or len(enc.layers) == 0:
+            return False
+        for l in enc.layers:
+            a = getattr(l, 'self_attn', None)
+            if not (isinstance(l, nn.TransformerEncoderLayer) and isinstance(a, nn.MultiheadAttention)):
+                return False
+            relu = getattr(l, 'activation_relu_or_gelu', 0) == 1 or l.activation is F.relu or isinstance(l.activation, nn.ReLU)
+            if (l.norm_first or not relu or a.batch_first or not a._qkv_same_embed_dim or a.in_proj_bias is None or
+                    a.bias_k is not None or a.add_zero_attn or (a.embed_dim, a.num_heads) not in _EncoderRows.SHAPES or
+                    l.linear1.out_features != 512 or l.linear1.bias is None or l.linear2.bias is None or
+                    a.out_proj.bias is None or not l.norm1.elementwise_affine or not l.norm2.elementwise_affine or
+                    a.embed_dim != enc.layers[0].self_attn.embed_dim):
+                return False
+        return True
+
+    def __init__(self, enc):
+        self.keep = []
+        self.d_model = enc.layers[0].self_attn.embed_dim
+        self.structs = [self._layer(l) for l in enc.layers]
+
+    def _pk(self, w):
+        t = ops.pack_rows_weight(w)
+        self.keep.append(t)
+        return t.data_ptr()
+
+    def _raw(self, t):
+        t = t.detach().contiguous()
+        self.keep.append(t)
+        return t.data_ptr()
+
+    def _layer(self, l):
+        a, pk, raw = l.self_attn, self._pk, self._raw
+        return _lib.EncoderLayer(
+            in_w=pk(a.in_proj_weight), in_b=raw(a.in_proj_bias), out_w=pk(a.out_proj.weight), out_b=raw(a.out_proj.bias),
+            n1_g=raw(l.norm1.weight), n1_b=raw(l.norm1.bias), f1_w=pk(l.linear1.weight), f1_b=raw(l.linear1.bias),
+            f2_w=pk(l.linear2.weight), f2_b=raw(l.linear2.bias), n2_g=raw(l.norm2.weight), n2_b=raw(l.norm2.bias),
+            d_model=a.embed_dim, num_heads=a.num_heads, ffn_dim=l.linear1.out_features, eps1=l.norm1.eps, eps2=l.norm2.eps)
+
+    @staticmethod
+    def arrays(packs):
+        """per layer index: a ctypes array with one struct per encoder (the E encoders of one launch)"""
+        E = len(packs)
+        return [(_lib.EncoderLayer * E)(*[p.structs[i] for p in packs]) for i in range(len(packs[0].structs))]
+
+
+def _run_encoders(packs, arrays, x_rows, S, L, seq_stride, pos_stride, qkv=None):
+    """E encoders (same depth and width) over the same input rows -> y (E, rows, D)."""
+    E, D, rows = len(packs), packs[0].d_model, S * L
+    if qkv is None:
+        qkv = ops.rel_qkv(arrays[0], E, D, rows, L, x=x_rows)
+    y, stride = x_rows, 0
+    for i in range(len(arrays)):
+        nxt = arrays[i + 1] if i + 1 < len(arrays) else None
+        y, qkv = ops.rel_encoder_layer(arrays[i], nxt, E, D, y, stride, qkv, S, L, seq_stride, pos_stride)
+        stride = rows * D
+    return y
+
+
+def encode_subject_object(subject_encoder, object_encoder, feats):
+    """(subject_encoder(feats), object_encoder(feats)) -- tools/rel_test.py:37-38.  Both ObjectEncoders read the same tubes:
+    when both are on the row kernels they share every launch (2 x T x ceil(N / 16) workgroups instead of two half-empty grids)."""
+    ok = (isinstance(subject_encoder, ObjectEncoder) and isinstance(object_encoder, ObjectEncoder) and feats.dim() == 3 and
+          feats.shape[0] > 0 and feats.shape[1] > 0 and _rows_enabled(feats, subject_encoder, object_encoder) and
+          subject_encoder._rows_ok() and object_encoder._rows_ok() and
+          len(subject_encoder.transformer_encoder.layers) == len(object_encoder.transformer_encoder.layers) and
+          feats.shape[2] == subject_encoder._d_model() == object_encoder._d_model())
+    if not ok:
+        return subject_encoder(feats), object_encoder(feats)
+    N, T, D = feats.shape
+    packs = [subject_encoder._pack(), object_encoder._pack()]
+    arrays = _cached(subject_encoder, '_rows_pair_' + str(id(object_encoder)), (subject_encoder, object_encoder),
+                     lambda: (_EncoderRows.arrays(packs), packs))[0]
+    y = _run_encoders(packs, arrays, feats.contiguous().view(N * T, D), T, N, 1, T)
+    return y[0].view(N, T, D), y[1].view(N, T, D)
 
 
 class _RelationModel(nn.Module):
@@ -38,6 +149,47 @@ class _RelationModel(nn.Module):
         x = F.relu(self.fc2(F.relu(self.fc1(x))))
         return self.span_head(x), self.pred_head(x).amax(dim=1)
 
+    # ---- csrc/relation_rows.hip: rel_tail_kernel ----------------------------------------------------------------------
+    def _tail_ok(self, x):
+        return x.dim() == 3 and self._tail_ok_dims(x.shape[0], x.shape[1], x.shape[2], x)
+
+    def _tail_ok_dims(self, P, T, C, ref):
+        """input (P, T, C) living where `ref` lives"""
+        return (P > 0 and T > 0 and C == 512 == self.fc1.in_features and
+                self.fc1.out_features == 256 and self.fc2.out_features == 128 and 0 < self.num_relations <= 64 and
+                all(m.bias is not None for m in (self.fc1, self.fc2, self.span_head, self.pred_head)) and _rows_enabled(ref, self))
+
+    def _tail_rows(self, x, layer_norm=None, filter_taps=None):
+        """[5-tap filter along T] [LayerNorm] fc1 relu fc2 relu span_head / max_t pred_head in ONE launch; x (P, T, 512)."""
+        def make():
+            keep = []
+
+            def pk(w):
+                keep.append(ops.pack_rows_weight(w))
+                return keep[-1].data_ptr()
+
+            def raw(t):
+                keep.append(t.detach().contiguous())
+                return keep[-1].data_ptr()
+            R = self.num_relations
+            hw = torch.zeros((128, 128), device=x.device, dtype=torch.float32)
+            hb = torch.zeros((128,), device=x.device, dtype=torch.float32)
+            hw[:R], hw[64:64 + R] = self.span_head.weight.detach(), self.pred_head.weight.detach()
+            hb[:R], hb[64:64 + R] = self.span_head.bias.detach(), self.pred_head.bias.detach()
+            taps = None if filter_taps is None else filter_taps.detach().to(device=x.device, dtype=torch.float32).contiguous()
+            if taps is not None:
+                keep.append(taps)
+            st = _lib.RelationTail(
+                ln_g=raw(layer_norm.weight) if layer_norm is not None else None,
+                ln_b=raw(layer_norm.bias) if layer_norm is not None else None,
+                fc1_w=pk(self.fc1.weight), fc1_b=raw(self.fc1.bias), fc2_w=pk(self.fc2.weight), fc2_b=raw(self.fc2.bias),
+                head_w=pk(hw), head_b=raw(hb), filter=taps.data_ptr() if taps is not None else None,
+                dim=512, num_relations=R, eps=layer_norm.eps if layer_norm is not None else 1e-5)
+            return st, keep
+        mods = (self.fc1, self.fc2, self.span_head, self.pred_head) + ((layer_norm,) if layer_norm is not None else ())
+        st = _cached(self, '_rows_tail_' + str(x.device), mods, make)[0]
+        return ops.rel_tail(st, x, self.num_relations)
+
 
 class VanillaModel(_RelationModel):
     def __init__(self, input_dim, num_relations):
@@ -45,6 +197,8 @@ class VanillaModel(_RelationModel):
         self._tail_init(input_dim, num_relations)
 
     def forward(self, x):
+        if self._tail_ok(x):
+            return self._tail_rows(x)
         return self._tail(x)
 
 
@@ -55,6 +209,8 @@ class HandcraftedFilter(_RelationModel):
         self.filter_weights = torch.tensor([1 / 4, 1 / 2, 1, 1 / 2, 1 / 4], dtype=torch.float32)
 
     def forward(self, x):
+        if self._tail_ok(x) and self.filter_weights.numel() == 5:
+            return self._tail_rows(x, filter_taps=self.filter_weights)        # the filter is applied while the rows are staged
         c = x.shape[-1]
         w = self.filter_weights.to(x.device).view(1, 1, -1).repeat(c, 1, 1)
         return self._tail(F.conv1d(x.permute(0, 2, 1), w, padding=2, groups=c).permute(0, 2, 1))
@@ -69,7 +225,25 @@ class Learnable1DConv(_RelationModel):
         self.conv_layers = nn.Sequential(*layers)
         self._tail_init(input_dim, num_relations)
 
+    def _conv_rows_ok(self):
+        convs = [m for m in self.conv_layers if isinstance(m, nn.Conv1d)]
+        return (len(self.conv_layers) == 2 * len(convs) and len(convs) > 0 and
+                all(c.in_channels == c.out_channels == 512 and c.kernel_size == (5,) and c.padding == (2,) and c.stride == (1,) and
+                    c.dilation == (1,) and c.groups == 1 and c.bias is not None and c.padding_mode == 'zeros' for c in convs) and
+                all(isinstance(m, nn.ReLU) for m in list(self.conv_layers)[1::2]))
+
     def forward(self, x):
+        if self._tail_ok(x) and self._conv_rows_ok():
+            convs = [m for m in self.conv_layers if isinstance(m, nn.Conv1d)]
+
+            def make():
+                # Conv1d weight (out, in, 5) -> five (out, in) matrices, each in fragment order: y[t] = relu(b + sum_k W_k x[t+k-2])
+                return [(torch.cat([ops.pack_rows_weight(c.weight.detach()[:, :, k].contiguous()) for k in range(5)]),
+                         c.bias.detach().contiguous()) for c in convs]
+            y = x.contiguous()
+            for wp, b in _cached(self, '_rows_conv_' + str(x.device), convs, make):
+                y = ops.rel_conv5(wp, b, y)
+            return self._tail_rows(y)
         return self._tail(self.conv_layers(x.permute(0, 2, 1)).permute(0, 2, 1))
 
 
@@ -98,9 +272,38 @@ class TemporalTransformer(_RelationModel):
         self.layer_norm = nn.LayerNorm(input_dim)
         self._tail_init(input_dim, num_relations)
 
+    def _rows_ok(self, P, T, C, ref):
+        pe = self.positional_encoding.pe
+        return (self._tail_ok_dims(P, T, C, ref) and _EncoderRows.supported(self.transformer_encoder) and
+                self.transformer_encoder.layers[0].self_attn.embed_dim == 512 and pe.shape[0] >= T and
+                pe.shape[-1] == 512 and pe.dtype == torch.float32 and pe.device == ref.device and
+                tuple(self.layer_norm.normalized_shape) == (512,) and self.layer_norm.elementwise_affine)
+
+    def _pack(self):
+        return _cached(self, '_rows_enc', (self.transformer_encoder,), lambda: (lambda p: (p, _EncoderRows.arrays([p])))(
+            _EncoderRows(self.transformer_encoder)))
+
+    def _forward_rows(self, P, T, x=None, gather=None):
+        pack, arrays = self._pack()
+        pe = self.positional_encoding.pe.view(-1, 512)
+        qkv, x0 = ops.rel_qkv(arrays[0], 1, 512, P * T, T, x=x, gather=gather, pe=pe, want_x0=True)
+        y = _run_encoders([pack], arrays, x0, P, T, T, 1, qkv=qkv)
+        return self._tail_rows(y[0].view(P, T, 512), layer_norm=self.layer_norm)
+
     def forward(self, x):
+        if x.dim() == 3 and self._rows_ok(x.shape[0], x.shape[1], x.shape[2], x):
+            return self._forward_rows(x.shape[0], x.shape[1], x=x.contiguous().view(-1, 512))
         y = self.transformer_encoder(self.positional_encoding(x.transpose(0, 1)))
         return self._tail(self.layer_norm(y).transpose(0, 1))
+
+    def forward_pairs(self, sub, obj, pairs):
+        """forward(concatenate_sub_obj(sub, obj, pairs)) without materialising the concatenation: the in_proj kernel gathers
+        row (p, t) = [sub[pairs[p, 0], t] | obj[pairs[p, 1], t]] itself (train_utils.py:67-81 + transformer.py:36-40)."""
+        P, T = pairs.shape[0], sub.shape[1]
+        if (sub.shape == obj.shape and sub.shape[2] == 256 and pairs.dtype == torch.int64 and pairs.device == sub.device and
+                obj.device == sub.device and obj.dtype == sub.dtype and self._rows_ok(P, T, 512, sub)):
+            return self._forward_rows(P, T, gather=(sub.contiguous(), obj.contiguous(), pairs.contiguous()))
+        return self.forward(torch.cat([sub[pairs[:, 0]], obj[pairs[:, 1]]], dim=-1))
 
 
 class ObjectEncoder(nn.Module):
@@ -110,7 +313,22 @@ class ObjectEncoder(nn.Module):
         self.transformer_encoder = nn.TransformerEncoder(layer, num_layers=num_layers,
                                                          enable_nested_tensor=False)
 
+    def _rows_ok(self):
+        return _EncoderRows.supported(self.transformer_encoder)
+
+    def _d_model(self):
+        return self.transformer_encoder.layers[0].self_attn.embed_dim
+
+    def _pack(self):
+        return _cached(self, '_rows_enc', (self.transformer_encoder,), lambda: _EncoderRows(self.transformer_encoder))
+
     def forward(self, x):  # [N, T, 256]; batch_first=False: attention across objects, batch = frames
+        if (x.dim() == 3 and x.shape[0] > 0 and x.shape[1] > 0 and _rows_enabled(x, self) and self._rows_ok() and
+                x.shape[2] == self._d_model()):
+            N, T, D = x.shape
+            pack = self._pack()
+            arrays = _cached(self, '_rows_solo', (self.transformer_encoder,), lambda: (_EncoderRows.arrays([pack]), pack))[0]
+            return _run_encoders([pack], arrays, x.contiguous().view(N * T, D), T, N, 1, T)[0].view(N, T, D)
         return self.transformer_encoder(x)
 
 
@@ -145,6 +363,10 @@ MODEL_CLASSES = {'vanilla': VanillaModel, 'filter': HandcraftedFilter, 'conv': L
 def pick_top_pairs_tensor(pred_matrix, num_total_pairs=100):
     """(P,2) int64 device tensor of [subject, object], best first; diagonal excluded."""
     n = pred_matrix.size(0)
+    p = min(n * n - n, num_total_pairs)
+    if (pred_matrix.is_cuda and pred_matrix.dtype == torch.float32 and 0 < p <= 1024 and n <= 128 and
+            os.environ.get('PVSG_TOP_PAIRS', 'kernel') != 'torch'):
+        return ops.top_pairs(pred_matrix, p)              # one launch (csrc/pair_score.hip: radix select + rank sort)
     m = pred_matrix.clone()
     m.fill_diagonal_(float('-inf'))
     flat = m.view(-1)
@@ -226,11 +448,13 @@ def _scalar(x):
 def relation_forward(subject_encoder, object_encoder, pair_proposal_model, relation_model, feats,
                      num_top_pairs=100):
     """The device-resident part of tools/rel_test.py:35-62 for one video."""
-    sub, obj = subject_encoder(feats), object_encoder(feats)
+    sub, obj = encode_subject_object(subject_encoder, object_encoder, feats)
     pred_matrix = pair_proposal_model(sub, obj)
     pairs = pick_top_pairs_tensor(pred_matrix, num_top_pairs)
-    cat = torch.cat([sub[pairs[:, 0]], obj[pairs[:, 1]]], dim=-1)
-    span_pred, prob = relation_model(cat)
+    if isinstance(relation_model, TemporalTransformer):
+        span_pred, prob = relation_model.forward_pairs(sub, obj, pairs)
+    else:
+        span_pred, prob = relation_model(torch.cat([sub[pairs[:, 0]], obj[pairs[:, 1]]], dim=-1))
     return dict(sub=sub, obj=obj, pred_matrix=pred_matrix, pairs=pairs, span_pred=span_pred, prob=prob)
 
 

@@ -38,3 +38,46 @@ def test_pair_score_golden(hip_lib, golden_dir):
                              sd['pair_ffn.0.weight'], sd['pair_ffn.0.bias'], sd['pair_ffn.2.weight'],
                              sd['pair_ffn.2.bias'])
         np.testing.assert_allclose(out.cpu().numpy(), g['pred_matrix'], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('N,P', [(2, 100), (3, 100), (12, 100), (17, 20), (100, 100), (100, 1000), (128, 64)])
+def test_top_pairs_kernel_vs_reference_statement(hip_lib, N, P):
+    """pvsg_top_pairs against pick_top_pairs_eval (models/relation_head/test_utils.py:4-22: diagonal masked, top min(N^2, P)
+    sorted, diagonal entries dropped) on matrices without ties."""
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + P)
+    m = torch.randn(N, N, generator=g)
+    m[0, 1 % N] = -3.0e38                      # extreme magnitudes and signs go through the key transform
+    m[N - 1, 0] = 3.0e38
+    m.view(-1)[1::7] *= -1.0
+    ref = m.clone()
+    ref[torch.eye(N).bool()] = float('-inf')
+    k = min(N * N - N, P)
+    _, top = torch.topk(ref.view(-1), k, sorted=True)
+    want = torch.stack([top // N, top % N], dim=1)
+    got = ops.top_pairs(m.to(DEV), k)
+    assert got.dtype == torch.int64 and got.shape == (k, 2)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_top_pairs_ties_go_to_the_lower_index(hip_lib):
+    from openpvsg_amd import ops
+    from openpvsg_amd import relation as prel
+    N = 40
+    m = torch.zeros(N, N)
+    m[3, 5] = 1.0
+    m[7, 7] = 9.0                              # diagonal: never selected
+    got = ops.top_pairs(m.to(DEV), 100).cpu().tolist()
+    flat = [i for i in range(N * N) if i // N != i % N and i != 3 * N + 5]
+    assert got == [[3, 5]] + [[i // N, i % N] for i in flat[:99]]
+    # through the helper tools/rel_test.py calls, both routes
+    a = prel.pick_top_pairs_eval(m.to(DEV), 100)
+    assert a == got
+    assert prel.pick_top_pairs_tensor(torch.zeros(1, 1, device=DEV), 100).shape == (0, 2)
+    # more than 128 objects: the torch statement (same list when there are no ties)
+    g = torch.Generator().manual_seed(3)
+    big = torch.randn(150, 150, generator=g)
+    ref = big.clone()
+    ref.fill_diagonal_(float('-inf'))
+    _, top = torch.topk(ref.view(-1), 100, sorted=True)
+    assert prel.pick_top_pairs_eval(big.to(DEV), 100) == torch.stack([top // 150, top % 150], dim=1).tolist()
