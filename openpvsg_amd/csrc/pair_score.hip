@@ -31,37 +31,62 @@ __global__ __launch_bounds__(256) void pair_prepare_kernel(const float* __restri
   W1T[idx] = W1[(long long)k * (2 * CF) + which * CF + c];
 }
 
-__global__ __launch_bounds__(256) void pair_token_proj_kernel(
+// 1024 threads: thread (q = tid & 255, part = tid >> 8).  Token phase: part = object of the block's four, q = channel, all
+// frames of the object in flight at once (the serial form -- 4 objects x T dependent-latency batches per thread -- was 2/3 of
+// this kernel's 34 us).  Projection: hidden unit k = 256 blockIdx.x + q, part = quarter of the 256 input channels, the four
+// partial sums meet in LDS.
+__global__ __launch_bounds__(1024) void pair_token_proj_kernel(
     const float* __restrict__ sub, const float* __restrict__ obj, const float* __restrict__ W1T,
     const float* __restrict__ b1, float* __restrict__ U, float* __restrict__ VT,
     float* __restrict__ tok_out, int N, int T) {
   __shared__ float tok[OB][CF];
+  __shared__ float part_sum[3][OB][256];
   const int which = blockIdx.z;  // 0 = subject half, 1 = object half
   const int i0 = blockIdx.y * OB;
-  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int q = threadIdx.x & 255, part = threadIdx.x >> 8;
+  const int k = blockIdx.x * 256 + q;
   const float* src = which == 0 ? sub : obj;
-#pragma unroll
-  for (int ob = 0; ob < OB; ++ob) {
-    const int i = i0 + ob;
+  {
+    const int i = i0 + part;
     float m = 0.f;
     if (i < N) {
-      const float* p = src + (long long)i * T * CF + threadIdx.x;
-      m = -INFINITY;
-#pragma unroll 8
-      for (int t = 0; t < T; ++t) m = fmaxf(m, p[(long long)t * CF]);      // 8 independent loads in flight
-      if (tok_out && blockIdx.x == 0) tok_out[((long long)which * N + i) * CF + threadIdx.x] = m;
+      const float* p = src + (long long)i * T * CF + q;
+      float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int t = 0;
+      for (; t + 16 <= T; t += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = p[(long long)(t + u) * CF];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) m4[u & 3] = fmaxf(m4[u & 3], v[u]);
+      }
+      for (; t < T; ++t) m4[0] = fmaxf(m4[0], p[(long long)t * CF]);
+      m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      if (tok_out && blockIdx.x == 0) tok_out[((long long)which * N + i) * CF + q] = m;
     }
-    tok[ob][threadIdx.x] = m;
+    tok[part][q] = m;
   }
   __syncthreads();
-  const float* wp = W1T + (long long)which * CF * HDN + k;
+  const float* wp = W1T + ((long long)which * CF + part * 64) * HDN + k;
   float acc[OB] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 32
-  for (int c = 0; c < CF; ++c) {
-    const float w = wp[(long long)c * HDN];
+#pragma unroll 2
+  for (int c0 = 0; c0 < 64; c0 += 32) {
+    float wv[32];
 #pragma unroll
-    for (int ob = 0; ob < OB; ++ob) acc[ob] += w * tok[ob][c];
+    for (int u = 0; u < 32; ++u) wv[u] = wp[(long long)(c0 + u) * HDN];
+#pragma unroll
+    for (int u = 0; u < 32; ++u)
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) acc[ob] += wv[u] * tok[ob][part * 64 + c0 + u];
   }
+  if (part > 0) {
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) part_sum[part - 1][ob][q] = acc[ob];
+  }
+  __syncthreads();
+  if (part > 0) return;
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob) acc[ob] = ((acc[ob] + part_sum[0][ob][q]) + part_sum[1][ob][q]) + part_sum[2][ob][q];
   if (which == 0) {
     const float bias = b1[k];
 #pragma unroll
@@ -114,98 +139,143 @@ __device__ __forceinline__ unsigned tp_key(float v) {      // order-preserving: 
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// count over the block of a per-thread number (every thread gets the total); two barriers
-__device__ __forceinline__ int tp_block_sum(int v, int* wave_tot, int lane, int w) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-  if (lane == 0) wave_tot[w] = v;
-  __syncthreads();
-  int tot = 0;
-#pragma unroll
-  for (int ww = 0; ww < TP_THREADS / 64; ++ww) tot += wave_tot[ww];
-  __syncthreads();
-  return tot;
-}
-
 __global__ __launch_bounds__(TP_THREADS) void top_pairs_kernel(const float* __restrict__ m, long long* __restrict__ pairs, int N,
                                                                int P) {
-  __shared__ unsigned cand_key[TP_MAXP];
-  __shared__ int cand_idx[TP_MAXP];
-  __shared__ int s_ngt;
+  __shared__ unsigned long long cand[TP_MAXP];             // (key << 32) | ~flat index: larger = better, ties to the lower index
+  __shared__ int rank_of[TP_MAXP];
+  __shared__ int digit_cnt[16][4];                         // per select step: keys with digit >= 3 / 2 / 1 / 0 under the prefix
+  __shared__ int s_ngt, s_eq;
   __shared__ int wave_tot[TP_THREADS / 64];
   const int n = N * N, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // slot s of thread t = flat element s * 1024 + t (consecutive threads = consecutive elements); key 0 = not a candidate
   unsigned key[TP_SLOTS];
-#pragma unroll
-  for (int s = 0; s < TP_SLOTS; ++s) {
-    const int i = s * TP_THREADS + tid;
-    unsigned k = 0u;
-    if (i < n) {
-      const int r = i / N;
-      if (i - r * N != r) k = tp_key(m[i]);                // the diagonal sorts below everything
+  {
+    float v[TP_SLOTS];                                     // every load issued before the first use (a load inside each
+#pragma unroll                                             // `if (i < n)` made sixteen dependent memory latencies)
+    for (int s = 0; s < TP_SLOTS; ++s) {
+      const int i = s * TP_THREADS + tid;
+      v[s] = m[i < n ? i : 0];
     }
-    key[s] = k;
+    const int r0 = tid / N, c0 = tid - r0 * N;              // element s * 1024 + tid: (row, col) advance by 1024 = qN * N + rN
+    const int qN = TP_THREADS / N, rN = TP_THREADS - qN * N;
+    int r = r0, c = c0;
+#pragma unroll
+    for (int s = 0; s < TP_SLOTS; ++s) {
+      const int i = s * TP_THREADS + tid;
+      key[s] = (i < n && r != c) ? tp_key(v[s]) : 0u;      // the diagonal sorts below everything
+      r += qN;
+      c += rN;
+      if (c >= N) { c -= N; ++r; }
+    }
   }
-  if (tid == 0) s_ngt = 0;
-  // the P-th largest key, bit by bit from the top: the candidate prefix with the next bit set is kept if at least `need` keys
-  // carry it (a histogram over float keys would pile its LDS atomics onto the two or three exponent bins the values live in)
+  if (tid < 64) (&digit_cnt[0][0])[tid] = 0;
+  if (tid == 0) { s_ngt = 0; s_eq = 0; }
+  if (tid < TP_MAXP) rank_of[tid] = 0;
+  __syncthreads();
+  // The P-th largest key, two bits at a time from the top: per digit value d = 3, 2, 1 the number of keys that share the prefix
+  // found so far and whose digit is >= d -- wave ballots + scalar pop-counts, three LDS atomics per wave and ONE barrier per
+  // step (a histogram over float keys piles its atomics onto the two or three exponent bins the values live in: 66 us for 10^4
+  // keys; sixteen waves each summing the sixteen per-wave counts made the LDS the limit: 15 us for an empty matrix).
   unsigned prefix = 0u;
   int need = P;
+  bool take_all = false;                                   // every key >= prefix is selected (the step loop ended early)
+  const int nslots = (n + TP_THREADS - 1) / TP_THREADS;
 #pragma unroll 1
-  for (int bit = 31; bit >= 0; --bit) {
-    const unsigned cand = prefix | (1u << bit), himask = 0xFFFFFFFFu << bit;
-    int c = 0;
+  for (int step = 0; step < 16; ++step) {
+    const int bit = 30 - 2 * step;
+    const unsigned himask = bit == 30 ? 0u : (0xFFFFFFFFu << (bit + 2));
+    int c3 = 0, c2 = 0, c1 = 0, c0 = 0;
 #pragma unroll
-    for (int s = 0; s < TP_SLOTS; ++s) c += (key[s] & himask) == cand ? 1 : 0;
-    const int tot = tp_block_sum(c, wave_tot, lane, w);
-    if (tot >= need) prefix = cand;                        // the P-th largest has this bit set
-    else need -= tot;                                      // all `tot` keys with the bit set are larger than it
+    for (int s = 0; s < TP_SLOTS; ++s) {
+      if (s < nslots) {                                    // uniform
+        const bool match = (key[s] & himask) == prefix && key[s] != 0u;
+        const unsigned d = (key[s] >> bit) & 3u;
+        c3 += __popcll(__ballot(match && d == 3u));
+        c2 += __popcll(__ballot(match && d >= 2u));
+        c1 += __popcll(__ballot(match && d >= 1u));
+        c0 += __popcll(__ballot(match));
+      }
+    }
+    if (lane == 0) {
+      if (c3) atomicAdd(&digit_cnt[step][0], c3);
+      if (c2) atomicAdd(&digit_cnt[step][1], c2);
+      if (c1) atomicAdd(&digit_cnt[step][2], c1);
+      if (c0) atomicAdd(&digit_cnt[step][3], c0);
+    }
+    __syncthreads();
+    const int t3 = digit_cnt[step][0], t2 = digit_cnt[step][1], t1 = digit_cnt[step][2], t0 = digit_cnt[step][3];
+    unsigned digit;
+    int left;                                              // keys that still share the prefix after this digit
+    if (t3 >= need) { digit = 3u; left = t3; }
+    else if (t2 >= need) { digit = 2u; need -= t3; left = t2 - t3; }
+    else if (t1 >= need) { digit = 1u; need -= t2; left = t1 - t2; }
+    else { digit = 0u; need -= t1; left = t0 - t1; }
+    prefix |= digit << bit;
+    if (left == need) {                                    // all of them are wanted: the lower bits do not matter (on
+      take_all = true;                                     // random scores this ends the search after 8 - 10 steps)
+      break;
+    }
   }
-  // prefix = key of the P-th best entry; `need` entries equal to it are taken (lowest index first), everything above it is
+  // full search: prefix = key of the P-th best entry; `need` entries equal to it are taken, everything above it is
+  if (!take_all) {
+    int ceq = 0;
+#pragma unroll
+    for (int s = 0; s < TP_SLOTS; ++s)
+      if (s < nslots) ceq += __popcll(__ballot(key[s] == prefix && prefix != 0u));
+    if (lane == 0 && ceq) atomicAdd(&s_eq, ceq);
+  }
+  __syncthreads();
+  const bool all_equal_taken = take_all || s_eq == need;   // the usual case (no ties at the threshold): order does not matter
 #pragma unroll
   for (int s = 0; s < TP_SLOTS; ++s) {
-    if (key[s] > prefix) {
+    if (s < nslots && (key[s] > prefix || (all_equal_taken && key[s] >= prefix && key[s] != 0u))) {
       const int pos = atomicAdd(&s_ngt, 1);
-      cand_key[pos] = key[s];
-      cand_idx[pos] = s * TP_THREADS + tid;
+      cand[pos] = ((unsigned long long)key[s] << 32) | (unsigned)(~(s * TP_THREADS + tid));
     }
   }
   __syncthreads();
-  const int ngt = s_ngt;                                   // == P - need
-  int taken = 0;
+  if (!all_equal_taken) {                                  // ties at the threshold: the lowest flat indices win
+    const int ngt = s_ngt;                                 // == P - need
+    int taken = 0;
 #pragma unroll
-  for (int s = 0; s < TP_SLOTS; ++s) {
-    if (taken < need && s * TP_THREADS < n) {              // uniform
-      const bool flag = key[s] == prefix && prefix != 0u;
-      const unsigned long long bal = __ballot(flag);
-      const int wpre = __popcll(bal & ((1ull << lane) - 1ull));
-      if (lane == 0) wave_tot[w] = __popcll(bal);
-      __syncthreads();
-      int off = 0, tot = 0;
+    for (int s = 0; s < TP_SLOTS; ++s) {
+      if (taken < need && s < nslots) {                    // uniform
+        const bool flag = key[s] == prefix && prefix != 0u;
+        const unsigned long long bal = __ballot(flag);
+        const int wpre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[w] = __popcll(bal);
+        __syncthreads();
+        int off = 0, tot = 0;
 #pragma unroll
-      for (int ww = 0; ww < TP_THREADS / 64; ++ww) {
-        const int c = wave_tot[ww];
-        off += ww < w ? c : 0;
-        tot += c;
+        for (int ww = 0; ww < TP_THREADS / 64; ++ww) {
+          const int c = wave_tot[ww];
+          off += ww < w ? c : 0;
+          tot += c;
+        }
+        const int pos = taken + off + wpre;
+        if (flag && pos < need) cand[ngt + pos] = ((unsigned long long)prefix << 32) | (unsigned)(~(s * TP_THREADS + tid));
+        taken += tot;
+        __syncthreads();
       }
-      const int pos = taken + off + wpre;
-      if (flag && pos < need) {
-        cand_key[ngt + pos] = prefix;
-        cand_idx[ngt + pos] = s * TP_THREADS + tid;
-      }
-      taken += tot;
-      __syncthreads();
     }
+    __syncthreads();
+  }
+  // rank sort of the P candidates: candidate c = tid % Ppad is compared against a 1 / G share of the list by each of G threads
+  int ppad = 1;
+  while (ppad < P) ppad <<= 1;
+  const int G = TP_THREADS / ppad, c = tid & (ppad - 1), part = tid / ppad;
+  if (c < P) {
+    const unsigned long long mine = cand[c];
+    int rank = 0;
+    const int per = (P + G - 1) / G, j0 = part * per, j1 = min(P, j0 + per);
+#pragma unroll 4
+    for (int jj = j0; jj < j1; ++jj) rank += cand[jj] > mine ? 1 : 0;
+    if (rank) atomicAdd(&rank_of[c], rank);
   }
   __syncthreads();
   if (tid < P) {
-    const unsigned k = cand_key[tid];
-    const int ix = cand_idx[tid];
-    int rank = 0;
-    for (int j = 0; j < P; ++j) {
-      const unsigned kj = cand_key[j];
-      rank += (kj > k || (kj == k && cand_idx[j] < ix)) ? 1 : 0;
-    }
+    const int ix = (int)(~(unsigned)cand[tid]);
+    const int rank = rank_of[tid];
     pairs[2 * rank] = ix / N;
     pairs[2 * rank + 1] = ix % N;
   }
@@ -246,7 +316,7 @@ extern "C" int pvsg_pair_score_forward(const float* sub_feats, const float* obj_
     return set_err(PVSG_ERR_UNSUPPORTED, "pair_score_forward: built for feature_dim 256 / hidden 1024 (got %d / %d)", C, Hd);
   float* U = work_uv;
   float* VT = work_uv + (long long)N * Hd;
-  hipLaunchKernelGGL(pair_token_proj_kernel, dim3(HDN / 256, (N + OB - 1) / OB, 2), dim3(256), 0, stream,
+  hipLaunchKernelGGL(pair_token_proj_kernel, dim3(HDN / 256, (N + OB - 1) / OB, 2), dim3(1024), 0, stream,
                      sub_feats, obj_feats, W1T, b1, U, VT, tokens_out, N, T);
   PVSG_LAUNCH_CHECK("pair_score_forward(proj)");
   hipLaunchKernelGGL(pair_score_kernel, dim3(N, (N + 63) / 64), dim3(256), 0, stream, U, VT, w2, b2,
