@@ -269,6 +269,17 @@ def cpu_baseline_and_parity_ips(det_gpu, pipe, args, dev, frames, reps):
                       segments=len(ids), segment_ids_equal=bool(seg_equal))
 
 
+def kernel_function(name, a):
+    """the kernel function a C-ABI launch runs (csrc dispatch rules), where an entry has more than one"""
+    if name == 'pvsg_gemm_f16x2':                      # gemm_split_run: wide layers (N >= 512, N % 256 == 0) on the 128 x 256 tile
+        N = a[5]
+        wide = N >= 512 and (N % 256 == 0 or os.environ.get('PVSG_W256_RAGGED') == '1')
+        return 'gemm_f16x2_ln128_kernel<false> (pvsg_gemm_f16x2, wide layers)' if wide else 'gemm_f16x2_dma_kernel (pvsg_gemm_f16x2)'
+    if name == 'pvsg_msda_fused_forward':
+        return 'msda_fused_m8d32 (pvsg_msda_fused_forward)'
+    return name
+
+
 class KernelTimer:
     """HIP events around C-ABI launches (same stream the launch goes to): all of them, or those named in `focus`."""
 
@@ -992,7 +1003,8 @@ def main():
                 line['roofline_step'] = dict(
                     bound='mfma', algorithmic_TFLOP_per_step=f0 * world / 1e12, library_TFLOP_per_gpu=lib_flops / 1e12,
                     handwritten_TFLOP_per_gpu=hw_flops_one / 1e12, peak=F32_MFMA_PEAK_TF, unit='TFLOP/s per GPU',
-                    achieved=f0 / (ms_per_step * 1e-3) / 1e12, frac=ideal_ms / ms_per_step, ideal_ms_per_step=ideal_ms,
+                    achieved=f0 / (ms_per_step * 1e-3) / 1e12, f32_equivalent_over_f32_peak=ideal_ms / ms_per_step,
+                    ideal_ms_per_step=ideal_ms,
                     handwritten_kernel_ms_per_step=hw_ms, other_ms_per_step=ms_per_step - hw_ms,
                     note='rank 0; other = library kernels (MIOpen / rocBLAS / hipBLASLt / ATen) + launch gaps + host syncs')
                 # the same step against the pipes its kernels actually issue on: every launch's ISSUED matrix flops (limb
@@ -1000,7 +1012,10 @@ def main():
                 # `frac` above prices the model's f32 arithmetic at the f32 matrix peak although most of it executes as
                 # 3 (f16x2) or 6 (bf16x3) limb products on the 16-bit pipe; this is the honest utilisation figure.
                 pipe_ms = sum(d['flops'] / table_steps / (KernelTimer.mfma_peak(k.split('[')[0])[0] * 1e12) * 1e3 for k, d in agg.items())
-                line['roofline_step'].update(ideal_ms_on_pipes_used=pipe_ms, frac_of_pipe_used=pipe_ms / ms_per_step)
+                # `frac` = that utilisation; `f32_equivalent_over_f32_peak` (> 1 is possible: the f32 arithmetic runs on the
+                # 16 x faster 16-bit pipe) is kept for comparison with rounds 1-5, where it was called `frac`
+                line['roofline_step'].update(ideal_ms_on_pipes_used=pipe_ms, frac_of_pipe_used=pipe_ms / ms_per_step,
+                                             frac=pipe_ms / ms_per_step)
             # graph replay in the timed region: the dominant entry and its figures come from the eager warm-up step's events
             pool, pool_steps = (agg, table_steps) if table_from_eager_step else (live, args.steps)
             dom = max((k for k in pool if pool[k]['bytes'] > 0), key=lambda k: pool[k]['ms'])
@@ -1039,6 +1054,37 @@ def main():
                                         frac=ach / HBM_PEAK_GBS, traffic=traffic, avg_launch_ms=per,
                                         launches_per_step=d['calls'] / pool_steps,
                                         algorithmic_bytes_per_launch=d['bytes'] / d['calls'], scope=scope)
+            # the same for the dominant kernel FUNCTION (a C-ABI entry may dispatch to several: pvsg_gemm_f16x2 runs the wide
+            # layers on gemm_f16x2_ln128_kernel and the rest on gemm_f16x2_dma_kernel), from the same HIP-event records
+            fagg = {}
+            for name, a, s_ev, e_ev in table_records:
+                fn = kernel_function(name, a)
+                by, fl = KernelTimer.work(name, a)
+                fd = fagg.setdefault(fn, dict(calls=0, ms=0.0, bytes=0.0, flops=0.0, entry=name))
+                fd['calls'] += 1
+                fd['ms'] += s_ev.elapsed_time(e_ev)
+                fd['bytes'] += by
+                fd['flops'] += fl
+            fdom = max((k for k in fagg if fagg[k]['bytes'] > 0), key=lambda k: fagg[k]['ms'])
+            fd = fagg[fdom]
+            fper = fd['ms'] / fd['calls']
+            fpeak_tf, fnote = KernelTimer.mfma_peak(fd['entry'])
+            f_mfma = fd['flops'] / (fpeak_tf * 1e12) > fd['bytes'] / (HBM_PEAK_GBS * 1e9)
+            ftraffic = None
+            if os.path.exists(tpath) and sum(1 for v in fagg.values() if v['entry'] == fd['entry']) == 1:   # PMC traffic is keyed by C-ABI entry
+                ent = json.load(open(tpath)).get(fd['entry'], {})
+                if ent.get('frames') == t_local:
+                    ftraffic = ent.get('hbm_bytes_per_launch')
+            fach = fd['flops'] / fd['calls'] / fper / 1e9 if f_mfma else fd['bytes'] / fd['calls'] / fper / 1e6
+            fpk = fpeak_tf if f_mfma else HBM_PEAK_GBS
+            line['roofline_function'] = dict(
+                kernel_function=fdom, c_abi_entry=fd['entry'], bound='mfma' if f_mfma else 'hbm', achieved=fach, peak=fpk,
+                unit='TFLOP/s' if f_mfma else 'GB/s', frac=fach / fpk, traffic=ftraffic, avg_launch_ms=fper,
+                launches_per_step=fd['calls'] / table_steps, ms_per_step=fd['ms'] / table_steps,
+                algorithmic_bytes_per_launch=fd['bytes'] / fd['calls'],
+                functions_ms_per_step={k: v['ms'] / table_steps for k, v in sorted(fagg.items(), key=lambda kv: -kv[1]['ms'])[:8]},
+                scope='dominant kernel FUNCTION by time over the same HIP-event records as `kernels` (`roofline` is the dominant '
+                      'C-ABI entry, whose launches may be spread over several functions)')
             if dom.startswith('pvsg_conv1x1_f16x2'):
                 # measured on this kernel itself (round 5): socket power / shader clock while one layer loops, and the timing
                 # ablations (no MFMAs / no stores) of the two heaviest shapes

@@ -115,3 +115,58 @@ def test_bottleneck_tail_into_the_next_stage(hip_lib, B, H, W):
         y_b, n_b, y2_b = ops.bottleneck_tail(mid, w3p, s3, h3, idn, ops.bottleneck_next_pack(w1), s1, h1, cnext=128, stride2_copy=True)
         assert torch.equal(y_b, y) and torch.equal(n_b, nxt) and torch.equal(y2_b, y2)
     assert ops.split_overflow_count() == 0
+
+
+@pytest.mark.parametrize('mode', [0, 1, 2, 3])
+def test_bottleneck_tail_repeats_bit_exact(hip_lib, mode):
+    """30 launches of each template instance of bottleneck_tail64_kernel at the 720p layer1 size, bit-exact run to run: the
+    run-time guard for the MFMA source write-after-read hazard this kernel met (lanes 48-63 of an accumulator wrong in about one
+    launch of three before the s_nop fix); tests/test_mfma_hazard.py is the build-time guard.
+    mode 0: conv3 + identity + ReLU + next conv1; 1: conv3 only (last block form); 2: first block's downsample + conv1;
+    3: conv3 + the next stage's conv1 + the stride-2 copy."""
+    from openpvsg_amd import ops
+    B, H, W = 2, 184, 320
+    mid, idn, w3, w1, s3, h3, s1, h1 = _case(B, H, W, 31 + mode)
+    w3p = ops.gemm_bf16x3_pack(w3, mode='f16x2')
+    g = torch.Generator().manual_seed(mode)
+    if mode == 0:
+        w1np = ops.bottleneck_next_pack(w1.view(64, 256, 1, 1))
+        run = lambda: ops.bottleneck_tail(mid, w3p, s3, h3, idn, w1np, s1, h1)                       # noqa: E731
+    elif mode == 1:
+        run = lambda: ops.bottleneck_tail(mid, w3p, s3, h3, idn)[:1]                                 # noqa: E731
+    elif mode == 2:
+        wds, wc1 = (torch.randn(256, 64, generator=g) / 8).to(DEV), (torch.randn(64, 64, generator=g) / 8).to(DEV)
+        wdsp, wc1p = ops.gemm_bf16x3_pack(wds, mode='f16x2'), ops.gemm_bf16x3_pack(wc1, mode='f16x2')
+        run = lambda: ops.bottleneck_head(mid, wdsp, s3, h3, wc1p, s1, h1)                           # noqa: E731
+    else:
+        wn = (torch.randn(128, 256, generator=g) / 16).to(DEV)
+        sn, hn = (torch.rand(128, generator=g) + 0.5).to(DEV), (torch.randn(128, generator=g) * 0.3).to(DEV)
+        wnp = ops.bottleneck_next_pack(wn)
+        run = lambda: ops.bottleneck_tail(mid, w3p, s3, h3, idn, wnp, sn, hn, cnext=128, stride2_copy=True)   # noqa: E731
+    first = [t.clone() for t in run() if t is not None]
+    for _ in range(30):
+        again = [t for t in run() if t is not None]
+        assert len(again) == len(first) and all(torch.equal(a, b) for a, b in zip(again, first))
+    assert ops.split_overflow_count() == 0
+
+
+@pytest.mark.parametrize('split', ['f16x2', 'bf16x3'])
+def test_split_kernels_repeat_bit_exact(hip_lib, split):
+    """the same run-to-run guard for the 1x1 convolution and token GEMM kernels of both split forms (the bf16x3 convolution is
+    where tests/test_mfma_hazard.py sees a packed-f32 write five slots behind a 32x32x16 MFMA)"""
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.relu(torch.randn(2, 256, 184, 320, generator=g)).to(DEV)
+    w = (torch.randn(64, 256, generator=g) / 16).to(DEV)
+    s, h = (torch.rand(64, generator=g) + 0.5).to(DEV), (torch.randn(64, generator=g) * 0.3).to(DEV)
+    a = torch.randn(4096, 256, generator=g).to(DEV)
+    wl = (torch.randn(1024, 256, generator=g) / 16).to(DEV)
+    with ops.force_split(split):
+        wp = ops.gemm_bf16x3_pack(w, mode=split)
+        wlp = ops.gemm_bf16x3_pack(wl, mode=split)
+        y0 = ops.conv1x1_bf16x3(x, wp, 64, s, h, None, relu=True).clone()
+        z0 = ops.gemm_bf16x3(a, wlp, 1024).clone()
+        for _ in range(30):
+            assert torch.equal(ops.conv1x1_bf16x3(x, wp, 64, s, h, None, relu=True), y0)
+            assert torch.equal(ops.gemm_bf16x3(a, wlp, 1024), z0)
+    assert ops.split_overflow_count() == 0
