@@ -178,7 +178,7 @@ def conv3x3_fast(conv, x, scale=None, shift=None, relu=False, out=None):
 
 def conv1x1_fast(conv, x, scale=None, shift=None, residual=None, relu=False, out=None, always=False, in_norm=None):
     """1x1 convolution (stride 1 or 2, NCHW) with BN affine / bias (`shift`), identity and ReLU in the epilogue on the
-    split-bf16 matrix-core kernel (csrc/gemm_bf16x3.hip: conv1x1_bf16x3), or None where another path is at least as fast
+    split-bf16 matrix-core kernel (csrc/conv1x1_split.hip: conv1x1_bf16x3), or None where another path is at least as fast
     (fewer than 64 input channels stay on csrc/conv1x1.hip) or the shape is unsupported.  A convolution bias is
     folded into `shift`."""
     w = conv.weight
@@ -241,7 +241,7 @@ def conv3x3_gn_fast(conv, gn, x):
 
 def linear_fast(owner, tag, weights, x, bias=None, relu=False):
     """act(F.linear(x, cat(weights), bias)) for a token-major f32 tensor.  On the HIP device this runs on the bf16 matrix
-    cores from an exact three-limb split of both operands (csrc/gemm_bf16x3.hip: f32-class accuracy, 1.3-1.45x the
+    cores from an exact three-limb split of both operands (csrc/token_gemm.hip: f32-class accuracy, 1.3-1.45x the
     library's f32 GEMM on the encoder's shapes); PVSG_GEMM=lib keeps the library GEMM.  The packed limbs of the weight(s)
     are cached on `owner` under `tag` and rebuilt when a weight tensor changes (address or version)."""
     ws = tuple(weights) if isinstance(weights, (list, tuple)) else (weights,)

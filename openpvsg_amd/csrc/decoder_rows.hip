@@ -222,74 +222,9 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
       *reinterpret_cast<float4*>(xb + r * DR_LD + c) = v;
     }
     __syncthreads();
-    {
-      const int h = w;
-      float* pm = big + h * (DR_MAXQ * 16);
-      const float* kvb = qkv + (long long)b * Q * (3 * DR_C);
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {                 // raw scores S[key][r] -> pm (private to this wave)
-        const int key = p * 64 + lane;
-        const bool kv = key < Q;
-        float kr[32];
-        const float* kp = kvb + (long long)(kv ? key : 0) * (3 * DR_C) + DR_C + h * 32;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float4 t = ld4(kp + 4 * i);
-          kr[4 * i] = t.x; kr[4 * i + 1] = t.y; kr[4 * i + 2] = t.z; kr[4 * i + 3] = t.w;
-        }
-#pragma unroll 2
-        for (int r = 0; r < 16; ++r) {
-          const float* qr = xb + r * DR_LD + h * 32;
-          float s = 0.f;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float4 t = *reinterpret_cast<const float4*>(qr + 4 * i);     // broadcast read
-            s += t.x * kr[4 * i] + t.y * kr[4 * i + 1] + t.z * kr[4 * i + 2] + t.w * kr[4 * i + 3];
-          }
-          pm[key * 16 + r] = kv ? s : -INFINITY;
-        }
-      }
-#pragma unroll 4
-      for (int r = 0; r < 16; ++r) {                // softmax over the keys of row r (lanes = keys)
-        const float s0 = pm[lane * 16 + r], s1 = pm[(64 + lane) * 16 + r];
-        const float m = wave_allreduce<true>(fmaxf(s0, s1));
-        const float e0 = __expf(s0 - m), e1 = __expf(s1 - m);
-        const float inv = 1.f / wave_allreduce<false>(e0 + e1);
-        pm[lane * 16 + r] = e0 * inv;
-        pm[(64 + lane) * 16 + r] = e1 * inv;
-      }
-      // P . V : lane = (d, key half)
-      const int d = lane & 31, half = lane >> 5;
-      float o16[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o16[r] = 0.f;
-      const int kend = min(64, Q - half * 64);
-      const float* vcol = kvb + 2 * DR_C + h * 32 + d;
-#pragma unroll 1
-      for (int k8 = 0; k8 < 64; k8 += 8) {           // 8 value rows in flight per step (uniform trip count)
-        float v8[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int kk = k8 + u;
-          v8[u] = kk < kend ? vcol[(long long)(half * 64 + kk) * (3 * DR_C)] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float* pr = pm + (half * 64 + k8 + u) * 16;     // rows past Q hold zeros
-          const float v = v8[u];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float4 t = *reinterpret_cast<const float4*>(pr + 4 * i);
-            o16[4 * i] += t.x * v; o16[4 * i + 1] += t.y * v; o16[4 * i + 2] += t.z * v; o16[4 * i + 3] += t.w * v;
-          }
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float t = o16[r] + __shfl_xor(o16[r], 32);
-        if (half == 0) xa[r * DR_LD + h * 32 + d] = t;
-      }
-    }
+    // one wave per head, on the matrix cores (rows_common.h: S = Q K^T and O = P V as 16 x 16 x 4 tiles, soft-max on the
+    // accumulators); the scalar-FMA form this replaces took ~12 of the kernel's 87 us
+    rows_attention_h32(xb, xa, DR_LD, big + w * (DR_MAXQ * 16), qkv + (long long)b * Q * (3 * DR_C), 3 * DR_C, DR_C, Q, w, lane);
     __syncthreads();
     // ---- out_proj + identity + LN -> x2 (xa) -------------------------------------------------
     {
@@ -442,7 +377,7 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
   }
   if (flags_zero && tile == 0 && threadIdx.x < 4) flags_zero[b * 4 + threadIdx.x] = 0u;   // the flag words the bits kernel ORs into
   if (emb_pack) {
-    // The mask embeddings of these 16 queries as the ROW operand of the attention-mask-bits GEMM (csrc/gemm_bf16x3.hip, f16x2
+    // The mask embeddings of these 16 queries as the ROW operand of the attention-mask-bits GEMM (csrc/split_conv1x1.h, f16x2
     // form: [k-tile 16][w_h | w_l][k-group 2][128 rows][8] f16), packed here instead of by f16x2_amax_kernel +
     // gemm_f16x2_pack_kernel + two zero_words launches per layer.  The bits only need the SIGN of embedding . feature, so each
     // query row gets its own exact power-of-two scale 2^e with max|row| 2^e in [2^13, 2^14): both limbs stay normal f16

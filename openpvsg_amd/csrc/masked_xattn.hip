@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
 
 // ------------------------------------------------------------------------------------------------
 // The same attention on the bf16 matrix pipe, exact: every f32 operand is split into three bf16 limbs (hi + mid + lo == x,
-// the scheme of gemm_bf16x3.hip) and a product is the six limb products of weight >= 2^-16 accumulated in f32 --
+// the scheme of split_common.h) and a product is the six limb products of weight >= 2^-16 accumulated in f32 --
 // f32-class error (tests/test_xattn.py runs both kernels against the same f64 statement at the same tolerance).
 // ------------------------------------------------------------------------------------------------
 typedef float xf32x2 __attribute__((ext_vector_type(2)));

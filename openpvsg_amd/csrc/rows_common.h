@@ -135,4 +135,113 @@ __device__ __forceinline__ void rows_layernorm_t(const float* __restrict__ x, co
   }
 }
 
+constexpr int ROWS_PLD = 64 + 4;           // row stride of a wave's probability tile [16 rows][64 keys]
+
+// all-reduce over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15)
+template <bool MAX>
+__device__ __forceinline__ float row16_allreduce(float v) {
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
+  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
+  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xf, 0xf, false)));  // row_half_mirror
+  v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x140, 0xf, 0xf, false)));  // row_mirror
+  return v;
+}
+
+// Soft-max attention of ONE head (32 channels) for the 16 LDS rows of `xq` (scaled queries, row stride ld) over L keys, on the
+// matrix cores, by one wave: xo[r][32 h ..] = softmax_k(q_r . k_k) v_k.  Key k's row lives at kvb + k * kstride with K at +D and
+// V at +2 D (+ 32 h).  Keys in chunks of 64 with an online soft-max, so any L works.
+//   S = Q K^T: A = q rows from LDS, B = key rows straight from memory (lane (key = lane & 15, g) reads the float4 at channel
+//   16 kc + 4 g: the operand layout of rows_gemm with the K matrix in the role of the weight);  the soft-max runs on the
+//   accumulators (lane (g, j) holds rows 4 g + e of key-tile column j: a row's keys are one DPP row x the tiles);  P goes through
+//   the wave-private LDS tile `pm` [16][ROWS_PLD] to become the A operand of O += P V, V rows read as B (lane = channel).
+__device__ __forceinline__ void rows_attention_h32(const float* xq, float* xo, int ld, float* pm, const float* __restrict__ kvb,
+                                                   long long kstride, int D, int L, int h, int lane) {
+  const int g = lane >> 4, j = lane & 15;
+  const float4 qa0 = *reinterpret_cast<const float4*>(xq + j * ld + h * 32 + 4 * g);
+  const float4 qa1 = *reinterpret_cast<const float4*>(xq + j * ld + h * 32 + 16 + 4 * g);
+  float M[4], l[4];
+  f32x4 O[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { M[i] = -INFINITY; l[i] = 0.f; }
+  O[0] = O[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int c0 = 0; c0 < L; c0 += 64) {
+    const int nk = min(64, L - c0);
+    f32x4 S[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      S[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (kt * 16 < nk) {                         // uniform
+        const int key = c0 + kt * 16 + j;
+        const float* kp = kvb + (long long)min(key, L - 1) * kstride + D + h * 32 + 4 * g;
+        const float4 b0 = ld4(kp), b1 = ld4(kp + 16);
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa0.x, b0.x, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa0.y, b0.y, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa0.z, b0.z, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa0.w, b0.w, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa1.x, b1.x, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa1.y, b1.y, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa1.z, b1.z, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa1.w, b1.w, a, 0, 0, 0);
+        if (key < L) S[kt] = a;                   // keys past the sequence stay at -inf
+      }
+    }
+    float alpha[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                 // row 4 g + i: maximum / sum over its keys = 4 tiles x the 16 lanes of the DPP row
+      const float mc = row16_allreduce<true>(fmaxf(fmaxf(S[0][i], S[1][i]), fmaxf(S[2][i], S[3][i])));
+      const float mn = fmaxf(M[i], mc);           // finite: every chunk holds at least one key
+      alpha[i] = __expf(M[i] - mn);               // first chunk: exp(-inf) = 0
+      float ps = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const float pv = __expf(S[kt][i] - mn);   // exp(-inf) = 0 for the padding keys
+        S[kt][i] = pv;
+        ps += pv;
+      }
+      l[i] = l[i] * alpha[i] + row16_allreduce<false>(ps);
+      M[i] = mn;
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pm[(4 * g + i) * ROWS_PLD + kt * 16 + j] = S[kt][i];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) O[nt][i] *= alpha[i];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      if (kt * 16 < nk) {                         // uniform
+        const float4 ap = *reinterpret_cast<const float4*>(pm + j * ROWS_PLD + kt * 16 + 4 * g);
+        const int k0 = c0 + kt * 16 + 4 * g;
+        float v[2][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* vp = kvb + (long long)min(k0 + u, L - 1) * kstride + 2 * D + h * 32 + j;   // P is 0 for the clamped keys
+          v[0][u] = vp[0];
+          v[1][u] = vp[16];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          O[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap.x, v[nt][0], O[nt], 0, 0, 0);
+          O[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap.y, v[nt][1], O[nt], 0, 0, 0);
+          O[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap.z, v[nt][2], O[nt], 0, 0, 0);
+          O[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap.w, v[nt][3], O[nt], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float inv = 1.f / l[i];
+    xo[(4 * g + i) * ld + h * 32 + j] = O[0][i] * inv;
+    xo[(4 * g + i) * ld + h * 32 + 16 + j] = O[1][i] * inv;
+  }
+}
+
 }  // namespace pvsg

@@ -1,0 +1,514 @@
+// 1x1 convolution kernels of the split arithmetic (NCHW, pixels as GEMM columns) and their 3x3 / attention-mask / mask-logit
+// modes; templates, included by conv1x1_split.hip (1x1, mask logits, mask bits) and conv3x3_halo.hip (stride-2 3x3 = the
+// TAPS = 9 form).
+#pragma once
+#include "split_common.h"
+
+namespace pvsg {
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// 1x1 convolution in NCHW on the same arithmetic:  y[b, co, p] = act( (sum_ci w[co, ci] x[b, ci, pin(p)]) * scale[co]
+// + shift[co] (+ residual[b, co, p]) ), pin(p) = p (stride 1) or the stride-2 sub-sampled pixel.  Per image a GEMM with
+// rows = output channels (the packed weight, same pack as above), columns = pixels, K = input channels.  The pixel
+// operand is K-strided in memory: a thread stages (pixel, k-group of 8) with eight coalesced dword loads (64 lanes =
+// 64 consecutive pixels of one channel), splits and packs them into the same [limb][kg][column][8] LDS tile -- the
+// transposition costs nothing extra.  Columns = pixels also makes the stores pixel-contiguous.
+// Replaces [3P] mmdet ResNet Bottleneck.conv1 / conv3 / downsample[0] (+ frozen BN, identity, ReLU) with > 128 input
+// channels and the pixel decoder's 1x1 input / lateral / mask-feature convolutions (library GEMM or MIOpen + separate
+// BN / bias pass before).
+// IN_NORM: the input is normalised on the way in, x' = relu(x * in_scale[b, ci] + in_shift[b, ci]) (a GroupNorm + ReLU
+// whose statistics are already known), so that pass never touches HBM.
+// BITS (attention-mask mode; rows = queries, one channel tile, no affine): the epilogue thresholds the logits in registers
+// (masked <=> sigmoid(x) < 0.5 <=> x < 0) and writes one 128-bit record per key -- bit q = query q masked -- plus the
+// "query has an unmasked key" flag words, exactly the format of csrc/mask_gemm.hip (`y` then points at the uint32 records of
+// this batch element, image = frame t, key = t * HWo + pixel; `flags` at its 4 flag words).
+template <bool RELU, bool RESIDUAL, bool IN_NORM, bool BITS = false>
+__global__ __launch_bounds__(256, 2)
+void conv1x1_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ scale,
+                           const float* __restrict__ shift, const float* __restrict__ residual,
+                           const float* __restrict__ in_scale, const float* __restrict__ in_shift, float* __restrict__ y,
+                           int Cin, int Cout, int Cpad, int HWin, int Win, int HWo, int Wo, int stride, int tiles_c,
+                           int tiles_p, unsigned* __restrict__ flags = nullptr) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * GB_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tc = logical % tiles_c;                    // channel tiles of one pixel tile are neighbours: x from L2
+  logical /= tiles_c;
+  const int tp = logical % tiles_p, img = logical / tiles_p;
+  const int c0 = tc * GB_M, p0 = tp * GB_N;
+
+  // staging: weights -- (k-group tid/128, row tid%128), 3 limbs; pixels -- (k-group tid/128, pixel tid%128), 8 channels
+  const int skg = __builtin_amdgcn_readfirstlane(tid >> 7), srow = tid & 127;
+  const size_t w_limb_stride = (size_t)2 * Cpad * 8;
+  const __bf16* wsrc = Wp + ((size_t)skg * Cpad + c0 + srow) * 8;
+  const int pix = p0 + srow;
+  const int pin = stride == 1 ? pix : (2 * (pix / Wo)) * Win + 2 * (pix % Wo);
+  const unsigned x_voff = pix < HWo ? (unsigned)pin * 4u : 0x80000000u;            // beyond the map: read as 0
+  const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)img * Cin * HWin, 0,
+                                                      (unsigned)((size_t)Cin * HWin * 4), 0x00020000);
+  const unsigned plane = (unsigned)HWin * 4u;
+
+  float x_regs[2][8];                                 // [fetch slot = K-step & 1]
+  u32x4 w_regs[2][3];
+  auto fetch = [&](int slot, int kt) {
+    const unsigned so = (unsigned)(kt * GB_K + 8 * skg) * plane;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      x_regs[slot][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, x_voff, so + j * plane, 0));
+    const __bf16* wk = wsrc + (size_t)kt * 3 * w_limb_stride;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) w_regs[slot][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
+  };
+  auto stash = [&](int slot, __bf16* st, int kt) {
+    unsigned hh[4], mm[4], ll[4];
+    if (IN_NORM) {                                     // channel kt*16 + 8*skg + j of this image: wave-uniform scalars
+      const int ci = img * Cin + kt * GB_K + 8 * skg;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x_regs[slot][j] = fmaxf(fmaf(x_regs[slot][j], in_scale[ci + j], in_shift[ci + j]), 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split2(x_regs[slot][2 * q], x_regs[slot][2 * q + 1], hh[q], mm[q], ll[q]);
+    const u32x4 h = {hh[0], hh[1], hh[2], hh[3]}, m = {mm[0], mm[1], mm[2], mm[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+    __bf16* pw = st + (skg * GB_M + srow) * 8;                  // row operand: weights
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(pw + i * GB_LIMB) = w_regs[slot][i];
+    __bf16* px = st + GB_TILE + (skg * GB_N + srow) * 8;        // column operand: pixels
+    *reinterpret_cast<u32x4*>(px) = h;
+    *reinterpret_cast<u32x4*>(px + GB_LIMB) = m;
+    *reinterpret_cast<u32x4*>(px + 2 * GB_LIMB) = l;
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int KT = Cin / GB_K;
+  const int kg = lane >> 5, li = lane & 31;
+  const int a_off = (kg * GB_M + wr * 64 + li) * 8, w_off = GB_TILE + (kg * GB_N + wc * 64 + li) * 8;
+  fetch(0, 0);
+  stash(0, lds, 0);
+  fetch(1, KT > 1 ? 1 : 0);
+  fetch(0, KT > 2 ? 2 : KT - 1);
+  auto kstep = [&](int kt, auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    __syncthreads();
+    const __bf16* cur = lds + par * GB_STAGE;
+    bf16x8 av[3][2], wv[3][2];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        av[l][b] = *reinterpret_cast<const bf16x8*>(cur + a_off + l * GB_LIMB + b * 32 * 8);
+        wv[l][b] = *reinterpret_cast<const bf16x8*>(cur + w_off + l * GB_LIMB + b * 32 * 8);
+      }
+    stash(par ^ 1, lds + (par ^ 1) * GB_STAGE, kt + 1 < KT ? kt + 1 : KT - 1);
+    fetch(par ^ 1, kt + 3 < KT ? kt + 3 : KT - 1);
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PW[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[p]][rb], wv[PW[p]][cb], acc[rb][cb], 0, 0, 0);
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  int kt = 0;
+  for (; kt + 2 <= KT; kt += 2) {
+    kstep(kt, P0{});
+    kstep(kt + 1, P1{});
+  }
+  if (kt < KT) kstep(kt, P0{});
+
+  if constexpr (BITS) {
+    // register r of block (rb, cb): query 64 wr + 32 rb + 4 kg + (r&3) + 8 (r>>2) = bit (4 kg + (r&3) + 8 (r>>2)) of word 2 wr + rb;
+    // key = pixel 64 wc + 32 cb + li.  The two k-group halves of a wave hold complementary bits of the same words.
+    unsigned w[2][2];                                    // [cb][rb]
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        unsigned v = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (acc[rb][cb][r] < 0.f) v |= 1u << (4 * kg + (r & 3) + 8 * (r >> 2));
+        v |= (unsigned)__shfl_xor((int)v, 32);
+        w[cb][rb] = v;
+      }
+    // lane (li, kg) stores the key of column block cb = kg: words 2 wr, 2 wr + 1 of its 16-byte record
+    const int p = p0 + wc * 64 + kg * 32 + li;
+    const unsigned w0 = kg ? w[1][0] : w[0][0], w1 = kg ? w[1][1] : w[0][1];
+    unsigned a0 = 0u, a1 = 0u;
+    if (p < HWo) {
+      unsigned* rec = reinterpret_cast<unsigned*>(y) + ((size_t)img * HWo + p) * 4 + 2 * wr;
+      *reinterpret_cast<uint2*>(rec) = make_uint2(w0, w1);
+      a0 = ~w0;
+      a1 = ~w1;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      a0 |= (unsigned)__shfl_xor((int)a0, off);
+      a1 |= (unsigned)__shfl_xor((int)a1, off);
+    }
+    // the flag words saturate after the first few workgroups (bits only ever get set): look before the atomic, or thousands
+    // of workgroups serialise on four L2 atomics
+    if (lane == 0) {
+      const unsigned c0w = __hip_atomic_load(flags + 2 * wr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned c1w = __hip_atomic_load(flags + 2 * wr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a0 & ~c0w) atomicOr(flags + 2 * wr, a0);
+      if (a1 & ~c1w) atomicOr(flags + 2 * wr + 1, a1);
+    }
+    return;
+  }
+  // BN affine (+ identity) (+ ReLU): register r of block (rb, cb) = channel (r&3) + 8 (r>>2) + 4 kg of the block, pixel li.
+  // Branch-free: scale / shift / identity are read through buffer descriptors (channels >= Cout read 0), the stores go
+  // through a descriptor of this image's output (channels >= Cout are dropped by the bounds check) and lanes of pixels
+  // beyond the map carry an offset outside every descriptor.  The guarded form was one load(scale, shift, identity) ->
+  // `s_waitcnt vmcnt(0)` -> store chain per element: 64 dependent memory round trips per lane.  Needs Cout % 4 == 0 for the
+  // float4 reads of scale / shift (checked by the entry point).
+  {
+    const auto srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scale), 0, scale ? (unsigned)Cout * 4u : 0u, 0x00020000);
+    const auto hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(shift), 0, shift ? (unsigned)Cout * 4u : 0u, 0x00020000);
+    const size_t obase = (size_t)img * Cout * HWo;
+    const unsigned img_bytes = (unsigned)((size_t)Cout * HWo * 4);
+    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(y + obase, 0, img_bytes, 0x00020000);
+    const auto rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual) + (RESIDUAL ? obase : 0), 0,
+                                                       RESIDUAL ? img_bytes : 0u, 0x00020000);
+    const unsigned chpitch = (unsigned)HWo * 4u;
+    unsigned pvoff[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int p = p0 + wc * 64 + cb * 32 + li;
+      pvoff[cb] = p < HWo ? (unsigned)p * 4u : 0x80000000u;
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int chb = c0 + wr * 64 + rb * 32 + 4 * kg;               // channels chb + (r&3) + 8 (r>>2)
+      f32x4 sc4[4], sh4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sc4[j] = scale ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)(chb + 8 * j) * 4u, 0, 0))
+                       : f32x4{1.f, 1.f, 1.f, 1.f};
+        sh4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, (unsigned)(chb + 8 * j) * 4u, 0, 0));
+      }
+      float res[2][16];
+      if (RESIDUAL) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            res[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                rrs, pvoff[cb] + (unsigned)(chb + (r & 3) + 8 * (r >> 2)) * chpitch, 0, 0));
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = fmaf(acc[rb][cb][r], sc4[r >> 2][r & 3], sh4[r >> 2][r & 3]);
+          if (RESIDUAL) v += res[cb][r];
+          if (RELU) v = fmaxf(v, 0.f);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
+                                                pvoff[cb] + (unsigned)(chb + (r & 3) + 8 * (r >> 2)) * chpitch, 0, 0);
+        }
+    }
+  }
+}
+
+// The 1x1 convolution on v_mfma_f32_16x16x32_bf16 with K = 32 stages (see gemm_bf16x3_k32_kernel): the same operands, epilogues
+// and record formats as the kernel above; default for Cin % 32 == 0.
+// TM = 64: layers with at most 64 output channels (the bottleneck's reducing 1x1 of layer1).  The packed weight is padded to 128
+// rows and is staged whole, but only rows 0..63 are multiplied: the four waves each take 32 pixel columns of the 64 rows, half
+// the matrix work of a 128-row tile, which leaves these layers to their HBM traffic.
+// TAPS = 9: the 3x3 convolution (pad 1, stride 1 or 2) as an implicit GEMM over K = 9 * Cin, ordered [block of 32 input channels][tap][32 channels] (weight packed from
+// pvsg_conv3x3_weight_matrix(w)): a 32-deep step lies inside one tap (Cin % 32 == 0), whose pixel offset replaces the 1x1 one;
+// out-of-image taps read 0 through the descriptor's bounds check.
+// F16: the two-limb f16 form (see split2h): weights (w_h, w_l, w_h2) resident in registers, pixels as (x_h, x_l').
+template <bool RELU, bool RESIDUAL, bool IN_NORM, bool BITS = false, int TM = 128, int TAPS = 1, bool F16 = false>
+__global__ __launch_bounds__(256, 3)
+void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ scale,
+                               const float* __restrict__ shift, const float* __restrict__ residual,
+                               const float* __restrict__ in_scale, const float* __restrict__ in_shift, float* __restrict__ y,
+                               int Cin, int Cout, int Cpad, int HWin, int Win, int HWo, int Wo, int stride, int tiles_c,
+                               int tiles_p, unsigned* __restrict__ flags = nullptr, unsigned* __restrict__ overflow = nullptr,
+                               int imgs_per_w = 0, long long w_batch_stride = 0, double* __restrict__ gn_part = nullptr) {
+  constexpr int XL = F16 ? 2 : 3;                                // limbs of the on-the-fly (pixel) operand
+  constexpr int WL = F16 ? 2 : 3;                                // arrays of the packed weight
+  constexpr int X_AT = WL * K32_LIMB;                            // where the pixel tile starts
+  __shared__ __attribute__((aligned(16))) __bf16 lds[X_AT + XL * K32_LIMB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  static_assert(TM == 128 || (TM == 64 && !BITS), "64-row tiles: plain convolution only");
+  static_assert(TAPS == 1 || (TAPS == 9 && !BITS && !IN_NORM && !RESIDUAL), "3x3 taps: affine / ReLU epilogue only");
+  constexpr int CB = TM == 128 ? 4 : 2;                          // 16-pixel column blocks per wave
+  const int wr = TM == 128 ? wave >> 1 : 0, wc = wave & 1;
+  const int wcol0 = TM == 128 ? wc * 64 : wave * 32;            // first pixel column of this wave in the tile
+  unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tc = logical % tiles_c;
+  logical /= tiles_c;
+  const int tp = logical % tiles_p, img = logical / tiles_p;
+  const int c0 = tc * GB_M, p0 = tp * GB_N;
+  if (BITS && imgs_per_w > 0) {                                  // one launch for a batch: image img belongs to batch element
+    const int bb = img / imgs_per_w;                             // img / imgs_per_w, which has its own packed embeddings / flags
+    Wp += (long long)bb * w_batch_stride;
+    flags += 4 * bb;
+  }
+  // staging: weights -- (k-group tid/128, row tid%128) of both 16-deep sub-steps, 3 limbs; pixels -- (k-group tid/128, pixel
+  // tid%128), the 8 channels of that k-group in each sub-step
+  const int skg = __builtin_amdgcn_readfirstlane(tid >> 7), srow = tid & 127;
+  const size_t w_limb_stride = (size_t)2 * Cpad * 8;
+  const __bf16* wsrc = Wp + ((size_t)skg * Cpad + c0 + srow) * 8;
+  const int pix = p0 + srow;
+  const int oy = pix / Wo, ox = pix - oy * Wo, Hin = HWin / Win;
+  const int pin = stride == 1 ? pix : (2 * oy) * Win + 2 * ox;
+  const unsigned x_voff = pix < HWo ? (unsigned)pin * 4u : 0x80000000u;            // beyond the map: read as 0
+  const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)img * Cin * HWin, 0,
+                                                      (unsigned)((size_t)Cin * HWin * 4), 0x00020000);
+  const unsigned plane = (unsigned)HWin * 4u;
+  float x_regs[2][8];                                 // [sub-step]
+  u32x4 w_regs[2][WL];
+  auto fetch = [&](int kt) {
+    int cstep = kt * 32;                               // first input channel of this step
+    unsigned voff = x_voff;
+    if (TAPS == 9) {                                   // K order: [block of 32 input channels][tap][32 channels]
+      const int cib = kt / 9, tap = kt - 9 * cib;
+      cstep = cib * 32;
+      const int dy = tap / 3, dx = tap - 3 * dy;
+      const int iy = stride * oy + dy - 1, ix = stride * ox + dx - 1;
+      voff = (pix < HWo && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) ? (unsigned)(iy * Win + ix) * 4u : 0x80000000u;
+    }
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      const unsigned so = (unsigned)(cstep + 16 * gq + 8 * skg) * plane;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#if defined(PVSG_ABL) && (PVSG_ABL == 8 || PVSG_ABL == 9)
+        x_regs[gq][j] = 0.5f + (float)(so + j);        // lab build: no pixel loads (timing only)
+#else
+        x_regs[gq][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff, so + j * plane, PVSG_NT_LD));
+#endif
+      }
+      const __bf16* wk = wsrc + (size_t)(2 * kt + gq) * WL * w_limb_stride;
+#pragma unroll
+      for (int l = 0; l < WL; ++l) w_regs[gq][l] = *reinterpret_cast<const u32x4*>(wk + l * w_limb_stride);
+    }
+  };
+  u32x4 limbs[2][XL];                                  // split of step kt+1 under the MFMAs of step kt (see the GEMM kernel)
+  float amax = 0.f;
+  auto split = [&](int kt) {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      if (IN_NORM) {                                   // channel kt*32 + 16*gq + 8*skg + j of this image: wave-uniform scalars
+        const int ci = img * Cin + kt * 32 + 16 * gq + 8 * skg;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x_regs[gq][j] = fmaxf(fmaf(x_regs[gq][j], in_scale[ci + j], in_shift[ci + j]), 0.f);
+      }
+      unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#if defined(PVSG_ABL) && PVSG_ABL == 9
+        hh[q] = __builtin_bit_cast(unsigned, x_regs[gq][2 * q]); mm[q] = __builtin_bit_cast(unsigned, x_regs[gq][2 * q + 1]); ll[q] = hh[q];   // lab: no split either
+#else
+        if constexpr (F16) split2h(x_regs[gq][2 * q], x_regs[gq][2 * q + 1], hh[q], mm[q], amax);
+        else split2(x_regs[gq][2 * q], x_regs[gq][2 * q + 1], hh[q], mm[q], ll[q]);
+#endif
+      }
+      limbs[gq][0] = u32x4{hh[0], hh[1], hh[2], hh[3]};
+      limbs[gq][1] = u32x4{mm[0], mm[1], mm[2], mm[3]};
+      if constexpr (!F16) limbs[gq][2] = u32x4{ll[0], ll[1], ll[2], ll[3]};
+    }
+  };
+  auto write = [&]() {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      __bf16* pw = lds + ((2 * gq + skg) * GB_M + srow) * 8;                  // row operand: weights
+#pragma unroll
+      for (int i = 0; i < WL; ++i) *reinterpret_cast<u32x4*>(pw + i * K32_LIMB) = w_regs[gq][i];
+      __bf16* px = lds + X_AT + ((2 * gq + skg) * GB_N + srow) * 8;           // column operand: pixels
+#pragma unroll
+      for (int i = 0; i < XL; ++i) *reinterpret_cast<u32x4*>(px + i * K32_LIMB) = limbs[gq][i];
+    }
+  };
+  f32x4 acc[4][CB];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int l15 = lane & 15, kg4 = lane >> 4;
+  const __bf16* afr = lds + (kg4 * GB_M + wr * 64 + l15) * 8;
+  const __bf16* wfr = lds + X_AT + (kg4 * GB_N + wcol0 + l15) * 8;
+  auto frag = [](const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); };
+  auto mf = [](u32x4 a, u32x4 b, f32x4 c) { return mfma_k32<F16>(a, b, c); };
+  const int KT = TAPS * Cin / 32;
+  fetch(0);
+  split(0);
+  write();
+  for (int kt = 0; kt < KT; ++kt) {
+    __syncthreads();
+    fetch(kt + 1 < KT ? kt + 1 : KT - 1);     // (issued a step earlier, behind write(), this kernel spills 46 registers)
+    u32x4 ahf[4], amf[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      ahf[rb] = frag(afr + rb * 128);
+      amf[rb] = frag(afr + K32_LIMB + rb * 128);
+    }
+    if constexpr (F16) {                       // weights (w_h, w_l, 2^-11 w_h) resident; pixels (x_h, x_l') per column block
+      u32x4 a2f[4];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) a2f[rb] = f16x2_lo_scale(ahf[rb]);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const u32x4 xh = frag(wfr + cb * 128), xl = frag(wfr + K32_LIMB + cb * 128);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(a2f[rb], xl, acc[rb][cb]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], xh, acc[rb][cb]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], xh, acc[rb][cb]);
+      }
+      split(kt + 1 < KT ? kt + 1 : KT - 1);
+    } else {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const u32x4 wh = frag(wfr + cb * 128), wm = frag(wfr + K32_LIMB + cb * 128), wl = frag(wfr + 2 * K32_LIMB + cb * 128);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wm, acc[rb][cb]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wl, acc[rb][cb]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wm, acc[rb][cb]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(ahf[rb], wh, acc[rb][cb]);
+      }
+      split(kt + 1 < KT ? kt + 1 : KT - 1);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) amf[rb] = frag(afr + 2 * K32_LIMB + rb * 128);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const u32x4 wh = frag(wfr + cb * 128);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = mf(amf[rb], wh, acc[rb][cb]);
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < KT) write();
+  }
+  if constexpr (F16) f16x2_count_overflow(amax, overflow);
+
+  if constexpr (BITS) {
+    // register r of block (rb, cb): query 64 wr + 16 rb + 4 kg4 + r = bit 16 (rb & 1) + 4 kg4 + r of word 2 wr + (rb >> 1);
+    // key = pixel 64 wc + 16 cb + l15.  The four lane groups of a wave hold complementary bits of the same words.
+    unsigned w[4][2];                                    // [cb][word]
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int ws = 0; ws < 2; ++ws) {
+        unsigned v = 0u;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (acc[2 * ws + h2][cb][r] < 0.f) v |= 1u << (16 * h2 + 4 * kg4 + r);
+        v |= (unsigned)__shfl_xor((int)v, 16);
+        v |= (unsigned)__shfl_xor((int)v, 32);
+        w[cb][ws] = v;
+      }
+    // lane (l15, kg4) stores the key of column block cb = kg4: words 2 wr, 2 wr + 1 of its 16-byte record
+    const int p = p0 + wc * 64 + kg4 * 16 + l15;
+    const unsigned w0 = kg4 == 0 ? w[0][0] : kg4 == 1 ? w[1][0] : kg4 == 2 ? w[2][0] : w[3][0];
+    const unsigned w1 = kg4 == 0 ? w[0][1] : kg4 == 1 ? w[1][1] : kg4 == 2 ? w[2][1] : w[3][1];
+    unsigned a0 = 0u, a1 = 0u;
+    if (p < HWo) {
+      unsigned* rec = reinterpret_cast<unsigned*>(y) + ((size_t)img * HWo + p) * 4 + 2 * wr;
+      *reinterpret_cast<uint2*>(rec) = make_uint2(w0, w1);
+      a0 = ~w0;
+      a1 = ~w1;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      a0 |= (unsigned)__shfl_xor((int)a0, off);
+      a1 |= (unsigned)__shfl_xor((int)a1, off);
+    }
+    if (lane == 0) {                                     // look before the atomic (see the kernel above)
+      const unsigned c0w = __hip_atomic_load(flags + 2 * wr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned c1w = __hip_atomic_load(flags + 2 * wr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a0 & ~c0w) atomicOr(flags + 2 * wr, a0);
+      if (a1 & ~c1w) atomicOr(flags + 2 * wr + 1, a1);
+    }
+    return;
+  }
+  // BN affine (+ identity) (+ ReLU), branch-free through buffer descriptors (see the kernel above): register r of block
+  // (rb, cb) = channel 16 rb + 4 kg4 + r, pixel 16 cb + l15 of the wave's 64 x 64 tile
+  {
+    const auto srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scale), 0, scale ? (unsigned)Cout * 4u : 0u, 0x00020000);
+    const auto hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(shift), 0, shift ? (unsigned)Cout * 4u : 0u, 0x00020000);
+    const size_t obase = (size_t)img * Cout * HWo;
+    const unsigned img_bytes = (unsigned)((size_t)Cout * HWo * 4);
+    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(y + obase, 0, img_bytes, 0x00020000);
+    const auto rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual) + (RESIDUAL ? obase : 0), 0,
+                                                       RESIDUAL ? img_bytes : 0u, 0x00020000);
+    const unsigned chpitch = (unsigned)HWo * 4u;
+    const float unscale = F16 ? f16x2_unscale(Wp, Cpad, TAPS * Cin) : 1.f;
+    unsigned pvoff[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const int p = p0 + wcol0 + cb * 16 + l15;
+      pvoff[cb] = p < HWo ? (unsigned)p * 4u : 0x80000000u;
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const int chb = c0 + wr * 64 + rb * 16 + 4 * kg4;              // channels chb .. chb + 3
+      f32x4 sc4 = scale ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)chb * 4u, 0, 0))
+                        : f32x4{1.f, 1.f, 1.f, 1.f};
+      if constexpr (F16) sc4 *= unscale;                             // the packed weight's 2^-e (exact)
+      const f32x4 sh4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, (unsigned)chb * 4u, 0, 0));
+      float res[CB][4];
+      if (RESIDUAL) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            res[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, pvoff[cb] + (unsigned)(chb + r) * chpitch, 0, PVSG_NT_LD));
+      }
+      float gs = 0.f, gq = 0.f;                                     // GroupNorm statistics of what is stored (gn_part != nullptr)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = fmaf(acc[rb][cb][r], sc4[r], sh4[r]);
+          if (RESIDUAL) v += res[cb][r];
+          if (RELU) v = fmaxf(v, 0.f);
+          if (pvoff[cb] != 0x80000000u) { gs += v; gq = fmaf(v, v, gq); }
+          if (PVSG_ABL == 11 && v != 1.2345e33f) continue;        // lab build: no epilogue stores (timing only)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, pvoff[cb] + (unsigned)(chb + r) * chpitch, 0, PVSG_NT_ST);
+        }
+      if constexpr (TM == 128) {
+        if (gn_part) {
+          // groups of 8 channels: lanes (l15 = 0..15, kg4 in {0,1} | {2,3}) x this row block hold one group's values of the wave's
+          // 64 pixels.  Fixed-order reduction (bit-reproducible); one (sum, sum of squares) pair per (image, group, pixel tile,
+          // wave column) into `gn_part`, summed in f64 by gn_finish_kernel: the statistics pass over the 1.9 GB the convolution
+          // has just written never runs.
+#pragma unroll
+          for (int off = 1; off <= 16; off <<= 1) { gs += __shfl_xor(gs, off); gq += __shfl_xor(gq, off); }
+          if (l15 == 0 && (kg4 & 1) == 0 && chb < Cout) {
+            const int g = (chb >> 3), G = Cout >> 3;
+            double* dst = gn_part + ((((size_t)img * G + g) * tiles_p + tp) * 2 + wc) * 2;
+            dst[0] = (double)gs;
+            dst[1] = (double)gq;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+}  // namespace pvsg
+

@@ -171,7 +171,7 @@ __global__ void stem7x7_pack_kernel(const float* __restrict__ w, float* __restri
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// The same stem on the f16 matrix pipe (two-limb split, csrc/gemm_bf16x3.hip section "Two-limb f16 split"): round 5.
+// The same stem on the f16 matrix pipe (two-limb split, csrc/split_common.h section "Two-limb f16 split"): round 5.
 // v_mfma_f32_32x32x2_f32 issues the stem's 168 padded taps in 84 K-steps of 64 cycles -- 2.0 ms at 32 x 720p, matrix-bound.
 // Here the patch is split ONCE while it is staged (a_h = f16(a), a_l' = f16(2^11 (a - a_h)), two 16-bit planes in the space of the
 // f32 patch) and the convolution runs on v_mfma_f32_16x16x32_f16: rows = 16 output channels, columns = 16 convolution pixels,

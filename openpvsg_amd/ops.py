@@ -105,7 +105,7 @@ def mask_logits(mask_embed, mask_feature):
     with _on(e.device):
         if (os.environ.get('PVSG_MASK_GEMM', 'bf16x3') != 'f32' and C % 16 == 0 and Q % 4 == 0 and C * N < 2 ** 29 and
                 (Q + 127) // 128 * 128 * N < 2 ** 29):
-            # split arithmetic on the 16-bit matrix cores (f32-class result; csrc/gemm_bf16x3.hip)
+            # split arithmetic on the 16-bit matrix cores (f32-class result; csrc/conv1x1_split.hip)
             if split_mode() == 'f16x2' and C % 32 == 0:
                 scratch = torch.empty((B * _lib.load().pvsg_gemm_f16x2_packed_elems(Q, C),), device=e.device, dtype=torch.bfloat16)
                 _lib.call('pvsg_mask_logits_f16x2', e.data_ptr(), f.data_ptr(), scratch.data_ptr(), out.data_ptr(), B, T, Q, C,
@@ -878,7 +878,7 @@ def conv3x3_weight_matrix(weight):
 
 def conv3x3_bf16x3(x, w_packed, cout, scale=None, shift=None, relu=True, out=None, stride=1):
     """act(conv3x3(x, w, stride 1 or 2, pad 1) * scale[c] + shift[c]) on the split-bf16 kernel (implicit GEMM over the nine
-    taps, csrc/gemm_bf16x3.hip); w_packed = conv3x3_bf16x3_pack(w)."""
+    taps, csrc/conv3x3_halo.hip); w_packed = conv3x3_bf16x3_pack(w)."""
     x = _chk(x, 'x')
     N, Cin, H, W = x.shape
     if stride not in (1, 2) or not conv3x3_bf16x3_supported(cout, Cin, H, W):
@@ -902,7 +902,7 @@ def conv3x3_bf16x3(x, w_packed, cout, scale=None, shift=None, relu=True, out=Non
     return out
 
 
-# ---- split arithmetic of the matrix-core GEMM / convolution kernels (csrc/gemm_bf16x3.hip) ---------------------------------
+# ---- split arithmetic of the matrix-core GEMM / convolution kernels (csrc/split_common.h: token_gemm / conv1x1_split / conv3x3_halo / bottleneck_tail .hip) ---------------------------------
 # 'f16x2' (default): two f16 limbs per operand, three limb products per multiply (half the matrix work of 'bf16x3'), the
 #   low limbs kept out of the f16 subnormals by exact power-of-two factors; f32-class like the other (tests/test_gemm_f16x2.py
 #   measures both against f64).  Operands must lie within the f16 range, |a| <= 65504: every kernel counts violations into a
@@ -1024,7 +1024,7 @@ def gemm_bf16x3_supported(n, k):
 
 
 def gemm_bf16x3_pack(weight, mode=None):
-    """(N,K) f32 linear weight -> its limbs in the staging order of csrc/gemm_bf16x3.hip (once per weight): the two-limb f16
+    """(N,K) f32 linear weight -> its limbs in the staging order of csrc/token_gemm.hip (once per weight): the two-limb f16
     form (K % 32 == 0, `split_mode()`) or the three-limb bf16 form."""
     w = _chk(weight, 'weight')
     if w.dim() != 2 or not gemm_bf16x3_supported(w.shape[0], w.shape[1]):
@@ -1041,7 +1041,7 @@ def gemm_bf16x3_pack(weight, mode=None):
 
 def gemm_bf16x3(a, w_packed, n, bias=None, relu=False, out=None):
     """act(a (M,K) @ w (n,K)^T + bias) in f32-class arithmetic on the bf16 matrix cores (exact three-limb split,
-    csrc/gemm_bf16x3.hip); w given as gemm_bf16x3_pack(w)."""
+    csrc/token_gemm.hip); w given as gemm_bf16x3_pack(w)."""
     a = _chk(a, 'a')
     if a.dim() != 2 or not gemm_bf16x3_supported(n, a.shape[1]):
         raise RuntimeError('gemm_bf16x3: unsupported shape %s x %d' % (tuple(a.shape), n))
@@ -1071,7 +1071,7 @@ def gemm_add_layernorm_supported(w_packed, n, k):
 
 def gemm_add_layernorm(a, w_packed, bias, residual, norm, out=None):
     """LayerNorm(residual + a (M,K) @ w (256,K)^T + bias) with `norm` an nn.LayerNorm(256), in one launch
-    (csrc/gemm_bf16x3.hip: gemm_f16x2_t256_kernel<.., LN>); w given as gemm_bf16x3_pack(w, mode='f16x2')."""
+    (csrc/token_gemm.hip: gemm_f16x2_ln128_kernel<true>); w given as gemm_bf16x3_pack(w, mode='f16x2')."""
     a = _chk(a, 'a')
     r = _chk(residual, 'residual')
     M, K = a.shape
@@ -1096,7 +1096,7 @@ def conv1x1_bf16x3_supported(cout, cin, h, w):
 def conv1x1_bf16x3(x, w_packed, cout, scale=None, shift=None, residual=None, relu=False, stride=1, out=None,
                    in_scale=None, in_shift=None):
     """act(conv1x1(x, w, stride) * scale[c] + shift[c] (+ residual)) in NCHW, f32-class arithmetic on the bf16 matrix
-    cores (csrc/gemm_bf16x3.hip); w given as gemm_bf16x3_pack(w.view(Cout, Cin)).  in_scale / in_shift (B*Cin,): the input
+    cores (csrc/conv1x1_split.hip); w given as gemm_bf16x3_pack(w.view(Cout, Cin)).  in_scale / in_shift (B*Cin,): the input
     is first normalised and rectified, relu(x * in_scale[b, ci] + in_shift[b, ci]) (GroupNorm + ReLU with known statistics)."""
     x = _chk(x, 'x')
     B, Cin, H, W = x.shape
@@ -1173,7 +1173,7 @@ def bottleneck_tail(mid, w3_packed, scale3, shift3, identity, w1n_packed=None, s
                     stride2_copy=False):
     """[3P] mmdet ResNet Bottleneck (64 planes): y = relu(conv3(mid) * scale3 + shift3 + identity) and, with w1n_packed
     (bottleneck_next_pack of the next block's conv1, `cnext` = 64 or 128 output channels), mid_next = relu(conv1_next(y) * scale1n +
-    shift1n) in the same pass over the pixels (csrc/gemm_bf16x3.hip bottleneck_tail64_kernel).  stride2_copy: also y[:, :, ::2, ::2]
+    shift1n) in the same pass over the pixels (csrc/bottleneck_tail.hip bottleneck_tail64_kernel).  stride2_copy: also y[:, :, ::2, ::2]
     as a compact tensor (the next stage's stride-2 downsample convolution then runs as a stride-1 convolution on it).
     -> (y, mid_next or None[, y_stride2])."""
     mid, identity = _chk(mid, 'mid'), _chk(identity, 'identity')
@@ -1328,7 +1328,7 @@ def decoder_kv_inputs(tokens, start, hw, level_embed, pos_enc):
 def decoder_kv_project(tokens, start, hw, w_packed, tab_cell, tab_frame, bias_v):
     """Key and value projections of one decoder level in one launch from the encoder memory `tokens` (F,S,256) (level rows
     start..start+hw): k = tokens Wk^T + tab_cell[cell] + tab_frame[frame % zrows], v = tokens Wv^T + bias_v; w_packed =
-    gemm_bf16x3_pack(cat(Wk, Wv), mode='f16x2').  -> (k (F*hw,256), v (F*hw,256)).  csrc/gemm_bf16x3.hip, KV form."""
+    gemm_bf16x3_pack(cat(Wk, Wv), mode='f16x2').  -> (k (F*hw,256), v (F*hw,256)).  csrc/token_gemm.hip, KV form."""
     x = _chk(tokens, 'tokens')
     Fr, S, C = x.shape
     tc, tf, bv = _chk(tab_cell, 'tab_cell'), _chk(tab_frame, 'tab_frame'), _chk(bias_v, 'bias_v')

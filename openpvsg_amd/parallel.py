@@ -55,7 +55,7 @@ def isolate_shared_gpu(slot, slots, device_index=0, cus=None):
     """Several PROCESSES on one MI355X (the gloo logic tests, `bench.py` with PVSG_ONE_DEVICE=1): give each its own
     range of compute units (HSA_CU_MASK), to be called before the process touches the HIP runtime.
 
-    Why it is needed, not just tidy: waves of csrc/gemm_bf16x3.hip (v_mfma_f32_32x32x16_bf16 at high occupancy) that are
+    Why it is needed, not just tidy: waves of the split kernels (csrc/token_gemm.hip, conv1x1_split.hip: v_mfma_f32_32x32x16_bf16 at high occupancy) that are
     CO-RESIDENT on a CU with waves of ANOTHER process were observed to corrupt that process's results -- e.g. its
     deformable-attention gather returns wrong values in lanes 48-63 of a wave (heads 6-7) in 1-20 % of launches, on every
     box tried; the same kernel built on the f32 MFMA does not, and neither process is affected once their CU sets are

@@ -589,7 +589,7 @@ def reconsdot_cost(trk_feats, det_feats, tmp=100.0, needed=None):
     Fd, Pd, Pdp = _padded_cells(det_feats)
     Nt, Nd, d = len(trk_feats), len(det_feats), Ft.shape[1]
     if d % 32 == 0 and d >= 64:
-        # the affinities on the split-f16 matrix-core GEMM (f32-class, csrc/gemm_bf16x3.hip): normalised features are within
+        # the affinities on the split-f16 matrix-core GEMM (f32-class, csrc/token_gemm.hip): normalised features are within
         # its range by construction; 0.46 ms against the library's f32 GEMM's 1.0 for 28 x 27 objects of 300 cells
         A = ops.gemm_bf16x3(Ft, ops.gemm_bf16x3_pack(Fd), Nd * Pdp)
     else:

@@ -1,4 +1,4 @@
-"""1x1 convolutions of the north-star step in NCHW at 32 x 720p: csrc/gemm_bf16x3.hip (conv1x1_bf16x3, BN / identity /
+"""1x1 convolutions of the north-star step in NCHW at 32 x 720p: csrc/conv1x1_split.hip (conv1x1_bf16x3, BN / identity /
 ReLU in the epilogue) vs what ran before -- the f32 matrix-core kernel csrc/conv1x1.hip where it applies (Cin <= 256) and
 the library path (tabled batched GEMM or MIOpen, + the separate BN pass).  usage: python scripts/conv1x1_bf16x3_bench.py"""
 import json

@@ -1,5 +1,5 @@
 """Two processes on ONE MI355X: rank 0 runs an 'aggressor' kernel in a loop, rank 1 only the deformable-attention gather
-on static inputs and compares every result bitwise with its first one.  Finding (round 2): with csrc/gemm_bf16x3.hip
+on static inputs and compares every result bitwise with its first one.  Finding (round 2): with csrc/token_gemm.hip
 (bf16 MFMA) as the aggressor, 1-20 % of rank 1's launches return wrong values in heads 6-7 (lanes 48-63 of a wave); with
 the same kernel built on the f32 MFMA, with the Winograd / stride-2 convolution kernels, or with the two processes on
 disjoint CU ranges (SPLIT_CUS=1 -> parallel.isolate_shared_gpu) there are none.  Inside one process kernels run back to

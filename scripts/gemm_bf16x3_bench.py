@@ -1,5 +1,5 @@
 """Token-major linear layers of the north-star step at 32 x 720p (encoder FFN / projections, decoder key-value
-projection): csrc/gemm_bf16x3.hip vs the library f32 GEMM (with the tuned selection table).
+projection): csrc/token_gemm.hip vs the library f32 GEMM (with the tuned selection table).
 usage: python scripts/gemm_bf16x3_bench.py [own]"""
 import json
 import os

@@ -1,4 +1,4 @@
-"""Where a wave of the f16x2 GEMM kernels spends its time (lab build -DPVSG_ABL=7 of csrc/gemm_bf16x3.hip, built by
+"""Where a wave of the f16x2 GEMM kernels spends its time (lab build -DPVSG_ABL=7 of csrc/token_gemm.hip, built by
 scripts/lab/abl_split.sh 7; run with PVSG_LIB_PATH=/tmp/libpvsg_abl7.so).  Prints per-step averages in s_memtime ticks
 (100 MHz: x ~20 = shader cycles) for the 128 x 128 (LDS-DMA) and the 256 x 256 kernels."""
 import ctypes

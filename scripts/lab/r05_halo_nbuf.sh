@@ -4,8 +4,8 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R
 OBJ=$R/openpvsg_amd/lib/obj
 O=gpurun_out/r05_halo_nbuf; mkdir -p $O
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DPVSG_HALO_NBUF=3 -c $R/openpvsg_amd/csrc/gemm_bf16x3.hip -o /tmp/gemm_nbuf3.o || exit 1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $OBJ/*.o | grep -v gemm_bf16x3.o) /tmp/gemm_nbuf3.o -o /tmp/libpvsg_nbuf3.so || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DPVSG_HALO_NBUF=3 -c $R/openpvsg_amd/csrc/conv3x3_halo.hip -o /tmp/conv3x3_halo_nbuf3.o || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $OBJ/*.o | grep -v conv3x3_halo.o) /tmp/conv3x3_halo_nbuf3.o -o /tmp/libpvsg_nbuf3.so || exit 1
 {
 PVSG_LIB_PATH=/tmp/libpvsg_nbuf3.so python -m pytest tests/test_winograd.py tests/test_glue_kernels.py -q -m gpu 2>&1 | tail -1
 for v in base nbuf3 base nbuf3; do

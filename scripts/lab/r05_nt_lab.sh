@@ -5,8 +5,10 @@ cd $R
 OBJ=$R/openpvsg_amd/lib/obj
 O=gpurun_out/r05_nt_lab; mkdir -p $O
 build() {  # name, extra flags
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $2 -c $R/openpvsg_amd/csrc/gemm_bf16x3.hip -o /tmp/gemm_$1.o || exit 1
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $OBJ/*.o | grep -v gemm_bf16x3.o) /tmp/gemm_$1.o -o /tmp/libpvsg_$1.so || exit 1
+  for f in token_gemm conv1x1_split conv3x3_halo bottleneck_tail; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $2 -c $R/openpvsg_amd/csrc/$f.hip -o /tmp/${f}_$1.o || exit 1
+  done
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $OBJ/*.o | grep -v "token_gemm.o\|conv1x1_split.o\|conv3x3_halo.o\|bottleneck_tail.o") /tmp/token_gemm_$1.o /tmp/conv1x1_split_$1.o /tmp/conv3x3_halo_$1.o /tmp/bottleneck_tail_$1.o -o /tmp/libpvsg_$1.so || exit 1
 }
 build ntst "-DPVSG_NT_ST=2" &
 build ntld "-DPVSG_NT_LD=2" &

@@ -46,7 +46,7 @@ def run_pass(counter, frames, workdir):
 
 
 def split_entry(fn):
-    """C-ABI entry of the split kernels of csrc/gemm_bf16x3.hip from their template arguments (round 4: the f16x2 forms)"""
+    """C-ABI entry of the split kernels (csrc/token_gemm.hip, conv1x1_split.hip, conv3x3_halo.hip) from their template arguments (round 4: the f16x2 forms)"""
     import re
     m = re.search(r'(\w+_kernel)<([^>]*)>', fn)
     if m:

@@ -1,4 +1,4 @@
-"""A/B of the two split forms of csrc/gemm_bf16x3.hip (three bf16 limbs / six limb products vs two f16 limbs / three) on the
+"""A/B of the two split forms of csrc/split_common.h (three bf16 limbs / six limb products vs two f16 limbs / three) on the
 token-major GEMMs and NCHW convolutions of the 32 x 720p step: time per launch and max error against float64 next to the
 library's f32 result.   usage: python scripts/split_ab.py [gemm|conv|all] [reps]"""
 import json

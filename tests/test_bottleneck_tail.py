@@ -1,4 +1,4 @@
-"""ops.bottleneck_tail (csrc/gemm_bf16x3.hip bottleneck_tail64_kernel): conv3 -> bn3 -> + identity -> ReLU of a 64-plane ResNet
+"""ops.bottleneck_tail (csrc/bottleneck_tail.hip bottleneck_tail64_kernel): conv3 -> bn3 -> + identity -> ReLU of a 64-plane ResNet
 bottleneck and conv1 -> bn1 -> ReLU of the next block in one pass ([3P] mmdet ResNet Bottleneck.forward), against float64 and
 against the two separate split-kernel launches; the backbone with and without the fusion."""
 import os

@@ -1,4 +1,4 @@
-"""Token-major linear layers on the bf16 matrix cores with an exact three-limb operand split (csrc/gemm_bf16x3.hip):
+"""Token-major linear layers on the bf16 matrix cores with an exact three-limb operand split (csrc/token_gemm.hip):
 f32-class accuracy is the claim, so the error against float64 is compared with the library's own f32 GEMM on the same
 operands ([3P] torch.nn.functional.linear as used by mmcv FFN / MultiScaleDeformableAttention)."""
 import pytest

@@ -1,4 +1,4 @@
-"""The two-limb f16 form of the split kernels (csrc/gemm_bf16x3.hip, F16 = true): what is specific to it -- the exponent-range
+"""The two-limb f16 form of the split kernels (csrc/split_common.h, F16 = true): what is specific to it -- the exponent-range
 handling (power-of-two factors on the packed weight and on the activation's low limb), the accuracy floor below 2^-13, the
 overflow counter for operands beyond the f16 range, the packed layout's trailer.  The shape / epilogue coverage it shares with
 the bf16 form lives in tests/test_gemm_bf16x3.py, test_mask_ops.py, test_winograd.py (all parametrised over PVSG_SPLIT)."""

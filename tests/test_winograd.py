@@ -92,7 +92,7 @@ def test_conv3x3s2_matches_direct_convolution(hip_lib, N, Cin, Cout, H, W, relu)
     assert err < 1e-5 * max(1.0, ref.abs().max().item()), err              # plain f32 fma chain of length 9 Cin
 
 
-# ---- 3x3 convolutions (stride 1 and 2) as an implicit GEMM over the nine taps on the split-bf16 kernel (csrc/gemm_bf16x3.hip) ----
+# ---- 3x3 convolutions (stride 1 and 2) as an implicit GEMM over the nine taps on the split-bf16 kernel (csrc/conv3x3_halo.hip, split_conv1x1.h) ----
 S2X_CASES = [(2, 128, 128, 32, 32), (1, 128, 128, 23, 41), (2, 256, 256, 46, 80), (1, 512, 512, 17, 19), (1, 32, 100, 5, 3),
              (1, 64, 8, 1, 1), (1, 64, 128, 92, 160), (1, 96, 260, 9, 9)]
 
