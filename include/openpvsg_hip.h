@@ -229,9 +229,13 @@ int pvsg_rel_encoder_layer(const pvsg_encoder_layer* layers, const pvsg_encoder_
                            long long seq_stride, long long pos_stride, void* stream);
 /* Learnable1DConv layer: y (P, T, C) = relu(Conv1d(C, C, 5, padding 2)(x along T));  w_packed = 5 x pvsg_pack_rows_weight(W[:, :, k]) */
 int pvsg_rel_conv5(const float* w_packed, const float* bias, const float* x, float* y, int P, int T, int C, void* stream);
-/* tail of every relation model on x (P, T, 512): span_pred (P, T, R), relation_pred (P, R) = max over T of pred_head */
-int pvsg_rel_tail(const pvsg_relation_tail* tail, const float* x, float* span_pred, float* relation_pred, int P, int T,
-                  void* stream);
+/* tail of every relation model on x (P, T, 512): span_pred (P, T, R), relation_pred (P, R) = max over T of pred_head.
+ *   workspace: NULL (one workgroup per pair walks its frame tiles), or pvsg_rel_tail_workspace_bytes(P, T) bytes ZEROED ONCE by
+ *   the caller and reused from call to call (one stream at a time): one workgroup per (pair, 16-frame tile), the tiles' maxima
+ *   meet in the workspace; every launch leaves its arrival counters at zero.  The byte count is 0 for T <= 16. */
+long long pvsg_rel_tail_workspace_bytes(int P, int T);
+int pvsg_rel_tail(const pvsg_relation_tail* tail, const float* x, float* span_pred, float* relation_pred, void* workspace,
+                  int P, int T, void* stream);
 
 /* ---- a11: pairwise relation proposal scorer -------------------------------------------------
  * Replaces models/relation_head/base.py:49-62 PairProposalNetwork.forward (N^2 Python loop).

@@ -71,7 +71,8 @@ SIGNATURES = {
     'pvsg_rel_encoder_layer': [ctypes.POINTER(EncoderLayer), ctypes.POINTER(EncoderLayer), _i, _c_f, _ll, _c_f, _c_f, _c_f, _i, _i,
                                _ll, _ll, _c_f],
     'pvsg_rel_conv5': [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _c_f],
-    'pvsg_rel_tail': [ctypes.POINTER(RelationTail), _c_f, _c_f, _c_f, _i, _i, _c_f],
+    'pvsg_rel_tail_workspace_bytes': [_i, _i],
+    'pvsg_rel_tail': [ctypes.POINTER(RelationTail), _c_f, _c_f, _c_f, _c_f, _i, _i, _c_f],
     'pvsg_top_pairs': [_c_f, _c_f, _i, _i, _c_f],
     'pvsg_pair_prepare_weights': [_c_f, _c_f, _i, _i, _c_f],
     'pvsg_pair_score_forward': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _c_f],
@@ -135,7 +136,7 @@ SIGNATURES = {
 VALUE_RETURNING = ('pvsg_xattn_num_splits', 'pvsg_gemm_bf16x3_packed_elems', 'pvsg_gemm_f16x2_packed_elems',
                    'pvsg_minvis_chain_workspace_bytes', 'pvsg_reconsdot_workspace_bytes', 'pvsg_rle_counts_to_chars',
                    'pvsg_decoder_rows_post_workspace_bytes', 'pvsg_tube_index_table_words', 'pvsg_conv1x1_stats_chunks',
-                   'pvsg_conv3x3_stats_chunks')
+                   'pvsg_conv3x3_stats_chunks', 'pvsg_rel_tail_workspace_bytes')
 
 _lib = None
 
@@ -165,7 +166,7 @@ def load():
             raise BackendMissingError('symbol %s missing from %s' % (name, LIB_PATH)) from e
         f.restype = _ll if name in ('pvsg_gemm_bf16x3_packed_elems', 'pvsg_gemm_f16x2_packed_elems', 'pvsg_minvis_chain_workspace_bytes',
                                    'pvsg_decoder_rows_post_workspace_bytes', 'pvsg_reconsdot_workspace_bytes',
-                                   'pvsg_rle_counts_to_chars', 'pvsg_tube_index_table_words') else _i
+                                   'pvsg_rle_counts_to_chars', 'pvsg_tube_index_table_words', 'pvsg_rel_tail_workspace_bytes') else _i
         f.argtypes = argtypes
     _lib = lib
     try:                                    # loud, once: a second tenant on the GPU without a CU partition (parallel.py)

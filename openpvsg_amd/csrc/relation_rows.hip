@@ -425,14 +425,20 @@ __global__ __launch_bounds__(ROWS_THREADS) void rel_conv5_kernel(const float* __
 // one workgroup per pair walks the frames in tiles of 16
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ROWS_THREADS) void rel_tail_kernel(pvsg_relation_tail Tl, const float* __restrict__ x,
-                                                                float* __restrict__ span, float* __restrict__ pred, int T) {
+                                                                float* __restrict__ span, float* __restrict__ pred, int T,
+                                                                float* __restrict__ ws_max, int* __restrict__ ws_cnt, int tiles) {
   constexpr int D = REL_D2, LD = REL_LD2, LD1 = 256 + 4, LDq = 128 + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xa = smem;                         // [16][LD] input rows
   float* xb = xa + 16 * LD;                 // [16][LD] normalised rows
   float* h1 = xb + 16 * LD;                 // [16][LD1]
   float* h2 = h1 + 16 * LD1;                // [16][LDq]
-  const int s = blockIdx.x;
+  // ws_max == null: one workgroup per pair walks all its frame tiles.  Otherwise one workgroup per (pair, tile): the tiles' column
+  // maxima of pred_head meet in ws_max, and the workgroup that arrives last (ws_cnt, left at zero again) reduces them -- a pair of
+  // a 300-frame video is 19 tiles that would otherwise run one after the other on one CU.
+  __shared__ int s_last;
+  const int s = ws_max ? blockIdx.x / tiles : blockIdx.x;
+  const int tile0 = ws_max ? blockIdx.x - s * tiles : 0;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;
   const int R = Tl.num_relations;
@@ -443,8 +449,9 @@ __global__ __launch_bounds__(ROWS_THREADS) void rel_tail_kernel(pvsg_relation_ta
     for (int k = 0; k < 5; ++k) fw[k] = Tl.filter[k];
   }
   float runmax = -INFINITY;                 // waves 4..7: lane (g, j) follows column 16 (w - 4) + j of pred_head over its rows
+  const int t_end = ws_max ? min(T, tile0 * 16 + 16) : T;
 #pragma unroll 1
-  for (int t0 = 0; t0 < T; t0 += 16) {
+  for (int t0 = tile0 * 16; t0 < t_end; t0 += 16) {
     const int valid = min(16, T - t0);
 #pragma unroll
     for (int it = 0; it < D / 128; ++it) {
@@ -513,7 +520,28 @@ __global__ __launch_bounds__(ROWS_THREADS) void rel_tail_kernel(pvsg_relation_ta
     runmax = fmaxf(runmax, __shfl_xor(runmax, 16));
     runmax = fmaxf(runmax, __shfl_xor(runmax, 32));
     const int col = (w - 4) * 16 + j;
-    if (g == 0 && col < R) pred[(long long)s * R + col] = runmax;
+    if (!ws_max) {
+      if (g == 0 && col < R) pred[(long long)s * R + col] = runmax;
+    } else if (g == 0) {
+      ws_max[((long long)s * tiles + tile0) * 64 + col] = runmax;
+    }
+  }
+  if (!ws_max) return;
+  __threadfence();                                             // the tile's maxima are visible device-wide before the count
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = atomicAdd(ws_cnt + s, 1);
+    s_last = old == tiles - 1;
+    if (s_last) ws_cnt[s] = 0;                                 // ready for the next launch
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (threadIdx.x < R) {
+    const float* pw = ws_max + (long long)s * tiles * 64 + threadIdx.x;
+    float m = -INFINITY;
+    for (int t = 0; t < tiles; ++t) m = fmaxf(m, __builtin_nontemporal_load(pw + (long long)t * 64));
+    pred[(long long)s * R + threadIdx.x] = m;
   }
 }
 
@@ -623,8 +651,16 @@ extern "C" int pvsg_rel_conv5(const float* w_packed, const float* bias, const fl
   return PVSG_OK;
 }
 
-extern "C" int pvsg_rel_tail(const pvsg_relation_tail* tail, const float* x, float* span_pred, float* relation_pred, int P,
-                             int T, void* stream_) {
+// workspace of pvsg_rel_tail's one-workgroup-per-tile form: per (pair, tile) 64 column maxima + one arrival counter per pair.
+// ZEROED ONCE by the caller; every launch leaves the counters at zero.  0 for a single tile (no workspace needed).
+extern "C" long long pvsg_rel_tail_workspace_bytes(int P, int T) {
+  if (P <= 0 || T <= 16) return 0;
+  const long long tiles = (T + 15) / 16;
+  return (long long)P * tiles * 64 * 4 + (long long)P * 4;
+}
+
+extern "C" int pvsg_rel_tail(const pvsg_relation_tail* tail, const float* x, float* span_pred, float* relation_pred,
+                             void* workspace, int P, int T, void* stream_) {
   using namespace pvsg;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   PVSG_REQUIRE(tail && x && span_pred && relation_pred, "rel_tail: null pointer argument");
@@ -638,8 +674,11 @@ extern "C" int pvsg_rel_tail(const pvsg_relation_tail* tail, const float* x, flo
   static std::atomic<unsigned long long> done;
   const hipError_t er = ensure_dynamic_lds(reinterpret_cast<const void*>(&rel_tail_kernel), (int)REL_TAIL_LDS, done);
   if (er != hipSuccess) return set_err(PVSG_ERR_HIP, "rel_tail: LDS attribute: %s", hipGetErrorString(er));
-  hipLaunchKernelGGL(rel_tail_kernel, dim3((unsigned)P), dim3(ROWS_THREADS), REL_TAIL_LDS, stream, *tail, x, span_pred,
-                     relation_pred, T);
+  const int tiles = (T + 15) / 16;
+  float* ws_max = (workspace && tiles > 1) ? static_cast<float*>(workspace) : nullptr;
+  int* ws_cnt = ws_max ? reinterpret_cast<int*>(ws_max + (size_t)P * tiles * 64) : nullptr;
+  hipLaunchKernelGGL(rel_tail_kernel, dim3((unsigned)(ws_max ? P * tiles : P)), dim3(ROWS_THREADS), REL_TAIL_LDS, stream, *tail, x,
+                     span_pred, relation_pred, T, ws_max, ws_cnt, tiles);
   PVSG_LAUNCH_CHECK("rel_tail");
   return PVSG_OK;
 }

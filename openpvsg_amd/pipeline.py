@@ -102,6 +102,7 @@ class PVSGPipeline(torch.nn.Module):
         # timed region because graphed launches cannot carry the per-kernel HIP events `roofline` is measured with.
         self.use_graph = use_graph
         self.graph_max_frames = 64
+        self.graph_pool_bytes = int(float(os.environ.get('PVSG_GRAPH_POOL_GB', '96')) * (1 << 30))
         self._graphs = {}
         self.detector = detector
         self.subject_encoder, self.object_encoder = subject_encoder, object_encoder
@@ -146,6 +147,10 @@ class PVSGPipeline(torch.nn.Module):
             def run(x):
                 return head.clip_logits(det.extract_feat(x), 1, T)
             try:
+                # the same shape captured on the other split form (a bf16x3 re-run after an f16x2 overflow, or the way back): its
+                # private activation pool goes first -- one pool per shape, not two
+                for k in [k for k in self._graphs if k[:2] == key[:2] and k != key]:
+                    self._graphs.pop(k)
                 static_in = clip.clone()
                 side = torch.cuda.Stream(device=clip.device)
                 torch.cuda.current_stream().synchronize()    # one-stream rule of _lib.call: hand over an idle stream
@@ -155,19 +160,26 @@ class PVSGPipeline(torch.nn.Module):
                         run(static_in)
                 torch.cuda.current_stream().wait_stream(side)
                 side.synchronize()
+                reserved0 = torch.cuda.memory_reserved(clip.device)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                     static_out = run(static_in)
+                pool_bytes = max(0, torch.cuda.memory_reserved(clip.device) - reserved0)   # what this capture's private pool pinned
                 entry = (graph, static_in, static_out, sig, pin_graph_caches(),   # (pins: see detectors._graphed)
-                         det.__dict__['_sig_links'].tensors())
+                         det.__dict__['_sig_links'].tensors(), pool_bytes)
             except Exception as e:   # capture unsupported for some op: stay eager, say so once
                 import warnings
                 warnings.warn('hipGraph capture of the VPS forward failed (%r); running eagerly' % (e,))
                 entry = False
             self._graphs.pop(key, None)
-            if len(self._graphs) >= 4:                    # every shape pins a private memory pool: keep the four newest
-                self._graphs.pop(next(iter(self._graphs)))
+            # every shape pins a private memory pool (3.6 GB per 720p frame): keep the four newest shapes, and no more than
+            # `graph_pool_bytes` in total (PVSG_GRAPH_POOL_GB, default 96 of the 288 GB) -- oldest entries go first
             self._graphs[key] = entry
+
+            def pinned():
+                return sum(e[6] for e in self._graphs.values() if e is not False and len(e) > 6)
+            while len(self._graphs) > 1 and (len(self._graphs) > 4 or pinned() > self.graph_pool_bytes):
+                self._graphs.pop(next(iter(self._graphs)))
         if entry is False:
             return head.clip_logits(det.extract_feat(clip), 1, T)
         graph, static_in, static_out = entry[:3]

@@ -1224,17 +1224,31 @@ def _np(x):
     return x.detach().cpu().numpy() if hasattr(x, 'detach') else np.asarray(x)
 
 
+def _write_seq_files(save_root, results, tubes):
+    """`<save_root>/quantitive/masks.txt` (MOTS) and `<save_root>/query_feats.pickle` (test_mots_from_mask2former.py:84-93)"""
+    write_mots_results(os.path.join(save_root, 'quantitive', 'masks.txt'), results)
+    with open(os.path.join(save_root, 'query_feats.pickle'), 'wb') as f:
+        pickle.dump(tubes, f)
+
+
 def eval_seq(data_cfg, tracker_cfg, outputs, classes, save_root=None, return_results=False, frames=None,
              app_model=None, batch=16, tracker_cls=None):
     """`_eval_seq` with the f16x2 range check of the split kernels it uses (appearance CNN, affinity GEMM): activations beyond
     the f16 range are counted on the device; the video is then associated again on the bf16x3 form (ops.rerun_on_bf16x3)."""
     def run():
-        return _eval_seq(data_cfg, tracker_cfg, outputs, classes, save_root, return_results, frames, app_model, batch, tracker_cls)
+        # no files from inside the checked region: a run whose activations left the f16 range is thrown away, and its MOTS /
+        # pickle files must never exist, not even until the re-run overwrites them.  Every run builds its own tracker (track ids
+        # and the seeded noise-embedding generator start afresh), so the re-run equals a single clean run.
+        return _eval_seq(data_cfg, tracker_cfg, outputs, classes, None, True, frames, app_model, batch, tracker_cls)
     dev = None
     if app_model is not None:
         p = next(app_model.parameters(), None)
         dev = p.device if p is not None and p.is_cuda else None
-    return ops.rerun_on_bf16x3(run, dev) if dev is not None else run()
+    results, tubes = ops.rerun_on_bf16x3(run, dev) if dev is not None else run()
+    if save_root is not None:
+        _write_seq_files(save_root, results, tubes)
+    if return_results:
+        return results, tubes
 
 
 def _eval_seq(data_cfg, tracker_cfg, outputs, classes, save_root=None, return_results=False, frames=None,
@@ -1289,8 +1303,6 @@ def _eval_seq(data_cfg, tracker_cfg, outputs, classes, save_root=None, return_re
         results.append((frame_id + 1, tlwhs, masks, ids))
     tubes = [q.complete_empty_postfix(frame_id) for q in tracker.query_feat_tubes]
     if save_root is not None:
-        write_mots_results(os.path.join(save_root, 'quantitive', 'masks.txt'), results)
-        with open(os.path.join(save_root, 'query_feats.pickle'), 'wb') as f:
-            pickle.dump(tubes, f)
+        _write_seq_files(save_root, results, tubes)
     if return_results:
         return results, tubes

@@ -188,7 +188,8 @@ def test_c_abi_rejects_what_it_is_not_built_for(hip_lib):
     assert hip_lib.pvsg_rel_encoder_layer(L, None, 1, one, 0, one, one, one, 4, 8, 1, 4, None) == 1    # qkv_next without next_layers
     assert hip_lib.pvsg_rel_conv5(one, one, one, ctypes.c_void_p(512), 2, 4, 256, None) == 2
     t = _lib.RelationTail(fc1_w=one, fc1_b=one, fc2_w=one, fc2_b=one, head_w=one, head_b=one, dim=512, num_relations=65, eps=1e-5)
-    assert hip_lib.pvsg_rel_tail(ctypes.byref(t), one, one, one, 2, 4, None) == 2
+    assert hip_lib.pvsg_rel_tail(ctypes.byref(t), one, one, one, None, 2, 4, None) == 2
+    assert hip_lib.pvsg_rel_tail_workspace_bytes(100, 16) == 0 and hip_lib.pvsg_rel_tail_workspace_bytes(100, 32) == 100 * 2 * 256 + 400
 
 
 def test_relation_forward_runs_without_library_gemms(hip_lib, monkeypatch):
