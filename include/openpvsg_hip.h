@@ -230,9 +230,9 @@ int pvsg_rel_encoder_layer(const pvsg_encoder_layer* layers, const pvsg_encoder_
 /* Learnable1DConv layer: y (P, T, C) = relu(Conv1d(C, C, 5, padding 2)(x along T));  w_packed = 5 x pvsg_pack_rows_weight(W[:, :, k]) */
 int pvsg_rel_conv5(const float* w_packed, const float* bias, const float* x, float* y, int P, int T, int C, void* stream);
 /* tail of every relation model on x (P, T, 512): span_pred (P, T, R), relation_pred (P, R) = max over T of pred_head.
- *   workspace: NULL (one workgroup per pair walks its frame tiles), or pvsg_rel_tail_workspace_bytes(P, T) bytes ZEROED ONCE by
- *   the caller and reused from call to call (one stream at a time): one workgroup per (pair, 16-frame tile), the tiles' maxima
- *   meet in the workspace; every launch leaves its arrival counters at zero.  The byte count is 0 for T <= 16. */
+ *   workspace: NULL (one workgroup per pair walks all its frames), or pvsg_rel_tail_workspace_bytes(P, T) bytes of scratch (no
+ *   initialisation): videos of more than 64 frames are then cut into chunks of frames, one workgroup per (pair, chunk), and a
+ *   second small launch folds the chunks' maxima.  The byte count is 0 where one workgroup per pair is used anyway. */
 long long pvsg_rel_tail_workspace_bytes(int P, int T);
 int pvsg_rel_tail(const pvsg_relation_tail* tail, const float* x, float* span_pred, float* relation_pred, void* workspace,
                   int P, int T, void* stream);

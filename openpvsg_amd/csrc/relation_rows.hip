@@ -26,24 +26,20 @@ namespace pvsg {
 
 template <int D> struct RelCfg;
 template <> struct RelCfg<256> {           // ObjectEncoder: 8 heads x 32, one wave per head over the tile's 16 rows
-  static constexpr int H = 8, HD = 32, RPW = 16, CH = 64;
+  static constexpr int H = 8, HD = 32;
 };
-template <> struct RelCfg<512> {           // TemporalTransformer: 4 heads x 128, two waves per head (8 rows each)
-  static constexpr int H = 4, HD = 128, RPW = 8, CH = 128;
+template <> struct RelCfg<512> {           // TemporalTransformer: 4 heads x 128, two waves per head (alternate 64-key chunks)
+  static constexpr int H = 4, HD = 128;
 };
 constexpr int REL_F = 512;                 // dim_feedforward of both reference modules
 constexpr int REL_LDH = REL_F + 4;
-
-__device__ __forceinline__ float uniform(float v) {      // a value known to be equal in all lanes -> a scalar register
-  return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
-}
 
 constexpr int REL_BIG = 8 * 16 * ROWS_PLD > 16 * REL_LDH ? 8 * 16 * ROWS_PLD : 16 * REL_LDH;      // floats
 template <int D>
 constexpr size_t rel_layer_lds() {
   return (size_t)(2 * 16 * (D + 4) + REL_BIG) * sizeof(float);
 }
-static_assert(8 * RelCfg<512>::CH * RelCfg<512>::RPW <= REL_BIG, "attention probabilities must fit in the FFN hidden buffer");
+static_assert(4 * 16 * 128 <= 16 * (512 + 4), "the heads' exchange tiles must fit in the q tile");
 
 
 // ------------------------------------------------------------------------------------------------
@@ -117,11 +113,11 @@ __device__ __forceinline__ void rel_layer_body(
     const float* __restrict__ qkv, float* __restrict__ y, float* __restrict__ qkv_next, long long rows, int L,
     long long seq_stride, long long pos_stride, int tiles_per_seq, float qscale, int esplit) {
   using C = RelCfg<D>;
-  constexpr int LD = D + 4, H = C::H, HD = C::HD, RPW = C::RPW, CH = C::CH;
+  constexpr int LD = D + 4, HD = C::HD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xa = smem;                        // attention output -> x1 -> y
   float* xb = xa + 16 * LD;                // q rows -> pre-norm sums
-  float* big = xb + 16 * LD;               // attention probabilities [8 waves][CH][RPW]  /  FFN hidden [16][REL_LDH]
+  float* big = xb + 16 * LD;               // attention probabilities [8 waves][16][ROWS_PLD]  /  FFN hidden [16][REL_LDH]
   // two encoders: workgroup b runs on XCD b % 8 -- XCDs 0-3 take encoder 0, XCDs 4-7 encoder 1, so that an XCD's 4 MB L2 holds
   // ONE encoder's 2 MB of layer weights (1-D grid of 8 * ceil(n / 4) workgroups, n per encoder)
   int e = blockIdx.y, bx = blockIdx.x;
@@ -152,156 +148,41 @@ __device__ __forceinline__ void rel_layer_body(
     rows_attention_h32(xb, xa, LD, big + w * (16 * ROWS_PLD), qkv_e + (long long)s * seq_stride * (3 * D), pos_stride * (3 * D), D,
                        L, w, lane);
   } else {
-    // ---- self-attention: wave = (head, row group); keys in chunks of CH with an online soft-max ------------------------
-    const int h = w % H, r0 = (w / H) * RPW;
-    float* pm = big + w * (CH * RPW);
-    const float* kvb = qkv_e + (long long)s * seq_stride * (3 * D);
-    const long long kstride = pos_stride * (3 * D);
-    float M[RPW], l[RPW], o[16];
+    // ---- 4 heads x 128 channels: two waves per head.  Wave (h, half) takes the 64-key chunks half, half + 2, ...; its
+    // un-normalised output, running maximum and sum meet the other half's through LDS (the merge of two key ranges) ----------
+    const int h = w & 3, half = w >> 2;
+    float* pm = big + w * (16 * ROWS_PLD);
+    f32x4 O[8];
+    float M[4], l[4];
+    rows_attention_core<128>(xb, LD, pm, qkv_e + (long long)s * seq_stride * (3 * D), pos_stride * (3 * D), D, L, h, lane, half * 64,
+                             128, O, M, l);
+    __syncthreads();                              // every wave is done with the q rows: xb becomes the exchange buffer
+    float* ox = xb + h * (16 * 128);              // [16 rows][128 channels] of this head (4 x 2048 floats <= 16 x LD)
+    if (half == 1) {
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) { M[r] = -INFINITY; l[r] = 0.f; }
+      for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll 1
-    for (int c0 = 0; c0 < L; c0 += CH) {
-#pragma unroll 1
-      for (int p = 0; p < CH / 64; ++p) {             // raw scores S[key][r] -> pm (private to this wave)
-        const int key = c0 + p * 64 + lane;
-        const bool kv = key < L;
-        const float* kp = kvb + (long long)(kv ? key : 0) * kstride + D + h * HD;
-        if constexpr (HD == 32) {                     // one 32-channel chunk: a row's score is complete after one pass
-          float kr[32];
+        for (int i = 0; i < 4; ++i) ox[(4 * g + i) * 128 + nt * 16 + j] = O[nt][i];
+      if (j == 0) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float4 t = ld4(kp + 4 * i);
-            kr[4 * i] = t.x; kr[4 * i + 1] = t.y; kr[4 * i + 2] = t.z; kr[4 * i + 3] = t.w;
-          }
-#pragma unroll 2
-          for (int r = 0; r < RPW; ++r) {
-            const float* qr = xb + (r0 + r) * LD + h * HD;
-            float a = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const float4 t = *reinterpret_cast<const float4*>(qr + 4 * i);     // broadcast read
-              a += t.x * kr[4 * i] + t.y * kr[4 * i + 1] + t.z * kr[4 * i + 2] + t.w * kr[4 * i + 3];
-            }
-            pm[(p * 64 + lane) * RPW + r] = kv ? a : -INFINITY;
-          }
-          continue;
-        }
-        float sc[RPW];
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) sc[r] = 0.f;
-#pragma unroll 1
-        for (int dc = 0; dc < HD / 32; ++dc) {
-          float kr[32];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float4 t = ld4(kp + dc * 32 + 4 * i);
-            kr[4 * i] = t.x; kr[4 * i + 1] = t.y; kr[4 * i + 2] = t.z; kr[4 * i + 3] = t.w;
-          }
-#pragma unroll
-          for (int r = 0; r < RPW; ++r) {
-            const float* qr = xb + (r0 + r) * LD + h * HD + dc * 32;
-            float a = sc[r];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const float4 t = *reinterpret_cast<const float4*>(qr + 4 * i);     // broadcast read
-              a += t.x * kr[4 * i] + t.y * kr[4 * i + 1] + t.z * kr[4 * i + 2] + t.w * kr[4 * i + 3];
-            }
-            sc[r] = a;
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) pm[(p * 64 + lane) * RPW + r] = kv ? sc[r] : -INFINITY;
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int r = 0; r < RPW; ++r) {                 // soft-max over the keys of row r (lanes = keys), running maximum M
-        const float s0 = pm[lane * RPW + r];
-        const float s1 = CH == 128 ? pm[(64 + lane) * RPW + r] : -INFINITY;
-        // M, l and the rescale factor are the same in every lane: kept in scalar registers (the VGPR budget of two
-        // workgroups per CU is 128)
-        const float mn = uniform(fmaxf(M[r], wave_allreduce<true>(fmaxf(s0, s1))));
-        const float alpha = uniform(__expf(M[r] - mn));        // first chunk: exp(-inf) = 0
-        const float e0 = __expf(s0 - mn), e1 = CH == 128 ? __expf(s1 - mn) : 0.f;
-        l[r] = uniform(l[r] * alpha + wave_allreduce<false>(e0 + e1));
-        M[r] = mn;
-        pm[lane * RPW + r] = e0;
-        if (CH == 128) pm[(64 + lane) * RPW + r] = e1;
-        if constexpr (HD == 32) {
-          o[r] *= alpha;
-        } else {
-          o[r] *= alpha;
-          o[8 + r] *= alpha;
+        for (int i = 0; i < 4; ++i) {
+          pm[(4 * g + i) * 2] = M[i];
+          pm[(4 * g + i) * 2 + 1] = l[i];
         }
       }
-      __builtin_amdgcn_wave_barrier();
-      const int nk = min(CH, L - c0);                 // keys of this chunk (uniform)
-      if constexpr (HD == 32) {
-        // P . V : lane = (d, key half)
-        const int d = lane & 31, half = lane >> 5;
-        const float* vcol = kvb + 2 * D + h * 32 + d;
-        const int kb = half * (CH / 2);
-        const int trips = min(CH / 2, nk);
-#pragma unroll 1
-        for (int k8 = 0; k8 < trips; k8 += 8) {       // 8 value rows in flight per step (uniform trip count)
-          float v8[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int kk = c0 + kb + k8 + u;
-            v8[u] = kk < L ? vcol[(long long)kk * kstride] : 0.f;
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const float* pr = pm + (kb + k8 + u) * RPW;            // keys past L hold zeros
-            const float v = v8[u];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float4 t = *reinterpret_cast<const float4*>(pr + 4 * i);
-              o[4 * i] += t.x * v; o[4 * i + 1] += t.y * v; o[4 * i + 2] += t.z * v; o[4 * i + 3] += t.w * v;
-            }
-          }
-        }
-      } else {
-        // P . V : lane owns channels lane and lane + 64 of the head, 8 rows
-        const float* vcol = kvb + 2 * D + h * HD + lane;
-#pragma unroll 1
-        for (int k4 = 0; k4 < nk; k4 += 4) {
-          float va[4], vb[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int kk = c0 + k4 + u;
-            const bool in = kk < L;
-            va[u] = in ? vcol[(long long)kk * kstride] : 0.f;
-            vb[u] = in ? vcol[(long long)kk * kstride + 64] : 0.f;
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float* pr = pm + (k4 + u) * RPW;
-            const float4 t0 = *reinterpret_cast<const float4*>(pr), t1 = *reinterpret_cast<const float4*>(pr + 4);
-            o[0] += t0.x * va[u]; o[1] += t0.y * va[u]; o[2] += t0.z * va[u]; o[3] += t0.w * va[u];
-            o[4] += t1.x * va[u]; o[5] += t1.y * va[u]; o[6] += t1.z * va[u]; o[7] += t1.w * va[u];
-            o[8] += t0.x * vb[u]; o[9] += t0.y * vb[u]; o[10] += t0.z * vb[u]; o[11] += t0.w * vb[u];
-            o[12] += t1.x * vb[u]; o[13] += t1.y * vb[u]; o[14] += t1.z * vb[u]; o[15] += t1.w * vb[u];
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
     }
-    if constexpr (HD == 32) {
-      const int d = lane & 31, half = lane >> 5;
+    __syncthreads();
+    if (half == 0) {
+      const float* p1 = big + (w + 4) * (16 * ROWS_PLD);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float t = o[r] + __shfl_xor(o[r], 32);
-        if (half == 0) xa[(r0 + r) * LD + h * 32 + d] = t / l[r];
-      }
-    } else {
+      for (int i = 0; i < 4; ++i) {
+        const float m1 = p1[(4 * g + i) * 2], l1 = p1[(4 * g + i) * 2 + 1];
+        const float mn = fmaxf(M[i], m1);         // M is finite (chunk 0 holds a key); a range without keys has m1 = -inf, l1 = 0
+        const float a0 = __expf(M[i] - mn), a1 = __expf(m1 - mn);
+        const float inv = 1.f / (l[i] * a0 + l1 * a1);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const float inv = 1.f / l[r];
-        xa[(r0 + r) * LD + h * HD + lane] = o[r] * inv;
-        xa[(r0 + r) * LD + h * HD + lane + 64] = o[8 + r] * inv;
+        for (int nt = 0; nt < 8; ++nt)
+          xa[(4 * g + i) * LD + h * 128 + nt * 16 + j] = (O[nt][i] * a0 + ox[(4 * g + i) * 128 + nt * 16 + j] * a1) * inv;
       }
     }
   }
@@ -426,19 +307,18 @@ __global__ __launch_bounds__(ROWS_THREADS) void rel_conv5_kernel(const float* __
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ROWS_THREADS) void rel_tail_kernel(pvsg_relation_tail Tl, const float* __restrict__ x,
                                                                 float* __restrict__ span, float* __restrict__ pred, int T,
-                                                                float* __restrict__ ws_max, int* __restrict__ ws_cnt, int tiles) {
+                                                                float* __restrict__ part_max, int chunks, int tiles_per_chunk) {
   constexpr int D = REL_D2, LD = REL_LD2, LD1 = 256 + 4, LDq = 128 + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xa = smem;                         // [16][LD] input rows
   float* xb = xa + 16 * LD;                 // [16][LD] normalised rows
   float* h1 = xb + 16 * LD;                 // [16][LD1]
   float* h2 = h1 + 16 * LD1;                // [16][LDq]
-  // ws_max == null: one workgroup per pair walks all its frame tiles.  Otherwise one workgroup per (pair, tile): the tiles' column
-  // maxima of pred_head meet in ws_max, and the workgroup that arrives last (ws_cnt, left at zero again) reduces them -- a pair of
-  // a 300-frame video is 19 tiles that would otherwise run one after the other on one CU.
-  __shared__ int s_last;
-  const int s = ws_max ? blockIdx.x / tiles : blockIdx.x;
-  const int tile0 = ws_max ? blockIdx.x - s * tiles : 0;
+  // chunks == 1: one workgroup per pair walks all its frame tiles and writes relation_pred.  chunks > 1 (long videos): workgroup
+  // (pair, chunk) walks `tiles_per_chunk` tiles and leaves its column maxima in part_max (P, chunks, 64); rel_tail_max_kernel
+  // folds them.  (A rendezvous inside one launch -- last workgroup reduces -- needs a device-scope fence per workgroup, which on
+  // the eight-XCD part writes the XCD's L2 back: it made this kernel 1.8 x SLOWER, profiles/r06_rel_tail_rendezvous_ab.txt.)
+  const int s = blockIdx.x / chunks, chunk = blockIdx.x - s * chunks;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;
   const int R = Tl.num_relations;
@@ -449,9 +329,9 @@ __global__ __launch_bounds__(ROWS_THREADS) void rel_tail_kernel(pvsg_relation_ta
     for (int k = 0; k < 5; ++k) fw[k] = Tl.filter[k];
   }
   float runmax = -INFINITY;                 // waves 4..7: lane (g, j) follows column 16 (w - 4) + j of pred_head over its rows
-  const int t_end = ws_max ? min(T, tile0 * 16 + 16) : T;
+  const int t_begin = chunk * tiles_per_chunk * 16, t_end = min(T, t_begin + tiles_per_chunk * 16);
 #pragma unroll 1
-  for (int t0 = tile0 * 16; t0 < t_end; t0 += 16) {
+  for (int t0 = t_begin; t0 < t_end; t0 += 16) {
     const int valid = min(16, T - t0);
 #pragma unroll
     for (int it = 0; it < D / 128; ++it) {
@@ -520,29 +400,24 @@ __global__ __launch_bounds__(ROWS_THREADS) void rel_tail_kernel(pvsg_relation_ta
     runmax = fmaxf(runmax, __shfl_xor(runmax, 16));
     runmax = fmaxf(runmax, __shfl_xor(runmax, 32));
     const int col = (w - 4) * 16 + j;
-    if (!ws_max) {
-      if (g == 0 && col < R) pred[(long long)s * R + col] = runmax;
-    } else if (g == 0) {
-      ws_max[((long long)s * tiles + tile0) * 64 + col] = runmax;
+    if (g == 0) {
+      if (chunks == 1) {
+        if (col < R) pred[(long long)s * R + col] = runmax;
+      } else {
+        part_max[((long long)s * chunks + chunk) * 64 + col] = runmax;     // -inf from a chunk past the last frame
+      }
     }
   }
-  if (!ws_max) return;
-  __threadfence();                                             // the tile's maxima are visible device-wide before the count
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int old = atomicAdd(ws_cnt + s, 1);
-    s_last = old == tiles - 1;
-    if (s_last) ws_cnt[s] = 0;                                 // ready for the next launch
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  if (threadIdx.x < R) {
-    const float* pw = ws_max + (long long)s * tiles * 64 + threadIdx.x;
-    float m = -INFINITY;
-    for (int t = 0; t < tiles; ++t) m = fmaxf(m, __builtin_nontemporal_load(pw + (long long)t * 64));
-    pred[(long long)s * R + threadIdx.x] = m;
-  }
+}
+
+__global__ void rel_tail_max_kernel(const float* __restrict__ part_max, float* __restrict__ pred, int P, int chunks, int R) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // (pair, column)
+  if (i >= P * 64) return;
+  const int s = i >> 6, col = i & 63;
+  if (col >= R) return;
+  float m = -INFINITY;
+  for (int c = 0; c < chunks; ++c) m = fmaxf(m, part_max[((long long)s * chunks + c) * 64 + col]);
+  pred[(long long)s * R + col] = m;
 }
 
 constexpr size_t REL_TAIL_LDS = (size_t)(2 * 16 * REL_LD2 + 16 * (256 + 4) + 16 * (128 + 4)) * sizeof(float);
@@ -651,12 +526,19 @@ extern "C" int pvsg_rel_conv5(const float* w_packed, const float* bias, const fl
   return PVSG_OK;
 }
 
-// workspace of pvsg_rel_tail's one-workgroup-per-tile form: per (pair, tile) 64 column maxima + one arrival counter per pair.
-// ZEROED ONCE by the caller; every launch leaves the counters at zero.  0 for a single tile (no workspace needed).
+// scratch of pvsg_rel_tail for videos of more than 64 frames (no initialisation needed): per (pair, chunk) 64 column maxima
+static int rel_tail_chunks(int P, int T) {
+  const int tiles = (T + 15) / 16;
+  if (tiles <= 4) return 1;
+  int want = (1024 + P - 1) / P;                                // about four workgroups per CU's worth of (pair, chunk) items
+  want = want < 1 ? 1 : want;
+  const int by_tiles = (tiles + 1) / 2;                         // at least two tiles per chunk
+  return want < by_tiles ? want : by_tiles;
+}
 extern "C" long long pvsg_rel_tail_workspace_bytes(int P, int T) {
-  if (P <= 0 || T <= 16) return 0;
-  const long long tiles = (T + 15) / 16;
-  return (long long)P * tiles * 64 * 4 + (long long)P * 4;
+  if (P <= 0 || T <= 0) return 0;
+  const int chunks = rel_tail_chunks(P, T);
+  return chunks > 1 ? (long long)P * chunks * 64 * 4 : 0;
 }
 
 extern "C" int pvsg_rel_tail(const pvsg_relation_tail* tail, const float* x, float* span_pred, float* relation_pred,
@@ -675,10 +557,13 @@ extern "C" int pvsg_rel_tail(const pvsg_relation_tail* tail, const float* x, flo
   const hipError_t er = ensure_dynamic_lds(reinterpret_cast<const void*>(&rel_tail_kernel), (int)REL_TAIL_LDS, done);
   if (er != hipSuccess) return set_err(PVSG_ERR_HIP, "rel_tail: LDS attribute: %s", hipGetErrorString(er));
   const int tiles = (T + 15) / 16;
-  float* ws_max = (workspace && tiles > 1) ? static_cast<float*>(workspace) : nullptr;
-  int* ws_cnt = ws_max ? reinterpret_cast<int*>(ws_max + (size_t)P * tiles * 64) : nullptr;
-  hipLaunchKernelGGL(rel_tail_kernel, dim3((unsigned)(ws_max ? P * tiles : P)), dim3(ROWS_THREADS), REL_TAIL_LDS, stream, *tail, x,
-                     span_pred, relation_pred, T, ws_max, ws_cnt, tiles);
+  const int chunks = workspace ? rel_tail_chunks(P, T) : 1;
+  const int tpc = (tiles + chunks - 1) / chunks;
+  hipLaunchKernelGGL(rel_tail_kernel, dim3((unsigned)(P * chunks)), dim3(ROWS_THREADS), REL_TAIL_LDS, stream, *tail, x, span_pred,
+                     relation_pred, T, static_cast<float*>(workspace), chunks, tpc);
+  if (chunks > 1)
+    hipLaunchKernelGGL(rel_tail_max_kernel, dim3((unsigned)((P * 64 + 255) / 256)), dim3(256), 0, stream,
+                       static_cast<const float*>(workspace), relation_pred, P, chunks, tail->num_relations);
   PVSG_LAUNCH_CHECK("rel_tail");
   return PVSG_OK;
 }

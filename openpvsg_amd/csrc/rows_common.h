@@ -148,25 +148,27 @@ __device__ __forceinline__ float row16_allreduce(float v) {
   return v;
 }
 
-// Soft-max attention of ONE head (32 channels) for the 16 LDS rows of `xq` (scaled queries, row stride ld) over L keys, on the
-// matrix cores, by one wave: xo[r][32 h ..] = softmax_k(q_r . k_k) v_k.  Key k's row lives at kvb + k * kstride with K at +D and
-// V at +2 D (+ 32 h).  Keys in chunks of 64 with an online soft-max, so any L works.
+// Soft-max attention of ONE head (HD = 32 or 128 channels) for the 16 LDS rows of `xq` (scaled queries, row stride ld) over the
+// keys of the 64-key chunks c_begin, c_begin + c_step, ... < L, on the matrix cores, by one wave; leaves the UN-normalised output
+// tiles O (lane (g, j): rows 4 g + e, channel 16 nt + j), the running maxima M and sums l of rows 4 g + e in registers.
+// Key k's row lives at kvb + k * kstride with K at +D and V at +2 D (+ HD h).
 //   S = Q K^T: A = q rows from LDS, B = key rows straight from memory (lane (key = lane & 15, g) reads the float4 at channel
 //   16 kc + 4 g: the operand layout of rows_gemm with the K matrix in the role of the weight);  the soft-max runs on the
 //   accumulators (lane (g, j) holds rows 4 g + e of key-tile column j: a row's keys are one DPP row x the tiles);  P goes through
 //   the wave-private LDS tile `pm` [16][ROWS_PLD] to become the A operand of O += P V, V rows read as B (lane = channel).
-__device__ __forceinline__ void rows_attention_h32(const float* xq, float* xo, int ld, float* pm, const float* __restrict__ kvb,
-                                                   long long kstride, int D, int L, int h, int lane) {
+template <int HD>
+__device__ __forceinline__ void rows_attention_core(const float* xq, int ld, float* pm, const float* __restrict__ kvb,
+                                                    long long kstride, int D, int L, int h, int lane, int c_begin, int c_step,
+                                                    f32x4 (&O)[HD / 16], float (&M)[4], float (&l)[4]) {
+  constexpr int NKC = HD / 16;              // 16-channel chunks of a head = float4 fragments per lane
   const int g = lane >> 4, j = lane & 15;
-  const float4 qa0 = *reinterpret_cast<const float4*>(xq + j * ld + h * 32 + 4 * g);
-  const float4 qa1 = *reinterpret_cast<const float4*>(xq + j * ld + h * 32 + 16 + 4 * g);
-  float M[4], l[4];
-  f32x4 O[2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { M[i] = -INFINITY; l[i] = 0.f; }
-  O[0] = O[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int nt = 0; nt < NKC; ++nt) O[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* qp = xq + j * ld + h * HD + 4 * g;
 #pragma unroll 1
-  for (int c0 = 0; c0 < L; c0 += 64) {
+  for (int c0 = c_begin; c0 < L; c0 += c_step) {
     const int nk = min(64, L - c0);
     f32x4 S[4];
 #pragma unroll
@@ -174,17 +176,19 @@ __device__ __forceinline__ void rows_attention_h32(const float* xq, float* xo, i
       S[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       if (kt * 16 < nk) {                         // uniform
         const int key = c0 + kt * 16 + j;
-        const float* kp = kvb + (long long)min(key, L - 1) * kstride + D + h * 32 + 4 * g;
-        const float4 b0 = ld4(kp), b1 = ld4(kp + 16);
+        const float* kp = kvb + (long long)min(key, L - 1) * kstride + D + h * HD + 4 * g;
+        float4 kb[NKC];
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) kb[kc] = ld4(kp + 16 * kc);
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa0.x, b0.x, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa0.y, b0.y, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa0.z, b0.z, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa0.w, b0.w, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa1.x, b1.x, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa1.y, b1.y, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa1.z, b1.z, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa1.w, b1.w, a, 0, 0, 0);
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+          const float4 qa = *reinterpret_cast<const float4*>(qp + 16 * kc);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.x, kb[kc].x, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.y, kb[kc].y, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.z, kb[kc].z, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.w, kb[kc].w, a, 0, 0, 0);
+        }
         if (key < L) S[kt] = a;                   // keys past the sequence stay at -inf
       }
     }
@@ -209,7 +213,7 @@ __device__ __forceinline__ void rows_attention_h32(const float* xq, float* xo, i
 #pragma unroll
       for (int i = 0; i < 4; ++i) pm[(4 * g + i) * ROWS_PLD + kt * 16 + j] = S[kt][i];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NKC; ++nt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) O[nt][i] *= alpha[i];
     __builtin_amdgcn_wave_barrier();
@@ -218,24 +222,32 @@ __device__ __forceinline__ void rows_attention_h32(const float* xq, float* xo, i
       if (kt * 16 < nk) {                         // uniform
         const float4 ap = *reinterpret_cast<const float4*>(pm + j * ROWS_PLD + kt * 16 + 4 * g);
         const int k0 = c0 + kt * 16 + 4 * g;
-        float v[2][4];
+        const float* vp[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float* vp = kvb + (long long)min(k0 + u, L - 1) * kstride + 2 * D + h * 32 + j;   // P is 0 for the clamped keys
-          v[0][u] = vp[0];
-          v[1][u] = vp[16];
-        }
+        for (int u = 0; u < 4; ++u)               // P is 0 for the clamped keys
+          vp[u] = kvb + (long long)min(k0 + u, L - 1) * kstride + 2 * D + h * HD + j;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          O[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap.x, v[nt][0], O[nt], 0, 0, 0);
-          O[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap.y, v[nt][1], O[nt], 0, 0, 0);
-          O[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap.z, v[nt][2], O[nt], 0, 0, 0);
-          O[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap.w, v[nt][3], O[nt], 0, 0, 0);
+        for (int nt = 0; nt < NKC; ++nt) {
+          const float v0 = vp[0][16 * nt], v1 = vp[1][16 * nt], v2 = vp[2][16 * nt], v3 = vp[3][16 * nt];
+          O[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap.x, v0, O[nt], 0, 0, 0);
+          O[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap.y, v1, O[nt], 0, 0, 0);
+          O[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap.z, v2, O[nt], 0, 0, 0);
+          O[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap.w, v3, O[nt], 0, 0, 0);
         }
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+// one wave = one 32-channel head over all L keys: xo[r][32 h ..] = softmax_k(q_r . k_k) v_k  (keys in chunks of 64 with an online
+// soft-max, so any L works)
+__device__ __forceinline__ void rows_attention_h32(const float* xq, float* xo, int ld, float* pm, const float* __restrict__ kvb,
+                                                   long long kstride, int D, int L, int h, int lane) {
+  f32x4 O[2];
+  float M[4], l[4];
+  rows_attention_core<32>(xq, ld, pm, kvb, kstride, D, L, h, lane, 0, 64, O, M, l);
+  const int g = lane >> 4, j = lane & 15;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float inv = 1.f / l[i];

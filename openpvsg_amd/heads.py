@@ -161,7 +161,8 @@ class DecoderRows:
         key = (x1.shape[0], x1.shape[1], str(x1.device))
         ws = self._ws.get(key, False)
         if ws is False:                              # zeroed once; the kernel leaves its arrival counters at zero
-            ws = self._ws[key] = ops.decoder_rows_post_workspace(x1.shape[0], x1.shape[1], x1.device)
+            ws = self._ws[key] = (ops.decoder_rows_post_workspace(x1.shape[0], x1.shape[1], x1.device)
+                                  if os.environ.get('PVSG_DECODER_ROWS_SPLIT', 'on') != 'off' else None)
         return ops.decoder_rows_post(self.layers[i], self.head, nxt, x1, qkv, q_pos, self.num_cls_out, workspace=ws, pack=pack)
 
 

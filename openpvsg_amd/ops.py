@@ -379,24 +379,16 @@ def rel_tail(tail_struct, x, num_relations):
     pred = torch.empty((P, num_relations), device=x.device, dtype=torch.float32)
     if P * T == 0:
         return span, pred
-    # one workgroup per (pair, 16-frame tile) meeting through a zeroed-once workspace (the kernel leaves its counters at zero):
-    # kept per (device, P, T); not while a hipGraph is being captured for the first time (its pool would own the tensor)
+    # long videos: (pair, chunk of frames) workgroups + a fold launch; the scratch needs no initialisation
     ws = None
     nbytes = int(_lib.load().pvsg_rel_tail_workspace_bytes(P, T))
-    if nbytes:
-        key = (str(x.device), P, T)
-        ws = _rel_tail_ws.get(key)
-        if ws is None and not torch.cuda.is_current_stream_capturing():
-            if len(_rel_tail_ws) >= 16:
-                _rel_tail_ws.pop(next(iter(_rel_tail_ws)))
-            ws = _rel_tail_ws[key] = torch.zeros(nbytes // 4, device=x.device, dtype=torch.int32)
+    if nbytes and os.environ.get('PVSG_REL_TAIL_SPLIT', 'on') != 'off':
+        ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     with _on(x.device):
         _lib.call('pvsg_rel_tail', ctypes.byref(tail_struct), x.data_ptr(), span.data_ptr(), pred.data_ptr(),
                   ws.data_ptr() if ws is not None else None, P, T, _stream_ptr())
     return span, pred
 
-
-_rel_tail_ws = {}
 
 
 def panoptic_fuse(mask_logits, kept_idx, kept_score, kept_class, out_hw, crop_hw, num_things,

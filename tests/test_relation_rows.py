@@ -189,7 +189,7 @@ def test_c_abi_rejects_what_it_is_not_built_for(hip_lib):
     assert hip_lib.pvsg_rel_conv5(one, one, one, ctypes.c_void_p(512), 2, 4, 256, None) == 2
     t = _lib.RelationTail(fc1_w=one, fc1_b=one, fc2_w=one, fc2_b=one, head_w=one, head_b=one, dim=512, num_relations=65, eps=1e-5)
     assert hip_lib.pvsg_rel_tail(ctypes.byref(t), one, one, one, None, 2, 4, None) == 2
-    assert hip_lib.pvsg_rel_tail_workspace_bytes(100, 16) == 0 and hip_lib.pvsg_rel_tail_workspace_bytes(100, 32) == 100 * 2 * 256 + 400
+    assert hip_lib.pvsg_rel_tail_workspace_bytes(100, 64) == 0 and hip_lib.pvsg_rel_tail_workspace_bytes(100, 300) == 100 * 10 * 256
 
 
 def test_relation_forward_runs_without_library_gemms(hip_lib, monkeypatch):
