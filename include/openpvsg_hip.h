@@ -227,6 +227,11 @@ int pvsg_rel_qkv(const pvsg_encoder_layer* layers, int E, const float* x, const 
 int pvsg_rel_encoder_layer(const pvsg_encoder_layer* layers, const pvsg_encoder_layer* next_layers, int E, const float* x,
                            long long x_encoder_stride, const float* qkv, float* y, float* qkv_next, int S, int L,
                            long long seq_stride, long long pos_stride, void* stream);
+/* the attention of such a layer alone: out (rows, D) = concat_heads(softmax(q k^T / sqrt(D / heads)) v) from qkv (rows, 3 D) with
+ * UN-scaled q -- for long videos, where the layer's linear parts run as token GEMMs (pvsg_gemm_bf16x3 / pvsg_add_layernorm) and
+ * only the attention stays a row kernel.  Same (S, L, seq_stride, pos_stride) row addressing. */
+int pvsg_rel_attention(const float* qkv, float* out, int S, int L, long long seq_stride, long long pos_stride, int d_model,
+                       int num_heads, void* stream);
 /* Learnable1DConv layer: y (P, T, C) = relu(Conv1d(C, C, 5, padding 2)(x along T));  w_packed = 5 x pvsg_pack_rows_weight(W[:, :, k]) */
 int pvsg_rel_conv5(const float* w_packed, const float* bias, const float* x, float* y, int P, int T, int C, void* stream);
 /* tail of every relation model on x (P, T, 512): span_pred (P, T, R), relation_pred (P, R) = max over T of pred_head.

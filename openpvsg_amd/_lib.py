@@ -70,6 +70,7 @@ SIGNATURES = {
     'pvsg_rel_qkv': [ctypes.POINTER(EncoderLayer), _i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _ll, _i, _c_f],
     'pvsg_rel_encoder_layer': [ctypes.POINTER(EncoderLayer), ctypes.POINTER(EncoderLayer), _i, _c_f, _ll, _c_f, _c_f, _c_f, _i, _i,
                                _ll, _ll, _c_f],
+    'pvsg_rel_attention': [_c_f, _c_f, _i, _i, _ll, _ll, _i, _i, _c_f],
     'pvsg_rel_conv5': [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _c_f],
     'pvsg_rel_tail_workspace_bytes': [_i, _i],
     'pvsg_rel_tail': [ctypes.POINTER(RelationTail), _c_f, _c_f, _c_f, _c_f, _i, _i, _c_f],

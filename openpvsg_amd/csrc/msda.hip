@@ -816,42 +816,66 @@ __global__ __launch_bounds__(MP_THREADS, 4) void msda_proj_ln_kernel(
   }
 }
 
-// out = LayerNorm(a + b + bias) * gamma + beta over the last dim C = 256; one wave per row.
-__global__ __launch_bounds__(256) void add_layernorm256_kernel(
+// out = LayerNorm(a + b + bias) * gamma + beta over the last dim C = 256 * NV (NV = 1: the encoder / decoder width; NV = 2: the
+// relation head's TemporalTransformer, d_model 512); one wave per row, lane owns the float4 groups at 4 (64 v + lane).
+template <int NV>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out,
     long long rows, float eps) {
+  constexpr int C = 256 * NV;
   const int lane = threadIdx.x & 63;
-  const float4 g = ld4(gamma + lane * 4), be = ld4(beta + lane * 4);
-  float4 bi = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (bias) bi = ld4(bias + lane * 4);
+  float4 g[NV], be[NV], bi[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    g[v] = ld4(gamma + 256 * v + lane * 4);
+    be[v] = ld4(beta + 256 * v + lane * 4);
+    bi[v] = bias ? ld4(bias + 256 * v + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   // two rows per wave and iteration (independent load / reduce chains); the row reductions run in the VALU (DPP +
   // permlane swaps) instead of twelve ds_bpermute round trips per row; streaming (touched-once) loads and stores
   const long long stride = (long long)gridDim.x * 8;
   for (long long row = (long long)blockIdx.x * 8 + (threadIdx.x >> 6) * 2; row < rows; row += stride) {
     const bool two = row + 1 < rows;
-    float4 x0 = ld4_stream(a + row * 256 + lane * 4);
-    float4 x1 = two ? ld4_stream(a + (row + 1) * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (b) {
-      const float4 y0 = ld4_stream(b + row * 256 + lane * 4);
-      const float4 y1 = two ? ld4_stream(b + (row + 1) * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      x0.x += y0.x; x0.y += y0.y; x0.z += y0.z; x0.w += y0.w;
-      x1.x += y1.x; x1.y += y1.y; x1.z += y1.z; x1.w += y1.w;
+    float4 x0[NV], x1[NV];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const long long o0 = row * C + 256 * v + lane * 4, o1 = o0 + C;
+      x0[v] = ld4_stream(a + o0);
+      x1[v] = two ? ld4_stream(a + o1) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b) {
+        const float4 y0 = ld4_stream(b + o0);
+        const float4 y1 = two ? ld4_stream(b + o1) : make_float4(0.f, 0.f, 0.f, 0.f);
+        x0[v].x += y0.x; x0[v].y += y0.y; x0[v].z += y0.z; x0[v].w += y0.w;
+        x1[v].x += y1.x; x1[v].y += y1.y; x1[v].z += y1.z; x1[v].w += y1.w;
+      }
+      x0[v].x += bi[v].x; x0[v].y += bi[v].y; x0[v].z += bi[v].z; x0[v].w += bi[v].w;
+      x1[v].x += bi[v].x; x1[v].y += bi[v].y; x1[v].z += bi[v].z; x1[v].w += bi[v].w;
+      s0 += (x0[v].x + x0[v].y) + (x0[v].z + x0[v].w);
+      s1 += (x1[v].x + x1[v].y) + (x1[v].z + x1[v].w);
     }
-    x0.x += bi.x; x0.y += bi.y; x0.z += bi.z; x0.w += bi.w;
-    x1.x += bi.x; x1.y += bi.y; x1.z += bi.z; x1.w += bi.w;
-    const float m0 = msda_wave_allreduce<false>((x0.x + x0.y) + (x0.z + x0.w)) * (1.f / 256.f);
-    const float m1 = msda_wave_allreduce<false>((x1.x + x1.y) + (x1.z + x1.w)) * (1.f / 256.f);
-    const float d0x = x0.x - m0, d0y = x0.y - m0, d0z = x0.z - m0, d0w = x0.w - m0;
-    const float d1x = x1.x - m1, d1y = x1.y - m1, d1z = x1.z - m1, d1w = x1.w - m1;
-    const float v0 = msda_wave_allreduce<false>((d0x * d0x + d0y * d0y) + (d0z * d0z + d0w * d0w));
-    const float v1 = msda_wave_allreduce<false>((d1x * d1x + d1y * d1y) + (d1z * d1z + d1w * d1w));
-    const float r0 = rsqrtf(v0 * (1.f / 256.f) + eps), r1 = rsqrtf(v1 * (1.f / 256.f) + eps);
-    st4_stream(out + row * 256 + lane * 4,
-               make_float4(d0x * r0 * g.x + be.x, d0y * r0 * g.y + be.y, d0z * r0 * g.z + be.z, d0w * r0 * g.w + be.w));
-    if (two)
-      st4_stream(out + (row + 1) * 256 + lane * 4,
-                 make_float4(d1x * r1 * g.x + be.x, d1y * r1 * g.y + be.y, d1z * r1 * g.z + be.z, d1w * r1 * g.w + be.w));
+    const float m0 = msda_wave_allreduce<false>(s0) * (1.f / C);
+    const float m1 = msda_wave_allreduce<false>(s1) * (1.f / C);
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      x0[v].x -= m0; x0[v].y -= m0; x0[v].z -= m0; x0[v].w -= m0;
+      x1[v].x -= m1; x1[v].y -= m1; x1[v].z -= m1; x1[v].w -= m1;
+      q0 += (x0[v].x * x0[v].x + x0[v].y * x0[v].y) + (x0[v].z * x0[v].z + x0[v].w * x0[v].w);
+      q1 += (x1[v].x * x1[v].x + x1[v].y * x1[v].y) + (x1[v].z * x1[v].z + x1[v].w * x1[v].w);
+    }
+    const float r0 = rsqrtf(msda_wave_allreduce<false>(q0) * (1.f / C) + eps);
+    const float r1 = rsqrtf(msda_wave_allreduce<false>(q1) * (1.f / C) + eps);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const long long o0 = row * C + 256 * v + lane * 4;
+      st4_stream(out + o0, make_float4(x0[v].x * r0 * g[v].x + be[v].x, x0[v].y * r0 * g[v].y + be[v].y,
+                                       x0[v].z * r0 * g[v].z + be[v].z, x0[v].w * r0 * g[v].w + be[v].w));
+      if (two)
+        st4_stream(out + o0 + C, make_float4(x1[v].x * r1 * g[v].x + be[v].x, x1[v].y * r1 * g[v].y + be[v].y,
+                                             x1[v].z * r1 * g[v].z + be[v].z, x1[v].w * r1 * g[v].w + be[v].w));
+    }
   }
 }
 
@@ -979,14 +1003,16 @@ extern "C" int pvsg_add_layernorm(const float* a, const float* b, const float* b
   using namespace pvsg;
   PVSG_REQUIRE(a && gamma && beta && out, "add_layernorm: null pointer argument");
   PVSG_REQUIRE(rows > 0, "add_layernorm: no rows");
-  if (C != 256) return set_err(PVSG_ERR_UNSUPPORTED, "add_layernorm: built for 256 channels (got %d)", C);
+  if (C != 256 && C != 512) return set_err(PVSG_ERR_UNSUPPORTED, "add_layernorm: built for 256 or 512 channels (got %d)", C);
   PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out) |
                   reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(gamma) |
                   reinterpret_cast<uintptr_t>(beta)) & 15u), "add_layernorm: 16-byte alignment required");
   long long nb = (rows + 7) / 8;
   if (nb > 256 * 16) nb = 256 * 16;
-  hipLaunchKernelGGL(add_layernorm256_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a, b, bias, gamma, beta,
-                     out, rows, eps);
+  if (C == 256)
+    hipLaunchKernelGGL(add_layernorm_kernel<1>, dim3((unsigned)nb), dim3(256), 0, stream, a, b, bias, gamma, beta, out, rows, eps);
+  else
+    hipLaunchKernelGGL(add_layernorm_kernel<2>, dim3((unsigned)nb), dim3(256), 0, stream, a, b, bias, gamma, beta, out, rows, eps);
   PVSG_LAUNCH_CHECK("add_layernorm");
   return PVSG_OK;
 }

@@ -261,6 +261,88 @@ __global__ __launch_bounds__(ROWS_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 __global__ __launch_bounds__(ROWS_THREADS) void rel_layer512_kernel(REL_LAYER_ARGS) { rel_layer_body<512>(REL_LAYER_PASS); }
 
 // ------------------------------------------------------------------------------------------------
+// soft-max(q k^T / sqrt(hd)) v alone, for the LONG-video route (relation.py): there the linear layers of an encoder layer run as
+// token GEMMs on the 16-bit matrix pipe (csrc/token_gemm.hip, 4 - 5 x the f32 MFMA rate once the rows fill 128-row tiles) and only
+// the attention stays a row kernel.  qkv (rows, 3 D) with UN-scaled q; out (rows, D) = the concatenated heads.
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(ROWS_THREADS) void rel_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L,
+                                                                     long long seq_stride, long long pos_stride, int tiles_per_seq,
+                                                                     float qscale) {
+  constexpr int LD = D + 4, HD = RelCfg<D>::HD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xq = smem;                        // [16][LD] scaled q rows (D = 512: afterwards the heads' exchange tiles)
+  float* xo = xq + 16 * LD;                // [16][LD] output rows
+  float* pmb = xo + 16 * LD;               // [8 waves][16][ROWS_PLD]
+  const int s = blockIdx.x / tiles_per_seq, tile = blockIdx.x - s * tiles_per_seq;
+  const int p0 = tile * 16;
+  const int valid = min(16, L - p0);
+  const long long row0 = (long long)s * seq_stride + (long long)p0 * pos_stride;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+  for (int it = 0; it < D / 128; ++it) {
+    const int idx = threadIdx.x + it * ROWS_THREADS;
+    const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
+    float4 v = r < valid ? ld4(qkv + (row0 + (long long)r * pos_stride) * (3 * D) + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v.x *= qscale; v.y *= qscale; v.z *= qscale; v.w *= qscale;
+    *reinterpret_cast<float4*>(xq + r * LD + c) = v;
+  }
+  __syncthreads();
+  const float* kvb = qkv + (long long)s * seq_stride * (3 * D);
+  const long long kstride = pos_stride * (3 * D);
+  if constexpr (HD == 32) {
+    rows_attention_h32(xq, xo, LD, pmb + w * (16 * ROWS_PLD), kvb, kstride, D, L, w, lane);
+  } else {
+    const int h = w & 3, half = w >> 2;
+    float* pm = pmb + w * (16 * ROWS_PLD);
+    f32x4 O[8];
+    float M[4], l[4];
+    rows_attention_core<128>(xq, LD, pm, kvb, kstride, D, L, h, lane, half * 64, 128, O, M, l);
+    __syncthreads();
+    float* ox = xq + h * (16 * 128);
+    if (half == 1) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ox[(4 * g + i) * 128 + nt * 16 + j] = O[nt][i];
+      if (j == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          pm[(4 * g + i) * 2] = M[i];
+          pm[(4 * g + i) * 2 + 1] = l[i];
+        }
+      }
+    }
+    __syncthreads();
+    if (half == 0) {
+      const float* p1 = pmb + (w + 4) * (16 * ROWS_PLD);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float m1 = p1[(4 * g + i) * 2], l1 = p1[(4 * g + i) * 2 + 1];
+        const float mn = fmaxf(M[i], m1);
+        const float a0 = __expf(M[i] - mn), a1 = __expf(m1 - mn);
+        const float inv = 1.f / (l[i] * a0 + l1 * a1);
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+          xo[(4 * g + i) * LD + h * 128 + nt * 16 + j] = (O[nt][i] * a0 + ox[(4 * g + i) * 128 + nt * 16 + j] * a1) * inv;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < D / 128; ++it) {
+    const int idx = threadIdx.x + it * ROWS_THREADS;
+    const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
+    if (r < valid) st4(out + (row0 + (long long)r * pos_stride) * D + c, *reinterpret_cast<const float4*>(xo + r * LD + c));
+  }
+}
+template <int D>
+constexpr size_t rel_attention_lds() {
+  return (size_t)(2 * 16 * (D + 4) + 8 * 16 * ROWS_PLD) * sizeof(float);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Conv1d(512, 512, kernel 5, padding 2) + ReLU along the frames of a pair (convolution.py:49-56): y[t] = relu(b + sum_k W_k x[t+k-2])
 // ------------------------------------------------------------------------------------------------
 constexpr int REL_D2 = 512;
@@ -509,6 +591,34 @@ extern "C" int pvsg_rel_encoder_layer(const pvsg_encoder_layer* layers, const pv
                        x_encoder_stride, qkv, y, qkv_next, rows, L, seq_stride, pos_stride, tiles, 0.08838834764831845f, esplit);
   }
   PVSG_LAUNCH_CHECK("rel_encoder_layer");
+  return PVSG_OK;
+}
+
+extern "C" int pvsg_rel_attention(const float* qkv, float* out, int S, int L, long long seq_stride, long long pos_stride, int d_model,
+                                  int num_heads, void* stream_) {
+  using namespace pvsg;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PVSG_REQUIRE(qkv && out, "rel_attention: null pointer argument");
+  PVSG_REQUIRE(S > 0 && L > 0 && seq_stride > 0 && pos_stride > 0, "rel_attention: non-positive dimension");
+  if (!((d_model == 256 && num_heads == 8) || (d_model == 512 && num_heads == 4)))
+    return set_err(PVSG_ERR_UNSUPPORTED, "rel_attention: built for (d_model 256, 8 heads) and (d_model 512, 4 heads) (got %d / %d)",
+                   d_model, num_heads);
+  const int tiles = (L + 15) / 16;
+  const dim3 grid((unsigned)(S * tiles));
+  if (d_model == 256) {
+    static std::atomic<unsigned long long> done;
+    const hipError_t er = ensure_dynamic_lds(reinterpret_cast<const void*>(&rel_attention_kernel<256>), (int)rel_attention_lds<256>(), done);
+    if (er != hipSuccess) return set_err(PVSG_ERR_HIP, "rel_attention: LDS attribute: %s", hipGetErrorString(er));
+    hipLaunchKernelGGL(rel_attention_kernel<256>, grid, dim3(ROWS_THREADS), rel_attention_lds<256>(), stream, qkv, out, L, seq_stride,
+                       pos_stride, tiles, 0.17677669529663687f);
+  } else {
+    static std::atomic<unsigned long long> done;
+    const hipError_t er = ensure_dynamic_lds(reinterpret_cast<const void*>(&rel_attention_kernel<512>), (int)rel_attention_lds<512>(), done);
+    if (er != hipSuccess) return set_err(PVSG_ERR_HIP, "rel_attention: LDS attribute: %s", hipGetErrorString(er));
+    hipLaunchKernelGGL(rel_attention_kernel<512>, grid, dim3(ROWS_THREADS), rel_attention_lds<512>(), stream, qkv, out, L, seq_stride,
+                       pos_stride, tiles, 0.08838834764831845f);
+  }
+  PVSG_LAUNCH_CHECK("rel_attention");
   return PVSG_OK;
 }
 

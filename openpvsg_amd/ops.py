@@ -357,6 +357,17 @@ def rel_encoder_layer(layers, next_layers, E, D, x, x_encoder_stride, qkv, S, L,
     return y, nxt
 
 
+def rel_attention(qkv, S, L, seq_stride, pos_stride, D, H):
+    """concat_heads(softmax(q k^T / sqrt(D / H)) v) of S sequences of L positions from qkv (S*L, 3D) with un-scaled q."""
+    qkv = _chk(qkv, 'qkv')
+    if tuple(qkv.shape) != (S * L, 3 * D):
+        raise RuntimeError('rel_attention: qkv must be (S * L, 3 D)')
+    out = torch.empty((S * L, D), device=qkv.device, dtype=torch.float32)
+    with _on(qkv.device):
+        _lib.call('pvsg_rel_attention', qkv.data_ptr(), out.data_ptr(), S, L, int(seq_stride), int(pos_stride), D, H, _stream_ptr())
+    return out
+
+
 def rel_conv5(w_packed, bias, x):
     """relu(Conv1d(C, C, 5, padding 2)) along T of x (P, T, C); w_packed = the 5 taps, each pack_rows_weight(W[:, :, k])."""
     x, w_packed, bias = _chk(x, 'x'), _chk(w_packed, 'w_packed'), _chk(bias, 'bias')
@@ -587,7 +598,7 @@ def msda_proj_ln(y, pos_oa, ref_points, spatial_shapes, level_start_index, wo_pa
 
 
 def add_layernorm(a, b, bias, norm):
-    """LayerNorm(a + b + bias) with `norm` an nn.LayerNorm(256): residual add + norm in one pass."""
+    """LayerNorm(a + b + bias) with `norm` an nn.LayerNorm(256) or (512): residual add + norm in one pass."""
     a = _chk(a, 'a')
     b = _chk(b, 'b') if b is not None else None
     out = torch.empty_like(a)

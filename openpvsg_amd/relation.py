@@ -104,6 +104,45 @@ class _EncoderRows:
         return [(_lib.EncoderLayer * E)(*[p.structs[i] for p in packs]) for i in range(len(packs[0].structs))]
 
 
+class _EncoderGemm:
+    """The LONG-video route of an encoder: its linear layers as token GEMMs on the 16-bit matrix pipe (three-limb bf16 split: the
+    whole f32 exponent range, no overflow bookkeeping; csrc/token_gemm.hip), add + LayerNorm as one streaming pass, and the
+    attention alone as a row kernel (pvsg_rel_attention).  Seven launches per layer instead of one -- worth it once the rows fill
+    the GEMMs' 128-row tiles on every CU: the fused row kernels run their matrix work on the f32 MFMA (1/16 of the 16-bit rate)."""
+
+    def __init__(self, enc):
+        def pk(w):
+            return ops.gemm_bf16x3_pack(w.detach().contiguous(), mode='bf16x3')
+
+        def raw(t):
+            return t.detach().contiguous()
+        self.layers = []
+        for l in enc.layers:
+            a = l.self_attn
+            self.layers.append(dict(in_w=pk(a.in_proj_weight), in_b=raw(a.in_proj_bias), out_w=pk(a.out_proj.weight),
+                                    out_b=raw(a.out_proj.bias), f1_w=pk(l.linear1.weight), f1_b=raw(l.linear1.bias),
+                                    f2_w=pk(l.linear2.weight), f2_b=raw(l.linear2.bias), n1=l.norm1, n2=l.norm2,
+                                    D=a.embed_dim, H=a.num_heads, F=l.linear1.out_features))
+
+    def run(self, x, S, L, seq_stride, pos_stride):
+        """x (S*L, D) -> (S*L, D)"""
+        for p in self.layers:
+            D = p['D']
+            qkv = ops.gemm_bf16x3(x, p['in_w'], 3 * D, p['in_b'])
+            att = ops.rel_attention(qkv, S, L, seq_stride, pos_stride, D, p['H'])
+            x1 = ops.add_layernorm(ops.gemm_bf16x3(att, p['out_w'], D, p['out_b']), x, None, p['n1'])
+            h = ops.gemm_bf16x3(x1, p['f1_w'], p['F'], p['f1_b'], relu=True)
+            x = ops.add_layernorm(ops.gemm_bf16x3(h, p['f2_w'], D, p['f2_b']), x1, None, p['n2'])
+        return x
+
+
+def _gemm_route(rows, wide=False):
+    """token rows from which the GEMM route beats the fused row kernels (profiles/r06_relation_routes.txt): 12 288 rows of the
+    256-wide ObjectEncoders (N x T), 8 192 of the 512-wide TemporalTransformer (pairs x T); PVSG_RELATION_GEMM_ROWS sets both"""
+    env = os.environ.get('PVSG_RELATION_GEMM_ROWS')
+    return rows >= (int(env) if env is not None else (8192 if wide else 12288))
+
+
 def _run_encoders(packs, arrays, x_rows, S, L, seq_stride, pos_stride, qkv=None):
     """E encoders (same depth and width) over the same input rows -> y (E, rows, D)."""
     E, D, rows = len(packs), packs[0].d_model, S * L
@@ -128,6 +167,10 @@ def encode_subject_object(subject_encoder, object_encoder, feats):
     if not ok:
         return subject_encoder(feats), object_encoder(feats)
     N, T, D = feats.shape
+    if _gemm_route(N * T):
+        x = feats.contiguous().view(N * T, D)
+        return (subject_encoder._gemm_pack().run(x, T, N, 1, T).view(N, T, D),
+                object_encoder._gemm_pack().run(x, T, N, 1, T).view(N, T, D))
     packs = [subject_encoder._pack(), object_encoder._pack()]
     arrays = _cached(subject_encoder, '_rows_pair_' + str(id(object_encoder)), (subject_encoder, object_encoder),
                      lambda: (_EncoderRows.arrays(packs), packs))[0]
@@ -284,8 +327,15 @@ class TemporalTransformer(_RelationModel):
             _EncoderRows(self.transformer_encoder)))
 
     def _forward_rows(self, P, T, x=None, gather=None):
-        pack, arrays = self._pack()
         pe = self.positional_encoding.pe.view(-1, 512)
+        if _gemm_route(P * T, wide=True):
+            if gather is not None:
+                sub, obj, pairs = gather
+                x = torch.cat([sub[pairs[:, 0]], obj[pairs[:, 1]]], dim=-1).view(P * T, 512)
+            x0 = (x.view(P, T, 512) + pe[:T]).view(P * T, 512)
+            gp = _cached(self, '_gemm_enc', (self.transformer_encoder,), lambda: _EncoderGemm(self.transformer_encoder))
+            return self._tail_rows(gp.run(x0, P, T, T, 1).view(P, T, 512), layer_norm=self.layer_norm)
+        pack, arrays = self._pack()
         qkv, x0 = ops.rel_qkv(arrays[0], 1, 512, P * T, T, x=x, gather=gather, pe=pe, want_x0=True)
         y = _run_encoders([pack], arrays, x0, P, T, T, 1, qkv=qkv)
         return self._tail_rows(y[0].view(P, T, 512), layer_norm=self.layer_norm)
@@ -322,10 +372,15 @@ class ObjectEncoder(nn.Module):
     def _pack(self):
         return _cached(self, '_rows_enc', (self.transformer_encoder,), lambda: _EncoderRows(self.transformer_encoder))
 
+    def _gemm_pack(self):
+        return _cached(self, '_gemm_enc', (self.transformer_encoder,), lambda: _EncoderGemm(self.transformer_encoder))
+
     def forward(self, x):  # [N, T, 256]; batch_first=False: attention across objects, batch = frames
         if (x.dim() == 3 and x.shape[0] > 0 and x.shape[1] > 0 and _rows_enabled(x, self) and self._rows_ok() and
                 x.shape[2] == self._d_model()):
             N, T, D = x.shape
+            if _gemm_route(N * T):
+                return self._gemm_pack().run(x.contiguous().view(N * T, D), T, N, 1, T).view(N, T, D)
             pack = self._pack()
             arrays = _cached(self, '_rows_solo', (self.transformer_encoder,), lambda: (_EncoderRows.arrays([pack]), pack))[0]
             return _run_encoders([pack], arrays, x.contiguous().view(N * T, D), T, N, 1, T)[0].view(N, T, D)

@@ -214,3 +214,68 @@ def test_relation_forward_runs_without_library_gemms(hip_lib, monkeypatch):
     bad = [n for n in names if n.startswith('Cijk_') or 'attn_fwd' in n or 'layer_norm' in n.lower() or 'gemm' in n.lower()]
     assert not bad, bad
     assert out['span_pred'].shape == (100, 32, 57) and out['prob'].shape == (100, 57)
+
+
+@pytest.mark.parametrize('N,T', [(40, 320), (100, 130), (7, 2000)])
+def test_long_video_route_object_encoders(hip_lib, monkeypatch, N, T):
+    """rows >= PVSG_RELATION_GEMM_ROWS: the encoders' linear layers on the token GEMMs (three-limb bf16), attention alone as a row
+    kernel (pvsg_rel_attention), add + LayerNorm as a streaming pass -- against the oracle and against the fused row kernels."""
+    from openpvsg_amd import relation as prel
+    ps, os_ = _pair(prel.ObjectEncoder, orel.ObjectEncoder, 3, 256)
+    po, oo = _pair(prel.ObjectEncoder, orel.ObjectEncoder, 4, 256)
+    x = det_input('rel_feats', (N, T, 256), 12)
+    spy = _Spy(monkeypatch)
+    with torch.no_grad():
+        s, o = prel.encode_subject_object(ps, po, x.to(DEV))
+        assert spy.count('pvsg_rel_attention') == 4 and spy.count('pvsg_gemm_bf16x3') == 16 and spy.count('pvsg_rel_encoder_layer') == 0
+        monkeypatch.setenv('PVSG_RELATION_GEMM_ROWS', '1000000000')
+        s2, o2 = prel.encode_subject_object(ps, po, x.to(DEV))
+        assert spy.count('pvsg_rel_encoder_layer') == 2
+        rs, ro = os_(x), oo(x)
+    np.testing.assert_allclose(s.cpu().numpy(), rs.numpy(), **TOL)
+    np.testing.assert_allclose(o.cpu().numpy(), ro.numpy(), **TOL)
+    np.testing.assert_allclose(s.cpu().numpy(), s2.cpu().numpy(), **TOL)
+    np.testing.assert_allclose(o.cpu().numpy(), o2.cpu().numpy(), **TOL)
+
+
+@pytest.mark.parametrize('P,T,layers', [(100, 130, 1), (20, 700, 2)])
+def test_long_video_route_temporal_transformer(hip_lib, monkeypatch, P, T, layers):
+    from openpvsg_amd import relation as prel
+    p, o = _pair(prel.TemporalTransformer, orel.TemporalTransformer, 5, 512, 57, num_transformer_layers=layers)
+    x = det_input('rel_cat', (P, T, 512), 13)
+    spy = _Spy(monkeypatch)
+    with torch.no_grad():
+        rspan, rpred = o(x)
+        span, pred = p(x.to(DEV))
+    assert spy.count('pvsg_rel_attention') == layers and spy.count('pvsg_gemm_bf16x3') == 4 * layers and spy.count('pvsg_rel_tail') == 1
+    np.testing.assert_allclose(span.cpu().numpy(), rspan.numpy(), **TOL)
+    np.testing.assert_allclose(pred.cpu().numpy(), rpred.numpy(), **TOL)
+    # the gather form takes the same route
+    N = 9
+    sub, obj = det_input('sub', (N, T, 256), 14), det_input('obj', (N, T, 256), 15)
+    pairs = torch.stack([torch.arange(P) % N, (torch.arange(P) * 5 + 1) % N], 1)
+    with torch.no_grad():
+        a = p.forward_pairs(sub.to(DEV), obj.to(DEV), pairs.to(DEV))
+        b = o(torch.cat([sub[pairs[:, 0]], obj[pairs[:, 1]]], dim=-1))
+    np.testing.assert_allclose(a[0].cpu().numpy(), b[0].numpy(), **TOL)
+    np.testing.assert_allclose(a[1].cpu().numpy(), b[1].numpy(), **TOL)
+
+
+@pytest.mark.parametrize('D,H,S,L', [(256, 8, 3, 100), (256, 8, 2, 1), (256, 8, 1, 200), (512, 4, 5, 32), (512, 4, 2, 150), (512, 4, 1, 70)])
+def test_rel_attention_vs_torch(hip_lib, D, H, S, L):
+    """pvsg_rel_attention against scaled_dot_product_attention in f64 on the same q, k, v (both row layouts)"""
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(D + L)
+    for layout in ('pos_fast', 'seq_fast'):
+        qkv = torch.randn(S * L, 3 * D, generator=g)
+        if layout == 'pos_fast':                     # row = s * L + pos (TemporalTransformer)
+            ss, ps = L, 1
+            x = qkv.view(S, L, 3, H, D // H)
+        else:                                        # row = pos * S + s (ObjectEncoder on (N, T, C))
+            ss, ps = 1, S
+            x = qkv.view(L, S, 3, H, D // H).transpose(0, 1)
+        q, k, v = (x[:, :, i].permute(0, 2, 1, 3).double() for i in range(3))          # (S, H, L, hd)
+        ref = torch.nn.functional.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(S, L, D)
+        got = ops.rel_attention(qkv.to(DEV), S, L, ss, ps, D, H).cpu()
+        got = got.view(S, L, D) if layout == 'pos_fast' else got.view(L, S, D).transpose(0, 1)
+        np.testing.assert_allclose(got.numpy(), ref.float().numpy(), rtol=1e-4, atol=1e-5)
