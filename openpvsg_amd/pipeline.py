@@ -116,12 +116,14 @@ class PVSGPipeline(torch.nn.Module):
         self.relation_graph = os.environ.get('PVSG_RELATION_GRAPH', 'on') != 'off'
         self._rel_graphs, self._rel_seen = {}, {}
 
-    def _graphed_forward(self, clip):
+    def _graphed_forward(self, clip, shard_key=()):
         """backbone + pixel decoder + decoder (about 2 000 launches, static shapes, no host sync) replayed as
         ONE hipGraph per input shape: the launches come from torch ops and from the C ABI alike, all on the
         capturing stream.  First call per shape: two eager warm-up runs (MIOpen / hipBLASLt pick their
-        kernels), then capture.  Falls back to eager if capture is not possible."""
-        key = (tuple(clip.shape), str(clip.device), ops.split_mode())
+        kernels), then capture.  Falls back to eager if capture is not possible.
+        shard_key: (frame offset, total frames, world) of a frame shard (PVSG_SHARD_GRAPH=on, RCCL only): the per-layer record
+        all-gathers are captured with the kernels -- every rank captures and replays the same sequence of collectives."""
+        key = (tuple(clip.shape), str(clip.device), ops.split_mode()) + tuple(shard_key)
         entry = self._graphs.get(key)
         det, head = self.detector, self.detector.panoptic_head
         T = clip.shape[0]
@@ -262,8 +264,15 @@ class PVSGPipeline(torch.nn.Module):
             shard = parallel.ClipShard(head, total_frames, group)
         try:
             graph = self.use_graph is True or (self.use_graph == 'auto' and clip.shape[0] <= self.graph_max_frames)
+            # a frame shard runs eagerly by default (its layers exchange records); PVSG_SHARD_GRAPH=on captures the exchanges as
+            # well -- RCCL collectives are capturable, gloo's are not (measured at one rank with PVSG_FORCE_COLLECTIVES:
+            # profiles/r06_shard_graph.txt; never run on more than one rank, hence opt-in)
+            shard_graph = (shard is not None and os.environ.get('PVSG_SHARD_GRAPH', 'off') == 'on' and
+                           torch.distributed.get_backend(group) == 'nccl')
             if graph and shard is None:
                 cls, masks4, q = self._graphed_forward(clip)
+            elif graph and shard_graph:
+                cls, masks4, q = self._graphed_forward(clip, (shard.t0, total_frames, shard.world))
             else:
                 feats = det.extract_feat(clip)
                 cls, masks4, q = head.clip_logits(feats, 1, T)      # (1,Q,C+1), (1,T,Q,H/4,W/4), (Q,1,C)

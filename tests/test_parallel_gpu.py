@@ -203,6 +203,48 @@ def test_rccl_world_size_1_runs_every_exchange_of_the_frame_sharded_clip(hip_lib
     assert backend == 'nccl' and int(n) >= 13
 
 
+def _rccl_shard_graph_worker(rank, tmp):
+    """PVSG_SHARD_GRAPH=on: the frame shard's backbone + head INCLUDING the nine per-layer record all-gathers replayed as one
+    hipGraph (RCCL collectives are capturable); results equal the eager shard and the local run; a replay issues only the id-row
+    gather from Python."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), PVSG_FORCE_COLLECTIVES='1', PVSG_SHARD_GRAPH='on')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    from openpvsg_amd import parallel
+    from oracle.detweights import det_input
+    calls = []
+    real = dist.all_gather_into_tensor
+
+    def counted(out, t, group=None, **kw):
+        calls.append(tuple(t.shape))
+        return real(out, t, group=group, **kw)
+    dist.all_gather_into_tensor = counted
+    torch.backends.cudnn.deterministic = True
+    pipe = _build()
+    T = 4
+    clip = det_input('clip', (T, 3, 64, 96), 6).cuda()
+    solo = pipe(clip, (64, 96), shard='none')
+    first = pipe(clip, (64, 96), total_frames=T, group=None, shard='frames')          # warm-ups + capture
+    n0 = len(calls)
+    again = pipe(clip, (64, 96), total_frames=T, group=None, shard='frames')          # replay
+    torch.cuda.synchronize()
+    assert len(calls) - n0 == 1, calls[n0:]                                            # the id rows; the 9 records are inside the graph
+    assert any(k[-3:] == (0, T, 1) for k in pipe._graphs), list(pipe._graphs)
+    for out in (first, again):
+        assert out['tube_ids'].tolist() == solo['tube_ids'].tolist()
+        assert torch.allclose(out['query'], solo['query'], rtol=1e-4, atol=1e-4)
+        assert torch.allclose(out['tube_feats'], solo['tube_feats'], rtol=1e-4, atol=1e-4)
+        assert float((out['pan_results'] != solo['pan_results']).float().mean()) < 2e-3
+    open(os.path.join(tmp, 'ok_graph'), 'w').write('%d' % len(calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_shard_with_its_exchanges_as_one_hipgraph(hip_lib, tmp_path):
+    mp.spawn(_rccl_shard_graph_worker, args=(str(tmp_path),), nprocs=1, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), 'ok_graph'))
+
+
 def test_bench_line_reports_rccl_ranks(hip_lib):
     import json
     import subprocess
