@@ -277,6 +277,15 @@ def kernel_function(name, a):
         return 'gemm_f16x2_ln128_kernel<false> (pvsg_gemm_f16x2, wide layers)' if wide else 'gemm_f16x2_dma_kernel (pvsg_gemm_f16x2)'
     if name == 'pvsg_msda_fused_forward':
         return 'msda_fused_m8d32 (pvsg_msda_fused_forward)'
+    if name in ('pvsg_conv1x1_f16x2', 'pvsg_conv1x1_f16x2_stats'):      # conv1x1_bf16x3_k32_kernel<RELU, RESIDUAL, IN_NORM, BITS, TM, 1, F16>
+        if name.endswith('_stats'):                                     # (x, wp, scale, shift, residual, y, part, B, Cin, Cout, ..)
+            return 'conv1x1_k32<stats> (%s)' % name
+        return 'conv1x1_k32<relu=%d, residual=%d, in_norm=%d, TM=%d> (%s)' % (
+            int(bool(a[14])), int(a[4] is not None), int(a[5] is not None), 64 if a[10] <= 64 else 128, name)
+    if name == 'pvsg_conv3x3_f16x2':                                   # stride 1: the halo kernel <RELU, CT>; stride 2: the TAPS = 9 k32 form
+        if a[10] == 1:
+            return 'conv3x3_f16x2_halo_kernel<relu=%d, CT=%d> (%s)' % (int(bool(a[11])), 64 if a[7] <= 64 else 128, name)
+        return 'conv1x1_k32<TAPS=9> (%s, stride 2)' % name
     return name
 
 
