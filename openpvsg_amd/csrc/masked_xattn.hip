@@ -620,45 +620,70 @@ __global__ __launch_bounds__(HW * 64, HW == 8 ? 1 : 2) void xattn_partial_bf16x3
 }
 
 // out[b, q, h*32+d] = sum_s e^{m_s - m*} o_s / sum_s e^{m_s - m*} l_s     (m* = max_s m_s)
-// One block per (q, b); thread = (range lane sl = tid>>8 ... ) see below: 8 heads x 32 dims x 4
-// range lanes; every range lane walks s = sl, sl+4, ... with an online (m, num, den) triple and the
-// 4 triples are merged through LDS.
+// Range merge shared by `xattn_combine_kernel` and `xattn_merge_local_kernel`: one 1024-thread block per (q, b), two passes
+// with no dependent chain across ranges.  Pass 1: thread (head = tid >> 7, lane = tid & 127) takes the maximum of its ranges'
+// m_s; two shuffles trees + 16 floats of LDS give m*[head].  Pass 2: thread (head, range lane sl = (tid & 127) >> 3, dim quad
+// d4 = tid & 7) walks s = sl, sl + 16, ... with INDEPENDENT 16-byte loads of o_s and accumulates w_s o_s, w_s l_s with
+// w_s = e^{m_s - m*}; the 16 range lanes meet through shuffles and LDS.  The round-5 form kept an online (m, num, den) triple per
+// lane -- a chain of NS / 4 dependent exponentials (combine, 30-39 us at NS = 256) or NS of them (merge_local, 97 us): the
+// step of a frame shard paid 0.87 ms for nine merges.
+struct RangeMerge { float4 num; float den, mstar; bool writer; int h, d4; };
+__device__ __forceinline__ RangeMerge merge_ranges(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                   int b, int q, int Q, int NS) {
+  constexpr int D = 32, M = 8;
+  __shared__ float s_m[M][2];
+  __shared__ float s_acc[M][8][5];
+  const int tid = threadIdx.x, h = tid >> 7, r = tid & 127, wave2 = (tid >> 6) & 1;
+  const long long base = (long long)b * NS * M + h;                 // slot(s) = base + s * M
+  float m = -INFINITY;
+  for (int s = r; s < NS; s += 128) m = fmaxf(m, part_ml[((base + (long long)s * M) * Q + q) * 2]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((tid & 63) == 0) s_m[h][wave2] = m;
+  __syncthreads();
+  const float mstar = fmaxf(s_m[h][0], s_m[h][1]);
+  const int d4 = r & 7, sl = r >> 3;
+  float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+  float den = 0.f;
+#pragma unroll 4
+  for (int s = sl; s < NS; s += 16) {
+    const long long row = (base + (long long)s * M) * Q + q;
+    const float2 ml = *reinterpret_cast<const float2*>(part_ml + row * 2);
+    const float4 ov = *reinterpret_cast<const float4*>(part_o + row * D + d4 * 4);
+    const float w = ml.x == -INFINITY ? 0.f : __expf(ml.x - mstar);   // an empty range publishes (-inf, 0, 0)
+    num.x = fmaf(w, ov.x, num.x); num.y = fmaf(w, ov.y, num.y); num.z = fmaf(w, ov.z, num.z); num.w = fmaf(w, ov.w, num.w);
+    den = fmaf(w, ml.y, den);
+  }
+  // range lanes: bits 3..5 of the lane within a wave, then the two waves of a head
+#pragma unroll
+  for (int off = 8; off <= 32; off <<= 1) {
+    num.x += __shfl_xor(num.x, off); num.y += __shfl_xor(num.y, off); num.z += __shfl_xor(num.z, off);
+    num.w += __shfl_xor(num.w, off); den += __shfl_xor(den, off);
+  }
+  if (wave2 == 1 && (tid & 63) < 8) {
+    float* a = s_acc[h][d4];
+    a[0] = num.x; a[1] = num.y; a[2] = num.z; a[3] = num.w; a[4] = den;
+  }
+  __syncthreads();
+  RangeMerge o;
+  o.writer = wave2 == 0 && (tid & 63) < 8;
+  if (o.writer) {
+    const float* a = s_acc[h][d4];
+    num.x += a[0]; num.y += a[1]; num.z += a[2]; num.w += a[3]; den += a[4];
+  }
+  o.num = num; o.den = den; o.mstar = mstar; o.h = h; o.d4 = d4;
+  return o;
+}
+
 __global__ __launch_bounds__(1024) void xattn_combine_kernel(const float* __restrict__ part_o,
                                                             const float* __restrict__ part_ml,
                                                             float* __restrict__ out, int Q, int NS) {
-  constexpr int D = 32, M = 8, SL = 4;
-  __shared__ float sm[SL][M * D], sn[SL][M * D], sd[SL][M * D];
+  constexpr int D = 32, M = 8;
   const int b = blockIdx.y, q = blockIdx.x;
-  const int hd = threadIdx.x & 255, sl = threadIdx.x >> 8;
-  const int h = hd >> 5, d = hd & 31;
-  float m = -INFINITY, num = 0.f, den = 0.f;
-  for (int s = sl; s < NS; s += SL) {
-    const long long slot = ((long long)b * NS + s) * M + h;
-    const float2 ml = *reinterpret_cast<const float2*>(part_ml + (slot * Q + q) * 2);
-    const float ov = part_o[(slot * Q + q) * D + d];
-    if (ml.x == -INFINITY) continue;
-    const float mn = fmaxf(m, ml.x);
-    const float a = __expf(m - mn), w = __expf(ml.x - mn);
-    num = num * a + w * ov;
-    den = den * a + w * ml.y;
-    m = mn;
-  }
-  sm[sl][hd] = m; sn[sl][hd] = num; sd[sl][hd] = den;
-  __syncthreads();
-  if (sl == 0) {
-    float mstar = sm[0][hd];
-#pragma unroll
-    for (int i = 1; i < SL; ++i) mstar = fmaxf(mstar, sm[i][hd]);
-    float n2 = 0.f, d2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < SL; ++i) {
-      if (sm[i][hd] == -INFINITY) continue;
-      const float w = __expf(sm[i][hd] - mstar);
-      n2 += w * sn[i][hd];
-      d2 += w * sd[i][hd];
-    }
-    out[((long long)b * Q + q) * (M * D) + hd] = n2 / d2;
-  }
+  const RangeMerge o = merge_ranges(part_o, part_ml, b, q, Q, NS);
+  if (o.writer)
+    *reinterpret_cast<float4*>(out + ((long long)b * Q + q) * (M * D) + o.h * D + o.d4 * 4) =
+        make_float4(o.num.x / o.den, o.num.y / o.den, o.num.z / o.den, o.num.w / o.den);
 }
 
 // ---- frame-sharded clips: one message per decoder layer and rank -------------------------------------------------------
@@ -668,30 +693,20 @@ __global__ __launch_bounds__(1024) void xattn_combine_kernel(const float* __rest
 // The all-blocked reset of mask2former_head.py:453-454 is a property of the WHOLE clip: a rank whose keys are all
 // blocked for a query attends unmasked (its kernel cannot know the other ranks' bits); the merge keeps that
 // contribution only if EVERY rank reported the query blocked -- so no flag exchange is needed before the attention.
-__global__ __launch_bounds__(256) void xattn_merge_local_kernel(const float* __restrict__ part_o,
-                                                               const float* __restrict__ part_ml,
-                                                               const uint32_t* __restrict__ flags,
-                                                               float* __restrict__ packed, int Q, int NS, int rec) {
+__global__ __launch_bounds__(1024) void xattn_merge_local_kernel(const float* __restrict__ part_o,
+                                                                const float* __restrict__ part_ml,
+                                                                const uint32_t* __restrict__ flags,
+                                                                float* __restrict__ packed, int Q, int NS, int rec) {
   constexpr int D = 32, M = 8;
   const int b = blockIdx.y, q = blockIdx.x;
-  const int hd = threadIdx.x, h = hd >> 5, d = hd & 31;
-  float m = -INFINITY, num = 0.f, den = 0.f;
-  for (int s = 0; s < NS; ++s) {
-    const long long slot = ((long long)b * NS + s) * M + h;
-    const float2 ml = *reinterpret_cast<const float2*>(part_ml + (slot * Q + q) * 2);
-    if (ml.x == -INFINITY) continue;
-    const float ov = part_o[(slot * Q + q) * D + d];
-    const float mn = fmaxf(m, ml.x);
-    const float a = __expf(m - mn), w = __expf(ml.x - mn);
-    num = num * a + w * ov;
-    den = den * a + w * ml.y;
-    m = mn;
-  }
+  const RangeMerge o = merge_ranges(part_o, part_ml, b, q, Q, NS);
   float* r = packed + (long long)b * rec;
-  r[((long long)h * Q + q) * D + d] = num;
-  if (d == 0) *reinterpret_cast<float2*>(r + (long long)M * Q * D + ((long long)h * Q + q) * 2) = make_float2(m, den);
-  if (q == 0 && hd < 4)
-    reinterpret_cast<uint32_t*>(r + (long long)M * Q * (D + 2))[hd] = flags ? flags[b * 4 + hd] : 0xffffffffu;
+  if (o.writer) {
+    *reinterpret_cast<float4*>(r + ((long long)o.h * Q + q) * D + o.d4 * 4) = o.num;
+    if (o.d4 == 0) *reinterpret_cast<float2*>(r + (long long)M * Q * D + ((long long)o.h * Q + q) * 2) = make_float2(o.mstar, o.den);
+  }
+  if (q == 0 && threadIdx.x < 4)
+    reinterpret_cast<uint32_t*>(r + (long long)M * Q * (D + 2))[threadIdx.x] = flags ? flags[b * 4 + threadIdx.x] : 0xffffffffu;
 }
 
 __global__ __launch_bounds__(256) void xattn_combine_packed_kernel(const float* __restrict__ packed,
@@ -816,7 +831,7 @@ extern "C" int pvsg_xattn_merge_local(const float* part_o, const float* part_ml,
   if (M != 8 || D != 32 || Q > 128)
     return set_err(PVSG_ERR_UNSUPPORTED, "xattn_merge_local: built for 8 heads x 32 dims, Q<=128");
   const int rec = M * Q * (D + 2) + 4;
-  hipLaunchKernelGGL(xattn_merge_local_kernel, dim3(Q, B), dim3(256), 0, stream, part_o, part_ml, mask_flags, packed, Q,
+  hipLaunchKernelGGL(xattn_merge_local_kernel, dim3(Q, B), dim3(1024), 0, stream, part_o, part_ml, mask_flags, packed, Q,
                      NS, rec);
   PVSG_LAUNCH_CHECK("xattn_merge_local");
   return PVSG_OK;
