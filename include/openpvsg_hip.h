@@ -120,6 +120,13 @@ int pvsg_masked_xattn_partial(const float* q_proj, const float* k_proj, const fl
                               const uint32_t* mask_bits, const uint32_t* mask_flags, float* part_o,
                               float* part_ml, int B, int Q, long long K, int M, int D, int NS,
                               void* stream);
+/* The same with `kv_row_stride` floats (>= M*D, multiple of 4) between consecutive rows of k_proj / v_proj, batch stride
+ * K * kv_row_stride: the key (value) projections of the three decoder layers that attend over one pyramid level
+ * (mask2former_head.py:457-468: level = layer % 3) are columns [256 j, 256 j + 256) of ONE (K, 768) GEMM output. */
+int pvsg_masked_xattn_partial_strided(const float* q_proj, const float* k_proj, const float* v_proj,
+                                      const uint32_t* mask_bits, const uint32_t* mask_flags, float* part_o,
+                                      float* part_ml, int B, int Q, long long K, int M, int D, int NS,
+                                      long long kv_row_stride, void* stream);
 int pvsg_xattn_combine(const float* part_o, const float* part_ml, float* out, int B, int Q, int M,
                        int D, int NS, void* stream);
 /* Frame-sharded clip (BASELINE config 4): ONE message per decoder layer and rank.

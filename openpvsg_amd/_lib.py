@@ -60,6 +60,7 @@ SIGNATURES = {
     'pvsg_center_downsample': [_c_f, _c_f, _c_f, _c_f, _ll, _i, _i, _c_f],
     'pvsg_xattn_num_splits': [_i, _ll],
     'pvsg_masked_xattn_partial': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _ll, _i, _i, _i, _c_f],
+    'pvsg_masked_xattn_partial_strided': [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _ll, _i, _i, _i, _ll, _c_f],
     'pvsg_xattn_combine': [_c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _c_f],
     'pvsg_xattn_merge_local': [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _c_f],
     'pvsg_xattn_combine_packed': [_c_f, _c_f, _i, _i, _i, _i, _i, _c_f],

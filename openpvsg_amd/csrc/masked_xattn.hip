@@ -83,8 +83,8 @@ template <bool LEAN>
 __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
     const float* __restrict__ qp, const float* __restrict__ kp, const float* __restrict__ vp,
     const uint32_t* __restrict__ bits, const uint32_t* __restrict__ flags, float* __restrict__ part_o,
-    float* __restrict__ part_ml, int Q, long long K, int NS, long long chunk) {
-  constexpr int HD = 256, D = 32, M = 8;
+    float* __restrict__ part_ml, int Q, long long K, int NS, long long chunk, long long kvs) {
+  constexpr int HD = 256, D = 32, M = 8;          // kvs: floats between consecutive key / value rows (>= HD)
   extern __shared__ __attribute__((aligned(16))) float xl[];   // [2][XLDS_TILE_FLOATS]
   const int b = blockIdx.x / NS, s = blockIdx.x - b * NS;
   const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -127,8 +127,8 @@ __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
     mrun[qt] = -INFINITY; lrun[qt] = 0.f;
     o[qt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const float* kb = kp + (long long)b * K * HD;
-  const float* vb = vp + (long long)b * K * HD;
+  const float* kb = kp + (long long)b * K * kvs;
+  const float* vb = vp + (long long)b * K * kvs;
   const uint32_t* mb = use_mask ? bits + (long long)b * K * 4 : nullptr;
   const long long klast = k1 - 1;
 
@@ -141,9 +141,9 @@ __global__ __launch_bounds__(512) void xattn_partial_lds_kernel(
       long long key = kt + r;
       key = key < klast ? key : klast;
       const int src_chunk = lane ^ (r & 15);
-      __builtin_amdgcn_global_load_lds(kb + key * HD + src_chunk * 4,
+      __builtin_amdgcn_global_load_lds(kb + key * kvs + src_chunk * 4,
                                        (__attribute__((address_space(3))) void*)(base + r * 256), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(vb + key * HD + src_chunk * 4,
+      __builtin_amdgcn_global_load_lds(vb + key * kvs + src_chunk * 4,
                                        (__attribute__((address_space(3))) void*)(base + TK * 256 + r * 256), 16, 0, 0);
     }
     if (use_mask && lane < 16) {
@@ -374,8 +374,8 @@ template <int HW>
 __global__ __launch_bounds__(HW * 64, HW == 8 ? 1 : 2) void xattn_partial_bf16x3_kernel(
     const float* __restrict__ qp, const float* __restrict__ kp, const float* __restrict__ vp,
     const uint32_t* __restrict__ bits, const uint32_t* __restrict__ flags, float* __restrict__ part_o,
-    float* __restrict__ part_ml, int Q, long long K, int NS, long long chunk) {
-  constexpr int HD = 256, D = 32, M = 8;
+    float* __restrict__ part_ml, int Q, long long K, int NS, long long chunk, long long kvs) {
+  constexpr int HD = 256, D = 32, M = 8;          // kvs: floats between consecutive key / value rows (>= HD)
   constexpr int TILE = xbx_tile_floats(HW), RS = HW * 32;            // RS: floats per staged row
   extern __shared__ __attribute__((aligned(16))) float xl[];          // [XBX_RING][TILE] then ql[HW][XQT][64] (16 B each)
   const int half = HW == 8 ? 0 : (int)(blockIdx.x & 1u), bs = HW == 8 ? (int)blockIdx.x : (int)(blockIdx.x >> 1);
@@ -427,8 +427,8 @@ __global__ __launch_bounds__(HW * 64, HW == 8 ? 1 : 2) void xattn_partial_bf16x3
     mrun[qt] = XNONE; lrun[qt] = 0.f;
     o[qt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const float* kb = kp + (long long)b * K * HD + half * RS;
-  const float* vb = vp + (long long)b * K * HD + half * RS;
+  const float* kb = kp + (long long)b * K * kvs + half * RS;
+  const float* vb = vp + (long long)b * K * kvs + half * RS;
   const uint32_t* mb = use_mask ? bits + (long long)b * K * 4 : nullptr;
   const long long klast = k1 - 1;
 
@@ -445,9 +445,9 @@ __global__ __launch_bounds__(HW * 64, HW == 8 ? 1 : 2) void xattn_partial_bf16x3
       long long key = kt + r;
       key = key < klast ? key : klast;
       const int src_chunk = ln ^ r;
-      __builtin_amdgcn_global_load_lds(kb + key * HD + src_chunk * 4,
+      __builtin_amdgcn_global_load_lds(kb + key * kvs + src_chunk * 4,
                                        (__attribute__((address_space(3))) void*)(base + r0 * RS), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(vb + key * HD + src_chunk * 4,
+      __builtin_amdgcn_global_load_lds(vb + key * kvs + src_chunk * 4,
                                        (__attribute__((address_space(3))) void*)(base + TKB * RS + r0 * RS), 16, 0, 0);
     }
     constexpr int MW = TKB * 4 / HW;                                   // mask dwords per wave
@@ -749,11 +749,25 @@ extern "C" int pvsg_xattn_num_splits(int B, long long K) {
   return (int)ns;
 }
 
+extern "C" int pvsg_masked_xattn_partial_strided(const float* q_proj, const float* k_proj, const float* v_proj,
+                                                 const uint32_t* mask_bits, const uint32_t* mask_flags,
+                                                 float* part_o, float* part_ml, int B, int Q, long long K,
+                                                 int M, int D, int NS, long long kv_row_stride, hipStream_t stream);
 extern "C" int pvsg_masked_xattn_partial(const float* q_proj, const float* k_proj, const float* v_proj,
                                          const uint32_t* mask_bits, const uint32_t* mask_flags,
                                          float* part_o, float* part_ml, int B, int Q, long long K,
                                          int M, int D, int NS, hipStream_t stream) {
+  return pvsg_masked_xattn_partial_strided(q_proj, k_proj, v_proj, mask_bits, mask_flags, part_o, part_ml, B, Q, K, M, D, NS,
+                                           (long long)M * D, stream);
+}
+
+extern "C" int pvsg_masked_xattn_partial_strided(const float* q_proj, const float* k_proj, const float* v_proj,
+                                                 const uint32_t* mask_bits, const uint32_t* mask_flags,
+                                                 float* part_o, float* part_ml, int B, int Q, long long K,
+                                                 int M, int D, int NS, long long kv_row_stride, hipStream_t stream) {
   using namespace pvsg;
+  const long long kvs = kv_row_stride;
+  PVSG_REQUIRE(kvs >= (long long)M * D && kvs % 4 == 0, "masked_xattn_partial: key / value row stride must be >= M*D floats and a multiple of 4");
   PVSG_REQUIRE(q_proj && k_proj && v_proj && part_o && part_ml, "masked_xattn_partial: null pointer argument");
   PVSG_REQUIRE((mask_bits == nullptr) == (mask_flags == nullptr),
                "masked_xattn_partial: mask_bits and mask_flags must be given together");
@@ -796,16 +810,16 @@ extern "C" int pvsg_masked_xattn_partial(const float* q_proj, const float* k_pro
       return set_err(PVSG_ERR_HIP, "masked_xattn_partial: cannot reserve %zu bytes of LDS: %s", ldsb, hipGetErrorString(e));
     if (hw4)
       hipLaunchKernelGGL(xattn_partial_bf16x3_kernel<4>, dim3(B * NS * 2), dim3(256), ldsb, stream, q_proj, k_proj, v_proj,
-                         mask_bits, mask_flags, part_o, part_ml, Q, K, NS, cb);
+                         mask_bits, mask_flags, part_o, part_ml, Q, K, NS, cb, kvs);
     else
       hipLaunchKernelGGL(xattn_partial_bf16x3_kernel<8>, dim3(B * NS), dim3(512), ldsb, stream, q_proj, k_proj, v_proj,
-                         mask_bits, mask_flags, part_o, part_ml, Q, K, NS, cb);
+                         mask_bits, mask_flags, part_o, part_ml, Q, K, NS, cb, kvs);
   } else if (lean) {
     hipLaunchKernelGGL(xattn_partial_lds_kernel<true>, dim3(B * NS), dim3(512), lds, stream, q_proj, k_proj, v_proj,
-                       mask_bits, mask_flags, part_o, part_ml, Q, K, NS, chunk);
+                       mask_bits, mask_flags, part_o, part_ml, Q, K, NS, chunk, kvs);
   } else {
     hipLaunchKernelGGL(xattn_partial_lds_kernel<false>, dim3(B * NS), dim3(512), lds, stream, q_proj, k_proj, v_proj,
-                       mask_bits, mask_flags, part_o, part_ml, Q, K, NS, chunk);
+                       mask_bits, mask_flags, part_o, part_ml, Q, K, NS, chunk, kvs);
   }
   PVSG_LAUNCH_CHECK("masked_xattn_partial");
   return PVSG_OK;

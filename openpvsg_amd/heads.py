@@ -27,7 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib, ops
-from .blocks import BaseModule, ModuleList, _ShapeCache
+from .blocks import BaseModule, ModuleList, _ShapeCache, linear_fast
 from .config import _wrap
 from .registry import (HEADS, build_plugin_layer, build_positional_encoding,
                        build_transformer_layer_sequence)
@@ -320,6 +320,22 @@ class _Mask2FormerHeadBase(BaseModule):
         k, v = ops.decoder_kv_project(tok, start, hw, ent[3], ent[0], ent[1], ent[2])
         return k.view(B, T * hw, C), v.view(B, T * hw, C)
 
+    def _kv_project_level(self, lvl, layer_ids, k_in, v_in):
+        """Projected keys and values (B, K, 256 * len(layer_ids)) of the decoder layers `layer_ids`, which all attend over level
+        `lvl` (mask2former_head.py:457-468: `level_idx = i % num_transformer_feat_level`): [3P] nn.MultiheadAttention in_proj
+        rows C..2C / 2C..3C of every layer stacked into one weight."""
+        C = 256
+        mhas = [self.transformer_decoder.layers[i].attentions[0].attn for i in layer_ids]
+        key = tuple((m.in_proj_bias.data_ptr(), m.in_proj_bias._version) for m in mhas)
+        cache = self.__dict__.setdefault('_pvsg_kv_bias', {})
+        ent = cache.get(lvl)
+        if ent is None or ent[0] != key:
+            with torch.no_grad():
+                ent = cache[lvl] = (key, torch.cat([m.in_proj_bias[C:2 * C] for m in mhas]).contiguous(),
+                                    torch.cat([m.in_proj_bias[2 * C:] for m in mhas]).contiguous())
+        return (linear_fast(self, 'kvb_k%d' % lvl, [m.in_proj_weight[C:2 * C] for m in mhas], k_in, ent[1]),
+                linear_fast(self, 'kvb_v%d' % lvl, [m.in_proj_weight[2 * C:] for m in mhas], v_in, ent[2]))
+
     def forward_head(self, decoder_out, mask_feature, attn_mask_target_size):
         """Reference signature (head.py:355): decoder_out (Q,B,C) -> cls_pred, mask_pred and the
         (B*heads, Q, K) bool attention mask (materialised here only for API parity / tests)."""
@@ -406,6 +422,20 @@ class _Mask2FormerHeadBase(BaseModule):
                 return self._mask_step(emb, mf, lows, level, want_logits, need_mask,
                                        packed=(pack, flags) if (pack is not None and flags is not None) else None)
 
+            # key / value projections of the layers that attend over one level (layer % L) from ONE GEMM each: the level's
+            # key (value) input is read once for N = 256 * (layers of the level) output columns on the wide tile instead of once
+            # per layer on 128 x 128 tiles; the attention kernel takes the layer's 256-column block by its row stride
+            kv_batched = {}
+            if (os.environ.get('PVSG_KV_BATCH', 'on') != 'off' and mask_features.is_cuda and n_layers > L and
+                    os.environ.get('PVSG_GEMM', 'bf16x3') != 'lib'):
+                for lvl in range(L):
+                    if lvl in kv_src or k_in[lvl] is None:
+                        continue
+                    ids = [i for i in range(n_layers) if i % L == lvl]
+                    kp_all, vp_all = self._kv_project_level(lvl, ids, k_in[lvl], v_in[lvl])
+                    for j, i in enumerate(ids):
+                        kv_batched[i] = (kp_all[..., j * C:(j + 1) * C], vp_all[..., j * C:(j + 1) * C])
+                    del kp_all, vp_all
             out = rows.start(q, q_pos2, pack)
             cls_pred, emb, qproj = out[:3]
             logits, mask = mask_step(emb, out[3] if pack is not None else None, 0, all_masks or n_layers == 0)
@@ -414,7 +444,9 @@ class _Mask2FormerHeadBase(BaseModule):
             for i in range(n_layers):
                 lvl = i % L
                 attn = self.transformer_decoder.layers[i].attentions[0]
-                if lvl in kv_src:
+                if i in kv_batched:
+                    kp, vp = kv_batched.pop(i)
+                elif lvl in kv_src:
                     kp, vp = self._kv_project(attn.attn, lvl, kv_src[lvl], B, T)
                 else:
                     kp, vp = attn.project_kv(k_in[lvl], v_in[lvl])

@@ -203,11 +203,16 @@ def masked_xattn_partial(q_proj, k_proj, v_proj, mask=None, num_heads=8, num_spl
 
     q_proj (B,Q,256) already scaled by 1/sqrt(D); k_proj/v_proj (B,K,256); mask: AttnMask or None.
     Returns part_o (B,NS,M,Q,D), part_ml (B,NS,M,Q,2)."""
-    q, k, v = _chk(q_proj, 'q_proj'), _chk(k_proj, 'k_proj'), _chk(v_proj, 'v_proj')
+    q = _chk(q_proj, 'q_proj')
+    # keys / values may be column blocks of a wider (B, K, n * 256) GEMM output (the projections of the decoder layers that share
+    # a pyramid level come from one launch): rows `kvs` floats apart, batch elements K * kvs
+    kvs = _kv_row_stride(k_proj, v_proj)
+    k, v = (k_proj, v_proj) if kvs else (_chk(k_proj, 'k_proj'), _chk(v_proj, 'v_proj'))
     B, Q, HD = q.shape
     K = k.shape[1]
     if k.shape != v.shape or k.shape[0] != B or k.shape[2] != HD or HD % num_heads:
         raise RuntimeError('masked_xattn: inconsistent shapes')
+    kvs = kvs or HD
     D = HD // num_heads
     NS = num_splits or xattn_num_splits(B, K)
     part_o = torch.empty((B, NS, num_heads, Q, D), device=q.device, dtype=torch.float32)
@@ -215,11 +220,24 @@ def masked_xattn_partial(q_proj, k_proj, v_proj, mask=None, num_heads=8, num_spl
     if mask is not None and (mask.bits.shape[1] != K or mask.bits.shape[0] != B):
         raise RuntimeError('masked_xattn: mask covers %d keys, K=%d' % (mask.bits.shape[1], K))
     with _on(q.device):
-        _lib.call('pvsg_masked_xattn_partial', q.data_ptr(), k.data_ptr(), v.data_ptr(),
+        _lib.call('pvsg_masked_xattn_partial_strided', q.data_ptr(), k.data_ptr(), v.data_ptr(),
                   mask.bits.data_ptr() if mask is not None else None,
                   mask.flags.data_ptr() if mask is not None else None,
-                  part_o.data_ptr(), part_ml.data_ptr(), B, Q, K, num_heads, D, NS, _stream_ptr())
+                  part_o.data_ptr(), part_ml.data_ptr(), B, Q, K, num_heads, D, NS, kvs, _stream_ptr())
     return part_o, part_ml
+
+
+def _kv_row_stride(k, v):
+    """Row stride (floats) of key / value tensors that are same-layout column blocks of wider row-major tensors, else 0."""
+    for t in (k, v):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 3):
+            return 0
+    if k.is_contiguous() or k.stride() != v.stride() or k.shape != v.shape:
+        return 0
+    sb, sr, sc = k.stride()
+    if sc != 1 or sr < k.shape[2] or sr % 4 or sb != k.shape[1] * sr or (k.data_ptr() | v.data_ptr()) & 15:
+        return 0
+    return sr
 
 
 def xattn_combine(part_o, part_ml):
