@@ -539,6 +539,19 @@ int pvsg_conv1x1_f16x2(const float* x, const void* w_packed, const float* scale,
                        int Cout, int H, int W, int stride, int relu, uint32_t* overflow, void* stream);
 int pvsg_conv3x3_f16x2(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B, int Cin,
                        int Cout, int H, int W, int stride, int relu, uint32_t* overflow, void* stream);
+/* K-sliced forms for SMALL maps ([3P] mmdet ResNet Bottleneck.conv1 / conv2 / conv3 / downsample of layer2-4 when tools/test.py
+ * feeds one 720p image per call: 46 x 80 and 23 x 40 pixels): a handful of 128 x 128 tiles with a K loop of up to 144 steps leave
+ * most of the 256 CUs idle and expose a memory round trip per step.  `slices` workgroups per tile each multiply a range of the
+ * K-steps (1x1, 3x3 stride 2) or of the 32-channel blocks (3x3 stride 1) and leave raw sums in `workspace` (slices * B * Cout * Ho *
+ * Wo floats); one pass folds the slices in index order and applies scale / shift / identity / ReLU.  Needs Ho * Wo % 4 == 0.
+ * pvsg_conv_slices(taps = 1 | 9, ...) returns the slice count worth using for a shape (1 = use the plain entry). */
+int pvsg_conv_slices(int taps, int B, int Cin, int Cout, int H, int W, int stride);
+int pvsg_conv1x1_f16x2_sliced(const float* x, const void* w_packed, const float* scale, const float* shift,
+                              const float* residual, float* y, float* workspace, int slices, int B, int Cin, int Cout, int H,
+                              int W, int stride, int relu, uint32_t* overflow, void* stream);
+int pvsg_conv3x3_f16x2_sliced(const float* x, const void* w_packed, const float* scale, const float* shift, float* y,
+                              float* workspace, int slices, int B, int Cin, int Cout, int H, int W, int stride, int relu,
+                              uint32_t* overflow, void* stream);
 int pvsg_mask_logits_f16x2(const float* mask_embed, const float* mask_feature, void* w_scratch, float* out, int B, int T,
                            int Q, int C, long long N, uint32_t* overflow, void* stream);
 int pvsg_attn_mask_bits_f16x2(const float* mask_embed, const float* feature_lowres, void* w_scratch, uint32_t* bits,

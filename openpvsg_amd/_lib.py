@@ -117,12 +117,15 @@ SIGNATURES = {
     'pvsg_decoder_kv_project_f16x2': [_c_f, _i, _i, _i, _i, _c_f, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f],
     'pvsg_conv1x1_f16x2': [_c_f] * 8 + [_i] * 7 + [_c_f, _c_f],
     'pvsg_conv3x3_f16x2': [_c_f] * 5 + [_i] * 7 + [_c_f, _c_f],
+    'pvsg_conv1x1_f16x2_sliced': [_c_f] * 7 + [_i] * 8 + [_c_f, _c_f],
+    'pvsg_conv3x3_f16x2_sliced': [_c_f] * 6 + [_i] * 8 + [_c_f, _c_f],
     'pvsg_mask_logits_f16x2': [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _ll, _c_f, _c_f],
     'pvsg_attn_mask_bits_f16x2': [_c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _ll, _c_f, _c_f],
     'pvsg_attn_mask_bits_packed_f16x2': [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _ll, _c_f, _c_f],
     'pvsg_stem7x7_pack': [_c_f, _c_f, _c_f],
     'pvsg_group_norm_affine': [_c_f] * 6 + [_i, _i, _i, _ll, _f, _c_f],
     'pvsg_conv1x1_stats_chunks': [_i, _i, _i],
+    'pvsg_conv_slices': [_i] * 7,
     'pvsg_conv1x1_f16x2_stats': [_c_f] * 7 + [_i] * 7 + [_c_f, _c_f],
     'pvsg_conv3x3_stats_chunks': [_i, _i],
     'pvsg_bottleneck_next_weight_matrix': [_c_f, _c_f, _i, _i, _c_f],
@@ -138,7 +141,7 @@ SIGNATURES = {
 VALUE_RETURNING = ('pvsg_xattn_num_splits', 'pvsg_gemm_bf16x3_packed_elems', 'pvsg_gemm_f16x2_packed_elems',
                    'pvsg_minvis_chain_workspace_bytes', 'pvsg_reconsdot_workspace_bytes', 'pvsg_rle_counts_to_chars',
                    'pvsg_decoder_rows_post_workspace_bytes', 'pvsg_tube_index_table_words', 'pvsg_conv1x1_stats_chunks',
-                   'pvsg_conv3x3_stats_chunks', 'pvsg_rel_tail_workspace_bytes')
+                   'pvsg_conv3x3_stats_chunks', 'pvsg_rel_tail_workspace_bytes', 'pvsg_conv_slices')
 
 _lib = None
 

@@ -11,7 +11,7 @@ extern "C" int pvsg_gemm_bf16x3_pack(const float* weight, void* w_packed, int N,
 static int conv1x1_split_run(const float* x, const void* w_packed, const float* scale, const float* shift,
                              const float* residual, const float* in_scale, const float* in_shift, float* y, int B, int Cin,
                              int Cout, int H, int W, int stride, int relu, bool f16, uint32_t* overflow, void* stream,
-                             double* gn_part = nullptr) {
+                             double* gn_part = nullptr, float* ws = nullptr, int slices = 1) {
   using namespace pvsg;
   const char* nm = f16 ? "conv1x1_f16x2" : "conv1x1_bf16x3";
   PVSG_REQUIRE(x && w_packed && y, "%s: null pointer argument", nm);
@@ -33,6 +33,29 @@ static int conv1x1_split_run(const float* x, const void* w_packed, const float* 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const __bf16* wp = static_cast<const __bf16*>(w_packed);
   unsigned* const noflags = nullptr;
+  if (slices > 1) {
+    // K slices: `slices` workgroups per tile leave raw sums in `ws` (slices x B x Cout x Ho x Wo), one pass folds them and applies
+    // the affine / identity / ReLU
+    if (!f16 || !ws || in_scale || gn_part || (Ho * Wo) % 4 || slices > Cin / 32 || blocks * slices >= (1LL << 31))
+      return set_err(PVSG_ERR_UNSUPPORTED, "%s: K slices need the f16x2 form, a workspace, Ho*Wo %% 4 == 0, slices <= Cin / 32", nm);
+    PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15u),
+                 "%s: workspace, y and residual must be 16-byte aligned", nm);
+    const long long slice_elems = (long long)B * Cout * Ho * Wo;
+    const dim3 gs((unsigned)(blocks * slices));
+    const float* nulf = nullptr;
+    if (Cout <= 64)
+      hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<false, false, false, false, 64, 1, true>), gs, block, 0, st, x, wp, nulf, nulf, nulf,
+                         nulf, nulf, ws, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p, noflags, overflow, 0, 0LL,
+                         (double*)nullptr, slices, slice_elems);
+    else
+      hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<false, false, false, false, 128, 1, true>), gs, block, 0, st, x, wp, nulf, nulf, nulf,
+                         nulf, nulf, ws, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p, noflags, overflow, 0, 0LL,
+                         (double*)nullptr, slices, slice_elems);
+    PVSG_LAUNCH_CHECK(nm);
+    launch_conv_slices_finish(ws, slices, slice_elems, scale, shift, residual, y, Cout, Ho * Wo, relu, st);
+    PVSG_LAUNCH_CHECK(nm);
+    return PVSG_OK;
+  }
   // PVSG_GEMM_K32=0: the 32x32x16 / K = 16 kernel for every shape, =1: the K = 32 kernel wherever Cin allows (A/B tests);
   // default: K = 32 except on the small stride-1 maps (23 x 40 at 720p: layer4 and its input convolution measured 3-5 %
   // slower there, profiles/r03_conv1x1_bf16x3_bench.jsonl).  The f16 form exists on the K = 32 kernel only.
@@ -85,6 +108,46 @@ extern "C" int pvsg_conv1x1_f16x2(const float* x, const void* w_packed, const fl
                                   int Cin, int Cout, int H, int W, int stride, int relu, uint32_t* overflow, void* stream) {
   return conv1x1_split_run(x, w_packed, scale, shift, residual, in_scale, in_shift, y, B, Cin, Cout, H, W, stride, relu, true,
                            overflow, stream);
+}
+
+// Small maps (one 720p image: 46 x 80 and 23 x 40 in layer3 / layer4): a handful of 128 x 128 tiles each walking a K loop of up to 64
+// steps -- 30 .. 60 workgroups on 256 CUs, every step an exposed memory round trip (92 us for 2048 -> 512 channels at 920 pixels,
+// 3.8 GF).  pvsg_conv_slices says into how many K slices a convolution of this shape should be cut (1 = not worth it); the
+// `_sliced` entries run `slices` workgroups per tile into a workspace of slices * B * Cout * Ho * Wo floats and fold them.
+//   taps = 1: [3P] Bottleneck.conv1 / conv3 / downsample;  taps = 9: Bottleneck.conv2 (stride 1: halo kernel, slices over the
+//   32-channel blocks; stride 2: the tap-by-tap form)
+extern "C" int pvsg_conv_slices(int taps, int B, int Cin, int Cout, int H, int W, int stride) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (taps != 1 && taps != 9) || (stride != 1 && stride != 2)) return 1;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const long long HWo = (long long)Ho * Wo;
+  if (Cin % 32 || Cout % 4 || HWo % 4) return 1;
+  const int Cpad = (Cout + 127) / 128 * 128;
+  long long blocks;
+  int units, min_units;                                           // K-steps (halo form: 32-channel blocks of nine steps)
+  if (taps == 9 && stride == 1) {
+    const bool wide = Cout > 64;
+    blocks = (long long)B * (wide ? Cpad / 128 : (Cout + 63) / 64) * ((W + 15) / 16) * (wide ? (H + 7) / 8 : (H + 15) / 16);
+    units = Cin / 32;
+    min_units = 2;
+  } else {
+    blocks = (long long)B * (Cpad / 128) * ((HWo + 127) / 128);
+    units = taps * Cin / 32;
+    min_units = 8;
+  }
+  if (blocks > 160) return 1;
+  long long s = (512 + blocks - 1) / blocks;
+  if (s > units / min_units) s = units / min_units;
+  if (s > 16) s = 16;
+  while (s > 1 && s * B * Cout * HWo * 4 > (64LL << 20)) --s;
+  return s < 2 ? 1 : (int)s;
+}
+
+extern "C" int pvsg_conv1x1_f16x2_sliced(const float* x, const void* w_packed, const float* scale, const float* shift,
+                                         const float* residual, float* y, float* workspace, int slices, int B, int Cin, int Cout,
+                                         int H, int W, int stride, int relu, uint32_t* overflow, void* stream) {
+  PVSG_REQUIRE(slices >= 1, "conv1x1_f16x2_sliced: slices must be >= 1");
+  return conv1x1_split_run(x, w_packed, scale, shift, residual, nullptr, nullptr, y, B, Cin, Cout, H, W, stride, relu, true, overflow,
+                           stream, nullptr, workspace, slices);
 }
 
 // pvsg_conv1x1_f16x2 that also leaves the GroupNorm statistics of its OUTPUT behind ([3P] mmcv ConvModule(norm_cfg=GN): conv -> GN;

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256, 2)
 void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ scale,
                                const float* __restrict__ shift, float* __restrict__ y, int Cin, int Cout, int Cpad, int H, int W,
                                int tiles_c, int tiles_x, int tiles_y, unsigned* __restrict__ overflow,
-                               double* __restrict__ gn_part = nullptr) {
+                               double* __restrict__ gn_part = nullptr, int kslices = 1, long long slice_elems = 0) {
   constexpr int PR = CT == 128 ? 8 : 16;                         // pixel rows of the tile
   constexpr int PH = PR + 2, PW = 18, PP = PH * PW;              // patch
   constexpr int P_KG = PP * 8, P_LIMB = 4 * P_KG;                // elements
@@ -43,6 +43,12 @@ void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __rest
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  // kslices > 1 (small maps, pvsg_conv3x3_f16x2_sliced): channel blocks [cib0, cib1) only, raw sums into slice `ks` of a workspace
+  const int ks = kslices > 1 ? (int)(logical % (unsigned)kslices) : 0;
+  if (kslices > 1) {
+    logical /= (unsigned)kslices;
+    y += (size_t)ks * slice_elems;
+  }
   const int tc = logical % tiles_c;
   logical /= tiles_c;
   const int tx = logical % tiles_x;
@@ -114,14 +120,16 @@ void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __rest
   const __bf16* xfr0 = lds + kg4 * P_KG + (pr_w * PW + l15) * 8;               // + limb * P_LIMB + ((cb + dy) * PW + dx) * 8
   auto frag = [](const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); };
   auto mf = [](u32x4 a, u32x4 b, f32x4 c) { return mfma_k32<true>(a, b, c); };
-  const int NCB = Cin / 32, NSTEP = NCB * 9;
-  loadX(0);
-  dmaW(0, 0);
-  if (NBUF == 3) dmaW(NSTEP > 1 ? 1 : 0, 1);
+  const int NCBall = Cin / 32;
+  const int cib0 = kslices > 1 ? (int)((long long)ks * NCBall / kslices) : 0;
+  const int NCB = kslices > 1 ? (int)((long long)(ks + 1) * NCBall / kslices) : NCBall, NSTEP = NCB * 9;
+  loadX(cib0);
+  dmaW(cib0 * 9, 0);
+  if (NBUF == 3) dmaW(cib0 * 9 + 1, 1);
   stashX();
-  int step = 0, buf = 0;                                          // buf = step % NBUF
+  int step = cib0 * 9, buf = 0;                                   // buf = (step - first step) % NBUF
   constexpr int DMA_OPS = 8 * (CT / 64) / 4, LOAD_OPS = 8 * NR;   // vector-memory operations of one dmaW / loadX per wave
-  for (int cib = 0; cib < NCB; ++cib) {
+  for (int cib = cib0; cib < NCB; ++cib) {
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap, ++step) {
       // own slabs of this tap (and, at tap 0, own patch rows: stashX waited for them) are in LDS.  NBUF == 3: the slabs of the NEXT
@@ -233,7 +241,7 @@ void conv3x3_f16x2_halo_kernel(const float* __restrict__ x, const __bf16* __rest
 // stride-2 layers (pvsg_conv3x3s2_affine) and, against Winograd (pvsg_conv3x3_winograd), the 64- and 512-channel layers.
 static int conv3x3_split_run(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B,
                              int Cin, int Cout, int H, int W, int stride, int relu, bool f16, uint32_t* overflow, void* stream,
-                             double* gn_part = nullptr) {
+                             double* gn_part = nullptr, float* ws = nullptr, int slices = 1) {
   using namespace pvsg;
   const char* nm = f16 ? "conv3x3_f16x2" : "conv3x3_bf16x3";
   PVSG_REQUIRE(x && w_packed && y, "%s: null pointer argument", nm);
@@ -254,6 +262,13 @@ static int conv3x3_split_run(const float* x, const void* w_packed, const float* 
   const __bf16* wp = static_cast<const __bf16*>(w_packed);
   const float* nul = nullptr;
   unsigned* const noflags = nullptr;
+  const long long slice_elems = (long long)B * Cout * Ho * Wo;
+  if (slices > 1) {
+    if (!f16 || !ws || gn_part || (Ho * Wo) % 4 || slices > (stride == 1 ? 1 : 9) * Cin / 32)
+      return set_err(PVSG_ERR_UNSUPPORTED, "%s: K slices need the f16x2 form, a workspace, Ho*Wo %% 4 == 0, slices <= Cin / 32 "
+                     "(stride 2: 9 Cin / 32)", nm);
+    PVSG_REQUIRE(!((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(y)) & 15u), "%s: workspace and y must be 16-byte aligned", nm);
+  }
   {
     const char* hsel = getenv("PVSG_CONV3X3_HALO");               // =0: the tap-by-tap form for stride 1 too (A/B tests)
     if (f16 && stride == 1 && !(hsel && hsel[0] == '0')) {
@@ -272,6 +287,23 @@ static int conv3x3_split_run(const float* x, const void* w_packed, const float* 
   } while (0)
       if (gn_part && (!wide || Cout % 8))
         return set_err(PVSG_ERR_UNSUPPORTED, "%s: the GroupNorm-statistics epilogue needs Cout > 64 in groups of 8 channels", nm);
+      if (slices > 1) {                                           // raw sums of `slices` channel-block ranges, then the fold
+        PVSG_REQUIRE(hb * slices < (1LL << 31), "%s: too many blocks", nm);
+#define PVSG_HALO_SLICED(C)                                                                                                        \
+  do {                                                                                                                             \
+    static std::atomic<unsigned long long> done{0};                                                                               \
+    const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_f16x2_halo_kernel<false, C>), halo_lds_bytes<C>(), done); \
+    if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "%s: dynamic LDS: %s", nm, hipGetErrorString(e));                           \
+    hipLaunchKernelGGL((conv3x3_f16x2_halo_kernel<false, C>), dim3((unsigned)(hb * slices)), block, halo_lds_bytes<C>(), st, x, wp, nul, \
+                       nul, ws, Cin, Cout, Cpad, H, W, tc, tiles_x, tiles_y, overflow, (double*)nullptr, slices, slice_elems);    \
+  } while (0)
+        if (wide) PVSG_HALO_SLICED(128); else PVSG_HALO_SLICED(64);
+#undef PVSG_HALO_SLICED
+        PVSG_LAUNCH_CHECK(nm);
+        launch_conv_slices_finish(ws, slices, slice_elems, scale, shift, nul, y, Cout, Ho * Wo, relu, st);
+        PVSG_LAUNCH_CHECK(nm);
+        return PVSG_OK;
+      }
       if (wide) { if (relu) PVSG_HALO_LAUNCH(true, 128); else PVSG_HALO_LAUNCH(false, 128); }
       else { if (relu) PVSG_HALO_LAUNCH(true, 64); else PVSG_HALO_LAUNCH(false, 64); }
 #undef PVSG_HALO_LAUNCH
@@ -280,6 +312,23 @@ static int conv3x3_split_run(const float* x, const void* w_packed, const float* 
     }
   }
   if (gn_part) return set_err(PVSG_ERR_UNSUPPORTED, "%s: the GroupNorm-statistics epilogue is built into the stride-1 f16x2 form", nm);
+  if (slices > 1) {                                               // tap-by-tap form (stride 2), K-steps [kt0, kt1) per slice
+    if (slices > 9 * Cin / 32 || blocks * slices >= (1LL << 31))
+      return set_err(PVSG_ERR_UNSUPPORTED, "%s: too many K slices", nm);
+    const dim3 gs((unsigned)(blocks * slices));
+    if (Cout <= 64)
+      hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<false, false, false, false, 64, 9, true>), gs, block, 0, st, x, wp, nul, nul, nul, nul,
+                         nul, ws, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p, noflags, overflow, 0, 0LL,
+                         (double*)nullptr, slices, slice_elems);
+    else
+      hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<false, false, false, false, 128, 9, true>), gs, block, 0, st, x, wp, nul, nul, nul, nul,
+                         nul, ws, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p, noflags, overflow, 0, 0LL,
+                         (double*)nullptr, slices, slice_elems);
+    PVSG_LAUNCH_CHECK(nm);
+    launch_conv_slices_finish(ws, slices, slice_elems, scale, shift, nul, y, Cout, Ho * Wo, relu, st);
+    PVSG_LAUNCH_CHECK(nm);
+    return PVSG_OK;
+  }
 #define PVSG_C3_LAUNCH(R, TMV, F)                                                                                               \
   hipLaunchKernelGGL((conv1x1_bf16x3_k32_kernel<R, false, false, false, TMV, 9, F>), grid, block, 0, st, x, wp, scale, shift, nul, \
                      nul, nul, y, Cin, Cout, Cpad, H * W, W, Ho * Wo, Wo, stride, tiles_c, tiles_p, noflags, overflow)
@@ -329,6 +378,15 @@ extern "C" int pvsg_conv3x3_bf16x3(const float* x, const void* w_packed, const f
 extern "C" int pvsg_conv3x3_f16x2(const float* x, const void* w_packed, const float* scale, const float* shift, float* y, int B,
                                   int Cin, int Cout, int H, int W, int stride, int relu, uint32_t* overflow, void* stream) {
   return conv3x3_split_run(x, w_packed, scale, shift, y, B, Cin, Cout, H, W, stride, relu, true, overflow, stream);
+}
+
+// K-sliced form for small maps (see pvsg_conv_slices, csrc/conv1x1_split.hip): workspace of slices * B * Cout * Ho * Wo floats
+extern "C" int pvsg_conv3x3_f16x2_sliced(const float* x, const void* w_packed, const float* scale, const float* shift, float* y,
+                                         float* workspace, int slices, int B, int Cin, int Cout, int H, int W, int stride, int relu,
+                                         uint32_t* overflow, void* stream) {
+  PVSG_REQUIRE(slices >= 1, "conv3x3_f16x2_sliced: slices must be >= 1");
+  return conv3x3_split_run(x, w_packed, scale, shift, y, B, Cin, Cout, H, W, stride, relu, true, overflow, stream, nullptr, workspace,
+                           slices);
 }
 
 // pvsg_conv3x3_f16x2 (stride 1) that also leaves the GroupNorm statistics of its OUTPUT behind ([3P] mmcv ConvModule(3x3 conv ->

@@ -237,7 +237,8 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
                                const float* __restrict__ in_scale, const float* __restrict__ in_shift, float* __restrict__ y,
                                int Cin, int Cout, int Cpad, int HWin, int Win, int HWo, int Wo, int stride, int tiles_c,
                                int tiles_p, unsigned* __restrict__ flags = nullptr, unsigned* __restrict__ overflow = nullptr,
-                               int imgs_per_w = 0, long long w_batch_stride = 0, double* __restrict__ gn_part = nullptr) {
+                               int imgs_per_w = 0, long long w_batch_stride = 0, double* __restrict__ gn_part = nullptr,
+                               int kslices = 1, long long slice_elems = 0) {
   constexpr int XL = F16 ? 2 : 3;                                // limbs of the on-the-fly (pixel) operand
   constexpr int WL = F16 ? 2 : 3;                                // arrays of the packed weight
   constexpr int X_AT = WL * K32_LIMB;                            // where the pixel tile starts
@@ -249,6 +250,13 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
   const int wr = TM == 128 ? wave >> 1 : 0, wc = wave & 1;
   const int wcol0 = TM == 128 ? wc * 64 : wave * 32;            // first pixel column of this wave in the tile
   unsigned logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  // kslices > 1 (small maps: a handful of tiles with a long K loop, see pvsg_conv1x1_f16x2_sliced): this workgroup multiplies the
+  // K-steps [kt0, kt1) of its tile only and leaves the raw sums in slice `ks` of a workspace (`y` = its base, affine off)
+  const int ks = kslices > 1 ? (int)(logical % (unsigned)kslices) : 0;
+  if (kslices > 1) {
+    logical /= (unsigned)kslices;
+    y += (size_t)ks * slice_elems;
+  }
   const int tc = logical % tiles_c;
   logical /= tiles_c;
   const int tp = logical % tiles_p, img = logical / tiles_p;
@@ -344,11 +352,13 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
   const __bf16* wfr = lds + X_AT + (kg4 * GB_N + wcol0 + l15) * 8;
   auto frag = [](const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); };
   auto mf = [](u32x4 a, u32x4 b, f32x4 c) { return mfma_k32<F16>(a, b, c); };
-  const int KT = TAPS * Cin / 32;
-  fetch(0);
-  split(0);
+  const int KTall = TAPS * Cin / 32;
+  const int kt0 = kslices > 1 ? (int)((long long)ks * KTall / kslices) : 0;
+  const int KT = kslices > 1 ? (int)((long long)(ks + 1) * KTall / kslices) : KTall;
+  fetch(kt0);
+  split(kt0);
   write();
-  for (int kt = 0; kt < KT; ++kt) {
+  for (int kt = kt0; kt < KT; ++kt) {
     __syncthreads();
     fetch(kt + 1 < KT ? kt + 1 : KT - 1);     // (issued a step earlier, behind write(), this kernel spills 46 registers)
     u32x4 ahf[4], amf[4];
@@ -506,6 +516,44 @@ void conv1x1_bf16x3_k32_kernel(const float* __restrict__ x, const __bf16* __rest
         }
       }
     }
+  }
+}
+
+// K-sliced convolutions (pvsg_conv1x1_f16x2_sliced / pvsg_conv3x3_f16x2_sliced): y = act((sum_s ws[s]) * scale[c] + shift[c]
+// (+ residual)), slices summed in index order (bit-reproducible); four pixels per thread (HWo % 4 == 0).
+template <bool RELU, bool RESIDUAL>
+__global__ __launch_bounds__(256) void conv_slices_finish_kernel(const float* __restrict__ ws, int S, long long slice_elems,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const float* __restrict__ residual, float* __restrict__ y,
+                                                                 int Cout, int HWo, long long total4) {
+  const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i4 >= total4) return;
+  const long long i = i4 * 4;
+  const int c = (int)((i / HWo) % Cout);
+  f32x4 v = *reinterpret_cast<const f32x4*>(ws + i);
+  for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(ws + (long long)s * slice_elems + i);
+  const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+  f32x4 r = RESIDUAL ? *reinterpret_cast<const f32x4*>(residual + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float o = fmaf(v[j], sc, sh);
+    if (RESIDUAL) o += r[j];
+    if (RELU) o = fmaxf(o, 0.f);
+    v[j] = o;
+  }
+  *reinterpret_cast<f32x4*>(y + i) = v;
+}
+
+static inline void launch_conv_slices_finish(const float* ws, int S, long long slice_elems, const float* scale, const float* shift,
+                                             const float* residual, float* y, int Cout, int HWo, int relu, hipStream_t st) {
+  const long long total4 = slice_elems / 4;
+  const dim3 grid((unsigned)((total4 + 255) / 256)), block(256);
+  if (relu) {
+    if (residual) hipLaunchKernelGGL((conv_slices_finish_kernel<true, true>), grid, block, 0, st, ws, S, slice_elems, scale, shift, residual, y, Cout, HWo, total4);
+    else hipLaunchKernelGGL((conv_slices_finish_kernel<true, false>), grid, block, 0, st, ws, S, slice_elems, scale, shift, residual, y, Cout, HWo, total4);
+  } else {
+    if (residual) hipLaunchKernelGGL((conv_slices_finish_kernel<false, true>), grid, block, 0, st, ws, S, slice_elems, scale, shift, residual, y, Cout, HWo, total4);
+    else hipLaunchKernelGGL((conv_slices_finish_kernel<false, false>), grid, block, 0, st, ws, S, slice_elems, scale, shift, residual, y, Cout, HWo, total4);
   }
 }
 

@@ -931,7 +931,13 @@ def conv3x3_bf16x3(x, w_packed, cout, scale=None, shift=None, relu=True, out=Non
         args = (x.data_ptr(), w_packed.data_ptr(), _chk(scale, 'scale').data_ptr() if scale is not None else None,
                 _chk(shift, 'shift').data_ptr() if shift is not None else None,
                 out.data_ptr(), N, Cin, cout, H, W, stride, int(bool(relu)))
-        if f16:
+        slices = _conv_slices(9, N, Cin, cout, H, W, stride) if f16 else 1
+        if slices > 1:
+            # small map (one image): the channel blocks of a tile go to `slices` workgroups (csrc/conv3x3_halo.hip)
+            ws = torch.empty((slices * out.numel(),), device=x.device, dtype=torch.float32)
+            _lib.call('pvsg_conv3x3_f16x2_sliced', *args[:5], ws.data_ptr(), slices, *args[5:],
+                      _overflow_counter(x.device).data_ptr(), _stream_ptr())
+        elif f16:
             _lib.call('pvsg_conv3x3_f16x2', *args, _overflow_counter(x.device).data_ptr(), _stream_ptr())
         else:
             _lib.call('pvsg_conv3x3_bf16x3', *args, _stream_ptr())
@@ -1158,11 +1164,30 @@ def conv1x1_bf16x3(x, w_packed, cout, scale=None, shift=None, residual=None, rel
                 _chk(in_scale, 'in_scale').data_ptr() if in_scale is not None else None,
                 _chk(in_shift, 'in_shift').data_ptr() if in_shift is not None else None,
                 out.data_ptr(), B, Cin, cout, H, W, stride, int(bool(relu)))
-        if f16:
+        slices = _conv_slices(1, B, Cin, cout, H, W, stride) if (f16 and in_scale is None) else 1
+        if slices > 1:
+            # small map (one image): the K loop of a tile goes to `slices` workgroups (csrc/conv1x1_split.hip)
+            ws = torch.empty((slices * out.numel(),), device=x.device, dtype=torch.float32)
+            _lib.call('pvsg_conv1x1_f16x2_sliced', *args[:5], out.data_ptr(), ws.data_ptr(), slices, *args[8:],
+                      _overflow_counter(x.device).data_ptr(), _stream_ptr())
+        elif f16:
             _lib.call('pvsg_conv1x1_f16x2', *args, _overflow_counter(x.device).data_ptr(), _stream_ptr())
         else:
             _lib.call('pvsg_conv1x1_bf16x3', *args, _stream_ptr())
     return out
+
+
+def _conv_slices(taps, B, Cin, cout, H, W, stride):
+    """K slices for a convolution on a small map (pvsg_conv_slices; PVSG_CONV_SLICES=off: never, =<n>: n wherever legal)."""
+    sel = os.environ.get('PVSG_CONV_SLICES', 'auto')
+    if sel == 'off':
+        return 1
+    s = int(_lib.load().pvsg_conv_slices(taps, B, Cin, cout, H, W, stride))
+    if sel not in ('auto', 'on'):
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        units = Cin // 32 if (taps == 9 and stride == 1) else taps * Cin // 32
+        s = max(1, min(int(sel), units)) if (Cin % 32 == 0 and (Ho * Wo) % 4 == 0) else 1
+    return s
 
 
 def conv1x1_f16x2_gn(x, w_packed, cout, gn, bias=None, out=None):
