@@ -134,8 +134,13 @@ extern "C" int pvsg_conv_slices(int taps, int B, int Cin, int Cout, int H, int W
     units = taps * Cin / 32;
     min_units = 8;
   }
-  if (blocks > 160) return 1;
-  long long s = (512 + blocks - 1) / blocks;
+  // lab knobs (scripts/lab/slices_ab.sh): workgroups aimed at, least K-steps per slice of the tap-by-tap / 1x1 form
+  static const int target = [] { const char* e = getenv("PVSG_SLICE_TARGET"); return e ? atoi(e) : 512; }();
+  static const int min_steps = [] { const char* e = getenv("PVSG_SLICE_MIN_STEPS"); return e ? atoi(e) : 8; }();
+  static const int max_blocks = [] { const char* e = getenv("PVSG_SLICE_MAX_BLOCKS"); return e ? atoi(e) : 160; }();
+  if (!(taps == 9 && stride == 1)) min_units = min_steps > 0 ? min_steps : 8;
+  if (blocks > max_blocks) return 1;
+  long long s = (target + blocks - 1) / blocks;
   if (s > units / min_units) s = units / min_units;
   if (s > 16) s = 16;
   while (s > 1 && s * B * Cout * HWo * 4 > (64LL << 20)) --s;

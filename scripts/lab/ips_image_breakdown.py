@@ -47,7 +47,7 @@ for name in ('_graphed', '_fused_frames'):
         rec.setdefault(_n, []).append((time.perf_counter() - t0, s, e))
         return r
     setattr(det, name, wrap)
-for mode in ('on', 'off'):
+for mode in (os.environ.get("B1_MODES", "on,off").split(",")):
     det.use_graph = mode == 'on'
     for i in range(6):
         det.forward([clip[i % 8:i % 8 + 1]], [[dict(meta)]], return_loss=False, rescale=True)

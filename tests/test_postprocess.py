@@ -184,3 +184,30 @@ def test_more_than_127_kept_queries_takes_the_unfused_path(hip_lib):
     cls[torch.arange(200), torch.arange(200) % 126] = 9.0
     assert not head.fused_capacity_ok(cls.to(DEV))
     assert head.fused_capacity_ok(cls[:100].to(DEV))
+
+
+@pytest.mark.parametrize('T,h,w,crop,n,per_frame', [(1, 184, 320, (720, 1280), 100, False), (2, 23, 40, (92, 160), 7, True),
+                                                     (1, 16, 24, (61, 96), 12, False), (3, 8, 12, (32, 48), 5, True),
+                                                     (1, 2, 2, (8, 8), 3, False)])
+def test_instance_masks_x4_kernel_equals_per_pixel_kernel(hip_lib, monkeypatch, T, h, w, crop, n, per_frame):
+    """inst_masks_x4_kernel (4 x 8 output pixels per thread from 12 shared taps) against inst_masks_kernel<true> (4 taps per pixel):
+    same ATen up-sampling expression per pixel -> identical masks, counts and boxes; sigmoid sums equal to f32 rounding."""
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(h * w + n)
+    logits = (torch.randn(T, 20, h, w, generator=g) * 3).to(DEV)
+    logits[:, 3] = -40.0                                            # an absent object: nothing on
+    logits[:, 5] = 40.0                                             # everything on
+    sel = torch.stack([torch.randperm(20, generator=g)[:n] if n <= 20 else torch.randint(0, 20, (n,), generator=g)
+                       for _ in range(T)]).to(DEV)
+    if not per_frame:
+        sel = sel[0]
+    out_hw = (4 * h, 4 * w)
+    monkeypatch.setenv('PVSG_INST_X4', '0')
+    m0, s0, b0 = ops.instance_masks(logits, sel, out_hw, crop)
+    monkeypatch.setenv('PVSG_INST_X4', '1')
+    m1, s1, b1 = ops.instance_masks(logits, sel, out_hw, crop)
+    assert torch.equal(m0, m1) and torch.equal(b0, b1)
+    torch.testing.assert_close(s1, s0, rtol=1e-6, atol=1e-6)     # f32 sigmoids: the compiler may contract the tap products differently
+    assert int(b1[..., 0].sum()) > 0
+    _, s2, b2 = ops.instance_masks(logits, sel, out_hw, crop, want_masks=False)
+    assert torch.equal(b2, b1)
