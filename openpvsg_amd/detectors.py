@@ -191,7 +191,7 @@ class _Base(BaseModule):
     def _finish(cls, res, num_things, keep_device=False):
         """Device -> host conversion of one image's result (mask2former.py:165-186)."""
         if 'pan_results' in res and not keep_device:
-            res['pan_results'] = res['pan_results'].detach().cpu().numpy()
+            res['pan_results'] = ops.to_host(res['pan_results'])
         if 'query_feats' in res and not keep_device:
             res['query_feats'] = {k: [x.detach().cpu().numpy() for x in v] for k, v in res['query_feats'].items()}
         if 'ins_results' in res:
@@ -236,7 +236,7 @@ class _Base(BaseModule):
                 return None
             pan, seg, keep = fusion.panoptic_fused(cls, masks4, meta['batch_input_shape'], meta['img_shape'], ori)
             kf_np = embds[keep].detach().cpu().numpy()
-            pan_np, seg_l = pan.cpu().numpy(), seg.tolist()
+            pan_np, seg_l = ops.to_host(pan), seg.tolist()
             for t in range(T):
                 qd = {}
                 for i, sid in enumerate(seg_l[t]):
@@ -386,7 +386,7 @@ class Mask2FormerVideoCustom(_Base):
             for b in range(len(res)):
                 r = res[b]
                 if 'pan_results' in r:
-                    r['pan_results'] = r['pan_results'].detach().cpu().numpy()
+                    r['pan_results'] = ops.to_host(r['pan_results'])
                 if 'query_feats' in r:
                     r['query_feats'] = {k: [x.detach().cpu().numpy() for x in v] for k, v in r['query_feats'].items()}
                 if 'ins_results' in r:

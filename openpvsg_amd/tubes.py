@@ -170,7 +170,8 @@ class DeviceMaskStack:
 
     def numpy(self):
         if self._np is None:
-            self._np = self.binm.detach().cpu().numpy()
+            from . import ops
+            self._np = ops.to_host(self.binm) if hasattr(self.binm, 'is_cuda') else np.asarray(self.binm)
         return self._np
 
     def rles(self, boundaries=None):
