@@ -223,6 +223,58 @@ class _Base(BaseModule):
                 tuple(m['ori_shape'][:2]) if rescale else None) for m in metas}
         return len(key) == 1
 
+    def _fused_image_device(self, cls, masks4, embds, meta, rescale):
+        """_fused_frames for the image detector with every decision left on the device until ONE group of transfers at the end
+        (the un-pipelined form waits nine times per image: capacity check, nonzero, three gathers of the kept set, three
+        boolean-index compactions of the instance list, the result rows): keep decision + compaction by pvsg_panoptic_select,
+        fusion kernels reading K from that record, the instance list as all max_per_image pairs with the things first, then
+        [K | kept queries | segment ids | number of things | labels | boxes] in one record, the kept query features (128 rows)
+        and the panoptic map.  -> the same host-side dicts, or None when the kept set exceeds the kernels' capacity."""
+        fusion = self.panoptic_fusion_head
+        cfg = fusion.test_cfg
+        T, Q = masks4.shape[0], masks4.shape[1]
+        ori = meta['ori_shape'] if rescale else None
+        pan_on, ins_on = cfg.get('panoptic_on', True), cfg.get('instance_on', False)
+        if Q > ops.SEL_MAXK:
+            return None
+        parts, feats, pan = [], None, None
+        if pan_on:
+            pan, seg, sel, _ = fusion.panoptic_fused_device(cls, masks4, meta['batch_input_shape'], meta['img_shape'], ori)
+            feats = embds.detach()[sel[4:4 + ops.SEL_MAXK].long().clamp_(0, Q - 1)]       # rows beyond K: unused
+            parts += [sel[:4 + ops.SEL_MAXK], seg[:T].reshape(-1)]
+        if ins_on:
+            scores, labels, qidx, n_things = fusion.instance_select_device(cls)
+            binm, ssum, sbox = ops.instance_masks(masks4, qidx, meta['batch_input_shape'], meta['img_shape'][:2],
+                                                  None if ori is None else ori[:2])
+            boxes = fusion._instance_boxes(scores, ssum, sbox)                             # (T,n,5)
+            n_all = int(labels.shape[0])
+            parts += [n_things.reshape(1).to(torch.int32), labels.to(torch.int32), boxes.float().contiguous().view(torch.int32).reshape(-1)]
+        rec = torch.cat(parts).cpu().numpy()                                               # the wait
+        out = [dict() for _ in range(T)]
+        at = 0
+        if pan_on:
+            K, K_all = int(rec[0]), int(rec[1])
+            if K_all > ops.PANOPTIC_FUSE_MAX_KEPT:
+                return None
+            seg_l = rec[4 + ops.SEL_MAXK:4 + ops.SEL_MAXK + T * ops.SEL_MAXK].reshape(T, ops.SEL_MAXK)
+            at = 4 + ops.SEL_MAXK + T * ops.SEL_MAXK
+            kf_np = feats[:K].cpu().numpy() if K else np.zeros((0, embds.shape[-1]), np.float32)
+            pan_np = ops.to_host(pan)
+            for t in range(T):
+                qd = {}
+                for i in range(K):
+                    sid = int(seg_l[t, i])
+                    if sid >= 0:
+                        qd.setdefault(sid, []).append(kf_np[i][None])
+                out[t].update(pan_results=pan_np[t], query_feats=qd)
+        if ins_on:
+            n = int(rec[at])
+            lab = rec[at + 1:at + 1 + n_all].astype(np.int64)[:n]
+            bx = rec[at + 1 + n_all:].view(np.float32).reshape(T, n_all, 5)
+            for t in range(T):
+                out[t]['ins_results'] = self._ins_from_host(bx[t, :n].copy(), lab, binm[t, :n], self.num_things_classes)
+        return out
+
     def _fused_frames(self, cls, masks4, embds, meta, rescale, video):
         """cls (Q,classes+1) shared by the T frames of masks4 (T,Q,h,w); embds (Q,C) query features.
         -> list of T host-side result dicts, or None when the kept set exceeds the kernel's capacity."""
@@ -283,7 +335,11 @@ class Mask2FormerCustom(_Base):
                     c, m4 = self.head_override(c, m4)
                 return c, m4, q
             cls, masks4, q = self._graphed('image', logits, imgs)
-            res = self._fused_frames(cls[0], masks4, q[:, 0], img_metas[0], rescale, video=False)
+            # PVSG_IMAGE_TAIL=host: the round-5 form with its nine waits per image (A/B tests)
+            if os.environ.get('PVSG_IMAGE_TAIL', 'device') != 'host':
+                res = self._fused_image_device(cls[0], masks4, q[:, 0], img_metas[0], rescale)
+            else:
+                res = self._fused_frames(cls[0], masks4, q[:, 0], img_metas[0], rescale, video=False)
             if res is not None:
                 return [r['ins_results'] for r in res] if self.num_stuff_classes == 0 else res
         feats = self.extract_feat(imgs)

@@ -162,6 +162,18 @@ class MaskFormerFusionHeadCustom(BaseModule):
         thing = top_labels < self.num_things_classes
         return top_scores[thing], top_labels[thing], (top_idx // self.num_classes)[thing]
 
+    def instance_select_device(self, mask_cls):
+        """instance_select without its three boolean-index compactions (= three host waits): ALL max_per_image (query, class)
+        pairs with the things FIRST in their original order (stable), and the number of things as a device scalar.
+        -> (scores (n,), labels (n,), query index (n,), n_things ())."""
+        max_per_image = self.test_cfg.get('max_per_image', 100)
+        scores = F.softmax(mask_cls, dim=-1)[:, :-1]
+        top_scores, top_idx = scores.flatten(0, 1).topk(max_per_image, sorted=False)
+        top_labels = top_idx % self.num_classes
+        thing = top_labels < self.num_things_classes
+        order = torch.argsort((~thing).to(torch.uint8), stable=True)
+        return top_scores[order], top_labels[order], (top_idx // self.num_classes)[order], thing.sum()
+
     @staticmethod
     def _instance_boxes(cls_scores, ssum, sbox):
         """mask-quality rescoring + mask2bbox from the kernel's statistics -> (T,n,5) [x0,y0,x1,y1,score]."""
