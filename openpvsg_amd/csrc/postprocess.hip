@@ -98,6 +98,15 @@ __global__ __launch_bounds__(256) void pan_owner_kernel(
 // clamped border rows/columns fall out of the same formula): 4 tap loads per kept query instead of 64,
 // 16 running arg-max states in registers.  Same arithmetic per pixel as pan_owner_kernel (ATen's
 // formula specialised to scale 1/4), so the two kernels agree bit for bit.
+// SKIP (default): a kept query whose logits are far below zero on a lane's four taps cannot own any of its 16 pixels once every
+// one of them has a better candidate: sigmoid(v) < e^v, v <= max of the taps (bilinear weights are a convex combination), so
+// s_k e^{vmax} (with a 1e-4 margin for the roundings) < min over the pixels of best[] means `sc > best[e]` is false sixteen times
+// and prob >= 0.5 is false too (vmax < -1e-3).  The wave then skips the 16 exact sigmoids (exp + IEEE division: 4/5 of the
+// kernel's instructions) for that query unless one of its lanes needs them -- most (query, region) pairs of a real frame, where
+// an object's mask is strongly negative away from the object.  The decisions are the unskipped kernel's, bit for bit
+// (tests/test_postprocess.py::test_pan_owner_skip_equals_full_evaluation).  Lanes of a wave form an 8 x 8 patch of 4 x 4
+// blocks (32 x 32 pixels) so that a wave's lanes tend to agree.
+template <bool SKIP>
 __global__ __launch_bounds__(256) void pan_owner_x4_kernel(
     const float* __restrict__ logits, const int* __restrict__ kept_idx, const float* __restrict__ kept_score,
     unsigned char* __restrict__ owner_out, int* __restrict__ counters, int Q, int K, int h, int w, int ih, int iw, const int* __restrict__ kdev) {
@@ -112,22 +121,49 @@ __global__ __launch_bounds__(256) void pan_owner_x4_kernel(
   }
   __syncthreads();
   // block (bx, by) of the (w+1) x (h+1) grid of 4x4 blocks; block (bj, bi) covers output rows 4*bi-2 .. 4*bi+1
-  const int bj = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int bi = blockIdx.y * 8 + (threadIdx.x >> 5);
+  const int bj = SKIP ? blockIdx.x * 32 + (int)(threadIdx.x >> 6) * 8 + (int)(threadIdx.x & 7) : blockIdx.x * 32 + (threadIdx.x & 31);
+  const int bi = SKIP ? blockIdx.y * 8 + (int)((threadIdx.x & 63) >> 3) : blockIdx.y * 8 + (threadIdx.x >> 5);
   const bool active = bj <= w && bi <= h;
   const int i0 = max(bi - 1, 0), i1 = min(bi, h - 1), j0 = max(bj - 1, 0), j1 = min(bj, w - 1);
   // output row 4*bi-2+a: src = (y+0.5)/4-0.5 -> weight of tap i1 is (2a+1)/8 inside, clamped rows give i0==i1
   float best[16], pown[16];
   int own[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { best[e] = -1.f; pown[e] = 0.f; own[e] = 0; }
+  for (int e = 0; e < 16; ++e) {
+    // SKIP: pixels outside the image never take a candidate (`ok` below): they must not hold the minimum of best[] down
+    const int y = 4 * bi - 2 + (e >> 2), x = 4 * bj - 2 + (e & 3);
+    best[e] = (SKIP && !(active && y >= 0 && y < ih && x >= 0 && x < iw)) ? INFINITY : -1.f;
+    pown[e] = 0.f; own[e] = 0;
+  }
+  float minbest = active ? -1.f : INFINITY;                 // min over the lane's pixels of best[] (SKIP)
   const float* base = logits + (long long)t * Q * h * w;
   const int lane = threadIdx.x & 63;
+  // SKIP, first pass: a floor under the FINAL best[] of all 16 pixels -- the largest, over the kept queries, of s_k sigmoid(min
+  // of the four taps) (1 - 1e-4).  A query whose bound stays below the floor is strictly beaten at every pixel by the query that
+  // set the floor, whichever comes first in the list, so passing it over changes neither the final owner (arg-max, first maximum)
+  // nor any count.  Without the floor only the queries BEHIND a block's owner in list order could be skipped.
+  float floor_best = -1.f;
+  if (SKIP && active) {
+    for (int k = 0; k < K; ++k) {
+      const float* p = base + (long long)s_idx[k] * h * w;
+      const float vmin = fminf(fminf(p[i0 * w + j0], p[i0 * w + j1]), fminf(p[i1 * w + j0], p[i1 * w + j1]));
+      const float vlo = vmin - 1e-5f * __builtin_fabsf(vmin) - 1e-6f;
+      const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * vlo));
+      floor_best = fmaxf(floor_best, s_score[k] * sg * 0.9999f);             // NaN taps: fmaxf keeps the old floor
+    }
+  }
   for (int k = 0; k < K; ++k) {
     const float* p = base + (long long)s_idx[k] * h * w;
     float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
     if (active) { v00 = p[i0 * w + j0]; v01 = p[i0 * w + j1]; v10 = p[i1 * w + j0]; v11 = p[i1 * w + j1]; }
     const float sc_k = s_score[k];
+    if (SKIP) {
+      const float vmax = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
+      // e^{vmax (1 - 2^-18)} (1 + 1e-4) s_k: above s_k sigmoid(v) of every pixel of the block for vmax < -1e-3
+      const float ub = sc_k * 1.0001f * __builtin_amdgcn_exp2f(vmax * (1.4426950408889634f * (1.f - 3.8e-6f)));
+      const bool need = active && !(vmax < -1e-3f && vmax > -80.f && ub < fmaxf(minbest, floor_best));     // below -80: e^v leaves the normal range
+      if (!__builtin_amdgcn_ballot_w64(need)) continue;       // wave-uniform: nobody's owner or counts can change
+    }
     int conf_cnt = 0;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -155,6 +191,12 @@ __global__ __launch_bounds__(256) void pan_owner_x4_kernel(
         if (ok && sc > best[e]) { best[e] = sc; own[e] = k; pown[e] = prob; }
         conf_cnt += (ok && prob >= 0.5f) ? 1 : 0;
       }
+    }
+    if (SKIP) {
+      float m = best[0];
+#pragma unroll
+      for (int e = 1; e < 16; ++e) m = fminf(m, best[e]);
+      minbest = m;
     }
     // per-query "original area": wave-sum of the per-lane counts
 #pragma unroll
@@ -529,9 +571,15 @@ static int panoptic_fuse_run(const char* nm, const float* mask_logits, const int
     if (oh != ih || ow != iw)
       hipLaunchKernelGGL(pan_owner_2stage_kernel, dim3((ow + 63) / 64, (oh + 3) / 4, T), dim3(256), 0, stream,
                          mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, H, W, ih, iw, oh, ow, kdev);
-    else if (H == 4 * h && W == 4 * w)
-      hipLaunchKernelGGL(pan_owner_x4_kernel, dim3((w + 1 + 31) / 32, (h + 1 + 7) / 8, T), dim3(256), 0, stream,
-                         mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, ih, iw, kdev);
+    else if (H == 4 * h && W == 4 * w) {
+      const char* sk = getenv("PVSG_PAN_SKIP");                  // =0: every sigmoid evaluated (A/B tests)
+      if (sk && sk[0] == '0')
+        hipLaunchKernelGGL(pan_owner_x4_kernel<false>, dim3((w + 1 + 31) / 32, (h + 1 + 7) / 8, T), dim3(256), 0, stream,
+                           mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, ih, iw, kdev);
+      else
+        hipLaunchKernelGGL(pan_owner_x4_kernel<true>, dim3((w + 1 + 31) / 32, (h + 1 + 7) / 8, T), dim3(256), 0, stream,
+                           mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, ih, iw, kdev);
+    }
     else
       hipLaunchKernelGGL(pan_owner_kernel, dim3((iw + 63) / 64, (ih + 3) / 4, T), dim3(256), 0, stream,
                          mask_logits, kept_idx, kept_score, owner_ws, counter_ws, Q, K, h, w, H, W, ih, iw, kdev);

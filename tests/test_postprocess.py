@@ -211,3 +211,35 @@ def test_instance_masks_x4_kernel_equals_per_pixel_kernel(hip_lib, monkeypatch, 
     assert int(b1[..., 0].sum()) > 0
     _, s2, b2 = ops.instance_masks(logits, sel, out_hw, crop, want_masks=False)
     assert torch.equal(b2, b1)
+
+
+@pytest.mark.parametrize('T,h,w,crop,nconf,low,kind', [
+    (2, 46, 80, (180, 320), 20, True, 'blobs'), (1, 184, 320, (720, 1280), 32, True, 'boxes'), (1, 23, 40, (90, 157), 9, False, 'blobs'),
+    (1, 32, 48, (128, 192), 12, True, 'deep'), (3, 16, 24, (61, 96), 6, False, 'boxes')])
+def test_pan_owner_skip_equals_full_evaluation(hip_lib, monkeypatch, T, h, w, crop, nconf, low, kind):
+    """pan_owner_x4_kernel<SKIP>: queries that cannot own a pixel of a wave's patch are passed over without their 16 sigmoids per
+    lane; owners, confidence bits and the three area counters (hence the panoptic map and the segment ids) must be those of the
+    kernel that evaluates everything.  'boxes' = +-40 offsets as bench.py adds them, 'deep' = logits below -80 (outside the
+    bound's range: evaluated), 'blobs' = smooth masks with noise."""
+    from openpvsg_amd import ops
+    g = torch.Generator().manual_seed(h + w + nconf)
+    cls, conf = peaky_cls(100, 126, nconf, 5)
+    if kind == 'blobs':
+        logits = torch.stack([blob_masks(100, h, w, conf, 70 + t) for t in range(T)])
+    else:
+        logits = torch.randn(T, 100, h, w, generator=g) * 2
+        off = -40.0 if kind == 'boxes' else -95.0
+        for i, q in enumerate(conf.tolist()):
+            logits[:, q] += off
+            y0, x0 = (i * 7) % max(1, h - 6), (i * 11) % max(1, w - 8)
+            logits[:, q, y0:y0 + max(4, h // 4), x0:x0 + max(6, w // 3)] -= 2 * off
+    scores, labels = F.softmax(cls, -1).max(-1)
+    keep = labels.ne(126) & (scores > 0.8)
+    idx = keep.nonzero()[:, 0]
+    args = (logits.to(DEV), idx.to(DEV), scores[idx].to(DEV), labels[idx].to(DEV), (4 * h, 4 * w), crop, 115, 126, 0.8, low)
+    monkeypatch.setenv('PVSG_PAN_SKIP', '0')
+    pan0, seg0 = ops.panoptic_fuse(*args)
+    monkeypatch.setenv('PVSG_PAN_SKIP', '1')
+    pan1, seg1 = ops.panoptic_fuse(*args)
+    assert idx.numel() >= 4 and torch.equal(pan0, pan1) and torch.equal(seg0, seg1)
+    assert int((seg1 >= 0).sum()) >= 1
