@@ -151,7 +151,7 @@ def test_group_norm_affine_equals_torch_group_norm(hip_lib, B, C, G, H, W):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('B,Cin,Cout,H,W', [(2, 256, 256, 23, 40), (3, 2048, 256, 8, 12), (1, 512, 256, 46, 80), (2, 64, 128, 17, 9)])
-def test_conv1x1_with_groupnorm_statistics_from_its_epilogue(hip_lib, B, Cin, Cout, H, W):
+def test_conv1x1_with_groupnorm_statistics_from_its_epilogue(hip_lib, monkeypatch, B, Cin, Cout, H, W):
     """ops.conv1x1_f16x2_gn: the 1x1 convolution's epilogue leaves per-(image, group, chunk) partial sums of what it stores, and
     pvsg_group_norm_finish turns them into the GroupNorm scale / shift -- against F.group_norm of the convolution in float64 and
     against the two-pass form (conv1x1 + pvsg_group_norm_affine); ragged pixel tiles included ([3P] mmcv ConvModule(norm_cfg=GN))."""
@@ -165,6 +165,9 @@ def test_conv1x1_with_groupnorm_statistics_from_its_epilogue(hip_lib, B, Cin, Co
         gn.bias.copy_(torch.randn(Cout, generator=g))
     wp = ops.gemm_bf16x3_pack(w, mode='f16x2')
     assert ops.conv1x1_gn_supported(wp, Cout, Cin, H, W, gn)
+    # small maps would take the K-sliced convolution + the separate statistics pass (tests/test_conv_slices.py, below): this test
+    # is about the epilogue form
+    monkeypatch.setenv('PVSG_CONV_SLICES', 'off')
     raw, sc, sh = ops.conv1x1_f16x2_gn(x, wp, Cout, gn)
     raw2 = ops.conv1x1_bf16x3(x, wp, Cout)
     assert torch.equal(raw, raw2)
@@ -176,12 +179,18 @@ def test_conv1x1_with_groupnorm_statistics_from_its_epilogue(hip_lib, B, Cin, Co
     assert torch.allclose(sc, sc2, rtol=1e-5, atol=1e-7) and torch.allclose(sh, sh2, rtol=1e-5, atol=1e-6)
     r3, s3, h3 = ops.conv1x1_f16x2_gn(x, wp, Cout, gn)
     assert torch.equal(sc, s3) and torch.equal(sh, h3)           # fixed-order reduction: bitwise run to run
+    # the sliced route of small maps gives the same normalisation
+    monkeypatch.setenv('PVSG_CONV_SLICES', 'auto' if ops._conv_slices(1, B, Cin, Cout, H, W, 1) > 1 else '2')
+    if (H * W) % 4 == 0 and Cin >= 64:
+        r4, s4, h4 = ops.conv1x1_f16x2_gn(x, wp, Cout, gn)
+        y4 = r4 * s4.view(B, Cout, 1, 1) + h4.view(B, Cout, 1, 1)
+        assert float((y4.double().cpu() - ref).abs().max()) < 2e-5
     assert ops.split_overflow_count() == 0
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('B,Cin,Cout,H,W', [(2, 256, 256, 23, 40), (1, 64, 128, 17, 35), (3, 128, 256, 8, 16)])
-def test_conv3x3_with_groupnorm_statistics_from_its_epilogue(hip_lib, B, Cin, Cout, H, W):
+def test_conv3x3_with_groupnorm_statistics_from_its_epilogue(hip_lib, monkeypatch, B, Cin, Cout, H, W):
     """ops.conv3x3_f16x2_gn: the same for the FPN output convolution ([3P] MSDeformAttnPixelDecoder.output_convs: 3x3 conv -> GN ->
     ReLU) -- partial sums per (image, group, 8 x 16 pixel tile, wave half), ragged tiles included."""
     from openpvsg_amd import ops
@@ -195,6 +204,7 @@ def test_conv3x3_with_groupnorm_statistics_from_its_epilogue(hip_lib, B, Cin, Co
     wp = ops.conv3x3_bf16x3_pack(w)
     assert ops.conv3x3_gn_supported(wp, Cout, Cin, H, W, gn)
     raw, sc, sh = ops.conv3x3_f16x2_gn(x, wp, Cout, gn)
+    monkeypatch.setenv('PVSG_CONV_SLICES', 'off')            # the plain kernel of the same arithmetic (small maps would be K-sliced)
     raw2 = ops.conv3x3_bf16x3(x, wp, Cout, relu=False)
     assert torch.equal(raw, raw2)
     sc2, sh2 = ops.group_norm_affine(raw2, gn)
