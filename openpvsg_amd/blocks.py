@@ -266,8 +266,11 @@ _CU_COUNT = {}
 def _fused_ln_fills_the_gpu(x, k):
     """The fused projection + LayerNorm kernel owns whole rows: 128-row tiles, two workgroups per CU (PVSG_LN_TILE=256: the
     round-4 form, 256-row tiles, one per CU).  With few rows the last round of workgroups leaves most CUs idle (4 frames of 720p
-    = 604 tiles on 512 slots); then the two-launch form (128 x 128 tiles + the add-LayerNorm kernel) is used.
-    PVSG_FUSE_LN=force keeps the fused kernel regardless."""
+    = 604 tiles on 512 slots) -- round 5 switched to the two-launch form (128 x 128 tiles + the add-LayerNorm kernel) below 0.85
+    of a full last round.  Re-measured in round 6 (profiles/r06_fuse_ln_small.txt): the fused kernel wins anyway, 11.65 -> 11.45 ms
+    at 4 frames, 20.55 -> 19.95 at 8, a tie at 1 (the two-launch form's own 128 x 128 grid has the same ragged last round and
+    then streams the rows once more), so the threshold is 0 now; PVSG_FUSE_LN_MINEFF=0.85 restores the round-5 choice,
+    PVSG_FUSE_LN=off the two-launch form everywhere."""
     if os.environ.get('PVSG_FUSE_LN', 'on') == 'force':
         return True
     dev = x.device.index or 0
@@ -278,7 +281,7 @@ def _fused_ln_fills_the_gpu(x, k):
     tile, slots = (256, cus) if big else (128, 2 * cus)
     tiles = (x.numel() // k + tile - 1) // tile
     rounds = (tiles + slots - 1) // slots
-    return tiles >= float(os.environ.get('PVSG_FUSE_LN_MINEFF', '0.85')) * rounds * slots
+    return tiles >= float(os.environ.get('PVSG_FUSE_LN_MINEFF', '0')) * rounds * slots
 
 
 def linear_add_layernorm_fast(owner, tag, weight, x, bias, identity, norm):
