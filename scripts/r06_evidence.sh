@@ -22,3 +22,17 @@ for f in sorted(glob.glob('$O/bench_line*.json')):
         d = json.load(open(f)); print(f.split('/')[-1], d['ms_per_step'], d['value'], d.get('roofline', {}).get('frac'), d.get('roofline_function', {}).get('kernel_function'))
     except Exception as e: print(f, 'ERR', e)
 PY
+# second half of round 6 (small shapes): per-image flow A/Bs, range-merge kernels, 4-frame step against 1/8 of the 32-frame one
+{
+  echo "# scripts/lab/ips_image_breakdown.py (one 720p image per call through the shipped IPS detector, hipGraph on), same box"
+  for cfg in "PVSG_CONV_SLICES=off PVSG_IMAGE_TAIL=host PVSG_INST_X4=0 PVSG_KV_BATCH=off PVSG_FUSE_LN_MINEFF=0.85" "PVSG_CONV_SLICES=auto PVSG_IMAGE_TAIL=host PVSG_INST_X4=0" \
+             "PVSG_CONV_SLICES=auto PVSG_IMAGE_TAIL=host PVSG_INST_X4=1" "PVSG_CONV_SLICES=auto PVSG_IMAGE_TAIL=device PVSG_INST_X4=1"; do
+    echo "$cfg: $(env $cfg B1_MODES=on python scripts/lab/ips_image_breakdown.py 2>&1 | grep 'graph on')"
+  done
+} > $O/batch1_ab.txt
+python scripts/lab/combine_time.py 2>/dev/null | grep "^B " > $O/combine_time.txt
+bash scripts/lab/t4_vs_t32.sh r06_final/t4cmp > $O/t4_vs_t32.txt 2>/dev/null
+B1_MODES=on bash scripts/lab/b1_seq.sh r06_final/b1seq > /dev/null 2>&1
+python scripts/lab/seq_short.py $O/b1seq/seq.txt > $O/batch1_seq.txt 2>/dev/null
+python scripts/lab/vps_breakdown.py 2>/dev/null | grep "wall ms" > $O/vps_breakdown.txt
+ls $O

@@ -906,3 +906,36 @@ def test_f16x2_overflow_reruns_the_call_on_bf16x3(hip_lib):
     assert ops.split_mode() == 'f16x2'
     again = run(x)                                               # back on the default form, same answer as before
     np.testing.assert_array_equal(again[0], small[0])
+
+
+@pytest.mark.parametrize('rescale,meta', [(True, dict(img_shape=(60, 90, 3), ori_shape=(45, 70, 3))),
+                                          (True, dict(img_shape=(64, 96, 3), ori_shape=(64, 96, 3))),
+                                          (False, dict(img_shape=(61, 93, 3), ori_shape=(61, 93, 3)))])
+def test_image_detector_device_tail_equals_host_tail(hip_lib, monkeypatch, rescale, meta):
+    """Mask2FormerCustom.simple_test with the post-process decisions left on the device until one group of transfers
+    (detectors._fused_image_device: kept set from pvsg_panoptic_select, instance list with the things first) against the round-5
+    flow with its host waits (`PVSG_IMAGE_TAIL=host`: nonzero / boolean-index compactions on the host side): same panoptic map, same
+    query features per segment, same instance list (mask2former.py:121-191, mask2former_fusion_head.py:96-242)."""
+    m = build_detector(False, 9, {'cls_embed.weight': 40.0})
+    outs = {}
+    for tail in ('host', 'device'):
+        monkeypatch.setenv('PVSG_IMAGE_TAIL', tail)
+        for seed in (21, 22):
+            img = det_input('img', (1, 3, 64, 96), seed).to(DEV)
+            outs[tail, seed] = m.forward([img], [[dict(meta)]], return_loss=False, rescale=rescale)[0]
+    for seed in (21, 22):
+        a, b = outs['host', seed], outs['device', seed]
+        assert a['pan_results'].dtype == b['pan_results'].dtype and (a['pan_results'] == b['pan_results']).all()
+        assert sorted(a['query_feats']) == sorted(b['query_feats']) and len(b['query_feats']) >= 1
+        for k in a['query_feats']:
+            assert len(a['query_feats'][k]) == len(b['query_feats'][k])
+            for x, y in zip(a['query_feats'][k], b['query_feats'][k]):
+                assert x.shape == y.shape == (1, 256) and (x == y).all()
+        (ba, ma), (bb, mb) = a['ins_results'], b['ins_results']
+        assert sum(len(c) for c in mb) >= 1
+        for c in range(len(ba)):
+            assert ba[c].shape == bb[c].shape and ba[c].dtype == bb[c].dtype
+            np.testing.assert_allclose(ba[c], bb[c], rtol=1e-6, atol=1e-6)          # same order: both keep topk's order of the things
+            assert len(ma[c]) == len(mb[c])
+            for x, y in zip(ma[c], mb[c]):
+                assert (np.asarray(x) == np.asarray(y)).all()
