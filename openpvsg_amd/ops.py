@@ -1048,11 +1048,26 @@ def split_overflow_count(device=None, reset=True):
         t = _overflow.get(d)
         if t is None:
             continue
-        c = int(t[0].item())
+        known = _overflow_known.pop(d, None)         # the caller's own transfer already carried the counter (note_overflow_count)
+        c = int(t[0].item()) if known is None else known
         if reset and c:
             t.zero_()
         n += c
     return n
+
+
+_overflow_known = {}
+
+
+def overflow_counter_view(device):
+    """The device's f16x2 overflow counter as a (1,) int32 tensor, for callers that move a record to the host anyway: append it,
+    then hand the value to note_overflow_count -- the range check of rerun_on_bf16x3 then needs no transfer of its own."""
+    return _overflow_counter(torch.device(device))[:1]
+
+
+def note_overflow_count(device, n):
+    d = torch.device(device)
+    _overflow_known[d.index if d.index is not None else torch.cuda.current_device()] = int(n)
 
 
 def split_overflow_check(device=None):
