@@ -314,6 +314,15 @@ int pvsg_panoptic_fuse_sel(const float* mask_logits, const int* sel, int* panopt
  *   tube_ids (T * 128) int64, first N valid; rowmap (T, 128) int32: tube row of a frame-first query, else -1
  * pvsg_tube_scatter: feats (N, T, C) from the query rows (row stride in floats) of the frame-first queries; zeros elsewhere.
  * Segment ids must be < 128 000 (class < 1000 = [3P] INSTANCE_OFFSET, at most 127 instances). */
+/* Run boundaries of (n, H, W) 0 / 1 byte masks in COCO's column-major scan order ([3P] pycocotools mask.encode behind mmdet
+ * `encode_mask_results`, applied to every `ins_results` mask by tools/test.py's single_gpu_test; models/unitrack/utils/io.py:14-36):
+ * position p = x * H + y; boundary value = the index of the LAST element of a run (numpy: flat[1:] != flat[:-1]).
+ *   pvsg_rle_count      counts (n, W, pvsg_rle_segments(H)) int32: boundaries per (mask, column, row segment), in scan order
+ *   pvsg_rle_positions  positions: written at `offsets` = the EXCLUSIVE prefix sum of `counts` (caller: any scan), i.e. sorted by
+ *                       (mask, position); sum(counts) ints.  W % 4 == 0, H * W < 2^31. */
+int pvsg_rle_segments(int H);
+int pvsg_rle_count(const unsigned char* masks, int n, int H, int W, int* counts, void* stream);
+int pvsg_rle_positions(const unsigned char* masks, int n, int H, int W, const int* offsets, int* positions, void* stream);
 long long pvsg_tube_index_table_words(void);
 int pvsg_tube_index(const int* seg_id, const int* sel, int T, int frames_per_block, int rows_per_block,
                     const uint32_t* overflow, int* table_ws, int* rec, long long* tube_ids, int* rowmap, void* stream);

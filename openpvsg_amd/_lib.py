@@ -126,6 +126,9 @@ SIGNATURES = {
     'pvsg_group_norm_affine': [_c_f] * 6 + [_i, _i, _i, _ll, _f, _c_f],
     'pvsg_conv1x1_stats_chunks': [_i, _i, _i],
     'pvsg_conv_slices': [_i] * 7,
+    'pvsg_rle_segments': [_i],
+    'pvsg_rle_count': [_c_f, _i, _i, _i, _c_f, _c_f],
+    'pvsg_rle_positions': [_c_f, _i, _i, _i, _c_f, _c_f, _c_f],
     'pvsg_conv1x1_f16x2_stats': [_c_f] * 7 + [_i] * 7 + [_c_f, _c_f],
     'pvsg_conv3x3_stats_chunks': [_i, _i],
     'pvsg_bottleneck_next_weight_matrix': [_c_f, _c_f, _i, _i, _c_f],
@@ -141,7 +144,7 @@ SIGNATURES = {
 VALUE_RETURNING = ('pvsg_xattn_num_splits', 'pvsg_gemm_bf16x3_packed_elems', 'pvsg_gemm_f16x2_packed_elems',
                    'pvsg_minvis_chain_workspace_bytes', 'pvsg_reconsdot_workspace_bytes', 'pvsg_rle_counts_to_chars',
                    'pvsg_decoder_rows_post_workspace_bytes', 'pvsg_tube_index_table_words', 'pvsg_conv1x1_stats_chunks',
-                   'pvsg_conv3x3_stats_chunks', 'pvsg_rel_tail_workspace_bytes', 'pvsg_conv_slices')
+                   'pvsg_conv3x3_stats_chunks', 'pvsg_rel_tail_workspace_bytes', 'pvsg_conv_slices', 'pvsg_rle_segments')
 
 _lib = None
 

@@ -180,3 +180,93 @@ extern "C" int pvsg_tube_scatter(const float* query, long long query_row_stride,
   PVSG_LAUNCH_CHECK("tube_scatter");
   return PVSG_OK;
 }
+
+// ---- run boundaries of instance masks in COCO's (column-major) scan order -------------------------------------------------------
+// [3P] mmdet `encode_mask_results` (pycocotools mask.encode) run-length codes every (H, W) mask of `ins_results` column by column
+// (tools/test.py -> single_gpu_test).  The masks are blobs: a few hundred boundaries per mask against 0.9 MB of mask bytes, so only
+// the boundaries travel.  Position p = x * H + y; a change AT (x, y) means mask(x, y) != mask(pred(x, y)), pred = the element before
+// it in scan order ((x, y - 1), or (x - 1, H - 1) for y == 0); it is recorded as p - 1, the index numpy's
+// `flat[1:] != flat[:-1]` would report.  A thread owns 4 columns x RLE_SEG rows (4-byte loads, coalesced along x);
+//   pass 1 (pvsg_rle_count):      changes per (mask, column, row segment), laid out in scan order -> the caller's exclusive scan
+//   pass 2 (pvsg_rle_positions):  the positions, written at the scanned offsets: sorted by (mask, position) by construction.
+// The tensor-op form this replaces (transpose copy, shifted compare, sum, nonzero, cat) made five passes over the 92 MB of one
+// 720p image x 100 masks: 1.0 ms of the 1.28 ms `rles()` took; these two read the masks twice.
+namespace pvsg {
+constexpr int RLE_SEG = 48;
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void rle_boundaries_kernel(const unsigned char* __restrict__ masks, int n, int H, int W, int nseg,
+                                                             int* __restrict__ counts, const int* __restrict__ offsets,
+                                                             int* __restrict__ positions) {
+  const int W4 = W >> 2;
+  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)n * nseg * W4;
+  if (tid >= total) return;
+  const int cg = (int)(tid % W4);
+  const int seg = (int)((tid / W4) % nseg), i = (int)(tid / ((long long)W4 * nseg));
+  const unsigned char* m = masks + (long long)i * H * W;
+  const int x0 = 4 * cg, y0 = seg * RLE_SEG, y1 = min(H, y0 + RLE_SEG);
+  unsigned prev;                                                 // the 4 predecessors of row y0, one byte per column (0 / 1)
+  if (y0 > 0) {
+    prev = *reinterpret_cast<const unsigned*>(m + (long long)(y0 - 1) * W + x0);
+  } else {
+    const unsigned char* last = m + (long long)(H - 1) * W;
+    const unsigned b0 = x0 > 0 ? last[x0 - 1] : m[0];            // column 0 has no predecessor: compare (0, 0) with itself
+    prev = b0 | ((unsigned)last[x0] << 8) | ((unsigned)last[x0 + 1] << 16) | ((unsigned)last[x0 + 2] << 24);
+  }
+  int cnt[4] = {0, 0, 0, 0};
+  int* dst[4];
+  if (WRITE) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[c] = positions + offsets[((long long)i * W + x0 + c) * nseg + seg];
+  }
+  for (int y = y0; y < y1; ++y) {
+    const unsigned cur = *reinterpret_cast<const unsigned*>(m + (long long)y * W + x0);
+    const unsigned diff = (cur ^ prev) & 0x01010101u;            // masks are 0 / 1 bytes (torch.bool)
+    if (diff) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if ((diff >> (8 * c)) & 1u) {
+          if (WRITE) dst[c][cnt[c]] = (x0 + c) * H + y - 1;
+          ++cnt[c];
+        }
+    }
+    prev = cur;
+  }
+  if (!WRITE) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) counts[((long long)i * W + x0 + c) * nseg + seg] = cnt[c];
+  }
+}
+}  // namespace pvsg
+
+extern "C" int pvsg_rle_segments(int H) { return (H + pvsg::RLE_SEG - 1) / pvsg::RLE_SEG; }
+
+extern "C" int pvsg_rle_count(const unsigned char* masks, int n, int H, int W, int* counts, void* stream_) {
+  using namespace pvsg;
+  PVSG_REQUIRE(masks && counts, "rle_count: null pointer argument");
+  PVSG_REQUIRE(n > 0 && H > 0 && W > 0, "rle_count: bad shape");
+  if (W % 4 || (long long)H * W >= (1LL << 31) || (reinterpret_cast<uintptr_t>(masks) & 3u))
+    return set_err(PVSG_ERR_UNSUPPORTED, "rle_count: built for W %% 4 == 0, H * W < 2^31, 4-byte aligned masks (got H=%d W=%d)", H, W);
+  const int nseg = pvsg_rle_segments(H);
+  const long long total = (long long)n * nseg * (W / 4);
+  PVSG_REQUIRE((total + 255) / 256 < (1LL << 31), "rle_count: too many blocks");
+  hipLaunchKernelGGL(rle_boundaries_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     masks, n, H, W, nseg, counts, (const int*)nullptr, (int*)nullptr);
+  PVSG_LAUNCH_CHECK("rle_count");
+  return PVSG_OK;
+}
+
+extern "C" int pvsg_rle_positions(const unsigned char* masks, int n, int H, int W, const int* offsets, int* positions, void* stream_) {
+  using namespace pvsg;
+  PVSG_REQUIRE(masks && offsets && positions, "rle_positions: null pointer argument");
+  PVSG_REQUIRE(n > 0 && H > 0 && W > 0, "rle_positions: bad shape");
+  if (W % 4 || (long long)H * W >= (1LL << 31) || (reinterpret_cast<uintptr_t>(masks) & 3u))
+    return set_err(PVSG_ERR_UNSUPPORTED, "rle_positions: built for W %% 4 == 0, H * W < 2^31, 4-byte aligned masks (got H=%d W=%d)", H, W);
+  const int nseg = pvsg_rle_segments(H);
+  const long long total = (long long)n * nseg * (W / 4);
+  hipLaunchKernelGGL(rle_boundaries_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     masks, n, H, W, nseg, (int*)nullptr, offsets, positions);
+  PVSG_LAUNCH_CHECK("rle_positions");
+  return PVSG_OK;
+}

@@ -184,13 +184,39 @@ class DeviceMaskStack:
             self._rles = []
             return self._rles
         if boundaries or (boundaries is None and self._np is None and self.binm.is_cuda):
-            flat = self.binm.transpose(1, 2).reshape(n, H * W)              # column-major scan order
-            change = flat[:, 1:] != flat[:, :-1]
-            m = int(change.sum())                                            # the one sync
-            if boundaries or m * 16 <= n * H * W:                            # boundaries are cheaper to move than the masks
-                idx = change.nonzero()                                       # (m, 2), sorted by mask, then position
-                host = torch.cat([idx.reshape(-1), flat[:, 0].to(idx.dtype)]).cpu().numpy()
-                idx, first = host[:2 * m].reshape(m, 2), host[2 * m:]
+            idx = first = None
+            if (self.binm.is_cuda and W % 4 == 0 and H * W < 2 ** 31 and self.binm.dtype in (torch.bool, torch.uint8) and
+                    os.environ.get('PVSG_RLE_KERNEL', 'on') != 'off'):
+                # csrc/tubes.hip: boundaries per (mask, column, row segment) -> prefix sum -> positions, two reads of the masks
+                from . import _lib, ops
+                mk = self.binm.contiguous().view(torch.uint8)
+                nseg = int(_lib.load().pvsg_rle_segments(H))
+                counts = torch.empty((n * W * nseg,), device=mk.device, dtype=torch.int32)
+                with ops._on(mk.device):
+                    _lib.call('pvsg_rle_count', mk.data_ptr(), n, H, W, counts.data_ptr(), ops._stream_ptr())
+                csum = torch.cumsum(counts, 0, dtype=torch.int32)
+                head = torch.cat([csum[W * nseg - 1::W * nseg], mk[:, 0, 0].to(torch.int32)]).cpu().numpy()      # first sync
+                m = int(head[n - 1])
+                if boundaries or m * 16 <= n * H * W:
+                    pos = np.zeros((0,), np.int32)
+                    if m:
+                        positions = torch.empty((m,), device=mk.device, dtype=torch.int32)
+                        with ops._on(mk.device):
+                            _lib.call('pvsg_rle_positions', mk.data_ptr(), n, H, W, (csum - counts).data_ptr(), positions.data_ptr(),
+                                      ops._stream_ptr())
+                        pos = positions.cpu().numpy()                        # second sync
+                    per = np.diff(np.concatenate(([0], head[:n].astype(np.int64))))
+                    idx = np.stack([np.repeat(np.arange(n, dtype=np.int64), per), pos.astype(np.int64)], 1)
+                    first = head[n:].astype(np.int64)
+            else:
+                flat = self.binm.transpose(1, 2).reshape(n, H * W)              # column-major scan order
+                change = flat[:, 1:] != flat[:, :-1]
+                m = int(change.sum())                                            # the one sync
+                if boundaries or m * 16 <= n * H * W:                            # boundaries are cheaper to move than the masks
+                    idx = change.nonzero()                                       # (m, 2), sorted by mask, then position
+                    host = torch.cat([idx.reshape(-1), flat[:, 0].to(idx.dtype)]).cpu().numpy()
+                    idx, first = host[:2 * m].reshape(m, 2), host[2 * m:]
+            if idx is not None:
                 # all masks in one vectorised pass: boundaries [0, p+1 ..., HW] per mask -> run lengths -> strings
                 per = np.bincount(idx[:, 0], minlength=n)                         # change points per mask
                 lead = (first != 0).astype(np.int64)                              # masks starting with a one: leading 0-run

@@ -114,6 +114,37 @@ def test_device_mask_stack_boundary_rle_equals_host_codec():
     assert tubes.DeviceMaskStack(torch.zeros(0, 4, 4, dtype=torch.bool)).rles() == []
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,H,W', [(7, 45, 72), (3, 100, 8), (5, 720, 1280), (2, 48, 4), (4, 97, 64)])
+def test_rle_boundary_kernels_equal_tensor_ops_and_host_codec(hip_lib, monkeypatch, n, H, W):
+    """pvsg_rle_count / pvsg_rle_positions (csrc/tubes.hip: boundaries per (mask, column, row segment) -> prefix sum -> positions)
+    behind DeviceMaskStack.rles(): the strings of the tensor-op form they replace (`PVSG_RLE_KERNEL=off`) and of the host codec,
+    including masks that start with a one, single first / last pixels, full and empty masks, noise, rows not a multiple of the
+    48-row segment."""
+    rs = np.random.RandomState(n * H + W)
+    m = np.zeros((n, H, W), bool)
+    m[0, H // 5:H // 2, W // 4:W // 2 + 1] = 1
+    m[1, :, :1] = 1                                   # starts with a one
+    m[1, H - 1, W - 1] = 1                            # and ends with one
+    if n > 2:
+        m[2] = rs.rand(H, W) < (0.5 if H * W < 10000 else 0.002)
+    if n > 3:
+        m[3] = 1
+    if n > 4:
+        m[4, 0, 0] = 1
+        m[4, 47:49, :] = 1                            # across a segment border in every column
+    dev = torch.from_numpy(m).cuda()
+    monkeypatch.setenv('PVSG_RLE_KERNEL', 'on')
+    a = tubes.DeviceMaskStack(dev).rles(boundaries=True)
+    monkeypatch.setenv('PVSG_RLE_KERNEL', 'off')
+    b = tubes.DeviceMaskStack(dev).rles(boundaries=True)
+    assert a == b
+    assert [r['counts'] for r in a] == [tubes.rle_encode(m[j])['counts'] for j in range(n)]
+    monkeypatch.setenv('PVSG_RLE_KERNEL', 'on')
+    assert tubes.DeviceMaskStack(dev).rles() == a or H * W < 10000      # default route (noise-like stacks fall back to the host codec: same strings)
+    assert tubes.DeviceMaskStack(dev.view(torch.uint8)).rles(boundaries=True) == a
+
+
 def _outputs(T=5):
     rs = np.random.RandomState(1)
     outs = []
