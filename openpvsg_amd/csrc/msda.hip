@@ -537,6 +537,9 @@ __device__ __forceinline__ int msda_band_query(int pos, const long long* __restr
   return pos;                                     // not reached for consistent shapes
 }
 
+// (round 6 lab, profiles/r06_msda_occupancy.txt: the kernel is latency-bound -- fewer resident workgroups are monotonically slower --
+// but asking the register allocator for 8 waves per SIMD instead of the 7 its 70 VGPRs allow, `__launch_bounds__(256, 8)`: 64 VGPRs,
+// no scratch, is a tie, 1.492 vs 1.490 ms)
 template <int L, int P, bool BANDS, bool COOP>
 __global__ __launch_bounds__(256) void msda_fused_m8d32(
     const float* __restrict__ value, long long value_stride, const float* __restrict__ oa,
@@ -949,8 +952,10 @@ extern "C" int pvsg_msda_fused_forward(const float* value, long long value_row_s
       return PVSG_OK;
     }
   }
+  // lab knob (profiles/r06_msda_occupancy.txt): unused dynamic LDS per workgroup caps the workgroups resident on a CU (160 KB / n)
+  static const unsigned occ_lds = [] { const char* e = getenv("PVSG_MSDA_OCC_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
 #define PVSG_MSDA_LAUNCH(BANDS, COOP)                                                                                        \
-  hipLaunchKernelGGL((msda_fused_m8d32<3, 4, BANDS, COOP>), dim3(nblk), dim3(256), 0, stream, value, value_row_stride, oa,  \
+  hipLaunchKernelGGL((msda_fused_m8d32<3, 4, BANDS, COOP>), dim3(nblk), dim3(256), occ_lds, stream, value, value_row_stride, oa,  \
                      oa_row_stride, pos_oa, ref_points, reinterpret_cast<const long long*>(spatial_shapes),                \
                      reinterpret_cast<const long long*>(level_start_index), out, S, Lq, nq, nblk)
   if (bands && coop) PVSG_MSDA_LAUNCH(true, true);
