@@ -190,6 +190,22 @@ int pvsg_decoder_rows_post(const pvsg_decoder_layer* layer, const pvsg_decoder_h
                            float* query_out, float* cls_out, float* mask_embed_out, float* next_q_out, void* workspace,
                            void* emb_pack_f16x2, uint32_t* flags_zero, int B, int Q, void* stream);
 
+/* The same two launches with every row GEMM on the 16-bit matrix pipe (f16x2 split arithmetic, the form of pvsg_gemm_f16x2:
+ * f32 operands split into two f16 limbs per lane, three limb products, f32 accumulation -- an f32-class result at 1/5 of the
+ * f32-MFMA time; a decoder layer chains ~11 of these 256 x 256 GEMMs on 16 rows whatever the clip length).  Every weight pointer
+ * of pvsg_decoder_layer / pvsg_decoder_head / next_q_w is then packed by pvsg_pack_rows_weight_f16x2 (W (N, K) row-major, K % 32
+ * == 0) into pvsg_rows_f16x2_packed_floats(N, K) floats, 16-byte aligned: [max|w|, 2^-e, 0, 0] + per (16-column tile, 32-wide k
+ * block) the w_h and w_l fragments of w 2^e.  overflow: NULL or the caller's device counter, incremented per lane that split an
+ * activation with |a| > 65504 (results invalid: re-run on the f32 entries above -- openpvsg_amd/ops.py does). */
+long long pvsg_rows_f16x2_packed_floats(int N, int K);
+int pvsg_pack_rows_weight_f16x2(const float* W, float* packed, int N, int K, void* stream);
+int pvsg_decoder_rows_pre_f16x2(const pvsg_decoder_layer* layer, const float* attn_core, const float* query,
+                                const float* query_pos, float* x1, float* qkv, int B, int Q, uint32_t* overflow, void* stream);
+int pvsg_decoder_rows_post_f16x2(const pvsg_decoder_layer* layer, const pvsg_decoder_head* head, const float* next_q_w,
+                                 const float* next_q_b, const float* x1, const float* qkv, const float* query_pos,
+                                 float* query_out, float* cls_out, float* mask_embed_out, float* next_q_out, void* workspace,
+                                 void* emb_pack_f16x2, uint32_t* flags_zero, int B, int Q, uint32_t* overflow, void* stream);
+
 /* ---- a10 + a13: the relation head's encoders and temporal models as fused row kernels (csrc/relation_rows.hip) ----------
  * Replace the nn.TransformerEncoder / nn.Linear / F.conv1d library calls of
  *   models/relation_head/base.py:26-40        ObjectEncoder (2 x TransformerEncoderLayer(256, nhead 8, ff 512), attention across

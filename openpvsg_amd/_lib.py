@@ -68,6 +68,10 @@ SIGNATURES = {
     'pvsg_decoder_rows_pre': [ctypes.POINTER(DecoderLayer), _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _c_f],
     'pvsg_decoder_rows_post_workspace_bytes': [_i, _i],
     'pvsg_decoder_rows_post': [ctypes.POINTER(DecoderLayer), ctypes.POINTER(DecoderHead)] + [_c_f] * 12 + [_i, _i, _c_f],
+    'pvsg_rows_f16x2_packed_floats': [_i, _i],
+    'pvsg_pack_rows_weight_f16x2': [_c_f, _c_f, _i, _i, _c_f],
+    'pvsg_decoder_rows_pre_f16x2': [ctypes.POINTER(DecoderLayer), _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _c_f, _c_f],
+    'pvsg_decoder_rows_post_f16x2': [ctypes.POINTER(DecoderLayer), ctypes.POINTER(DecoderHead)] + [_c_f] * 12 + [_i, _i, _c_f, _c_f],
     'pvsg_rel_qkv': [ctypes.POINTER(EncoderLayer), _i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _ll, _i, _c_f],
     'pvsg_rel_encoder_layer': [ctypes.POINTER(EncoderLayer), ctypes.POINTER(EncoderLayer), _i, _c_f, _ll, _c_f, _c_f, _c_f, _i, _i,
                                _ll, _ll, _c_f],
@@ -144,7 +148,8 @@ SIGNATURES = {
 VALUE_RETURNING = ('pvsg_xattn_num_splits', 'pvsg_gemm_bf16x3_packed_elems', 'pvsg_gemm_f16x2_packed_elems',
                    'pvsg_minvis_chain_workspace_bytes', 'pvsg_reconsdot_workspace_bytes', 'pvsg_rle_counts_to_chars',
                    'pvsg_decoder_rows_post_workspace_bytes', 'pvsg_tube_index_table_words', 'pvsg_conv1x1_stats_chunks',
-                   'pvsg_conv3x3_stats_chunks', 'pvsg_rel_tail_workspace_bytes', 'pvsg_conv_slices', 'pvsg_rle_segments')
+                   'pvsg_conv3x3_stats_chunks', 'pvsg_rel_tail_workspace_bytes', 'pvsg_conv_slices', 'pvsg_rle_segments',
+                   'pvsg_rows_f16x2_packed_floats')
 
 _lib = None
 
@@ -174,7 +179,8 @@ def load():
             raise BackendMissingError('symbol %s missing from %s' % (name, LIB_PATH)) from e
         f.restype = _ll if name in ('pvsg_gemm_bf16x3_packed_elems', 'pvsg_gemm_f16x2_packed_elems', 'pvsg_minvis_chain_workspace_bytes',
                                    'pvsg_decoder_rows_post_workspace_bytes', 'pvsg_reconsdot_workspace_bytes',
-                                   'pvsg_rle_counts_to_chars', 'pvsg_tube_index_table_words', 'pvsg_rel_tail_workspace_bytes') else _i
+                                   'pvsg_rle_counts_to_chars', 'pvsg_tube_index_table_words', 'pvsg_rel_tail_workspace_bytes',
+                                   'pvsg_rows_f16x2_packed_floats') else _i
         f.argtypes = argtypes
     _lib = lib
     try:                                    # loud, once: a second tenant on the GPU without a CU partition (parallel.py)

@@ -46,6 +46,51 @@ __global__ void pack_rows_weight_kernel(const float* __restrict__ W, float* __re
   P[i] = n < N ? W[(long long)n * K + k] : 0.f;
 }
 
+// f16x2 pack (rows_common.h: rows_gemm_h).  One workgroup reduces max|w| (weights of at most a few MB, once per checkpoint)
+// and writes the header [max|w|, 2^-e, 0, 0]; e as in split_common.h: max|w| 2^e in [2^13, 2^14).
+__global__ __launch_bounds__(1024) void rows_f16x2_header_kernel(const float* __restrict__ W, float* __restrict__ P, long long n) {
+  __shared__ float red[16];
+  float m = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, __builtin_fabsf(W[i]));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+    int e = 0;
+    if (m > 0.f && m < 3.0e38f) {
+      e = 13 - ilogbf(m);
+      e = e > 126 ? 126 : (e < -126 ? -126 : e);
+    }
+    P[0] = m;
+    P[1] = ldexpf(1.f, -e);
+    P[2] = 0.f;
+    P[3] = 0.f;
+  }
+}
+// one thread per (column tile, k block, lane, pair of k): the two f16 of each limb it owns
+__global__ void pack_rows_weight_f16x2_kernel(const float* __restrict__ W, float* __restrict__ P, int N, int K, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int jp = (int)(i & 3), lane = (int)((i >> 2) & 63);
+  const long long rest = i >> 8;
+  const int nkb = K >> 5;
+  const int kb = (int)(rest % nkb), tile = (int)(rest / nkb);
+  const int n = tile * 16 + (lane & 15), k = kb * 32 + 8 * (lane >> 4) + 2 * jp;
+  const float un = P[1];                                  // 2^-e, a power of two: dividing by it is exact
+  float a0 = 0.f, a1 = 0.f;
+  if (n < N) {
+    a0 = W[(long long)n * K + k] / un;
+    a1 = W[(long long)n * K + k + 1] / un;
+  }
+  const rows_f16x2 hh = __builtin_convertvector(f32x2{a0, a1}, rows_f16x2);
+  const rows_f16x2 ll = __builtin_convertvector(f32x2{a0 - (float)hh[0], a1 - (float)hh[1]}, rows_f16x2);
+  unsigned* dst = reinterpret_cast<unsigned*>(P + 4) + ((long long)tile * nkb + kb) * 512 + lane * 4 + jp;   // 2 KiB = 512 words
+  dst[0] = __builtin_bit_cast(unsigned, hh);
+  dst[256] = __builtin_bit_cast(unsigned, ll);
+}
+
 // LayerNorm over the 256 columns of the 16 LDS rows of `x` (two-pass statistics like ATen), 32 threads per row.
 // out_a / out_b: LDS destinations (either may be null); add_b: optional (16 x 256, row stride 256... see use)
 // row-wise addend for out_b (query_pos); g_out: optional global destination (row pointer of row 0, stride 256).
@@ -126,10 +171,12 @@ __device__ __forceinline__ void store_tiles_lds(const f32x4 (&acc)[NT], int t0, 
 // ------------------------------------------------------------------------------------------------
 // pre: x1 = LN(core Wo^T + bo + query);  qkv = [ ((x1+pos) Wq^T + bq) * scale | (x1+pos) Wk^T + bk | x1 Wv^T + bv ]
 // ------------------------------------------------------------------------------------------------
+template <bool H>
 __global__ __launch_bounds__(DR_THREADS) void decoder_rows_pre_kernel(
     pvsg_decoder_layer L, const float* __restrict__ core, const float* __restrict__ query,
     const float* __restrict__ qpos, float* __restrict__ x1, float* __restrict__ qkv, int Q, int tiles_per_b,
-    float scale, float eps) {
+    float scale, float eps, unsigned* __restrict__ overflow) {
+  float amax = 0.f;                         // H: largest |activation| this lane split into f16 limbs
   __shared__ __attribute__((aligned(16))) float xa[16 * DR_LD], xb[16 * DR_LD], xc[16 * DR_LD];
   const int b = blockIdx.x / tiles_per_b, tile = blockIdx.x - b * tiles_per_b;
   const int q0 = tile * 16;
@@ -142,7 +189,7 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_pre_kernel(
   {
     f32x4 acc[2];
     zero_acc(acc);
-    rows_gemm<2, 16, 8>(xa, DR_LD, L.xo_w, 16, 0, w * 2, acc, lane);
+    rows_mm<H, 2, 16, 8>(xa, DR_LD, L.xo_w, 16, 0, w * 2, acc, lane, amax);
     store_tiles_lds<2>(acc, w * 2, L.xo_b, xc, DR_LD, xb, DR_LD, 0, false, lane);
   }
   __syncthreads();
@@ -153,7 +200,7 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_pre_kernel(
   {
     f32x4 acc[4];
     zero_acc(acc);
-    rows_gemm<4, 16, 4>(xc, DR_LD, L.sa_in_w, 16, 0, w * 4, acc, lane);      // q | k columns 0..511
+    rows_mm<H, 4, 16, 4>(xc, DR_LD, L.sa_in_w, 16, 0, w * 4, acc, lane, amax);      // q | k columns 0..511
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int col = (w * 4 + i) * 16 + j;
@@ -169,7 +216,7 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_pre_kernel(
   {
     f32x4 acc[2];
     zero_acc(acc);
-    rows_gemm<2, 16, 8>(xa, DR_LD, L.sa_in_w, 16, 0, 32 + w * 2, acc, lane);  // v columns 512..767
+    rows_mm<H, 2, 16, 8>(xa, DR_LD, L.sa_in_w, 16, 0, 32 + w * 2, acc, lane, amax);  // v columns 512..767
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int col = (32 + w * 2 + i) * 16 + j;
@@ -181,19 +228,22 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_pre_kernel(
       }
     }
   }
+  if constexpr (H) rows_count_overflow(amax, overflow);
 }
 
 // ------------------------------------------------------------------------------------------------
 // post
 // ------------------------------------------------------------------------------------------------
+template <bool H>
 __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
     pvsg_decoder_layer L, pvsg_decoder_head Hd, int has_layer, const float* __restrict__ next_q_w,
     const float* __restrict__ next_q_b, const float* __restrict__ x1, const float* __restrict__ qkv,
     const float* __restrict__ qpos, float* __restrict__ query_out, float* __restrict__ cls_out,
     float* __restrict__ emb_out, float* __restrict__ next_q_out, int Q, int tiles_per_b, float scale, float eps,
     float* __restrict__ ws_part, int* __restrict__ ws_count, int nspl, unsigned short* __restrict__ emb_pack,
-    unsigned* __restrict__ flags_zero) {
+    unsigned* __restrict__ flags_zero, unsigned* __restrict__ overflow) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  float amax = 0.f;                         // H: largest |activation| this lane split into f16 limbs
   __shared__ int s_last;
   float* xa = smem;                       // [16][DR_LD]
   float* xb = xa + 16 * DR_LD;
@@ -230,7 +280,7 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
     {
       f32x4 acc[2];
       zero_acc(acc);
-      rows_gemm<2, 16, 8>(xa, DR_LD, L.sa_out_w, 16, 0, w * 2, acc, lane);
+      rows_mm<H, 2, 16, 8>(xa, DR_LD, L.sa_out_w, 16, 0, w * 2, acc, lane, amax);
       store_tiles_lds<2>(acc, w * 2, L.sa_out_b, xc, DR_LD, xb, DR_LD, 0, false, lane);
     }
     __syncthreads();
@@ -242,13 +292,13 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
       {
         f32x4 acc[2];
         zero_acc(acc);
-        rows_gemm<2, 16, 8>(xa, DR_LD, L.f1_w, 16, 0, slice * 16 + w * 2, acc, lane);
+        rows_mm<H, 2, 16, 8>(xa, DR_LD, L.f1_w, 16, 0, slice * 16 + w * 2, acc, lane, amax);
         store_tiles_lds<2>(acc, slice * 16 + w * 2, L.f1_b, nullptr, 0, big, DR_LD, slice * DR_C, true, lane);
       }
       __syncthreads();
       f32x4 yacc[2];
       zero_acc(yacc);
-      rows_gemm<2, 16, 8>(big, DR_LD, L.f2_w, wkc2, slice * 16, w * 2, yacc, lane);
+      rows_mm<H, 2, 16, 8>(big, DR_LD, L.f2_w, wkc2, slice * 16, w * 2, yacc, lane, amax);
       float* part = ws_part + ((long long)bt * nspl + slice) * (16 * DR_C);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -262,7 +312,10 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
         if (s_last) ws_count[bt] = 0;                            // ready for the next launch
       }
       __syncthreads();
-      if (!s_last) return;
+      if (!s_last) {
+        if constexpr (H) rows_count_overflow(amax, overflow);
+        return;
+      }
       __threadfence();
       const float* pall = ws_part + (long long)bt * nspl * (16 * DR_C);
 #pragma unroll
@@ -281,20 +334,23 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
     } else
     // ---- FFN in hidden chunks of 512 -----------------------------------------------------------
     {
-      f32x4 yacc[2];
+      f32x4 yacc[2], ylo[2];                                     // ylo: the f16x2 form's second accumulator set, finished after the loop
       zero_acc(yacc);
+      zero_acc(ylo);
       const int nchunk = L.ffn_dim / DR_FC, wkc2 = L.ffn_dim >> 4;
       for (int c = 0; c < nchunk; ++c) {
         {
           f32x4 acc[4];
           zero_acc(acc);
-          rows_gemm<4, 16, 4>(xa, DR_LD, L.f1_w, 16, 0, c * 32 + w * 4, acc, lane);
+          rows_mm<H, 4, 16, 4>(xa, DR_LD, L.f1_w, 16, 0, c * 32 + w * 4, acc, lane, amax);
           store_tiles_lds<4>(acc, c * 32 + w * 4, L.f1_b, nullptr, 0, big, DR_LDH, c * DR_FC, true, lane);
         }
         __syncthreads();
-        rows_gemm<2, DR_FC / 16, 8>(big, DR_LDH, L.f2_w, wkc2, c * (DR_FC / 16), w * 2, yacc, lane);
+        if constexpr (H) rows_gemm_h<2, DR_FC / 32, 6>(big, DR_LDH, L.f2_w, wkc2 >> 1, c * (DR_FC / 32), w * 2, yacc, ylo, lane, amax);
+        else rows_gemm<2, DR_FC / 16, 8>(big, DR_LDH, L.f2_w, wkc2, c * (DR_FC / 16), w * 2, yacc, lane);
         __syncthreads();
       }
+      if constexpr (H) rows_finish_h<2>(yacc, ylo, L.f2_w);
       store_tiles_lds<2>(yacc, w * 2, L.f2_b, xa, DR_LD, xb, DR_LD, 0, false, lane);
     }
     __syncthreads();
@@ -323,7 +379,7 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
   {  // class logits: one column tile per wave (classes + 1 <= 128)
     f32x4 acc[1];
     zero_acc(acc);
-    rows_gemm<1, 16, 8>(xa, DR_LD, Hd.cls_w, 16, 0, w, acc, lane);
+    rows_mm<H, 1, 16, 8>(xa, DR_LD, Hd.cls_w, 16, 0, w, acc, lane, amax);
     const int col = w * 16 + j;
     if (col < Hd.num_cls_out) {
       const float bv = Hd.cls_b[col];
@@ -337,7 +393,7 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
   if (next_q_w) {  // next layer's cross-attention query: ((x3 + pos) Wq^T + bq) * scale
     f32x4 acc[2];
     zero_acc(acc);
-    rows_gemm<2, 16, 8>(xb, DR_LD, next_q_w, 16, 0, w * 2, acc, lane);
+    rows_mm<H, 2, 16, 8>(xb, DR_LD, next_q_w, 16, 0, w * 2, acc, lane, amax);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int col = (w * 2 + i) * 16 + j;
@@ -352,16 +408,16 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
   {  // mask_embed MLP: xa -> (relu) xc -> (relu) xb -> global
     f32x4 acc[2];
     zero_acc(acc);
-    rows_gemm<2, 16, 8>(xa, DR_LD, Hd.m0_w, 16, 0, w * 2, acc, lane);
+    rows_mm<H, 2, 16, 8>(xa, DR_LD, Hd.m0_w, 16, 0, w * 2, acc, lane, amax);
     __syncthreads();                                        // xb (next-q operand) and xc no longer read
     store_tiles_lds<2>(acc, w * 2, Hd.m0_b, nullptr, 0, xc, DR_LD, 0, true, lane);
     __syncthreads();
     zero_acc(acc);
-    rows_gemm<2, 16, 8>(xc, DR_LD, Hd.m1_w, 16, 0, w * 2, acc, lane);
+    rows_mm<H, 2, 16, 8>(xc, DR_LD, Hd.m1_w, 16, 0, w * 2, acc, lane, amax);
     store_tiles_lds<2>(acc, w * 2, Hd.m1_b, nullptr, 0, xb, DR_LD, 0, true, lane);
     __syncthreads();
     zero_acc(acc);
-    rows_gemm<2, 16, 8>(xb, DR_LD, Hd.m2_w, 16, 0, w * 2, acc, lane);
+    rows_mm<H, 2, 16, 8>(xb, DR_LD, Hd.m2_w, 16, 0, w * 2, acc, lane, amax);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int col = (w * 2 + i) * 16 + j;
@@ -413,6 +469,7 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
     *reinterpret_cast<h8*>(dst) = hi;
     *reinterpret_cast<h8*>(dst + LIMB) = lo;
   }
+  if constexpr (H) rows_count_overflow(amax, overflow);
 }
 
 constexpr size_t DR_POST_LDS = (size_t)(3 * 16 * DR_LD + 8 * DR_MAXQ * 16) * sizeof(float);
@@ -441,6 +498,24 @@ extern "C" int pvsg_pack_rows_weight(const float* W, float* packed, int N, int K
   return PVSG_OK;
 }
 
+extern "C" long long pvsg_rows_f16x2_packed_floats(int N, int K) {
+  return (N > 0 && K > 0 && K % 32 == 0) ? 4 + (long long)((N + 15) / 16) * 16 * K : 0;
+}
+
+extern "C" int pvsg_pack_rows_weight_f16x2(const float* W, float* packed, int N, int K, void* stream_) {
+  using namespace pvsg;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PVSG_REQUIRE(W && packed, "pack_rows_weight_f16x2: null pointer argument");
+  PVSG_REQUIRE(N > 0 && K > 0 && K % 32 == 0, "pack_rows_weight_f16x2: K must be a positive multiple of 32 (N=%d K=%d)", N, K);
+  PVSG_REQUIRE(!(reinterpret_cast<uintptr_t>(packed) & 15u), "pack_rows_weight_f16x2: packed must be 16-byte aligned");
+  hipLaunchKernelGGL(rows_f16x2_header_kernel, dim3(1), dim3(1024), 0, stream, W, packed, (long long)N * K);
+  const long long total = (long long)((N + 15) / 16) * (K / 32) * 256;
+  hipLaunchKernelGGL(pack_rows_weight_f16x2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, W, packed,
+                     N, K, total);
+  PVSG_LAUNCH_CHECK("pack_rows_weight_f16x2");
+  return PVSG_OK;
+}
+
 static int check_layer(const pvsg_decoder_layer* L, const char* who) {
   using namespace pvsg;
   PVSG_REQUIRE(L->xo_w && L->xo_b && L->n0_g && L->n0_b && L->sa_in_w && L->sa_in_b && L->sa_out_w && L->sa_out_b &&
@@ -452,9 +527,9 @@ static int check_layer(const pvsg_decoder_layer* L, const char* who) {
   return PVSG_OK;
 }
 
-extern "C" int pvsg_decoder_rows_pre(const pvsg_decoder_layer* layer, const float* attn_core, const float* query,
-                                     const float* query_pos, float* x1, float* qkv, int B, int Q,
-                                     void* stream_) {
+template <bool H>
+static int rows_pre_impl(const pvsg_decoder_layer* layer, const float* attn_core, const float* query, const float* query_pos,
+                         float* x1, float* qkv, int B, int Q, unsigned* overflow, void* stream_) {
   using namespace pvsg;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   PVSG_REQUIRE(layer && attn_core && query && query_pos && x1 && qkv, "decoder_rows_pre: null pointer argument");
@@ -462,17 +537,29 @@ extern "C" int pvsg_decoder_rows_pre(const pvsg_decoder_layer* layer, const floa
   if (Q > DR_MAXQ) return set_err(PVSG_ERR_UNSUPPORTED, "decoder_rows_pre: at most %d queries (got %d)", DR_MAXQ, Q);
   if (int rc = check_layer(layer, "decoder_rows_pre")) return rc;
   const int tiles = (Q + 15) / 16;
-  hipLaunchKernelGGL(decoder_rows_pre_kernel, dim3(B * tiles), dim3(DR_THREADS), 0, stream, *layer, attn_core, query,
-                     query_pos, x1, qkv, Q, tiles, 0.17677669529663687f, 1e-5f);
+  hipLaunchKernelGGL(decoder_rows_pre_kernel<H>, dim3(B * tiles), dim3(DR_THREADS), 0, stream, *layer, attn_core, query,
+                     query_pos, x1, qkv, Q, tiles, 0.17677669529663687f, 1e-5f, overflow);
   PVSG_LAUNCH_CHECK("decoder_rows_pre");
   return PVSG_OK;
 }
 
-extern "C" int pvsg_decoder_rows_post(const pvsg_decoder_layer* layer, const pvsg_decoder_head* head,
-                                      const float* next_q_w, const float* next_q_b, const float* x1,
-                                      const float* qkv, const float* query_pos, float* query_out, float* cls_out,
-                                      float* mask_embed_out, float* next_q_out, void* workspace, void* emb_pack_f16x2,
-                                      uint32_t* flags_zero, int B, int Q, void* stream_) {
+extern "C" int pvsg_decoder_rows_pre(const pvsg_decoder_layer* layer, const float* attn_core, const float* query,
+                                     const float* query_pos, float* x1, float* qkv, int B, int Q,
+                                     void* stream_) {
+  return rows_pre_impl<false>(layer, attn_core, query, query_pos, x1, qkv, B, Q, nullptr, stream_);
+}
+extern "C" int pvsg_decoder_rows_pre_f16x2(const pvsg_decoder_layer* layer, const float* attn_core, const float* query,
+                                           const float* query_pos, float* x1, float* qkv, int B, int Q,
+                                           uint32_t* overflow, void* stream_) {
+  return rows_pre_impl<true>(layer, attn_core, query, query_pos, x1, qkv, B, Q, overflow, stream_);
+}
+
+template <bool H>
+static int rows_post_impl(const pvsg_decoder_layer* layer, const pvsg_decoder_head* head,
+                          const float* next_q_w, const float* next_q_b, const float* x1,
+                          const float* qkv, const float* query_pos, float* query_out, float* cls_out,
+                          float* mask_embed_out, float* next_q_out, void* workspace, void* emb_pack_f16x2,
+                          uint32_t* flags_zero, int B, int Q, unsigned* overflow, void* stream_) {
   using namespace pvsg;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   PVSG_REQUIRE(head && x1 && query_pos && cls_out && mask_embed_out, "decoder_rows_post: null pointer argument");
@@ -495,17 +582,34 @@ extern "C" int pvsg_decoder_rows_post(const pvsg_decoder_layer* layer, const pvs
   const int tiles = (Q + 15) / 16;
   static std::atomic<unsigned long long> attr_done;
   {
-    const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&decoder_rows_post_kernel), (int)DR_POST_LDS, attr_done);
+    const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&decoder_rows_post_kernel<H>), (int)DR_POST_LDS, attr_done);
     if (e != hipSuccess) return set_err(PVSG_ERR_HIP, "decoder_rows_post: LDS attribute: %s", hipGetErrorString(e));
   }
   // few row tiles (a clip, or a handful of frames): split the FFN over DR_SPLIT workgroups per tile (needs the workspace)
   const int nspl = (layer && workspace && B * tiles <= DR_SPLIT_MAX_TILES && L.ffn_dim == DR_SPLIT * DR_C) ? DR_SPLIT : 1;
   float* ws_part = static_cast<float*>(workspace);
   int* ws_count = workspace ? reinterpret_cast<int*>(ws_part + (size_t)B * tiles * DR_SPLIT * 16 * DR_C) : nullptr;
-  hipLaunchKernelGGL(decoder_rows_post_kernel, dim3(B * tiles * nspl), dim3(DR_THREADS), DR_POST_LDS, stream, L, *head,
+  hipLaunchKernelGGL(decoder_rows_post_kernel<H>, dim3(B * tiles * nspl), dim3(DR_THREADS), DR_POST_LDS, stream, L, *head,
                      layer ? 1 : 0, next_q_w, next_q_b, x1, qkv, query_pos, query_out, cls_out, mask_embed_out,
                      next_q_out, Q, tiles, 0.17677669529663687f, 1e-5f, ws_part, ws_count, nspl,
-                     static_cast<unsigned short*>(emb_pack_f16x2), flags_zero);
+                     static_cast<unsigned short*>(emb_pack_f16x2), flags_zero, overflow);
   PVSG_LAUNCH_CHECK("decoder_rows_post");
   return PVSG_OK;
+}
+
+extern "C" int pvsg_decoder_rows_post(const pvsg_decoder_layer* layer, const pvsg_decoder_head* head,
+                                      const float* next_q_w, const float* next_q_b, const float* x1,
+                                      const float* qkv, const float* query_pos, float* query_out, float* cls_out,
+                                      float* mask_embed_out, float* next_q_out, void* workspace, void* emb_pack_f16x2,
+                                      uint32_t* flags_zero, int B, int Q, void* stream_) {
+  return rows_post_impl<false>(layer, head, next_q_w, next_q_b, x1, qkv, query_pos, query_out, cls_out, mask_embed_out, next_q_out,
+                               workspace, emb_pack_f16x2, flags_zero, B, Q, nullptr, stream_);
+}
+extern "C" int pvsg_decoder_rows_post_f16x2(const pvsg_decoder_layer* layer, const pvsg_decoder_head* head,
+                                            const float* next_q_w, const float* next_q_b, const float* x1,
+                                            const float* qkv, const float* query_pos, float* query_out, float* cls_out,
+                                            float* mask_embed_out, float* next_q_out, void* workspace, void* emb_pack_f16x2,
+                                            uint32_t* flags_zero, int B, int Q, uint32_t* overflow, void* stream_) {
+  return rows_post_impl<true>(layer, head, next_q_w, next_q_b, x1, qkv, query_pos, query_out, cls_out, mask_embed_out, next_q_out,
+                              workspace, emb_pack_f16x2, flags_zero, B, Q, overflow, stream_);
 }

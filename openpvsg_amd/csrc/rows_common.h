@@ -47,6 +47,120 @@ __device__ __forceinline__ void rows_gemm(const float* __restrict__ xl, int ld, 
   }
 }
 
+// ---- the same GEMM on the 16-bit matrix pipe (f16x2 split, split_common.h has the arithmetic's derivation) ------------------
+// v_mfma_f32_16x16x4_f32 runs at 1/16 of the f16 rate: a 256 x 256 layer on 16 rows is 3.4 us of matrix time on one CU, and a
+// decoder layer chains ~11 of them whatever the clip length.  Here a = a_h + 2^-11 a_l' is split per lane while it is read from
+// LDS, the packed weight carries (w_h, w_l) of w 2^e, and two accumulator sets avoid the 2^-11 w_h operand:
+//   acc += a_h w_h + a_h w_l,   lo += a_l' w_h,   out = 2^-e (acc + 2^-11 lo)          (rows_finish_h)
+// Packed layout (pvsg_pack_rows_weight_f16x2): [max|w|, 2^-e, 0, 0] then per (column tile, 32-wide k block) 2 KiB:
+// w_h fragment (lane (r, g): W[16 t + r][32 kb + 8 g + 0..7] as eight f16) | w_l fragment.  Same bytes per weight as the f32 pack.
+typedef unsigned rows_u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 rows_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 rows_f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void rows_split_pair(float a0, float a1, unsigned& h, unsigned& l, float& amax) {
+  const rows_f16x2 hh = __builtin_convertvector(f32x2{a0, a1}, rows_f16x2);
+  h = __builtin_bit_cast(unsigned, hh);
+  const float r0 = __builtin_fmaf((float)hh[0], -2048.f, a0 * 2048.f), r1 = __builtin_fmaf((float)hh[1], -2048.f, a1 * 2048.f);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, rows_f16x2));
+  amax = fmaxf(fmaxf(amax, __builtin_fabsf(a0)), __builtin_fabsf(a1));
+}
+
+__device__ __forceinline__ void rows_count_overflow(float amax, unsigned* overflow) {
+  if (overflow && !(amax <= 65504.f)) atomicAdd(overflow, 1u);            // also counts NaN operands (as the split GEMMs do)
+}
+
+__device__ __forceinline__ rows_u32x4 rows_ldg16(const rows_u32x4* p) { return *p; }
+
+// acc / lo += X[16 x (32 * nkb)] . W^T for column tiles t0 + i, k blocks kb0 .. kb0 + NKB - 1 of a weight with `wkb` blocks per tile
+template <int NT, int NKB, int DEPTH>
+__device__ __forceinline__ void rows_gemm_h(const float* __restrict__ xl, int ld, const float* __restrict__ wp, int wkb, int kb0,
+                                            int t0, f32x4 (&acc)[NT], f32x4 (&lo)[NT], int lane, float& amax) {
+  const float* xa = xl + (lane & 15) * ld + 8 * (lane >> 4);
+  // the tile index is uniform in a wave: a SCALAR base + the lane's 16-byte slot keeps the ~50 fragment addresses of a layer in
+  // SGPRs (as VGPR pairs they made this kernel spill)
+  const int t0s = __builtin_amdgcn_readfirstlane(t0);
+  const rows_u32x4* wb = reinterpret_cast<const rows_u32x4*>(wp + 4) + ((long long)t0s * wkb + kb0) * 128 + lane;
+  const long long tstride = (long long)wkb * 128;
+  rows_u32x4 ring[DEPTH][NT][2];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      ring[d][i][0] = rows_ldg16(wb + i * tstride + d * 128);
+      ring[d][i][1] = rows_ldg16(wb + i * tstride + d * 128 + 64);
+    }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    const float4 x0 = *reinterpret_cast<const float4*>(xa + kb * 32), x1 = *reinterpret_cast<const float4*>(xa + kb * 32 + 4);
+    rows_u32x4 ah, al;
+    {
+      unsigned h, l;
+      rows_split_pair(x0.x, x0.y, h, l, amax); ah[0] = h; al[0] = l;
+      rows_split_pair(x0.z, x0.w, h, l, amax); ah[1] = h; al[1] = l;
+      rows_split_pair(x1.x, x1.y, h, l, amax); ah[2] = h; al[2] = l;
+      rows_split_pair(x1.z, x1.w, h, l, amax); ah[3] = h; al[3] = l;
+      asm volatile("" : "+v"(amax));        // the running maximum is taken HERE (sunk to the end, it kept every x alive in scratch)
+    }
+    rows_u32x4 cur[NT][2];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      cur[i][0] = ring[kb % DEPTH][i][0];
+      cur[i][1] = ring[kb % DEPTH][i][1];
+    }
+    if (kb + DEPTH < NKB) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        ring[kb % DEPTH][i][0] = rows_ldg16(wb + i * tstride + (kb + DEPTH) * 128);
+        ring[kb % DEPTH][i][1] = rows_ldg16(wb + i * tstride + (kb + DEPTH) * 128 + 64);
+      }
+    }
+    const rows_f16x8 a_h = __builtin_bit_cast(rows_f16x8, ah), a_l = __builtin_bit_cast(rows_f16x8, al);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const rows_f16x8 w_h = __builtin_bit_cast(rows_f16x8, cur[i][0]), w_l = __builtin_bit_cast(rows_f16x8, cur[i][1]);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, w_h, acc[i], 0, 0, 0);
+      lo[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l, w_h, lo[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, w_l, acc[i], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// out = 2^-e (acc + 2^-11 lo); `wp` = the packed weight (its header carries 2^-e)
+template <int NT>
+__device__ __forceinline__ void rows_finish_h(f32x4 (&acc)[NT], const f32x4 (&lo)[NT], const float* __restrict__ wp) {
+  const float un = wp[1];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[i][e] = (acc[i][e] + lo[i][e] * (1.f / 2048.f)) * un;
+}
+
+// One call site for both arithmetic forms: H = false -> rows_gemm (f32 MFMA, packed by pvsg_pack_rows_weight), H = true ->
+// rows_gemm_h + rows_finish_h (packed by pvsg_pack_rows_weight_f16x2).  NKC / wkc / kc0 count 16-wide k chunks in both forms.
+// `acc` must be ZERO on entry (the f16x2 form scales what it finds in it).
+template <int NT>
+struct rows_ring_depth {                        // k blocks of B fragments in flight: <= 96 registers of ring per wave
+  static constexpr int value = NT >= 4 ? 3 : (NT == 2 ? 6 : 8);
+};
+template <bool H, int NT, int NKC, int DEPTH>
+__device__ __forceinline__ void rows_mm(const float* __restrict__ xl, int ld, const float* __restrict__ wp, int wkc, int kc0,
+                                        int t0, f32x4 (&acc)[NT], int lane, float& amax) {
+  if constexpr (H) {
+    static_assert(NKC % 2 == 0, "rows_mm: the f16x2 form walks 32-wide k blocks");
+    constexpr int NKB = NKC / 2, DH = rows_ring_depth<NT>::value < NKB ? rows_ring_depth<NT>::value : NKB;
+    f32x4 lo[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) lo[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    rows_gemm_h<NT, NKB, DH>(xl, ld, wp, wkc >> 1, kc0 >> 1, t0, acc, lo, lane, amax);
+    rows_finish_h<NT>(acc, lo, wp);
+  } else {
+    rows_gemm<NT, NKC, DEPTH>(xl, ld, wp, wkc, kc0, t0, acc, lane);
+  }
+}
+
 // all-reduce over the 64 lanes in the VALU: DPP quad / row permutations for the first four steps,
 // v_permlane16_swap / v_permlane32_swap for the last two (no LDS crossbar round trips).
 template <bool MAX>

@@ -16,7 +16,7 @@ int set_err(int code, const char* fmt, ...) {
 
 extern "C" const char* pvsg_last_error(void) { return pvsg::err_buf(); }
 extern "C" const char* pvsg_version(void) { return "openpvsg_amd-hip 0.1 (gfx950)"; }
-extern "C" int pvsg_abi_version(void) { return 10; }
+extern "C" int pvsg_abi_version(void) { return 11; }
 
 // ---- host-side codec of the result formats (no device work) ----------------------------------------------------------------
 // COCO compressed run-length strings of MANY masks at once ([3P] pycocotools rleToString: the 4th and later counts delta-coded

@@ -102,12 +102,15 @@ class DecoderRows:
         # once per forward: ~150 tensors; walking nn.Module.parameters() cost 1.2 ms per call (a tenth of a one-image forward)
         return tuple((p.data_ptr(), p._version) for m in cls._modules(head) for p in m._parameters.values() if p is not None)
 
-    def __init__(self, head):
+    def __init__(self, head, f16=None):
         self.sig = self.signature(head)
         self.keep = []                       # packed tensors / contiguous views the structs point to
+        # f16: every row GEMM on the 16-bit matrix pipe (f16x2 split, ops.rows_f16x2: the default); False: exact-f32 MFMA
+        self.f16 = ops.rows_f16x2() if f16 is None else bool(f16)
+        pack = ops.pack_rows_weight_f16x2 if self.f16 else ops.pack_rows_weight
 
         def pk(w):
-            t = ops.pack_rows_weight(w)
+            t = pack(w)
             self.keep.append(t)
             return t.data_ptr()
 
@@ -130,7 +133,7 @@ class DecoderRows:
                 f1_w=pk(f1.weight), f1_b=raw(f1.bias), f2_w=pk(f2.weight), f2_b=raw(f2.bias),
                 n2_g=raw(n2.weight), n2_b=raw(n2.bias), embed_dims=C, num_heads=8, ffn_dim=f1.out_features)
             self.layers.append(st)
-            wq = ops.pack_rows_weight(xa.in_proj_weight[:C])
+            wq = pack(xa.in_proj_weight[:C])
             bq = xa.in_proj_bias[:C].detach().contiguous()
             self.next_q.append((wq, bq))
         pn, me = head.transformer_decoder.post_norm, head.mask_embed
@@ -151,19 +154,20 @@ class DecoderRows:
     def start(self, q, q_pos, pack=None):
         """forward_head's query side on the initial queries + layer 0's cross-attention query [+ flags with `pack`]."""
         out = ops.decoder_rows_post(None, self.head, self.next_q[0] if self.layers else None, q, None,
-                                    q_pos, self.num_cls_out, pack=pack)
+                                    q_pos, self.num_cls_out, pack=pack, f16=self.f16)
         return out[1:]
 
     def layer(self, i, attn_core, q, q_pos, pack=None):
         """layer i after its cross-attention core -> (new queries, class logits, mask embeddings, next layer's q [, flags])."""
-        x1, qkv = ops.decoder_rows_pre(self.layers[i], attn_core, q, q_pos)
+        x1, qkv = ops.decoder_rows_pre(self.layers[i], attn_core, q, q_pos, f16=self.f16)
         nxt = self.next_q[i + 1] if i + 1 < len(self.layers) else None
         key = (x1.shape[0], x1.shape[1], str(x1.device))
         ws = self._ws.get(key, False)
         if ws is False:                              # zeroed once; the kernel leaves its arrival counters at zero
             ws = self._ws[key] = (ops.decoder_rows_post_workspace(x1.shape[0], x1.shape[1], x1.device)
                                   if os.environ.get('PVSG_DECODER_ROWS_SPLIT', 'on') != 'off' else None)
-        return ops.decoder_rows_post(self.layers[i], self.head, nxt, x1, qkv, q_pos, self.num_cls_out, workspace=ws, pack=pack)
+        return ops.decoder_rows_post(self.layers[i], self.head, nxt, x1, qkv, q_pos, self.num_cls_out, workspace=ws, pack=pack,
+                                     f16=self.f16)
 
 
 class _Mask2FormerHeadBase(BaseModule):
@@ -277,10 +281,12 @@ class _Mask2FormerHeadBase(BaseModule):
             self._rows_ok = DecoderRows.supported(self)
         if not self._rows_ok or not self.query_feat.weight.is_cuda or torch.is_grad_enabled():
             return None                      # forward-only kernels: under autograd the module path runs, like the other fast paths
-        st = getattr(self, '_rows_state', None)
+        f16 = ops.rows_f16x2()               # both forms' packs live side by side (the bf16x3 re-run takes the f32 rows)
+        states = self.__dict__.setdefault('_rows_states', {})
+        st = states.get(f16)
         if st is None or st.sig != DecoderRows.signature(self):
             with torch.no_grad():
-                st = self._rows_state = DecoderRows(self)
+                st = states[f16] = DecoderRows(self, f16)
         return st
 
     def _kv_project(self, mha, level, src, B, T):

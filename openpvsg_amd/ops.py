@@ -1471,15 +1471,41 @@ def pack_rows_weight(W):
     return out
 
 
-def decoder_rows_pre(layer_struct, attn_core, query, query_pos):
-    """x1 = LN(attn_core Wo^T + bo + query); qkv = self-attention in_proj of x1 (q scaled). (B,Q,256) -> x1, qkv (B,Q,768)."""
+def rows_f16x2():
+    """True: the query-row kernels (decoder_rows.hip) run their GEMMs on the 16-bit matrix pipe (f16x2 split, weights packed by
+    pack_rows_weight_f16x2) -- the default wherever the token GEMMs do; PVSG_ROWS=f32 or the bf16x3 split mode (the re-run after
+    an f16 range overflow) keep the exact-f32 MFMA form."""
+    return split_mode() == 'f16x2' and os.environ.get('PVSG_ROWS', 'f16x2') != 'f32'
+
+
+def pack_rows_weight_f16x2(W):
+    """(N,K) Linear weight -> f16x2 fragment order of the row kernels (header + roundup16(N)*K floats of limb pairs), once per
+    checkpoint."""
+    W = _chk(W.detach(), 'W')
+    N, K = W.shape
+    n = int(_lib.load().pvsg_rows_f16x2_packed_floats(N, K))
+    if n <= 0:
+        raise RuntimeError('pack_rows_weight_f16x2: K must be a multiple of 32 (N=%d K=%d)' % (N, K))
+    out = torch.empty((n,), device=W.device, dtype=torch.float32)
+    with _on(W.device):
+        _lib.call('pvsg_pack_rows_weight_f16x2', W.data_ptr(), out.data_ptr(), N, K, _stream_ptr())
+    return out
+
+
+def decoder_rows_pre(layer_struct, attn_core, query, query_pos, f16=False):
+    """x1 = LN(attn_core Wo^T + bo + query); qkv = self-attention in_proj of x1 (q scaled). (B,Q,256) -> x1, qkv (B,Q,768).
+    f16: the struct's weights are pack_rows_weight_f16x2 packs (the f16x2 entry, counting range overflows)."""
     core, q, pos = _chk(attn_core, 'attn_core'), _chk(query, 'query'), _chk(query_pos, 'query_pos')
     B, Q, C = q.shape
     x1 = torch.empty_like(q)
     qkv = torch.empty((B, Q, 3 * C), device=q.device, dtype=torch.float32)
     with _on(q.device):
-        _lib.call('pvsg_decoder_rows_pre', ctypes.byref(layer_struct), core.data_ptr(), q.data_ptr(), pos.data_ptr(),
-                  x1.data_ptr(), qkv.data_ptr(), B, Q, _stream_ptr())
+        if f16:
+            _lib.call('pvsg_decoder_rows_pre_f16x2', ctypes.byref(layer_struct), core.data_ptr(), q.data_ptr(), pos.data_ptr(),
+                      x1.data_ptr(), qkv.data_ptr(), B, Q, _overflow_counter(q.device).data_ptr(), _stream_ptr())
+        else:
+            _lib.call('pvsg_decoder_rows_pre', ctypes.byref(layer_struct), core.data_ptr(), q.data_ptr(), pos.data_ptr(),
+                      x1.data_ptr(), qkv.data_ptr(), B, Q, _stream_ptr())
     return x1, qkv
 
 
@@ -1498,7 +1524,7 @@ def decoder_rows_pack_buffer(B, Q, device):
     return buf
 
 
-def decoder_rows_post(layer_struct, head_struct, next_q, x1, qkv, query_pos, num_cls_out, workspace=None, pack=None):
+def decoder_rows_post(layer_struct, head_struct, next_q, x1, qkv, query_pos, num_cls_out, workspace=None, pack=None, f16=False):
     """Self-attention + FFN + norms (layer_struct None: skipped, x1 = the queries) and the query side of
     forward_head; next_q = (packed Wq, bq) of the next layer's cross-attention or None.
     pack: None, or a decoder_rows_pack_buffer: the kernel also writes the packed mask embeddings there and zeroes a fresh
@@ -1513,15 +1539,18 @@ def decoder_rows_post(layer_struct, head_struct, next_q, x1, qkv, query_pos, num
     nq = torch.empty_like(x1) if next_q is not None else None
     flags = torch.empty((B, 4), device=dev, dtype=torch.int32) if pack is not None else None
     with _on(dev):
-        _lib.call('pvsg_decoder_rows_post', ctypes.byref(layer_struct) if layer_struct is not None else None,
-                  ctypes.byref(head_struct), next_q[0].data_ptr() if next_q is not None else None,
-                  next_q[1].data_ptr() if next_q is not None else None, x1.data_ptr(),
-                  _chk(qkv, 'qkv').data_ptr() if qkv is not None else None, pos.data_ptr(),
-                  q_out.data_ptr() if q_out is not None else None, cls.data_ptr(), emb.data_ptr(),
-                  nq.data_ptr() if nq is not None else None,
-                  workspace.data_ptr() if workspace is not None else None,
-                  pack.data_ptr() if pack is not None else None, flags.data_ptr() if flags is not None else None,
-                  B, Q, _stream_ptr())
+        args = [ctypes.byref(layer_struct) if layer_struct is not None else None,
+                ctypes.byref(head_struct), next_q[0].data_ptr() if next_q is not None else None,
+                next_q[1].data_ptr() if next_q is not None else None, x1.data_ptr(),
+                _chk(qkv, 'qkv').data_ptr() if qkv is not None else None, pos.data_ptr(),
+                q_out.data_ptr() if q_out is not None else None, cls.data_ptr(), emb.data_ptr(),
+                nq.data_ptr() if nq is not None else None,
+                workspace.data_ptr() if workspace is not None else None,
+                pack.data_ptr() if pack is not None else None, flags.data_ptr() if flags is not None else None, B, Q]
+        if f16:                                  # the struct's weights are pack_rows_weight_f16x2 packs
+            _lib.call('pvsg_decoder_rows_post_f16x2', *args, _overflow_counter(dev).data_ptr(), _stream_ptr())
+        else:
+            _lib.call('pvsg_decoder_rows_post', *args, _stream_ptr())
     return (q_out, cls, emb, nq) if pack is None else (q_out, cls, emb, nq, flags)
 
 

@@ -23,7 +23,7 @@ def test_header_declares_something():
 def test_library_exports_every_declared_symbol(hip_lib):
     for fn in header_functions():
         assert hasattr(hip_lib, fn), 'missing export: ' + fn
-    assert hip_lib.pvsg_abi_version() == 10
+    assert hip_lib.pvsg_abi_version() == 11
     assert b'gfx950' in hip_lib.pvsg_version()
 
 

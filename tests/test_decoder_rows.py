@@ -55,11 +55,12 @@ def _torch_head_side(head, x3, q_pos, next_layer):
     return cls, emb, nq
 
 
+@pytest.mark.parametrize('f16', [True, False], ids=['f16x2', 'f32'])      # 16-bit matrix pipe (default) / exact-f32 MFMA form
 @pytest.mark.parametrize('B,Q', [(1, 100), (3, 100), (2, 37), (1, 128), (5, 16), (8, 100)])   # (8,100): 56 row tiles, un-split FFN
-def test_rows_kernels_vs_torch(hip_lib, B, Q):
+def test_rows_kernels_vs_torch(hip_lib, B, Q, f16):
     from openpvsg_amd.heads import DecoderRows
     head = _head(True, 11)
-    rows = DecoderRows(head)
+    rows = DecoderRows(head, f16=f16)
     core = det_input('core', (B, Q, 256), 1).to(DEV)
     q = det_input('q', (B, Q, 256), 2).to(DEV)
     q_pos = det_input('pos', (Q, 256), 3).to(DEV)
@@ -85,18 +86,19 @@ def test_rows_kernels_vs_torch(hip_lib, B, Q):
         np.testing.assert_allclose(nq.cpu().numpy(), nq_ref.cpu().numpy(), rtol=2e-4, atol=2e-4)
 
 
-def test_pre_kernel_outputs(hip_lib):
+@pytest.mark.parametrize('f16', [True, False], ids=['f16x2', 'f32'])
+def test_pre_kernel_outputs(hip_lib, f16):
     """x1 and the self-attention in-projection (scaled q | k | v) of decoder_rows_pre on their own."""
     from openpvsg_amd import ops
     from openpvsg_amd.heads import DecoderRows
     head = _head(False, 12)
-    rows = DecoderRows(head)
+    rows = DecoderRows(head, f16=f16)
     B, Q = 2, 100
     core, q = det_input('core', (B, Q, 256), 4).to(DEV), det_input('q', (B, Q, 256), 5).to(DEV)
     q_pos = det_input('pos', (Q, 256), 6).to(DEV)
     layer = head.transformer_decoder.layers[3]
     with torch.no_grad():
-        x1, qkv = ops.decoder_rows_pre(rows.layers[3], core, q, q_pos)
+        x1, qkv = ops.decoder_rows_pre(rows.layers[3], core, q, q_pos, f16=f16)
         x1_ref = layer.norms[0](q + layer.attentions[0].attn.out_proj(core))
         sa = layer.attentions[1].attn
         W, b = sa.in_proj_weight, sa.in_proj_bias
@@ -240,3 +242,55 @@ def test_fused_kv_projection_equals_inputs_plus_two_gemms(hip_lib, video, B, T, 
         k_old, v_old = head.transformer_decoder.layers[4].attentions[0].project_kv(k2.view(B, -1, 256), v2.view(B, -1, 256))
     assert float((kp - k_old).abs().max()) < 1e-4 and float((vp - v_old).abs().max()) < 1e-4
     assert ops.split_overflow_count() == 0
+
+
+def test_rows_f16x2_error_vs_f64_is_f32_class(hip_lib):
+    """The f16x2 row GEMMs against an f64 statement of the in-projection: their error is at the level of the exact-f32 MFMA
+    form's (both are f32-accumulated dot products of 256 terms), far below the parity tolerances."""
+    from openpvsg_amd import ops
+    from openpvsg_amd.heads import DecoderRows
+    head = _head(False, 21)
+    B, Q = 2, 100
+    core, q = det_input('core', (B, Q, 256), 4).to(DEV), det_input('q', (B, Q, 256), 5).to(DEV)
+    q_pos = det_input('pos', (Q, 256), 6).to(DEV)
+    layer = head.transformer_decoder.layers[2]
+    sa = layer.attentions[1].attn
+    err = {}
+    with torch.no_grad():
+        for f16 in (True, False):
+            rows = DecoderRows(head, f16=f16)
+            x1, qkv = ops.decoder_rows_pre(rows.layers[2], core, q, q_pos, f16=f16)
+            x1d, W, b = x1.double(), sa.in_proj_weight.double(), sa.in_proj_bias.double()
+            ref = torch.cat([F.linear(x1d + q_pos.double(), W[:256], b[:256]) * 32 ** -0.5,
+                             F.linear(x1d + q_pos.double(), W[256:512], b[256:512]), F.linear(x1d, W[512:], b[512:])], -1)
+            err[f16] = float((qkv.double() - ref).abs().max() / ref.abs().max())
+    assert err[True] < 2e-6 and err[False] < 2e-6, err
+    assert err[True] < 4 * err[False] + 2e-7, err
+    assert ops.split_overflow_count(DEV) == 0
+
+
+def test_rows_f16x2_counts_range_overflow_and_head_falls_back(hip_lib):
+    """|activation| > 65504 cannot be split into f16 limbs: the f16x2 row kernels count it (the detectors / the pipeline then
+    re-run the call under force_split('bf16x3'), where the head takes the exact-f32 rows), small magnitudes do not count."""
+    from openpvsg_amd import ops
+    head = _head(False, 22)
+    q = det_input('q', (1, 100, 256), 7).to(DEV)
+    q_pos = det_input('pos', (100, 256), 8).to(DEV)
+    with torch.no_grad():
+        ops.split_overflow_count(DEV)
+        st = head._rows()
+        assert st.f16 == ops.rows_f16x2()
+        if not st.f16:
+            pytest.skip('PVSG_ROWS=f32 / PVSG_SPLIT=bf16x3 in the environment')
+        st.start(q, q_pos)
+        assert ops.split_overflow_count(DEV) == 0
+        big = q.clone()
+        big[0, 3, 5] = 1.0e6                   # post_norm of the head-only form sees it before any GEMM: use the next-q operand
+        st.start(big, q_pos)                   # x + pos feeds the next-q projection un-normalised
+        assert ops.split_overflow_count(DEV) > 0
+        with ops.force_split('bf16x3'):
+            st32 = head._rows()
+            assert st32 is not st and not st32.f16
+            out = st32.start(big, q_pos)
+        assert ops.split_overflow_count(DEV) == 0 and all(torch.isfinite(o).all() for o in out if o is not None)
+        assert head._rows() is st              # both packs stay cached side by side
