@@ -34,6 +34,21 @@ constexpr int DR_MAXQ = 128;
 constexpr int DR_SPLIT = 8;               // workgroups per row tile in the split form of decoder_rows_post (256 hidden units each)
 constexpr int DR_SPLIT_MAX_TILES = 32;    // above this many row tiles the chip is full without the split
 
+// lab builds only (scripts/lab/rows_stamps.sh): wall-clock stamps (s_memrealtime, 10 ns) of the stages of decoder_rows_post for the
+// eight workgroups of row tile 0, read back through pvsg_debug_rows_stamps
+#ifndef PVSG_ROWS_STAMPS
+#define PVSG_ROWS_STAMPS 0
+#endif
+#if PVSG_ROWS_STAMPS
+__device__ unsigned long long g_rows_stamps[8 * 32];
+#define DR_STAMP(i)                                                                          \
+  do {                                                                                       \
+    if (threadIdx.x == 0 && bt == 0) g_rows_stamps[slice * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define DR_STAMP(i) do { } while (0)
+#endif
+
 __global__ void pack_rows_weight_kernel(const float* __restrict__ W, float* __restrict__ P, int N, int K,
                                         long long total) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -262,6 +277,7 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
   const int g = lane >> 4, j = lane & 15;
 
   if (has_layer) {
+    DR_STAMP(0);
     // ---- self-attention: wave = head ---------------------------------------------------------
     load_tile(xc, x1 + row0 * DR_C, valid);                    // x1 tile (identity of the self-attention)
 #pragma unroll
@@ -272,10 +288,12 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
       *reinterpret_cast<float4*>(xb + r * DR_LD + c) = v;
     }
     __syncthreads();
+    DR_STAMP(1);
     // one wave per head, on the matrix cores (rows_common.h: S = Q K^T and O = P V as 16 x 16 x 4 tiles, soft-max on the
     // accumulators); the scalar-FMA form this replaces took ~12 of the kernel's 87 us
     rows_attention_h32(xb, xa, DR_LD, big + w * (DR_MAXQ * 16), qkv + (long long)b * Q * (3 * DR_C), 3 * DR_C, DR_C, Q, w, lane);
     __syncthreads();
+    DR_STAMP(2);
     // ---- out_proj + identity + LN -> x2 (xa) -------------------------------------------------
     {
       f32x4 acc[2];
@@ -284,8 +302,10 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
       store_tiles_lds<2>(acc, w * 2, L.sa_out_b, xc, DR_LD, xb, DR_LD, 0, false, lane);
     }
     __syncthreads();
+    DR_STAMP(3);
     rows_layernorm(xb, L.n1_g, L.n1_b, eps, xa, nullptr, nullptr, nullptr, valid);
     __syncthreads();
+    DR_STAMP(4);
     if (nspl > 1) {
       // ---- FFN, hidden units [256 slice, 256 slice + 256) ------------------------------------------------------
       const int wkc2 = L.ffn_dim >> 4;
@@ -296,16 +316,29 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
         store_tiles_lds<2>(acc, slice * 16 + w * 2, L.f1_b, nullptr, 0, big, DR_LD, slice * DR_C, true, lane);
       }
       __syncthreads();
+      DR_STAMP(5);
       f32x4 yacc[2];
       zero_acc(yacc);
       rows_mm<H, 2, 16, 8>(big, DR_LD, L.f2_w, wkc2, slice * 16, w * 2, yacc, lane, amax);
-      float* part = ws_part + ((long long)bt * nspl + slice) * (16 * DR_C);
+      // The partial meets the other seven through memory WITHOUT a release fence: __threadfence() is buffer_wbl2 -- a write-back
+      // of everything dirty in this XCD's 4 MB L2 (7.9 us here, and 12 us for the fence + loads on the reading side:
+      // profiles/r06_rows_stamps.txt).  Instead the partial itself is stored / loaded at AGENT scope (relaxed atomics = sc1
+      // accesses: written through the non-coherent L2, read past it), the stores are complete before the barrier that precedes
+      // the arrival count, and the reader's loads are issued after the barrier that follows it.  Layout: the accumulator
+      // fragments as the lanes hold them, [wave][tile i][lane][e] -- 8-byte accesses, 512 B per wave instruction.
+      unsigned long long* part = reinterpret_cast<unsigned long long*>(ws_part + ((long long)bt * nspl + slice) * (16 * DR_C));
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) part[(4 * g + e) * DR_C + (w * 2 + i) * 16 + j] = yacc[i][e];
-      __threadfence();                                           // the partial is visible device-wide before the count
+        for (int hh = 0; hh < 2; ++hh) {
+          const unsigned long long bits = (unsigned long long)__float_as_uint(yacc[i][2 * hh]) |
+                                          ((unsigned long long)__float_as_uint(yacc[i][2 * hh + 1]) << 32);
+          __hip_atomic_store(part + ((w * 2 + i) * 64 + lane) * 2 + hh, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      DR_STAMP(6);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the write-through stores have been acknowledged
       __syncthreads();
+      DR_STAMP(7);
       if (threadIdx.x == 0) {
         const int old = atomicAdd(ws_count + bt, 1);
         s_last = old == nspl - 1;
@@ -316,21 +349,29 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
         if constexpr (H) rows_count_overflow(amax, overflow);
         return;
       }
-      __threadfence();
-      const float* pall = ws_part + (long long)bt * nspl * (16 * DR_C);
+      DR_STAMP(8);
+      const unsigned long long* pall = reinterpret_cast<const unsigned long long*>(ws_part + (long long)bt * nspl * (16 * DR_C));
+      f32x4 sum[2];
+      zero_acc(sum);
+      unsigned long long bits[DR_SPLIT][2][2];                   // nspl > 1 means nspl == DR_SPLIT: all 32 loads in flight at once
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int idx = threadIdx.x + it * DR_THREADS;
-        const int r = idx >> 6, c = (idx & 63) * 4;
-        float4 v = ld4(L.f2_b + c);
-        const float4 x2 = *reinterpret_cast<const float4*>(xa + r * DR_LD + c);
-        v.x += x2.x; v.y += x2.y; v.z += x2.z; v.w += x2.w;
-        for (int sl = 0; sl < nspl; ++sl) {
-          const float4 p = ld4_stream(pall + (long long)sl * (16 * DR_C) + r * DR_C + c);
-          v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-        }
-        *reinterpret_cast<float4*>(xb + r * DR_LD + c) = v;
-      }
+      for (int sl = 0; sl < DR_SPLIT; ++sl)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+            bits[sl][i][hh] = __hip_atomic_load(pall + (long long)sl * (8 * DR_C) + ((w * 2 + i) * 64 + lane) * 2 + hh,
+                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int sl = 0; sl < DR_SPLIT; ++sl)                      // slice order: the sum does not depend on who arrived when
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            sum[i][2 * hh] += __uint_as_float((unsigned)bits[sl][i][hh]);
+            sum[i][2 * hh + 1] += __uint_as_float((unsigned)(bits[sl][i][hh] >> 32));
+          }
+      store_tiles_lds<2>(sum, w * 2, L.f2_b, xa, DR_LD, xb, DR_LD, 0, false, lane);     // + bias + x2 (identity) -> xb
     } else
     // ---- FFN in hidden chunks of 512 -----------------------------------------------------------
     {
@@ -354,6 +395,7 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
       store_tiles_lds<2>(yacc, w * 2, L.f2_b, xa, DR_LD, xb, DR_LD, 0, false, lane);
     }
     __syncthreads();
+    DR_STAMP(9);
     // x3 -> xc (+ global), x3 + pos -> xb is done below after the head reads
     rows_layernorm(xb, L.n2_g, L.n2_b, eps, xc, nullptr, nullptr, query_out + row0 * DR_C, valid);
     __syncthreads();
@@ -376,6 +418,7 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
     }
   }
   __syncthreads();
+  DR_STAMP(10);
   {  // class logits: one column tile per wave (classes + 1 <= 128)
     f32x4 acc[1];
     zero_acc(acc);
@@ -390,6 +433,7 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
       }
     }
   }
+  DR_STAMP(11);
   if (next_q_w) {  // next layer's cross-attention query: ((x3 + pos) Wq^T + bq) * scale
     f32x4 acc[2];
     zero_acc(acc);
@@ -405,6 +449,7 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
       }
     }
   }
+  DR_STAMP(12);
   {  // mask_embed MLP: xa -> (relu) xc -> (relu) xb -> global
     f32x4 acc[2];
     zero_acc(acc);
@@ -412,10 +457,12 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
     __syncthreads();                                        // xb (next-q operand) and xc no longer read
     store_tiles_lds<2>(acc, w * 2, Hd.m0_b, nullptr, 0, xc, DR_LD, 0, true, lane);
     __syncthreads();
+    DR_STAMP(13);
     zero_acc(acc);
     rows_mm<H, 2, 16, 8>(xc, DR_LD, Hd.m1_w, 16, 0, w * 2, acc, lane, amax);
     store_tiles_lds<2>(acc, w * 2, Hd.m1_b, nullptr, 0, xb, DR_LD, 0, true, lane);
     __syncthreads();
+    DR_STAMP(14);
     zero_acc(acc);
     rows_mm<H, 2, 16, 8>(xb, DR_LD, Hd.m2_w, 16, 0, w * 2, acc, lane, amax);
 #pragma unroll
@@ -431,6 +478,7 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
       }
     }
   }
+  DR_STAMP(15);
   if (flags_zero && tile == 0 && threadIdx.x < 4) flags_zero[b * 4 + threadIdx.x] = 0u;   // the flag words the bits kernel ORs into
   if (emb_pack) {
     // The mask embeddings of these 16 queries as the ROW operand of the attention-mask-bits GEMM (csrc/split_conv1x1.h, f16x2
@@ -469,6 +517,7 @@ __global__ __launch_bounds__(DR_THREADS) void decoder_rows_post_kernel(
     *reinterpret_cast<h8*>(dst) = hi;
     *reinterpret_cast<h8*>(dst + LIMB) = lo;
   }
+  DR_STAMP(16);
   if constexpr (H) rows_count_overflow(amax, overflow);
 }
 
@@ -497,6 +546,12 @@ extern "C" int pvsg_pack_rows_weight(const float* W, float* packed, int N, int K
   PVSG_LAUNCH_CHECK("pack_rows_weight");
   return PVSG_OK;
 }
+
+#if PVSG_ROWS_STAMPS
+extern "C" int pvsg_debug_rows_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pvsg::g_rows_stamps), sizeof(unsigned long long) * 8 * 32);
+}
+#endif
 
 extern "C" long long pvsg_rows_f16x2_packed_floats(int N, int K) {
   return (N > 0 && K > 0 && K % 32 == 0) ? 4 + (long long)((N + 15) / 16) * 16 * K : 0;

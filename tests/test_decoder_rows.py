@@ -294,3 +294,46 @@ def test_rows_f16x2_counts_range_overflow_and_head_falls_back(hip_lib):
             out = st32.start(big, q_pos)
         assert ops.split_overflow_count(DEV) == 0 and all(torch.isfinite(o).all() for o in out if o is not None)
         assert head._rows() is st              # both packs stay cached side by side
+
+
+@pytest.mark.parametrize('f16', [True, False], ids=['f16x2', 'f32'])
+def test_split_rendezvous_never_meets_a_stale_partial(hip_lib, f16):
+    """The eight workgroups of a row tile exchange their FFN partials through agent-scope (write-through / L2-bypassing) accesses
+    instead of a fence: 400 back-to-back launches over changing layers and inputs, each compared with the un-split kernel's
+    result for the same (layer, input) -- a partial left over from the previous launch, or one not yet visible, would be off by
+    O(1); and the launches are bit-reproducible."""
+    from openpvsg_amd import ops
+    from openpvsg_amd.heads import DecoderRows
+    head = _head(True, 31)
+    rows = DecoderRows(head, f16=f16)
+    B, Q = 1, 100
+    q_pos = det_input('pos', (Q, 256), 3).to(DEV)
+    combos = []
+    with torch.no_grad():
+        for k in range(9):
+            core = det_input('core', (B, Q, 256), 100 + k).to(DEV)
+            q = det_input('q', (B, Q, 256), 200 + k).to(DEV)
+            x1, qkv = ops.decoder_rows_pre(rows.layers[k], core, q, q_pos, f16=f16)
+            nxt = rows.next_q[k + 1] if k + 1 < 9 else None
+            ref = ops.decoder_rows_post(rows.layers[k], rows.head, nxt, x1, qkv, q_pos, rows.num_cls_out, workspace=None, f16=f16)
+            combos.append((k, x1, qkv, nxt, ref))
+        ws = ops.decoder_rows_post_workspace(B, Q, DEV)
+        assert ws is not None
+        order = [(7 * i * i + 3 * i) % 9 for i in range(400)]
+        outs = [ops.decoder_rows_post(rows.layers[k], rows.head, combos[k][3], combos[k][1], combos[k][2], q_pos,
+                                      rows.num_cls_out, workspace=ws, f16=f16) for k in order]
+        torch.cuda.synchronize()
+        first = {}
+        for k, out in zip(order, outs):
+            ref = combos[k][4]
+            for a, b in zip(out, ref):
+                if a is None:
+                    assert b is None
+                    continue
+                scale = float(b.abs().max())
+                assert float((a - b).abs().max()) <= 2e-5 * scale, (k, float((a - b).abs().max()), scale)
+            if k in first:
+                assert all(torch.equal(a, b) for a, b in zip(out, first[k]) if a is not None)
+            else:
+                first[k] = out
+        assert int(ws.view(torch.int32)[-7:].abs().sum()) == 0        # the arrival counters are back at zero
