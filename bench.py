@@ -328,7 +328,7 @@ class KernelTimer:
     SPLIT_F16X2 = ('pvsg_gemm_f16x2', 'pvsg_gemm_f16x2_add_layernorm', 'pvsg_conv1x1_f16x2', 'pvsg_conv3x3_f16x2',
                    'pvsg_mask_logits_f16x2', 'pvsg_attn_mask_bits_f16x2', 'pvsg_attn_mask_bits_packed_f16x2',
                    'pvsg_conv1x1_f16x2_stats', 'pvsg_conv3x3_f16x2_stats', 'pvsg_bottleneck_tail_f16x2',
-                   'pvsg_stem7x7_f16x2_bn_relu_pool')
+                   'pvsg_stem7x7_f16x2_bn_relu_pool', 'pvsg_decoder_rows_pre_f16x2', 'pvsg_decoder_rows_post_f16x2')
 
     @classmethod
     def work(cls, name, a):
@@ -354,6 +354,11 @@ class KernelTimer:
         if name == 'pvsg_conv3x3_f16x2_stats':          # (x, wp, scale, shift, y, part, B, Cin, Cout, H, W, relu, ..), stride 1
             N, Cin, Cout, H, W = a[6:11]
             return 4.0 * N * H * W * (Cin + Cout) + 54.0 * Cin * Cout, 3 * 18.0 * N * Cin * Cout * H * W
+        if name in ('pvsg_decoder_rows_pre_f16x2', 'pvsg_decoder_rows_post_f16x2'):
+            # the query-row kernels with their GEMMs on the f16 pipe (same arguments + overflow): 3 limb products per multiply-add
+            # (the 100 x 100 self-attention stays on the f32 MFMA: < 2 % of the kernel's flops, counted with the rest)
+            by, fl = cls._work(name[:-len('_f16x2')], a)
+            return by, 3.0 * fl
         if name in cls.SPLIT_F16X2:
             # two-limb f16 form: same arguments up to the trailing (overflow, stream); flops = the f16 limb products issued,
             # 3 per f32 multiply-add (the bf16 form issues 6)
