@@ -136,13 +136,24 @@ def test_bench_gpus_8_ranks_of_4_frames_at_720p_equals_single_process(hip_lib):
               '--sub-benchmarks', 'off', '--checksum']
     env = dict(os.environ, PVSG_ONE_DEVICE='1', PVSG_GEMM_TABLE='off', MASTER_PORT=str(_free_port()))
 
+    torch.cuda.empty_cache()                 # nine more processes are about to share this GPU: hand the suite's cached blocks back
+
     def run(extra):
-        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + extra + common, env=env, capture_output=True,
-                           text=True, timeout=580)
-        assert r.returncode == 0, r.stderr[-2000:]
+        # A rank that DIES (rendezvous port taken between _free_port() and the bind, out of device memory next to the suite's
+        # process, a neighbour's job on the box) says nothing about the sharded arithmetic: one more attempt on a fresh port.
+        # What the ranks COMPUTE is never retried -- any difference from the single process fails below.
+        for attempt in (0, 1):
+            env['MASTER_PORT'] = str(_free_port())
+            r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + extra + common, env=env, capture_output=True,
+                               text=True, timeout=280)
+            if r.returncode == 0:
+                break
+            print('bench.py %s: exit code %d (attempt %d)\n%s' % (extra, r.returncode, attempt, r.stderr[-3000:]))
+        assert r.returncode == 0, r.stderr[-3000:]
         return json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     eight = run(['--gpus', '8', '--backend', 'gloo'])
     one = run([])
+    print('8 ranks:', eight['checksum'], '\n1 rank: ', one['checksum'])
     assert eight['n_gpus'] == 8 and eight['scaling'] == 'strong' and eight['config']['frames_per_gpu'] == 4
     assert one['n_gpus'] == 1 and one['config']['frames_per_gpu'] == 32
     assert eight['checksum']['tube_ids'] == one['checksum']['tube_ids'] and len(one['checksum']['tube_ids']) >= 30
