@@ -4,8 +4,8 @@
 //   span small  (16 KB)         -> L1 (TCP) hits
 //   span medium (1 MB / XCD)    -> L2 hits, L1 misses
 //   span large  (64 MB)         -> MALL / HBM
-// pattern 0: one contiguous 1 KiB per wave instruction; pattern 1: eight 128-byte rows 1 KiB apart (the MSDA shape: lane (h, q)
-// reads 16 bytes of row h).  Prints bytes / clock / CU (s_memtime clocks of the shader) and GB/s per CU.
+// patterns: 0 contiguous 1 KiB per wave instruction; 1 eight 128-byte rows 1 KiB apart; 2 eight 128-byte rows at random places
+// (the MSDA gather: lane (h, q) reads 16 bytes of head h's row).  Prints GB/s per CU (HIP events) and bytes per s_memtime tick.
 //   hipcc --offload-arch=gfx950 -O3 scripts/lab/vmem_ceiling.hip -o /tmp/vmem_ceiling && /tmp/vmem_ceiling
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -19,22 +19,36 @@ __global__ __launch_bounds__(1024) void walk(const char* __restrict__ buf, long 
                                              float* __restrict__ sink, unsigned long long* __restrict__ clocks) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const char* base = buf + (long long)blockIdx.x * wg_stride;
-  // PATTERN 0: lane l reads bytes [16 l, 16 l + 16) of a 1 KiB slab; PATTERN 1: lane (h = l >> 3, q = l & 7) reads 16 bytes at
-  // h * 1 KiB + 16 q of an 8 KiB slab (eight 128-byte rows): 8 slabs' worth of row 0..7 segments are visited by 8 instructions
-  const long long slab = PATTERN == 0 ? 1024 : 8192;
-  const long long nslab = span / slab;
+  // Eight independent wave loads per step in every pattern (8 KiB requested per wave and step):
+  //  0: eight contiguous 1 KiB slabs (lane l: bytes 16 l .. 16 l + 15 of each)
+  //  1: an 8 KiB slab as eight 128-byte rows 1 KiB apart, segment k of every row per instruction (lane (h = l >> 3, q = l & 7))
+  //  2: GATHER -- per instruction eight 128-byte rows at pseudo-random 128-byte-aligned places of the span, one per lane group
+  //     (the shape of msda_fused's corner loads: a head's 32 channels of one token)
+  const long long nstep = span / 8192;
+  const unsigned nrow = (unsigned)(span / 128);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  unsigned seed = (blockIdx.x * 131u + wave * 17u + (lane >> 3)) * 2654435761u + 12345u;
   __syncthreads();
   const unsigned long long t0 = __builtin_readcyclecounter();
   for (int r = 0; r < reps; ++r) {
-    for (long long s = wave; s < nslab; s += nw) {
-      if (PATTERN == 0) {
-        acc += *reinterpret_cast<const f32x4*>(base + s * 1024 + lane * 16);
-      } else {
+    const long long steps = nstep > nw ? nstep : nw;            // small spans: every wave still walks (step -> slab modulo the span)
+    for (long long s0 = wave; s0 < steps; s0 += nw) {
+      const long long s = s0 % nstep;
+      f32x4 v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)       // segment k of each of the 8 rows of this slab
-          acc += *reinterpret_cast<const f32x4*>(base + s * 8192 + (lane >> 3) * 1024 + k * 128 + (lane & 7) * 16);
+      for (int k = 0; k < 8; ++k) {
+        if (PATTERN == 0) {
+          v[k] = *reinterpret_cast<const f32x4*>(base + s * 8192 + k * 1024 + lane * 16);
+        } else if (PATTERN == 1) {
+          v[k] = *reinterpret_cast<const f32x4*>(base + s * 8192 + (lane >> 3) * 1024 + k * 128 + (lane & 7) * 16);
+        } else {
+          seed = seed * 1664525u + 1013904223u;
+          const unsigned row = (seed >> 8) % nrow;
+          v[k] = *reinterpret_cast<const f32x4*>(base + (long long)row * 128 + (lane & 7) * 16);
+        }
       }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += v[k];
     }
   }
   __syncthreads();
@@ -59,18 +73,20 @@ int main() {
   printf("# %s, %d CUs, shader clock %d MHz nominal\n", prop.gcnArchName, cus, prop.clockRate / 1000);
   printf("# pattern  waves/CU  span/CU                bytes per s_memtime tick per CU   GB/s/CU (HIP events)   aggregate TB/s\n");
   struct Cfg { long long span, stride; const char* what; };
-  const Cfg cfgs[] = {{16 << 10, 8 << 20, "16 KB private (L1)"}, {64 << 10, 8 << 20, "64 KB private (L2)"},
+  const Cfg cfgs[] = {{16 << 10, 8 << 20, "16 KB private (L1)"}, {256 << 10, 8 << 20, "256 KB private (L2)"},
                       {1 << 20, 0, "1 MB shared (L2)"}, {8 << 20, 8 << 20, "8 MB private (HBM)"}};
-  for (int pattern = 0; pattern < 2; ++pattern)
-    for (int waves : {4, 8, 16})
+  for (int pattern = 0; pattern < 3; ++pattern)
+    for (int waves : {8, 16})
       for (const Cfg& c : cfgs) {
         const long long bytes_target = 64ll << 20;               // bytes each CU pulls
-        const int reps = (int)(bytes_target / c.span > 0 ? bytes_target / c.span : 1);
+        const long long per_rep = c.span > (long long)waves * 8192 ? c.span : (long long)waves * 8192;
+        const int reps = (int)(bytes_target / per_rep > 0 ? bytes_target / per_rep : 1);
         for (int it = 0; it < 2; ++it) {
           hipEvent_t e0, e1;
           hipEventCreate(&e0); hipEventCreate(&e1);
           hipEventRecord(e0);
-          if (pattern == 0) hipLaunchKernelGGL(walk<0>, dim3(cus), dim3(waves * 64), 0, 0, buf, c.span, c.stride, reps, sink, clocks);
+          if (pattern == 2) hipLaunchKernelGGL(walk<2>, dim3(cus), dim3(waves * 64), 0, 0, buf, c.span, c.stride, reps, sink, clocks);
+          else if (pattern == 0) hipLaunchKernelGGL(walk<0>, dim3(cus), dim3(waves * 64), 0, 0, buf, c.span, c.stride, reps, sink, clocks);
           else hipLaunchKernelGGL(walk<1>, dim3(cus), dim3(waves * 64), 0, 0, buf, c.span, c.stride, reps, sink, clocks);
           hipEventRecord(e1);
           hipEventSynchronize(e1);
@@ -81,7 +97,7 @@ int main() {
           double clk = 0;
           for (int i = 0; i < cus; ++i) clk += (double)h[i];
           clk /= cus;
-          const double bytes = (double)c.span * reps;
+          const double bytes = (double)per_rep * reps;
           printf("  %d        %2d        %-22s %8.1f                        %8.1f             %8.2f\n", pattern, waves, c.what, bytes / clk, bytes / (ms * 1e6),
                  bytes * cus / (ms * 1e9));
         }
