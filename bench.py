@@ -1159,9 +1159,17 @@ def main():
                         if ent:
                             tb = ent['l1_accesses_per_query'] * queries * 64.0 / per_ms / 1e9          # TB/s through the L1
                             peak = 256 * 64 * 2.4e9 / 1e12
-                            named.append(dict(kernel=k, bound='ta_l1', achieved=tb, peak=peak, unit='TB/s (vector-L1 / texture path)',
-                                              frac=tb / peak, l1_accesses_per_query=ent['l1_accesses_per_query'],
-                                              ta_busy_frac_under_pmc=ent['ta_busy_frac'], source='profiles/msda_texture_path.json'))
+                            rec = dict(kernel=k, bound='ta_l1', achieved=tb, peak=peak, unit='TB/s (vector-L1 / texture path)',
+                                       frac=tb / peak, l1_accesses_per_query=ent['l1_accesses_per_query'],
+                                       ta_busy_frac_under_pmc=ent['ta_busy_frac'], source='profiles/msda_texture_path.json')
+                            gc = json.load(open(tex)).get('gather_ceiling_GBps_per_cu')
+                            if gc:       # what PURE gathers of this shape reach (scripts/lab/vmem_ceiling.hip), blended by the kernel's hit rates
+                                h1, h2 = ent['l1_hit_rate'], ent['l2_hit_rate']
+                                blend = 1.0 / (h1 / gc['l1'] + (1 - h1) * h2 / gc['l2'] + (1 - h1) * (1 - h2) / gc['beyond_l2'])
+                                rec['measured_gather_ceiling_TBps'] = blend * 256 / 1e3
+                                rec['frac_of_measured_gather_ceiling'] = tb / (blend * 256 / 1e3)
+                                rec['gather_ceiling_source'] = gc['source']
+                            named.append(rec)
                 elif bound == 'mfma':
                     a_ = dd['flops'] / dd['calls'] / per_ms / 1e9
                     pk, what = KernelTimer.mfma_peak(k.split('[')[0])
